@@ -1,0 +1,204 @@
+/*
+ * polystokes.h — C ABI of the MI355X-native PolyStokes hot path.
+ *
+ * Drop-in boundary for the reference's per-step reduced-viscosity Stokes solve
+ * (panuelosj/polystokes).  Every entry point names the reference interface it
+ * replaces (paths relative to the reference tree, file:line).
+ *
+ * The boundary is plain C: POD structs, raw pointers and sizes.  Host buffers
+ * are owned by the caller (Houdini owns its SIM fields, exec/HDK_PolyStokes.C:235-246);
+ * device memory is owned by the opaque ps_context and reused across steps.
+ *
+ * Array layout (all dense, x-fastest, i + dim0*(j + dim1*k)):
+ *   cell   fields : nx   * ny   * nz
+ *   faceX  fields : (nx+1)* ny   * nz        faceY: nx*(ny+1)*nz     faceZ: nx*ny*(nz+1)
+ *   edgeXY fields : (nx+1)*(ny+1)* nz        edgeXZ: (nx+1)*ny*(nz+1) edgeYZ: nx*(ny+1)*(nz+1)
+ * (exec/HDK_PolyStokesSolver.h:294-314 are the matching out-of-bounds predicates.)
+ */
+#ifndef POLYSTOKES_H
+#define POLYSTOKES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_REDUCED_DOF 26 /* lib/include/units.h:13-15 (QUADRATIC_REGIONS) */
+
+/* exec/HDK_PolyStokesSolver.h:61-70  enum class SolverResult */
+enum ps_result {
+    PS_UNSUPPORTED_SOLVER = -4,
+    PS_INCOMPLETE = -3,
+    PS_INVALID = -2,
+    PS_FAILED = -1,
+    PS_NOCONVERGE = 0,
+    PS_SUCCESS = 1,
+    PS_NOCHANGE = 2
+};
+
+/* exec/HDK_PolyStokesSolver.h:71-82  enum MaterialLabels */
+enum ps_label {
+    PS_UNASSIGNED = -1,
+    PS_UNSOLVED = -2,
+    PS_GENERICFLUID = -3,
+    PS_ACTIVEFLUID = -4,
+    PS_SOLID = -5,
+    PS_REDUCED = -6,
+    PS_UNVISITED = -7,
+    PS_VISITED = -8,
+    PS_BOUNDARY = -9
+};
+
+/* lib/include/units.h:76-94 */
+enum ps_matrix_scheme { PS_PRESSURE_STRESS = 0 };
+enum ps_solver_type { PS_PCG_MATRIX_VECTOR_PRODUCTS = 0, PS_EIGEN = 1 };
+/* lib/include/units.h:47-53; DIAGONAL is the empty stub at
+ * exec/HDK_PolyStokesSolver_Preconditioners.cpp:37-41 that BASELINE.json asks for (Jacobi-PCG). */
+enum ps_preconditioner { PS_PRE_IDENTITY = 1, PS_PRE_DIAGONAL = 5 };
+/* order in which serialAssignFieldIndices walks a field (Classifier.cpp:1738-1770):
+ * 0 = UT_VoxelArray order (16^3 voxel tiles, tile-linear, x-fastest inside), 1 = plain x-fastest. */
+enum ps_index_order { PS_ORDER_VOXEL_TILES = 0, PS_ORDER_LINEAR = 1 };
+
+/*
+ * Node parameters: one member per entry of the reference's PRM template
+ * (exec/HDK_PolyStokes.C:88-208, accessors exec/HDK_PolyStokes.h:23-43), same names.
+ * Field-name string parms stay in the Houdini shim; they have no meaning below it.
+ */
+typedef struct ps_params {
+    double mindensity;                  /* 1      (unused by the live path, kept for the surface) */
+    double maxdensity;                  /* 100000 */
+    int32_t matrixSetup;                /* ps_matrix_scheme, 0 */
+    int32_t solverType;                 /* ps_solver_type,   0 */
+    int32_t doSolve;                    /* 1 */
+    int32_t keepNonConvergedResults;    /* 1 */
+    int32_t exportMatrices;             /* 0 */
+    int32_t exportComponentMatrices;    /* 0 */
+    int32_t exportStats;                /* 0 */
+    int32_t useWarmStart;               /* 1 (built, then discarded: Solver.cpp:768) */
+    double tolerance;                   /* 1e-3 */
+    int32_t maxSolverIterations;        /* 5000 */
+    int32_t useInputSurfaceWeights;     /* 1 (read, ignored by buildIntegrationWeightsAlt) */
+    int32_t useInputCollisionWeights;   /* 1 (idem) */
+    int32_t activeLiquidBoundaryLayerSize; /* 2 */
+    int32_t activeSolidBoundaryLayerSize;  /* 2 */
+    int32_t doReducedRegions;           /* 1 */
+    int32_t doTile;                     /* 1 */
+    int32_t tileSize;                   /* 16 */
+    int32_t tilePadding;                /* 2 */
+    /* --- extensions (not in the reference's template) --- */
+    int32_t preconditioner;             /* ps_preconditioner, default PS_PRE_IDENTITY */
+    int32_t indexOrder;                 /* ps_index_order, default PS_ORDER_VOXEL_TILES */
+    int32_t negateCollision;            /* 1: `collision` is Houdini-convention (negative inside the
+                                           solid) and is negated before the reference's
+                                           computeSDFWeightsSampled(invert=false) call is applied
+                                           (Solver.cpp:308-326); 0: use as given. default 1 */
+    int32_t reserved;
+    const char* exportDataPrefix;       /* may be NULL */
+} ps_params;
+
+/* Inputs of solveGasSubclass (exec/HDK_PolyStokes.C:235-246, :319-320; Solver.cpp:39-44). */
+typedef struct ps_fields_in {
+    int32_t nx, ny, nz;
+    double dx;                          /* max voxel size, HDK_PolyStokes.C:320 */
+    double dt;                          /* timestep,       HDK_PolyStokes.C:319 */
+    double orig[3];                     /* grid origin (debug output only, Solver.cpp:1134) */
+    float density;                      /* constant liquid density, HDK_PolyStokes.C:298-304 */
+    int32_t reserved;
+    const float* vel[3];                /* face sampled velocity (in) */
+    const float* surface;               /* cell, liquid SDF (<0 inside liquid) */
+    const float* collision;             /* cell, solid SDF */
+    const float* viscosity;             /* cell */
+    const float* collisionvel[3];       /* face sampled */
+    /* optional precomputed volume fractions, order:
+     * 0 centerLiquid 1 faceXLiquid 2 faceYLiquid 3 faceZLiquid 4 edgeYZLiquid 5 edgeXZLiquid 6 edgeXYLiquid
+     * 7..13 the same for Fluid.  All NULL -> the library samples the SDFs itself (Solver.cpp:238-326). */
+    const float* weights[14];
+} ps_fields_in;
+
+/* Outputs (Solver.cpp:937-1028 velocity, Classifier.cpp:4-54 valid). */
+typedef struct ps_fields_out {
+    float* vel[3];                      /* may alias ps_fields_in.vel */
+    float* valid[3];
+} ps_fields_out;
+
+/* exportStats(): dimData (27) + solveData (6), Solver.cpp:574-606, same order. */
+typedef struct ps_stats {
+    double dimData[27];
+    double solveData[6];                /* error, iterations, solve CPU ms, solve wall ms, setup CPU ms, setup wall ms */
+    int32_t result;                     /* ps_result */
+    int32_t usedBiCGStab;               /* CG hit maxit and the fallback ran (Solver.cpp:784-799) */
+    double stage_ms[16];                /* device time per stage, see PS_STAGE_* */
+} ps_stats;
+
+enum ps_stage {
+    PS_STAGE_WEIGHTS = 0, PS_STAGE_CLASSIFY = 1, PS_STAGE_REGIONS = 2, PS_STAGE_INDICES = 3,
+    PS_STAGE_TILE_MATRICES = 4, PS_STAGE_BLOCKS = 5, PS_STAGE_ASSEMBLE = 6, PS_STAGE_PRECOND = 7,
+    PS_STAGE_SOLVE = 8, PS_STAGE_RECOVER = 9, PS_STAGE_WRITEBACK = 10, PS_STAGE_COUNT = 11
+};
+
+typedef struct ps_context ps_context;
+
+/* Library/ABI version and a loud availability check (0 devices -> error string). */
+int32_t ps_abi_version(void);
+
+/* Context = what `Solver mySolver(...)` owns for one call (HDK_PolyStokes.C:333-343), kept alive
+ * across steps so device buffers are reused.  One context per GPU. */
+ps_context* ps_context_create(int32_t device);
+void ps_context_destroy(ps_context* ctx);
+const char* ps_last_error(const ps_context* ctx); /* replaces addError strings, HDK_PolyStokes.C:251-314 */
+
+void ps_params_default(ps_params* p);             /* defaults of HDK_PolyStokes.C:88-208 */
+
+/* Host -> device copy of the SIM fields (no reference equivalent: Houdini fields are host memory). */
+int32_t ps_upload_fields(ps_context* ctx, const ps_params* p, const ps_fields_in* in);
+
+/* The whole hot path on device-resident inputs: buildIntegrationWeightsAlt ... solve ...
+ * recoverVelocityFromPressureStress, applySolutionToVelocity (HDK_PolyStokes.C:344-583).
+ * Returns ps_result. */
+int32_t ps_step_device(ps_context* ctx, ps_stats* stats);
+
+/* Setup only (everything before solve(), HDK_PolyStokes.C:344-476); used by tests and exports. */
+int32_t ps_setup_device(ps_context* ctx, ps_stats* stats);
+/* solve() + recover + write-back on an already set-up context (HDK_PolyStokes.C:518-583). */
+int32_t ps_solve_device(ps_context* ctx, ps_stats* stats);
+
+/* Device -> host copy of vel / valid. */
+int32_t ps_download_fields(ps_context* ctx, ps_fields_out* out);
+
+/* solveGasSubclass equivalent on host buffers: upload + step + download (HDK_PolyStokes.C:222-609). */
+int32_t polystokes_step(ps_context* ctx, const ps_params* p, const ps_fields_in* in,
+                        ps_fields_out* out, ps_stats* stats);
+
+/* y = A x for host vectors of length nPressures+nStresses:
+ * ApplyPressureStressMatrix::apply (lib/include/ApplyPressureStressMatrix.h:102-184). */
+int32_t ps_apply_operator(ps_context* ctx, const double* x, double* y);
+
+/* Inspection of solver state by name — the data behind printAllData()'s 43 point clouds
+ * (Solver.cpp:1030-1074) and exportComponentMatrices() (Solver.cpp:543-566).
+ * ps_query_array returns the element count (or <0 if unknown) and the element size in bytes;
+ * ps_read_array copies it to host. */
+int64_t ps_query_array(ps_context* ctx, const char* name, int32_t* elem_bytes);
+int32_t ps_read_array(ps_context* ctx, const char* name, void* dst, int64_t dst_bytes);
+
+/* MatrixMarket export with the reference's file names and text format
+ * (Solver.cpp:533-606; extern/eigen/unsupported/Eigen/src/SparseExtra/MarketIO.h:310-380). */
+int32_t ps_export_component_matrices(ps_context* ctx, const char* prefix);
+int32_t ps_export_stats(ps_context* ctx, const ps_stats* stats, const char* prefix);
+
+/* Micro-benchmark hooks used by bench.py for the roofline object: run `iters` launches of the
+ * dominant kernel(s) on the solver stream bracketed by HIP events, return avg ms per launch. */
+int32_t ps_bench_kernel(ps_context* ctx, const char* kernel, int32_t iters, double* avg_ms,
+                        double* algorithmic_bytes);
+
+/* Multi-GPU: slab decomposition over z in multiples of the tile size.  The host harness gives each
+ * rank its slab (plus halo) as an ordinary ps_fields_in; these hooks let torch.distributed (RCCL)
+ * carry the two per-iteration exchanges.  See DESIGN.md §multi-GPU. */
+typedef void (*ps_allreduce_fn)(double* device_buf, int32_t count, void* user);
+typedef void (*ps_halo_fn)(double* device_vec, void* user);
+int32_t ps_set_collectives(ps_context* ctx, ps_allreduce_fn allreduce, ps_halo_fn halo, void* user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYSTOKES_H */

@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE — ctypes binding of the CPU oracle (oracle/ps_oracle.hpp).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from polystokes_amd._abi import FieldsIn, Params, Stats
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libps_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("ps_oracle_grid.cpp", "ps_oracle_blocks.cpp", "ps_oracle_solve.cpp",
+                                              "ps_oracle.hpp", "Makefile")]
+    srcs.append(os.path.join(_HERE, "..", "include", "polystokes.h"))
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.po_create.restype = C.c_void_p
+        L.po_destroy.argtypes = [C.c_void_p]
+        L.po_run.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(FieldsIn), C.c_int32, C.POINTER(Stats)]
+        L.po_run.restype = C.c_int32
+        L.po_query_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
+        L.po_query_array.restype = C.c_int64
+        L.po_read_array.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+        L.po_read_array.restype = C.c_int32
+        L.po_apply_operator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.po_build_explicit_A.argtypes = [C.c_void_p]
+        L.po_build_jacobi.argtypes = [C.c_void_p]
+        L.po_time_cg_iterations.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.po_time_cg_iterations.restype = C.c_double
+        L.po_last_error.argtypes = [C.c_void_p]
+        L.po_last_error.restype = C.c_char_p
+        L.po_basis.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.po_fullpivlu_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_fullpivlu_solve.restype = C.c_int32
+        L.po_partialpiv_inverse.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_partialpiv_inverse.restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+_DT = {(4, "i"): np.int32, (4, "f"): np.float32, (8, "f"): np.float64, (8, "i"): np.int64}
+
+
+def _kind(name):
+    if name.endswith("Labels") or name.endswith("Indices") or name.endswith(".col"):
+        return "i"
+    if name.endswith(".ptr"):
+        return "i"
+    return "f"
+
+
+class Oracle:
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.po_create())
+        self.stats = Stats()
+        self.scene = None
+
+    def __del__(self):
+        try:
+            self.L.po_destroy(self.h)
+        except Exception:
+            pass
+
+    def run(self, scene, params, solve=True):
+        self.scene = scene
+        fi = scene.fields_in()
+        self.result = self.L.po_run(self.h, C.byref(params), C.byref(fi), 1 if solve else 0, C.byref(self.stats))
+        return self.result
+
+    def array(self, name):
+        eb = C.c_int32(0)
+        n = self.L.po_query_array(self.h, name.encode(), C.byref(eb))
+        if n < 0:
+            raise KeyError(name)
+        out = np.empty(n, dtype=_DT[(eb.value, _kind(name))])
+        if n:
+            rc = self.L.po_read_array(self.h, name.encode(), out.ctypes.data, out.nbytes)
+            assert rc == 0
+        return out
+
+    def csr(self, name):
+        import scipy.sparse as sp
+        ptr, col, val = self.array(name + ".ptr"), self.array(name + ".col"), self.array(name + ".val")
+        ncols = {"G": self.nP, "JG": self.nP, "Dt": self.nT, "JDt": self.nT, "A": self.nP + self.nT}[name]
+        return sp.csr_matrix((val, col, ptr), shape=(len(ptr) - 1, ncols))
+
+    @property
+    def nP(self):
+        return int(self.stats.dimData[12])
+
+    @property
+    def nT(self):
+        return int(self.stats.dimData[13])
+
+    @property
+    def nA(self):
+        return int(self.stats.dimData[7])
+
+    @property
+    def nRegions(self):
+        return int(self.stats.dimData[24])
+
+    def apply(self, x, fair=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self.L.po_apply_operator(self.h, x.ctypes.data, y.ctypes.data, 1 if fair else 0)
+        return y
+
+    def build_explicit_A(self):
+        self.L.po_build_explicit_A(self.h)
+
+    def build_jacobi(self):
+        self.L.po_build_jacobi(self.h)
+
+    def time_cg(self, iters, fair=False):
+        return self.L.po_time_cg_iterations(self.h, iters, 1 if fair else 0)
+
+
+def basis(off, axis):
+    off = np.ascontiguousarray(off, dtype=np.float64)
+    out = np.empty(26)
+    lib().po_basis(off.ctypes.data, axis, out.ctypes.data)
+    return out
+
+
+def fullpivlu_solve(N, rhs):
+    N = np.ascontiguousarray(N, dtype=np.float64)
+    rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+    x = np.empty(26)
+    lib().po_fullpivlu_solve(N.ctypes.data, rhs.ctypes.data, x.ctypes.data)
+    return x
+
+
+def partialpiv_inverse(B):
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    out = np.empty((26, 26))
+    lib().po_partialpiv_inverse(B.ctypes.data, out.ctypes.data)
+    return out
