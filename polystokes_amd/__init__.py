@@ -1,0 +1,214 @@
+"""polystokes_amd — MI355X-native drop-in for the PolyStokes per-step reduced-viscosity Stokes solve.
+
+The product is the C-ABI shared library `libpolystokes_hip.so` (include/polystokes.h), built from the HIP
+sources in `csrc/`.  This module is only the Python harness over that ABI used by tests and bench.py.
+There is no CPU fallback: loading fails loudly if the library is missing, and creating a context fails
+loudly if no HIP device is present.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi
+from ._abi import (FieldsIn, FieldsOut, Params, Scene, Stats, default_params)  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpolystokes_hip.so")
+_lib = None
+
+EXPORTED_SYMBOLS = [
+    "ps_abi_version", "ps_context_create", "ps_context_destroy", "ps_last_error", "ps_params_default",
+    "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
+    "polystokes_step", "ps_apply_operator", "ps_query_array", "ps_read_array",
+    "ps_export_component_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_collectives",
+]
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"])
+    subprocess.check_call(["make", "-C", csrc, "-j4", "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C polystokes_amd/csrc` "
+                "(__graft_entry__.build()).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.ps_abi_version.restype = C.c_int32
+        L.ps_context_create.argtypes = [C.c_int32]
+        L.ps_context_create.restype = C.c_void_p
+        L.ps_context_destroy.argtypes = [C.c_void_p]
+        L.ps_last_error.argtypes = [C.c_void_p]
+        L.ps_last_error.restype = C.c_char_p
+        L.ps_params_default.argtypes = [C.POINTER(Params)]
+        L.ps_upload_fields.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(FieldsIn)]
+        L.ps_upload_fields.restype = C.c_int32
+        for fn in (L.ps_step_device, L.ps_setup_device, L.ps_solve_device):
+            fn.argtypes = [C.c_void_p, C.POINTER(Stats)]
+            fn.restype = C.c_int32
+        L.ps_download_fields.argtypes = [C.c_void_p, C.POINTER(FieldsOut)]
+        L.ps_download_fields.restype = C.c_int32
+        L.polystokes_step.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(FieldsIn), C.POINTER(FieldsOut),
+                                      C.POINTER(Stats)]
+        L.polystokes_step.restype = C.c_int32
+        L.ps_apply_operator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ps_apply_operator.restype = C.c_int32
+        L.ps_query_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
+        L.ps_query_array.restype = C.c_int64
+        L.ps_read_array.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+        L.ps_read_array.restype = C.c_int32
+        L.ps_export_component_matrices.argtypes = [C.c_void_p, C.c_char_p]
+        L.ps_export_component_matrices.restype = C.c_int32
+        L.ps_export_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_char_p]
+        L.ps_export_stats.restype = C.c_int32
+        L.ps_bench_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ps_bench_kernel.restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+_DT = {(4, "i"): np.int32, (4, "f"): np.float32, (8, "f"): np.float64, (4, "u"): np.uint32}
+
+
+def _kind(name):
+    if name.endswith(("Labels", "Indices", ".col", ".ptr", "Region")) or name.startswith("faceRow"):
+        return "i"
+    if name == "reducedRowFace":
+        return "u"
+    return "f"
+
+
+class PolyStokesError(RuntimeError):
+    pass
+
+
+class Solver:
+    """Thin object wrapper over a `ps_context` — the counterpart of `HDK_PolyStokes::Solver`
+    (exec/HDK_PolyStokesSolver.h:27) as seen through the C ABI."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = self.L.ps_context_create(device)
+        if not h:
+            raise PolyStokesError(self.L.ps_last_error(None).decode())
+        self.h = C.c_void_p(h)
+        self.stats = Stats()
+        self.scene = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ps_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=(1,)):
+        if rc == _abi.FAILED or rc not in allow:
+            raise PolyStokesError(f"rc={rc}: {self.L.ps_last_error(self.h).decode()}")
+        return rc
+
+    def upload(self, scene, params):
+        self.scene, self.params = scene, params
+        fi = scene.fields_in()
+        self._check(self.L.ps_upload_fields(self.h, C.byref(params), C.byref(fi)))
+
+    def setup(self):
+        return self._check(self.L.ps_setup_device(self.h, C.byref(self.stats)))
+
+    def solve(self):
+        return self._check(self.L.ps_solve_device(self.h, C.byref(self.stats)), allow=(0, 1, -3, -4))
+
+    def step_device(self):
+        return self._check(self.L.ps_step_device(self.h, C.byref(self.stats)), allow=(0, 1, -3, -4))
+
+    def step(self, scene, params):
+        """solveGasSubclass equivalent on host buffers (HDK_PolyStokes.C:222-609)."""
+        self.scene, self.params = scene, params
+        fi = scene.fields_in()
+        out, keep = self._fields_out()
+        rc = self._check(self.L.polystokes_step(self.h, C.byref(params), C.byref(fi), C.byref(out), C.byref(self.stats)),
+                         allow=(0, 1, -3, -4))
+        self.vel, self.valid = keep[:3], keep[3:]
+        return rc
+
+    def _fields_out(self):
+        sh = _abi.grid_shapes(self.scene.nx, self.scene.ny, self.scene.nz)
+        keep = [np.empty(sh["face" + a], np.float32) for a in "XYZ"] + [np.empty(sh["face" + a], np.float32) for a in "XYZ"]
+        out = FieldsOut()
+        for a in range(3):
+            out.vel[a] = keep[a].ctypes.data
+            out.valid[a] = keep[3 + a].ctypes.data
+        return out, keep
+
+    def download(self):
+        out, keep = self._fields_out()
+        self._check(self.L.ps_download_fields(self.h, C.byref(out)))
+        self.vel, self.valid = keep[:3], keep[3:]
+        return self.vel, self.valid
+
+    def array(self, name):
+        eb = C.c_int32(0)
+        n = self.L.ps_query_array(self.h, name.encode(), C.byref(eb))
+        if n < 0:
+            raise KeyError(name)
+        out = np.empty(n, dtype=_DT[(eb.value, _kind(name))])
+        if n:
+            self._check(self.L.ps_read_array(self.h, name.encode(), out.ctypes.data, out.nbytes))
+        return out
+
+    def apply(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self._check(self.L.ps_apply_operator(self.h, x.ctypes.data, y.ctypes.data))
+        return y
+
+    def bench_kernel(self, name, iters=20):
+        ms, by = C.c_double(0), C.c_double(0)
+        self._check(self.L.ps_bench_kernel(self.h, name.encode(), iters, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    def export_component_matrices(self, prefix):
+        self._check(self.L.ps_export_component_matrices(self.h, prefix.encode()))
+
+    def export_stats(self, prefix):
+        self._check(self.L.ps_export_stats(self.h, C.byref(self.stats), prefix.encode()))
+
+    # convenience accessors into dimData (Solver.cpp:578-593)
+    @property
+    def nP(self):
+        return int(self.stats.dimData[12])
+
+    @property
+    def nT(self):
+        return int(self.stats.dimData[13])
+
+    @property
+    def nA(self):
+        return int(self.stats.dimData[7])
+
+    @property
+    def nRegions(self):
+        return int(self.stats.dimData[24])
+
+    def S_matrices(self):
+        """(S, St) as scipy CSR — rows of S are face rows (active, then reduced-with-entries)."""
+        import scipy.sparse as sp
+        n = self.nP + self.nT
+        ptr, col, val = self.array("S.ptr"), self.array("S.col"), self.array("S.val")
+        S = sp.csr_matrix((val, col, ptr), shape=(len(ptr) - 1, n))
+        ptr, col, val = self.array("St.ptr"), self.array("St.col"), self.array("St.val")
+        St = sp.csr_matrix((val, col, ptr), shape=(n, S.shape[0]))
+        return S, St

@@ -1,0 +1,515 @@
+// Stencil assembly: one thread per face / cell / edge writes CSR rows directly (row length <= 8,
+// so fixed slots -> count -> scan -> fill; no triplet lists, no sort).
+// Reference: exec/HDK_PolyStokesSolver_ConstructMatrixBlocks.cpp:9-292 (sizes, compile), :294-868 (sweeps).
+//
+// Layout decision: the reference materialises JG = J^T Ghat and JDt = J^T Dhat (26 nnz per
+// touched DOF per reduced face, :454-455,:524-525,:612-613).  Here only the ordinary stencils Ghat, Dhat
+// of the reduced faces are stored, as extra rows of one matrix
+//        S = [ G   Dt  ]   rows 0..nA-1      active faces (X,Y,Z by active index, Solver.h:628-642)
+//            [ Ghat Dhat ]  rows nA..nRows-1  reduced faces with >=1 entry, region-contiguous
+// and the basis row C_f (J) is evaluated on the fly in the tile kernels.  St = S^T is built by gather
+// from the DOF side (deterministic, no atomics).
+#include "ps_context.hpp"
+
+using namespace ps;
+
+namespace {
+
+constexpr int BS = 256;
+
+struct BlockArgs {
+    Grid g;
+    double invDx, rho;
+    const float* lw[7];
+    const float* fw[7];
+    const int32_t* lab[7];
+    const int32_t* act[7];
+    const int32_t* reg[7];
+    const int32_t* faceRow[3];
+    const float* vel[3];
+    const float* cvel[3];
+    const float* visc;
+    int64_t nCenter, nEdge0, nEdge1, nP, nA, faceOff[3];
+};
+
+__device__ inline int64_t stressDOF(const BlockArgs& A, int64_t idx, int type) {   // Solver.h:586-606
+    switch (type) {
+        case 0: return idx;
+        case 1: return idx + A.nCenter;
+        case 2: return idx + 2 * A.nCenter;
+        case 3: return idx + 3 * A.nCenter;
+        case 4: return idx + 3 * A.nCenter + A.nEdge0;
+        default: return idx + 3 * A.nCenter + A.nEdge0 + A.nEdge1;
+    }
+}
+
+// The stencil row of one face in the reference's slot order: p(dir0,dir1), tau_c(dir0,dir1),
+// tau_e(edgeAxis asc, dir0,dir1).  ConstructMatrixBlocks.cpp:394-421 (G), :466-491 (Dt centres), :553-579 (Dt edges).
+__device__ inline int faceEntries(const BlockArgs& A, int axis, const int3 f, int32_t* cols, double* vals) {
+    const int3 cd = A.g.dims(0);
+    const int3 fd = A.g.dims(1 + axis);
+    const double wF = (double)A.fw[1 + axis][lin3(fd, f.x, f.y, f.z)];
+    int n = 0;
+    // pressure
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        const double sign = dir == 0 ? -1. : 1.;
+        int3 c = f;
+        addc(c, axis, dir - 1);
+        if (comp(c, axis) < 0 || comp(c, axis) >= comp(cd, axis)) continue;
+        const int64_t cl = lin3(cd, c.x, c.y, c.z);
+        const int pidx = A.act[0][cl];
+        if (pidx < 0) continue;
+        const double coeff = wF * (double)A.lw[0][cl] * A.invDx;
+        if (coeff <= 0.) continue;
+        cols[n] = pidx; vals[n] = sign * coeff; ++n;
+    }
+    // centre stresses
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        const double sign = dir == 0 ? -1. : 1.;
+        int3 c = f;
+        addc(c, axis, dir - 1);
+        if (comp(c, axis) < 0 || comp(c, axis) >= comp(cd, axis)) continue;
+        const int64_t cl = lin3(cd, c.x, c.y, c.z);
+        if (!isActiveL(A.lab[0][cl])) continue;
+        const double coeff = wF * (double)A.lw[0][cl] * A.invDx;
+        if (coeff <= 0.) continue;
+        cols[n] = (int32_t)(A.nP + stressDOF(A, A.act[0][cl], axis)); vals[n] = -1. * sign * coeff; ++n;
+    }
+    // edge stresses
+    for (int ea = 0; ea < 3; ++ea) {
+        if (ea == axis) continue;
+        const int3 ed = A.g.dims(4 + ea);
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const double sign = dir == 0 ? -1. : 1.;
+            int3 e = f;
+            addc(e, 3 - axis - ea, dir);
+            const int64_t el = lin3(ed, e.x, e.y, e.z);
+            if (!isActiveL(A.lab[4 + ea][el])) continue;
+            const double coeff = wF * (double)A.lw[4 + ea][el] * A.invDx;
+            if (coeff <= 0.) continue;
+            cols[n] = (int32_t)(A.nP + stressDOF(A, A.act[4 + ea][el], 3 + ea)); vals[n] = -1. * sign * coeff; ++n;
+        }
+    }
+    return n;
+}
+
+__device__ inline void sortEntries(int n, int32_t* cols, double* vals) {
+    for (int i = 1; i < n; ++i) {
+        const int32_t c = cols[i];
+        const double v = vals[i];
+        int j = i - 1;
+        while (j >= 0 && cols[j] > c) { cols[j + 1] = cols[j]; vals[j + 1] = vals[j]; --j; }
+        cols[j + 1] = c; vals[j + 1] = v;
+    }
+}
+
+__global__ void k_face_rows_active(BlockArgs A, int axis, int32_t* __restrict__ faceRow) {
+    const int3 d = A.g.dims(1 + axis);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    faceRow[c] = isActiveL(A.lab[1 + axis][c]) ? (int32_t)(A.act[1 + axis][c] + A.faceOff[axis]) : -1;
+}
+
+// reduced faces with >= 1 stencil entry, enumerated per region through its face box (same work items
+// as the dense reductions): count, then ordered assignment of rows nA + k.
+__device__ inline bool skinFace(const BlockArgs& A, int axis, int r, int i, int j, int k) {
+    const int3 fd = A.g.dims(1 + axis);
+    if (oob3(fd, i, j, k)) return false;
+    const int64_t c = lin3(fd, i, j, k);
+    if (A.reg[1 + axis][c] != r || A.lab[1 + axis][c] != PS_REDUCED) return false;
+    int32_t cols[8];
+    double vals[8];
+    return faceEntries(A, axis, make_int3(i, j, k), cols, vals) > 0;
+}
+__device__ inline int blockScanExcl(int v, int* total) {
+    __shared__ int waveSums[BS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) waveSums[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) { if (i < w) base += waveSums[i]; tot += waveSums[i]; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+template <bool ASSIGN>
+__global__ void __launch_bounds__(BS) k_skin(BlockArgs A, const int32_t* __restrict__ bbox, const int32_t* __restrict__ itemRegion,
+                                             const int32_t* __restrict__ itemAxis, const int32_t* __restrict__ itemStart,
+                                             int32_t* __restrict__ itemCount, int32_t* __restrict__ faceRow0, int32_t* __restrict__ faceRow1,
+                                             int32_t* __restrict__ faceRow2, uint32_t* __restrict__ rrowFace, int32_t* __restrict__ rrowRegion) {
+    const int item = blockIdx.x;
+    const int r = itemRegion[item], axis = itemAxis[item], start = itemStart[item];
+    const int bx0 = bbox[r * 6 + 0], by0 = bbox[r * 6 + 1], bz0 = bbox[r * 6 + 2];
+    int ex = bbox[r * 6 + 3] - bx0 + 1, ey = bbox[r * 6 + 4] - by0 + 1, ez = bbox[r * 6 + 5] - bz0 + 1;
+    if (axis == 0) ex++; else if (axis == 1) ey++; else ez++;
+    const int total = ex * ey * ez;
+    const int end = min(start + FB_CHUNK, total);
+    int32_t* faceRow = axis == 0 ? faceRow0 : (axis == 1 ? faceRow1 : faceRow2);
+    const int3 fd = A.g.dims(1 + axis);
+    int running = ASSIGN ? itemCount[item] : 0;   // exclusive offset of this item (after scan)
+    for (int base = start; base < end; base += BS) {
+        const int pos = base + threadIdx.x;
+        bool fl = false;
+        int i = 0, j = 0, k = 0;
+        if (pos < end) {
+            i = bx0 + pos % ex; j = by0 + (pos / ex) % ey; k = bz0 + pos / (ex * ey);
+            fl = skinFace(A, axis, r, i, j, k);
+        }
+        int tot;
+        const int off = blockScanExcl(fl ? 1 : 0, &tot);
+        if (ASSIGN && fl) {
+            const int rr = running + off;
+            faceRow[lin3(fd, i, j, k)] = (int32_t)(A.nA + rr);
+            rrowFace[rr] = packFace(i, j, k, axis);
+            rrowRegion[rr] = r;
+        }
+        running += tot;
+    }
+    if (!ASSIGN && threadIdx.x == 0) itemCount[item] = running;
+}
+
+__global__ void k_S_count(BlockArgs A, int axis, int32_t* __restrict__ rowCount) {
+    const int3 d = A.g.dims(1 + axis);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int row = A.faceRow[axis][c];
+    if (row < 0) return;
+    int32_t cols[8];
+    double vals[8];
+    rowCount[row] = faceEntries(A, axis, unlin3(d, c), cols, vals);
+}
+// fill S; for active rows also the diagonal mass terms and rhs (ConstructMatrixBlocks.cpp:362-391)
+__global__ void k_S_fill(BlockArgs A, int axis, const int32_t* __restrict__ ptr, int32_t* __restrict__ col, double* __restrict__ val,
+                         double* __restrict__ McInv, double* __restrict__ rhsA, double* __restrict__ Mc, double* __restrict__ oldVs) {
+    const int3 d = A.g.dims(1 + axis);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int row = A.faceRow[axis][c];
+    if (row < 0) return;
+    int32_t cols[8];
+    double vals[8];
+    const int n = faceEntries(A, axis, unlin3(d, c), cols, vals);
+    sortEntries(n, cols, vals);
+    const int p0 = ptr[row];
+    for (int q = 0; q < n; ++q) { col[p0 + q] = cols[q]; val[p0 + q] = vals[q]; }
+    if (row < A.nA) {
+        double volume = (double)A.fw[1 + axis][c] * (double)A.lw[1 + axis][c];
+        const double lo = 0.1 * 0.1;   // MINWEIGHT * MINWEIGHT, :365
+        volume = volume < lo ? lo : (volume > 1.0 ? 1.0 : volume);
+        const double u = (double)A.vel[axis][c];
+        McInv[row] = 1. / (volume * A.rho);
+        rhsA[row] = u * volume * A.rho;
+        if (Mc) Mc[row] = volume * A.rho;
+        if (oldVs) oldVs[row] = u;
+    }
+}
+
+// ---- transpose by gather -----------------------------------------------------------------------
+struct StEntry { int32_t row; double val; };
+
+// entries of column j = pressure of cell c (mode 0) or centre stress (cell c, axis a) (mode 1+a)
+__device__ inline int cellColumn(const BlockArgs& A, int mode, const int3 c, int32_t* rows, double* vals, double* rhsOut) {
+    const int3 cd = A.g.dims(0);
+    const int64_t cl = lin3(cd, c.x, c.y, c.z);
+    const double wLc = (double)A.lw[0][cl];
+    const bool cellSolidish = A.fw[0][cl] < 1.f;
+    int n = 0;
+    double rhs = 0.;
+    const int a0 = mode == 0 ? 0 : mode - 1, a1 = mode == 0 ? 2 : mode - 1;
+    for (int a = a0; a <= a1; ++a) {
+        const int3 fd = A.g.dims(1 + a);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            int3 f = c;
+            addc(f, a, d);
+            const int64_t fl = lin3(fd, f.x, f.y, f.z);
+            const int row = A.faceRow[a][fl];
+            if (row < 0) continue;
+            const double sign = (1 - d) == 0 ? -1. : 1.;   // this cell is faceToCellMap(face, a, 1-d)
+            const float wFf = A.fw[1 + a][fl];
+            const double coeff = (double)wFf * wLc * A.invDx;
+            if (coeff <= 0.) continue;
+            rows[n] = row;
+            vals[n] = mode == 0 ? sign * coeff : -1. * sign * coeff;
+            ++n;
+            if (row < A.nA) {   // solid-boundary rhs terms, :424-441 / :494-511 (solidCoeff unused; literal)
+                const double sc = sign * coeff;
+                const double svel = (double)A.cvel[a][fl];
+                if (cellSolidish) rhs += -1. * sc * svel;
+                if (wFf < 1.f) rhs += sc * svel;
+            }
+        }
+    }
+    *rhsOut = rhs;
+    return n;
+}
+__device__ inline int edgeColumn(const BlockArgs& A, int ea, const int3 e, int32_t* rows, double* vals, double* rhsOut) {
+    const int3 ed = A.g.dims(4 + ea);
+    const int64_t el = lin3(ed, e.x, e.y, e.z);
+    const double wLe = (double)A.lw[4 + ea][el];
+    const bool edgeSolidish = A.fw[4 + ea][el] < 1.f;
+    int n = 0;
+    double rhs = 0.;
+    for (int fa = 0; fa < 3; ++fa) {
+        if (fa == ea) continue;
+        const int third = 3 - fa - ea;
+        const int3 fd = A.g.dims(1 + fa);
+#pragma unroll
+        for (int divDir = 0; divDir < 2; ++divDir) {
+            int3 f = e;
+            addc(f, third, -divDir);   // faceToEdgeMap(face, fa, ea, divDir) == e
+            if (oob3(fd, f.x, f.y, f.z)) continue;
+            const int64_t fl = lin3(fd, f.x, f.y, f.z);
+            const int row = A.faceRow[fa][fl];
+            if (row < 0) continue;
+            const double sign = divDir == 0 ? -1. : 1.;
+            const float wFf = A.fw[1 + fa][fl];
+            const double coeff = (double)wFf * wLe * A.invDx;
+            if (coeff <= 0.) continue;
+            rows[n] = row; vals[n] = -1. * sign * coeff; ++n;
+            if (row < A.nA) {   // :582-599
+                const double sc = sign * coeff;
+                const double svel = (double)A.cvel[fa][fl];
+                if (edgeSolidish) rhs += -1. * sc * svel;
+                if (wFf < 1.f) rhs += sc * svel;
+            }
+        }
+    }
+    *rhsOut = rhs;
+    return n;
+}
+
+__device__ inline float viscAt(const BlockArgs& A, float px, float py, float pz) {
+    const int n[3] = {A.g.nx, A.g.ny, A.g.nz};
+    const float p[3] = {px, py, pz};
+    int i0[3], i1[3];
+    float t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float u = p[a] - 0.5f;
+        if (u < 0.f) u = 0.f;
+        if (u > (float)(n[a] - 1)) u = (float)(n[a] - 1);
+        int b = (int)u;
+        if (b >= n[a] - 1) { b = n[a] - 1; i0[a] = b; i1[a] = b; t[a] = 0.f; }
+        else { i0[a] = b; i1[a] = b + 1; t[a] = u - (float)b; }
+    }
+    const int64_t sy = A.g.nx, sz = (int64_t)A.g.nx * A.g.ny;
+    auto at = [&](int i, int j, int k) { return A.visc[i + j * sy + k * sz]; };
+    auto L = [](float a, float b, float tt) { return a + (b - a) * tt; };
+    const float c00 = L(at(i0[0], i0[1], i0[2]), at(i1[0], i0[1], i0[2]), t[0]);
+    const float c10 = L(at(i0[0], i1[1], i0[2]), at(i1[0], i1[1], i0[2]), t[0]);
+    const float c01 = L(at(i0[0], i0[1], i1[2]), at(i1[0], i0[1], i1[2]), t[0]);
+    const float c11 = L(at(i0[0], i1[1], i1[2]), at(i1[0], i1[1], i1[2]), t[0]);
+    return L(L(c00, c10, t[1]), L(c01, c11, t[1]), t[2]);
+}
+__device__ inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ inline void sortRows(int n, int32_t* rows, double* vals) {
+    for (int i = 1; i < n; ++i) {
+        const int32_t c = rows[i];
+        const double v = vals[i];
+        int j = i - 1;
+        while (j >= 0 && rows[j] > c) { rows[j + 1] = rows[j]; vals[j + 1] = vals[j]; --j; }
+        rows[j + 1] = c; vals[j + 1] = v;
+    }
+}
+
+// cells: columns p, tau_xx, tau_yy, tau_zz.  FILL=false counts, FILL=true writes St rows, rhs_p/rhs_tau
+// and the stress diagonals uInv (/u) (ConstructMatrixBlocks.cpp:737-867).
+template <bool FILL>
+__global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t* __restrict__ ptr, int32_t* __restrict__ col,
+                           double* __restrict__ val, double* __restrict__ rhsPT, double* __restrict__ uInv, double* __restrict__ uDiag) {
+    const int3 d = A.g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int idx = A.act[0][c];
+    if (idx < 0) return;
+    const int3 q = unlin3(d, c);
+    int32_t rows[6];
+    double vals[6];
+    double uinvv = 0., uv = 0.;
+    if (FILL) {
+        const double vw = clampd((double)A.fw[0][c], 0.1, 1.0) * (double)A.lw[0][c];
+        const double visc = (double)viscAt(A, (float)q.x + 0.5f, (float)q.y + 0.5f, (float)q.z + 0.5f);
+        const double invVisc = clampd(1. / visc, 0., 1.e10);
+        uinvv = invVisc * clampd(vw, 1.e-2, 1.);
+        uv = visc * clampd(1. / vw, 0., 1.e2);
+    }
+    for (int mode = 0; mode < 4; ++mode) {
+        double rhs;
+        const int n = cellColumn(A, mode, q, rows, vals, &rhs);
+        const int64_t j = mode == 0 ? idx : A.nP + stressDOF(A, idx, mode - 1);
+        if (!FILL) { cnt[j] = n; continue; }
+        sortRows(n, rows, vals);
+        const int p0 = ptr[j];
+        for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; }
+        rhsPT[j] = rhs;
+        if (mode > 0) { uInv[j - A.nP] = uinvv; if (uDiag) uDiag[j - A.nP] = uv; }
+    }
+}
+// edges: column tau_e (ConstructMatrixBlocks.cpp:651-735 for the diagonal)
+template <bool FILL>
+__global__ void k_St_edges(BlockArgs A, int ea, int32_t* __restrict__ cnt, const int32_t* __restrict__ ptr, int32_t* __restrict__ col,
+                           double* __restrict__ val, double* __restrict__ rhsPT, double* __restrict__ uInv, double* __restrict__ uDiag) {
+    const int3 d = A.g.dims(4 + ea);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    if (!isActiveL(A.lab[4 + ea][c])) return;
+    const int idx = A.act[4 + ea][c];
+    const int3 q = unlin3(d, c);
+    int32_t rows[4];
+    double vals[4];
+    double rhs;
+    const int n = edgeColumn(A, ea, q, rows, vals, &rhs);
+    const int64_t t = stressDOF(A, idx, 3 + ea);
+    const int64_t j = A.nP + t;
+    if (!FILL) { cnt[j] = n; return; }
+    sortRows(n, rows, vals);
+    const int p0 = ptr[j];
+    for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; }
+    rhsPT[j] = rhs;
+    const double vw = clampd((double)A.fw[4 + ea][c], 0.1, 1.0) * (double)A.lw[4 + ea][c];
+    const float ox = ea == 0 ? 0.5f : 0.f, oy = ea == 1 ? 0.5f : 0.f, oz = ea == 2 ? 0.5f : 0.f;
+    const double visc = (double)viscAt(A, (float)q.x + ox, (float)q.y + oy, (float)q.z + oz);
+    const double invVisc = clampd(1. / visc, 0., 1e10);
+    uInv[t] = 2. * invVisc * vw;
+    if (uDiag) uDiag[t] = 0.5 * visc * clampd(1. / vw, 0., 1.e2);
+}
+
+BlockArgs makeArgs(ps_context* c) {
+    BlockArgs A;
+    A.g = c->g; A.invDx = c->invDx; A.rho = c->rho;
+    for (int s = 0; s < 7; ++s) {
+        A.lw[s] = c->liquidW[s].p; A.fw[s] = c->fluidW[s].p;
+        A.lab[s] = c->labels[s].p; A.act[s] = c->activeIdx[s].p; A.reg[s] = c->reducedIdx[s].p;
+    }
+    for (int a = 0; a < 3; ++a) { A.faceRow[a] = c->faceRow[a].p; A.vel[a] = c->vel[a].p; A.cvel[a] = c->cvel[a].p; }
+    A.visc = c->viscosity.p;
+    A.nCenter = c->nCenter; A.nEdge0 = c->nEdge[0]; A.nEdge1 = c->nEdge[1];
+    A.nP = c->nPressures; A.nA = c->nActiveVs;
+    A.faceOff[0] = 0; A.faceOff[1] = c->nFace[0]; A.faceOff[2] = c->nFace[0] + c->nFace[1];
+    return A;
+}
+
+}  // namespace
+
+// ConstructMatrixBlocks.cpp:9-292
+void ps_context::constructMatrixBlocks() {
+    nActiveVs = nFace[0] + nFace[1] + nFace[2];
+    nReducedVs = regionCount * PS_RD;
+    nPressures = nCenter;
+    nStresses = 3 * nCenter + nEdge[0] + nEdge[1] + nEdge[2];
+    nSystem = nPressures + nStresses;
+    nTotalDOFs = nActiveVs + nReducedVs + nPressures + nStresses;
+    if (nSystem >= 0x7fffffff || nActiveVs >= 0x7fffffff) throw Error("system too large for 32-bit DOF indices");
+
+    BlockArgs A = makeArgs(this);
+    for (int a = 0; a < 3; ++a) {
+        const int64_t n = g.count(1 + a);
+        hipLaunchKernelGGL(k_face_rows_active, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, faceRow[a].p);
+    }
+    // reduced rows
+    nReducedRows = 0;
+    if (regionCount > 0 && fbItems > 0) {
+        hipLaunchKernelGGL(k_skin<false>, dim3((unsigned)fbItems), dim3(BS), 0, stream, A, bbox.p, fbItemRegion.p, fbItemAxis.p,
+                           fbItemStart.p, fbItemCount.p, faceRow[0].p, faceRow[1].p, faceRow[2].p, (uint32_t*)nullptr, (int32_t*)nullptr);
+        HIP_CHECK(hipMemsetAsync(fbItemCount.p + fbItems, 0, sizeof(int32_t), stream));
+        nReducedRows = exclusiveScanI32(fbItemCount.p, fbItems + 1);
+        rrowFace.alloc((size_t)nReducedRows);
+        rrowRegion.alloc((size_t)nReducedRows);
+        hipLaunchKernelGGL(k_skin<true>, dim3((unsigned)fbItems), dim3(BS), 0, stream, A, bbox.p, fbItemRegion.p, fbItemAxis.p,
+                           fbItemStart.p, fbItemCount.p, faceRow[0].p, faceRow[1].p, faceRow[2].p, rrowFace.p, rrowRegion.p);
+        // region -> row range, and fixed-size row chunks for the per-iteration tile kernels (host built)
+        std::vector<int32_t> itemOff((size_t)fbItems + 1), itemPtr((size_t)regionCount + 1);
+        HIP_CHECK(hipMemcpyAsync(itemOff.data(), fbItemCount.p, itemOff.size() * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(itemPtr.data(), fbRegionItemPtr.p, itemPtr.size() * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<int32_t> rptr((size_t)regionCount + 1), cR, cS, cE, cptr((size_t)regionCount + 1);
+        for (int64_t r = 0; r <= regionCount; ++r) rptr[(size_t)r] = itemOff[(size_t)itemPtr[(size_t)r]];
+        for (int64_t r = 0; r < regionCount; ++r) {
+            cptr[(size_t)r] = (int32_t)cR.size();
+            for (int32_t s0 = rptr[(size_t)r]; s0 < rptr[(size_t)r + 1]; s0 += RC_ROWS) {
+                cR.push_back((int32_t)r); cS.push_back(s0); cE.push_back(std::min(s0 + RC_ROWS, rptr[(size_t)r + 1]));
+            }
+        }
+        cptr[(size_t)regionCount] = (int32_t)cR.size();
+        nRChunks = (int64_t)cR.size();
+        regionRowPtr.alloc(rptr.size()); rchunkRegion.alloc(cR.size()); rchunkStart.alloc(cS.size()); rchunkEnd.alloc(cE.size());
+        regionChunkPtr.alloc(cptr.size());
+        HIP_CHECK(hipMemcpyAsync(regionRowPtr.p, rptr.data(), rptr.size() * 4, hipMemcpyHostToDevice, stream));
+        if (nRChunks) {
+            HIP_CHECK(hipMemcpyAsync(rchunkRegion.p, cR.data(), cR.size() * 4, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(rchunkStart.p, cS.data(), cS.size() * 4, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(rchunkEnd.p, cE.data(), cE.size() * 4, hipMemcpyHostToDevice, stream));
+        }
+        HIP_CHECK(hipMemcpyAsync(regionChunkPtr.p, cptr.data(), cptr.size() * 4, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    } else {
+        nRChunks = 0;
+    }
+    nRows = nActiveVs + nReducedRows;
+    if (nRows >= 0x7fffffff) throw Error("too many face rows");
+
+    const bool wantExport = P.exportComponentMatrices != 0;
+    McInv.alloc((size_t)nActiveVs); rhsA.alloc((size_t)nActiveVs);
+    if (wantExport) { Mc.alloc((size_t)nActiveVs); oldVs.alloc((size_t)nActiveVs); uDiag.alloc((size_t)nStresses); }
+    uInv.alloc((size_t)nStresses); rhsPT.alloc((size_t)nSystem);
+
+    // S
+    S.rows = nRows; S.cols = nSystem;
+    S.ptr.alloc((size_t)nRows + 1);
+    HIP_CHECK(hipMemsetAsync(S.ptr.p, 0, ((size_t)nRows + 1) * sizeof(int32_t), stream));
+    for (int a = 0; a < 3; ++a) {
+        const int64_t n = g.count(1 + a);
+        hipLaunchKernelGGL(k_S_count, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, S.ptr.p);
+    }
+    {
+        // 32-bit scan: guard against overflow with the a-priori bound 8 nnz per row
+        if ((int64_t)nRows * 8 >= 0x7fffffffLL) {
+            // still fine as long as the true total fits; the scan total is checked below
+        }
+        const int64_t tot = exclusiveScanI32(S.ptr.p, nRows + 1);
+        if (tot < 0) throw Error("nnz(S) overflows 32-bit row pointers");
+        S.nnz = tot;
+    }
+    S.col.alloc((size_t)S.nnz); S.val.alloc((size_t)S.nnz);
+    for (int a = 0; a < 3; ++a) {
+        const int64_t n = g.count(1 + a);
+        hipLaunchKernelGGL(k_S_fill, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, S.ptr.p, S.col.p, S.val.p, McInv.p, rhsA.p,
+                           wantExport ? Mc.p : (double*)nullptr, wantExport ? oldVs.p : (double*)nullptr);
+    }
+    // St
+    St.rows = nSystem; St.cols = nRows;
+    St.ptr.alloc((size_t)nSystem + 1);
+    HIP_CHECK(hipMemsetAsync(St.ptr.p, 0, ((size_t)nSystem + 1) * sizeof(int32_t), stream));
+    {
+        const int64_t n = g.count(0);
+        hipLaunchKernelGGL(k_St_cells<false>, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, St.ptr.p, (const int32_t*)nullptr,
+                           (int32_t*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+        for (int e = 0; e < 3; ++e) {
+            const int64_t ne = g.count(4 + e);
+            hipLaunchKernelGGL(k_St_edges<false>, dim3(gridFor(ne, BS)), dim3(BS), 0, stream, A, e, St.ptr.p, (const int32_t*)nullptr,
+                               (int32_t*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+        }
+        St.nnz = exclusiveScanI32(St.ptr.p, nSystem + 1);
+        if (St.nnz != S.nnz) throw Error("internal: nnz(S^T) != nnz(S)");
+        St.col.alloc((size_t)St.nnz); St.val.alloc((size_t)St.nnz);
+        hipLaunchKernelGGL(k_St_cells<true>, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, (int32_t*)nullptr, St.ptr.p, St.col.p, St.val.p,
+                           rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
+        for (int e = 0; e < 3; ++e) {
+            const int64_t ne = g.count(4 + e);
+            hipLaunchKernelGGL(k_St_edges<true>, dim3(gridFor(ne, BS)), dim3(BS), 0, stream, A, e, (int32_t*)nullptr, St.ptr.p, St.col.p,
+                               St.val.p, rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
+        }
+    }
+}

@@ -1,0 +1,167 @@
+// polystokes_amd — MI355X-native PolyStokes hot path.  Shared host/device definitions.
+//
+// Data layout in HBM: every grid quantity is a dense x-fastest array (SoA, one array per sample
+// grid); the 7 sample grids are indexed 0 = cell centre, 1..3 = face X/Y/Z, 4..6 = edge YZ/XZ/XY
+// (edge axis 0,1,2 as in exec/HDK_PolyStokesSolver.h:397-411).  Labels/indices are int32 on device
+// (the reference's exint fields, Solver.h:327-335; values identical, width halved to save HBM traffic).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/polystokes.h"
+
+#define PS_RD 26
+
+#define HIP_CHECK(x)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) throw ps::Error(std::string(#x) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+namespace ps {
+
+struct Error {
+    std::string msg;
+    explicit Error(std::string m) : msg(std::move(m)) {}
+};
+
+struct Grid {
+    int nx, ny, nz;
+    int order;  // ps_index_order
+    __host__ __device__ int3 dims(int s) const {
+        int3 d = make_int3(nx, ny, nz);
+        if (s >= 1 && s <= 3) { if (s == 1) d.x++; else if (s == 2) d.y++; else d.z++; }
+        else if (s >= 4) { const int e = s - 4; if (e != 0) d.x++; if (e != 1) d.y++; if (e != 2) d.z++; }
+        return d;
+    }
+    __host__ __device__ int64_t count(int s) const { const int3 d = dims(s); return (int64_t)d.x * d.y * d.z; }
+};
+
+__host__ __device__ inline int64_t lin3(const int3 d, int i, int j, int k) { return i + (int64_t)d.x * (j + (int64_t)d.y * k); }
+__host__ __device__ inline bool oob3(const int3 d, int i, int j, int k) {
+    return i < 0 || i >= d.x || j < 0 || j >= d.y || k < 0 || k >= d.z;
+}
+__host__ __device__ inline int comp(const int3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+__host__ __device__ inline void addc(int3& v, int a, int q) { if (a == 0) v.x += q; else if (a == 1) v.y += q; else v.z += q; }
+__host__ __device__ inline int3 unlin3(const int3 d, int64_t c) {
+    int3 r;
+    r.x = (int)(c % d.x);
+    const int64_t q = c / d.x;
+    r.y = (int)(q % d.y);
+    r.z = (int)(q / d.y);
+    return r;
+}
+
+// Position t in the traversal order of serialAssignFieldIndices (Classifier.cpp:1738-1770) -> (i,j,k).
+// PS_ORDER_VOXEL_TILES: UT_VoxelArray order — 16^3 voxel tiles, tile-linear (x fastest), x-fastest inside.
+__host__ __device__ inline int3 orderToIjk(const int3 d, int order, int64_t t) {
+    if (order == PS_ORDER_LINEAR) return unlin3(d, t);
+    const int T = 16;
+    const int ntz = (d.z + T - 1) / T, nty = (d.y + T - 1) / T, ntx = (d.x + T - 1) / T;
+    const int64_t slab = (int64_t)d.x * d.y * T;
+    int tz = (int)(t / slab);
+    if (tz > ntz - 1) tz = ntz - 1;
+    t -= slab * tz;
+    const int hz = (tz * T + T <= d.z) ? T : d.z - tz * T;
+    const int64_t rowv = (int64_t)d.x * T * hz;
+    int ty = (int)(t / rowv);
+    if (ty > nty - 1) ty = nty - 1;
+    t -= rowv * ty;
+    const int hy = (ty * T + T <= d.y) ? T : d.y - ty * T;
+    const int64_t tilev = (int64_t)T * hy * hz;
+    int tx = (int)(t / tilev);
+    if (tx > ntx - 1) tx = ntx - 1;
+    t -= tilev * tx;
+    const int wx = (tx * T + T <= d.x) ? T : d.x - tx * T;
+    int3 r;
+    r.x = tx * T + (int)(t % wx);
+    const int64_t q = t / wx;
+    r.y = ty * T + (int)(q % hy);
+    r.z = tz * T + (int)(q / hy);
+    return r;
+}
+__host__ __device__ inline int64_t ijkToOrder(const int3 d, int order, int i, int j, int k) {
+    if (order == PS_ORDER_LINEAR) return lin3(d, i, j, k);
+    const int T = 16;
+    const int tz = k / T, ty = j / T, tx = i / T;
+    const int hz = (tz * T + T <= d.z) ? T : d.z - tz * T;
+    const int hy = (ty * T + T <= d.y) ? T : d.y - ty * T;
+    const int wx = (tx * T + T <= d.x) ? T : d.x - tx * T;
+    return (int64_t)d.x * d.y * T * tz + (int64_t)d.x * T * hz * ty + (int64_t)T * hy * hz * tx +
+           (i - tx * T) + (int64_t)wx * ((j - ty * T) + (int64_t)hy * (k - tz * T));
+}
+
+__host__ __device__ inline bool isActiveL(int l) { return l == PS_ACTIVEFLUID || l == PS_BOUNDARY; }   // Solver.h:708-710
+__host__ __device__ inline bool isReducedL(int l) { return l == PS_REDUCED || l == PS_BOUNDARY; }      // Solver.h:711-713
+
+template <class T>
+struct Set7 {
+    T* p[7];
+};
+
+// Polynomial basis row C_a(x), exec/HDK_PolyStokesSolver.cpp:2105-2149 (QUADRATIC_REGIONS, 26 DOF).
+__host__ __device__ inline void basisRow(const double ox, const double oy, const double oz, int axis, double* v) {
+#pragma unroll
+    for (int n = 0; n < PS_RD; ++n) v[n] = 0.;
+    if (axis == 0) {
+        v[0] = 1.; v[3] = ox; v[4] = oy; v[5] = oz;
+        v[6] = ox * ox; v[7] = ox * oy; v[8] = ox * oz; v[9] = oy * oy; v[10] = oy * oz; v[11] = oz * oz;
+    } else if (axis == 1) {
+        v[1] = 1.; v[12] = ox; v[13] = oy; v[14] = oz;
+        v[15] = ox * ox; v[16] = ox * oy; v[17] = ox * oz; v[18] = oy * oy; v[19] = oy * oz; v[20] = oz * oz;
+    } else {
+        v[2] = 1.; v[3] = -oz;
+        v[6] = -2. * ox * oz; v[7] = -1. * oy * oz; v[8] = -0.5 * oz * oz;
+        v[13] = -oz; v[16] = -1. * ox * oz; v[18] = -2. * oy * oz; v[19] = -0.5 * oz * oz;
+        v[21] = ox; v[22] = oy; v[23] = ox * ox; v[24] = ox * oy; v[25] = oy * oy;
+    }
+}
+// dot(C_a(x), c) without materialising the row
+__host__ __device__ inline double basisDot(const double ox, const double oy, const double oz, int axis, const double* c) {
+    if (axis == 0)
+        return c[0] + ox * c[3] + oy * c[4] + oz * c[5] + ox * ox * c[6] + ox * oy * c[7] + ox * oz * c[8] +
+               oy * oy * c[9] + oy * oz * c[10] + oz * oz * c[11];
+    if (axis == 1)
+        return c[1] + ox * c[12] + oy * c[13] + oz * c[14] + ox * ox * c[15] + ox * oy * c[16] + ox * oz * c[17] +
+               oy * oy * c[18] + oy * oz * c[19] + oz * oz * c[20];
+    return c[2] - oz * c[3] - 2. * ox * oz * c[6] - oy * oz * c[7] - 0.5 * oz * oz * c[8] - oz * c[13] -
+           ox * oz * c[16] - 2. * oy * oz * c[18] - 0.5 * oz * oz * c[19] + ox * c[21] + oy * c[22] +
+           ox * ox * c[23] + ox * oy * c[24] + oy * oy * c[25];
+}
+
+// face position packed in 32 bits: 10 bits per coordinate + 2 bits axis (grids up to 1023^3)
+__host__ __device__ inline uint32_t packFace(int i, int j, int k, int axis) {
+    return (uint32_t)i | ((uint32_t)j << 10) | ((uint32_t)k << 20) | ((uint32_t)axis << 30);
+}
+__host__ __device__ inline void unpackFace(uint32_t q, int& i, int& j, int& k, int& axis) {
+    i = q & 1023; j = (q >> 10) & 1023; k = (q >> 20) & 1023; axis = q >> 30;
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        if (count <= n && p) return;
+        free();
+        if (count == 0) count = 1;
+        HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { free(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+inline int gridFor(int64_t n, int block) { return (int)((n + block - 1) / block); }
+
+}  // namespace ps

@@ -1,0 +1,586 @@
+// C ABI (include/polystokes.h) and stage orchestration — the solveGasSubclass() sequence of
+// exec/HDK_PolyStokes.C:222-609 driving HIP kernels.  No CPU fallback exists: every entry point that
+// computes requires a HIP device and fails loudly otherwise.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+
+#include "ps_context.hpp"
+
+using namespace ps;
+
+namespace {
+
+struct StageTimer {
+    hipEvent_t ev[PS_STAGE_COUNT + 1];
+    hipStream_t s;
+    int n = 0;
+    explicit StageTimer(hipStream_t st) : s(st) {
+        for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+    }
+    ~StageTimer() { for (auto& e : ev) (void)hipEventDestroy(e); }
+    void mark(int i) { HIP_CHECK(hipEventRecord(ev[i], s)); }
+    double ms(int a, int b) { float f = 0; HIP_CHECK(hipEventElapsedTime(&f, ev[a], ev[b])); return f; }
+};
+
+void uploadField(DevBuf<float>& d, const float* src, int64_t n, hipStream_t s) {
+    d.alloc((size_t)n);
+    if (src) HIP_CHECK(hipMemcpyAsync(d.p, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+    else HIP_CHECK(hipMemsetAsync(d.p, 0, (size_t)n * sizeof(float), s));
+}
+
+__global__ void k_fill32(int32_t* a, int64_t n, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
+const char* kSampleName[7] = {"center", "faceX", "faceY", "faceZ", "edgeYZ", "edgeXZ", "edgeXY"};
+
+}  // namespace
+
+void ps_context::upload(const ps_params* p, const ps_fields_in* in) {
+    if (!p || !in) throw Error("null params/fields");
+    if (in->nx <= 0 || in->ny <= 0 || in->nz <= 0) throw Error("bad resolution");
+    if (in->nx > 1022 || in->ny > 1022 || in->nz > 1022) throw Error("resolution above 1022 per axis is not supported");
+    if (!in->vel[0] || !in->vel[1] || !in->vel[2]) throw Error("Velocity field is missing.");
+    if (!in->surface) throw Error("Surface field is missing.");
+    if (!in->collision) throw Error("Collision field is missing.");
+    if (!in->viscosity) throw Error("Viscosity field is missing.");
+    if (p->matrixSetup != PS_PRESSURE_STRESS) throw Error("Unsupported matrix setup.");
+    P = *p;
+    g.nx = in->nx; g.ny = in->ny; g.nz = in->nz; g.order = p->indexOrder;
+    dx = in->dx; invDx = 1. / dx; dt = in->dt; invDt = 1. / dt; rho = (double)in->density;
+    HIP_CHECK(hipSetDevice(device));
+    const int64_t nc = g.count(0);
+    uploadField(surface, in->surface, nc, stream);
+    uploadField(collision, in->collision, nc, stream);
+    uploadField(viscosity, in->viscosity, nc, stream);
+    for (int a = 0; a < 3; ++a) {
+        uploadField(vel[a], in->vel[a], g.count(1 + a), stream);
+        uploadField(cvel[a], in->collisionvel[a], g.count(1 + a), stream);
+        velOut[a].alloc((size_t)g.count(1 + a));
+        valid[a].alloc((size_t)g.count(1 + a));
+        faceRow[a].alloc((size_t)g.count(1 + a));
+    }
+    haveInputWeights = true;
+    for (int w = 0; w < 14; ++w) if (!in->weights[w]) haveInputWeights = false;
+    for (int s = 0; s < 7; ++s) {
+        const int64_t n = g.count(s);
+        liquidW[s].alloc((size_t)n); fluidW[s].alloc((size_t)n);
+        labels[s].alloc((size_t)n); activeIdx[s].alloc((size_t)n); reducedIdx[s].alloc((size_t)n);
+        if (haveInputWeights) {
+            HIP_CHECK(hipMemcpyAsync(liquidW[s].p, in->weights[s], (size_t)n * 4, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(fluidW[s].p, in->weights[7 + s], (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        }
+    }
+    for (int q = 0; q < 3; ++q) cellScratch[q].alloc((size_t)nc);
+    counters.alloc(64);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    uploaded = true; isSetup = false; isSolved = false;
+}
+
+void ps_context::fillDimData(ps_stats* st) const {   // Solver.cpp:578-593
+    double* dd = st->dimData;
+    dd[0] = (double)nCenter; dd[1] = (double)nFace[0]; dd[2] = (double)nFace[1]; dd[3] = (double)nFace[2];
+    dd[4] = (double)nEdge[0]; dd[5] = (double)nEdge[1]; dd[6] = (double)nEdge[2];
+    dd[7] = (double)nActiveVs; dd[8] = (double)nFace[0]; dd[9] = (double)nFace[1]; dd[10] = (double)nFace[2];
+    dd[11] = (double)nReducedVs; dd[12] = (double)nPressures; dd[13] = (double)nStresses;
+    dd[14] = dd[15] = dd[16] = (double)nCenter;
+    dd[17] = (double)nEdge[0]; dd[18] = (double)nEdge[1]; dd[19] = (double)nEdge[2];
+    dd[20] = (double)nTotalDOFs; dd[21] = (double)nSystem; dd[22] = 1.; dd[23] = 0.;
+    dd[24] = (double)regionCount; dd[25] = dx; dd[26] = dt;
+}
+
+// HDK_PolyStokes.C:344-476: everything between setupClockStart() and setupClockEnd()
+int ps_context::setup(ps_stats* stats) {
+    if (!uploaded) throw Error("ps_upload_fields has not been called");
+    HIP_CHECK(hipSetDevice(device));
+    const std::clock_t c0 = std::clock();
+    const auto w0 = std::chrono::high_resolution_clock::now();
+    StageTimer T(stream);
+    // Solver ctor: labels / indices start UNASSIGNED (Solver.cpp:86-152)
+    for (int s = 0; s < 7; ++s) {
+        const int64_t n = g.count(s);
+        const dim3 gr(gridFor(n, 256)), bl(256);
+        hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, labels[s].p, n, (int32_t)PS_UNASSIGNED);
+        hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, activeIdx[s].p, n, (int32_t)PS_UNASSIGNED);
+        hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, reducedIdx[s].p, n, (int32_t)PS_UNASSIGNED);
+    }
+    regionCount = 0;
+    T.mark(0);
+    buildIntegrationWeightsAlt();
+    T.mark(1);
+    classifyCells();
+    if (P.doReducedRegions) constructReducedRegions(); else constructOnlyActiveRegions();
+    classifyFaces();
+    classifyEdges();
+    T.mark(2);
+    if (P.doReducedRegions) {
+        constructCenterReducedIndices();
+        constructFacesReducedIndices();
+        constructEdgesReducedIndices();
+    }
+    T.mark(3);
+    constructActiveIndices();
+    T.mark(4);
+    if (P.doReducedRegions) {
+        computeCenterOfMasses();
+        computeLeastSquaresFits();
+        computeReducedMassMatrices();
+        computeReducedViscosityMatricesInteriorOnly();
+    } else {
+        fbItems = 0;
+    }
+    T.mark(5);
+    constructMatrixBlocks();
+    T.mark(6);
+    assembleSystemPressureStressFactored();
+    T.mark(7);
+    constructPreconditioner();
+    T.mark(8);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const auto w1 = std::chrono::high_resolution_clock::now();
+    std::memset(&lastStats, 0, sizeof(lastStats));
+    lastStats.result = PS_INCOMPLETE;
+    fillDimData(&lastStats);
+    lastStats.solveData[0] = -1; lastStats.solveData[1] = -1; lastStats.solveData[2] = -1; lastStats.solveData[3] = -1;
+    lastStats.solveData[4] = 1000.0 * (double)(std::clock() - c0) / CLOCKS_PER_SEC;
+    lastStats.solveData[5] = std::chrono::duration<double, std::milli>(w1 - w0).count();
+    lastStats.stage_ms[PS_STAGE_WEIGHTS] = T.ms(0, 1);
+    lastStats.stage_ms[PS_STAGE_CLASSIFY] = T.ms(1, 2);
+    lastStats.stage_ms[PS_STAGE_REGIONS] = T.ms(2, 3);
+    lastStats.stage_ms[PS_STAGE_INDICES] = T.ms(3, 4);
+    lastStats.stage_ms[PS_STAGE_TILE_MATRICES] = T.ms(4, 5);
+    lastStats.stage_ms[PS_STAGE_BLOCKS] = T.ms(5, 6);
+    lastStats.stage_ms[PS_STAGE_ASSEMBLE] = T.ms(6, 7);
+    lastStats.stage_ms[PS_STAGE_PRECOND] = T.ms(7, 8);
+    isSetup = true; isSolved = false;
+    registerArrays();
+    if (stats) *stats = lastStats;
+    return PS_SUCCESS;
+}
+
+// HDK_PolyStokes.C:509-583: solve(), buildValidFaces, recoverVelocityFromPressureStress, applySolutionToVelocity
+int ps_context::solveStage(ps_stats* stats) {
+    if (!isSetup) throw Error("ps_setup_device has not been called");
+    HIP_CHECK(hipSetDevice(device));
+    StageTimer T(stream);
+    int result = PS_INCOMPLETE;
+    const std::clock_t c0 = std::clock();
+    const auto w0 = std::chrono::high_resolution_clock::now();
+    T.mark(0);
+    if (P.doSolve) {
+        result = solve();
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const auto w1 = std::chrono::high_resolution_clock::now();
+        lastStats.solveData[0] = solveError;
+        lastStats.solveData[1] = solveIterations;
+        lastStats.solveData[2] = 1000.0 * (double)(std::clock() - c0) / CLOCKS_PER_SEC;
+        lastStats.solveData[3] = std::chrono::duration<double, std::milli>(w1 - w0).count();
+    }
+    T.mark(1);
+    buildValidFaces();
+    const bool apply = P.doSolve && result != PS_UNSUPPORTED_SOLVER && (result == PS_SUCCESS || P.keepNonConvergedResults);
+    if (apply) {
+        recoverVelocityFromPressureStress();
+        T.mark(2);
+        applySolutionToVelocity();
+    } else {
+        T.mark(2);
+        for (int a = 0; a < 3; ++a)
+            HIP_CHECK(hipMemcpyAsync(velOut[a].p, vel[a].p, (size_t)g.count(1 + a) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    T.mark(3);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    lastStats.stage_ms[PS_STAGE_SOLVE] = T.ms(0, 1);
+    lastStats.stage_ms[PS_STAGE_RECOVER] = T.ms(1, 2);
+    lastStats.stage_ms[PS_STAGE_WRITEBACK] = T.ms(2, 3);
+    lastStats.result = result;
+    lastStats.usedBiCGStab = usedBiCGStab;
+    isSolved = true;
+    registerArrays();
+    if (stats) *stats = lastStats;
+    return result;
+}
+
+void ps_context::registerArrays() {
+    arrays.clear();
+    auto reg = [&](const std::string& n, const void* p, int64_t c, int e) { arrays[n] = ArrayInfo{p, c, e}; };
+    for (int s = 0; s < 7; ++s) {
+        const int64_t n = g.count(s);
+        reg(std::string(kSampleName[s]) + "LiquidWeights", liquidW[s].p, n, 4);
+        reg(std::string(kSampleName[s]) + "FluidWeights", fluidW[s].p, n, 4);
+        reg(std::string(kSampleName[s]) + "Labels", labels[s].p, n, 4);
+        reg(std::string(kSampleName[s]) + "ActiveIndices", activeIdx[s].p, n, 4);
+        reg(std::string(kSampleName[s]) + "ReducedIndices", reducedIdx[s].p, n, 4);
+    }
+    const int64_t R = regionCount;
+    reg("reducedRegionCOM", COM.p, R * 3, 8);
+    reg("reducedRegionBestFitVectors", cfit.p, R * PS_RD, 8);
+    reg("reducedMassMatrices", Mr.p, R * PS_RD * PS_RD, 8);
+    reg("reducedViscosityMatrices", Kv.p, R * PS_RD * PS_RD, 8);
+    reg("Inv_Mr_plus_2JDtuDJ", Binv.p, R * PS_RD * PS_RD, 8);
+    reg("reducedRHSVector", rhsR.p, R * PS_RD, 8);
+    reg("McInv", McInv.p, nActiveVs, 8);
+    reg("activeRHSVector", rhsA.p, nActiveVs, 8);
+    reg("uInv", uInv.p, nStresses, 8);
+    if (P.exportComponentMatrices) {
+        reg("Mc", Mc.p, nActiveVs, 8);
+        reg("oldActiveVs", oldVs.p, nActiveVs, 8);
+        reg("u", uDiag.p, nStresses, 8);
+    }
+    reg("pressureRHSVector", rhsPT.p, nPressures, 8);
+    reg("stressRHSVector", rhsPT.p ? rhsPT.p + nPressures : nullptr, nStresses, 8);
+    reg("b", b.p, nSystem, 8);
+    reg("solutionVector", x.p, nSystem, 8);
+    if (P.preconditioner == PS_PRE_DIAGONAL) reg("dinv", dinv.p, nSystem, 8);
+    if (isSolved) reg("recoveredVelocity", recovered.p, nActiveVs + nReducedVs, 8);
+    reg("S.ptr", S.ptr.p, S.rows + 1, 4); reg("S.col", S.col.p, S.nnz, 4); reg("S.val", S.val.p, S.nnz, 8);
+    reg("St.ptr", St.ptr.p, St.rows + 1, 4); reg("St.col", St.col.p, St.nnz, 4); reg("St.val", St.val.p, St.nnz, 8);
+    reg("reducedRowFace", rrowFace.p, nReducedRows, 4);
+    reg("reducedRowRegion", rrowRegion.p, nReducedRows, 4);
+    static const char* ax[3] = {"X", "Y", "Z"};
+    for (int a = 0; a < 3; ++a) {
+        reg(std::string("vel") + ax[a], velOut[a].p, g.count(1 + a), 4);
+        reg(std::string("valid") + ax[a], valid[a].p, g.count(1 + a), 4);
+        reg(std::string("faceRow") + ax[a], faceRow[a].p, g.count(1 + a), 4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+#define PS_TRY(ctx, ...)                                                     \
+    try { __VA_ARGS__ } catch (const ps::Error& e) {                         \
+        if (ctx) (ctx)->err = e.msg;                                         \
+        return PS_FAILED;                                                    \
+    } catch (const std::exception& e) {                                      \
+        if (ctx) (ctx)->err = e.what();                                      \
+        return PS_FAILED;                                                    \
+    }
+
+static std::string g_createError;
+
+// ---- MatrixMarket export (Solver.cpp:533-606; MarketIO.h:310-380) --------------------------------
+static bool writeMarketVector(const std::string& fn, const std::vector<double>& v) {
+    std::ofstream out(fn.c_str(), std::ios::out);
+    if (!out) return false;
+    out.flags(std::ios_base::scientific);
+    out.precision(17);   // digits10 + 2
+    out << "%%MatrixMarket matrix array real general\n";
+    out << v.size() << " " << 1 << "\n";
+    for (double d : v) out << d << "\n";
+    return true;
+}
+static bool writeMarketSparse(const std::string& fn, int64_t rows, int64_t cols, const std::vector<int64_t>& ptr,
+                              const std::vector<int32_t>& col, const std::vector<double>& val) {
+    std::ofstream out(fn.c_str(), std::ios::out);
+    if (!out) return false;
+    out.flags(std::ios_base::scientific);
+    out.precision(17);
+    out << "%%MatrixMarket matrix coordinate  real general" << std::endl;
+    out << rows << " " << cols << " " << val.size() << "\n";
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t p = ptr[(size_t)r]; p < ptr[(size_t)r + 1]; ++p) out << r + 1 << " " << col[(size_t)p] + 1 << " " << val[(size_t)p] << "\n";
+    return true;
+}
+template <class T>
+static std::vector<T> fetch(ps_context* c, const T* dptr, int64_t n) {
+    std::vector<T> h((size_t)std::max<int64_t>(n, 0));
+    if (n > 0) {
+        HIP_CHECK(hipMemcpyAsync(h.data(), dptr, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return h;
+}
+
+extern "C" {
+
+int32_t ps_abi_version(void) { return 1; }
+
+ps_context* ps_context_create(int32_t device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_createError = "polystokes: no HIP device available (the product path has no CPU fallback)";
+        std::fprintf(stderr, "%s\n", g_createError.c_str());
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        g_createError = "polystokes: device index out of range";
+        std::fprintf(stderr, "%s\n", g_createError.c_str());
+        return nullptr;
+    }
+    ps_context* c = new ps_context();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        g_createError = "polystokes: cannot initialise HIP device";
+        std::fprintf(stderr, "%s\n", g_createError.c_str());
+        return nullptr;
+    }
+    ps_params_default(&c->P);
+    return c;
+}
+
+void ps_context_destroy(ps_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    hipStream_t s = c->stream;
+    delete c;
+    if (s) (void)hipStreamDestroy(s);
+}
+
+const char* ps_last_error(const ps_context* c) { return c ? c->err.c_str() : g_createError.c_str(); }
+
+void ps_params_default(ps_params* p) {
+    std::memset(p, 0, sizeof(*p));
+    p->mindensity = 1; p->maxdensity = 100000;
+    p->matrixSetup = PS_PRESSURE_STRESS; p->solverType = PS_PCG_MATRIX_VECTOR_PRODUCTS;
+    p->doSolve = 1; p->keepNonConvergedResults = 1; p->useWarmStart = 1;
+    p->tolerance = 1e-3; p->maxSolverIterations = 5000;
+    p->useInputSurfaceWeights = 1; p->useInputCollisionWeights = 1;
+    p->activeLiquidBoundaryLayerSize = 2; p->activeSolidBoundaryLayerSize = 2;
+    p->doReducedRegions = 1; p->doTile = 1; p->tileSize = 16; p->tilePadding = 2;
+    p->preconditioner = PS_PRE_IDENTITY; p->indexOrder = PS_ORDER_VOXEL_TILES; p->negateCollision = 1;
+}
+
+int32_t ps_upload_fields(ps_context* c, const ps_params* p, const ps_fields_in* in) {
+    if (!c) return PS_FAILED;
+    PS_TRY(c, { c->upload(p, in); return PS_SUCCESS; })
+}
+int32_t ps_setup_device(ps_context* c, ps_stats* st) {
+    if (!c) return PS_FAILED;
+    PS_TRY(c, { return c->setup(st); })
+}
+int32_t ps_solve_device(ps_context* c, ps_stats* st) {
+    if (!c) return PS_FAILED;
+    PS_TRY(c, { return c->solveStage(st); })
+}
+int32_t ps_step_device(ps_context* c, ps_stats* st) {
+    if (!c) return PS_FAILED;
+    PS_TRY(c, {
+        const int rc = c->setup(nullptr);
+        if (rc != PS_SUCCESS) return rc;
+        return c->solveStage(st);
+    })
+}
+int32_t ps_download_fields(ps_context* c, ps_fields_out* out) {
+    if (!c || !out) return PS_FAILED;
+    PS_TRY(c, {
+        HIP_CHECK(hipSetDevice(c->device));
+        for (int a = 0; a < 3; ++a) {
+            const size_t nb = (size_t)c->g.count(1 + a) * sizeof(float);
+            if (out->vel[a]) HIP_CHECK(hipMemcpyAsync(out->vel[a], c->velOut[a].p, nb, hipMemcpyDeviceToHost, c->stream));
+            if (out->valid[a]) HIP_CHECK(hipMemcpyAsync(out->valid[a], c->valid[a].p, nb, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return PS_SUCCESS;
+    })
+}
+int32_t polystokes_step(ps_context* c, const ps_params* p, const ps_fields_in* in, ps_fields_out* out, ps_stats* st) {
+    if (!c) return PS_FAILED;
+    PS_TRY(c, {
+        c->upload(p, in);
+        const int rc = c->setup(nullptr);
+        if (rc != PS_SUCCESS) return rc;
+        const int result = c->solveStage(st);
+        if (out) {
+            const int rc2 = ps_download_fields(c, out);
+            if (rc2 != PS_SUCCESS) return rc2;
+        }
+        if (p->exportComponentMatrices && p->exportDataPrefix) ps_export_component_matrices(c, p->exportDataPrefix);
+        if (p->exportStats && p->exportDataPrefix) ps_export_stats(c, st, p->exportDataPrefix);
+        return result;
+    })
+}
+
+int32_t ps_apply_operator(ps_context* c, const double* x, double* y) {
+    if (!c) return PS_FAILED;
+    PS_TRY(c, {
+        if (!c->isSetup) throw Error("not set up");
+        HIP_CHECK(hipSetDevice(c->device));
+        const size_t n = (size_t)c->nSystem;
+        c->tmp1.alloc(n); c->tmp2.alloc(n);
+        HIP_CHECK(hipMemcpyAsync(c->tmp1.p, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->applyOperator(c->tmp1.p, c->tmp2.p, c->dotPartials.p);
+        HIP_CHECK(hipMemcpyAsync(y, c->tmp2.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return PS_SUCCESS;
+    })
+}
+
+int64_t ps_query_array(ps_context* c, const char* name, int32_t* elem_bytes) {
+    if (!c || !name) return -1;
+    auto it = c->arrays.find(name);
+    if (it == c->arrays.end()) return -1;
+    if (elem_bytes) *elem_bytes = it->second.elem;
+    return it->second.count;
+}
+int32_t ps_read_array(ps_context* c, const char* name, void* dst, int64_t dst_bytes) {
+    if (!c || !name) return PS_FAILED;
+    PS_TRY(c, {
+        auto it = c->arrays.find(name);
+        if (it == c->arrays.end()) throw Error(std::string("unknown array ") + name);
+        const int64_t need = it->second.count * it->second.elem;
+        if (dst_bytes < need) throw Error("destination too small");
+        if (need > 0) {
+            HIP_CHECK(hipSetDevice(c->device));
+            HIP_CHECK(hipMemcpyAsync(dst, it->second.dptr, (size_t)need, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        return PS_SUCCESS;
+    })
+}
+
+// kernel micro-benchmarks for bench.py's roofline object (HIP events on the solver stream)
+int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double* avg_ms, double* algorithmic_bytes) {
+    if (!c || !kernel) return PS_FAILED;
+    PS_TRY(c, {
+        if (!c->isSetup) throw Error("not set up");
+        HIP_CHECK(hipSetDevice(c->device));
+        const std::string k(kernel);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        const size_t n = (size_t)c->nSystem;
+        c->tmp1.alloc(n); c->tmp2.alloc(n);
+        HIP_CHECK(hipMemcpyAsync(c->tmp1.p, c->b.p, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        for (int w = 0; w < 3; ++w) ps_bench_launch(c, k, c->tmp1.p, c->tmp2.p);
+        HIP_CHECK(hipEventRecord(e0, c->stream));
+        for (int i = 0; i < iters; ++i) ps_bench_launch(c, k, c->tmp1.p, c->tmp2.p);
+        HIP_CHECK(hipEventRecord(e1, c->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (avg_ms) *avg_ms = (double)ms / (double)iters;
+        if (algorithmic_bytes) {
+            // CSR with fp64 values, int32 columns, int32 row pointers:
+            // 12 nnz + 4 (rows+1) + 8 rows (y) + 8 cols (x read once)
+            const double nnz = (double)c->S.nnz, rowsS = (double)c->nRows, rowsT = (double)c->nSystem;
+            const double bS = 12. * nnz + 4. * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
+            const double bT = 12. * nnz + 4. * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * (double)c->nStresses;
+            if (k == "spmv_S") *algorithmic_bytes = bS;
+            else if (k == "spmv_St") *algorithmic_bytes = bT;
+            else if (k == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);
+            else *algorithmic_bytes = 0;
+        }
+        return PS_SUCCESS;
+    })
+}
+
+int32_t ps_set_collectives(ps_context* c, ps_allreduce_fn, ps_halo_fn, void*) {
+    if (c) c->err = "multi-GPU domain decomposition is not implemented in this build";
+    return PS_FAILED;
+}
+
+int32_t ps_export_stats(ps_context* c, const ps_stats* st, const char* prefix) {
+    if (!c || !st || !prefix) return PS_FAILED;
+    PS_TRY(c, {
+        std::vector<double> dd(st->dimData, st->dimData + 27), sd(st->solveData, st->solveData + 6);
+        if (!writeMarketVector(std::string(prefix) + "dimData.mtx", dd)) throw Error("cannot write dimData.mtx");
+        if (!writeMarketVector(std::string(prefix) + "solveData.mtx", sd)) throw Error("cannot write solveData.mtx");
+        return PS_SUCCESS;
+    })
+}
+
+// exportComponentMatrices (Solver.cpp:543-566): G, Dt, JG, JDt are materialised on the host from S and the
+// per-row basis (the device never stores JG/JDt), diagonals as sparse diagonal matrices.
+int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
+    if (!c || !prefix) return PS_FAILED;
+    PS_TRY(c, {
+        if (!c->isSetup) throw Error("not set up");
+        HIP_CHECK(hipSetDevice(c->device));
+        const std::string pre(prefix);
+        const int64_t nA = c->nActiveVs, nP = c->nPressures, nT = c->nStresses, R = c->regionCount;
+        auto sp = fetch(c, c->S.ptr.p, c->S.rows + 1);
+        auto sc = fetch(c, c->S.col.p, c->S.nnz);
+        auto sv = fetch(c, c->S.val.p, c->S.nnz);
+        auto rface = fetch(c, c->rrowFace.p, c->nReducedRows);
+        auto rreg = fetch(c, c->rrowRegion.p, c->nReducedRows);
+        auto com = fetch(c, c->COM.p, R * 3);
+        // G, Dt
+        for (int which = 0; which < 2; ++which) {
+            std::vector<int64_t> ptr((size_t)nA + 1, 0);
+            std::vector<int32_t> col;
+            std::vector<double> val;
+            for (int64_t r = 0; r < nA; ++r) {
+                ptr[(size_t)r] = (int64_t)val.size();
+                for (int p = sp[(size_t)r]; p < sp[(size_t)r + 1]; ++p) {
+                    const bool isP = sc[(size_t)p] < nP;
+                    if ((which == 0) == isP) { col.push_back(isP ? sc[(size_t)p] : (int32_t)(sc[(size_t)p] - nP)); val.push_back(sv[(size_t)p]); }
+                }
+            }
+            ptr[(size_t)nA] = (int64_t)val.size();
+            writeMarketSparse(pre + (which == 0 ? "Mat_G.mtx" : "Mat_Dt.mtx"), nA, which == 0 ? nP : nT, ptr, col, val);
+        }
+        // JG, JDt: row 26 r + n collects C_f[n] * S_f,j over the region's reduced rows
+        for (int which = 0; which < 2; ++which) {
+            std::vector<std::map<int32_t, double>> rowsM((size_t)R * PS_RD);
+            for (int64_t rr = 0; rr < c->nReducedRows; ++rr) {
+                int i, j, k, a;
+                unpackFace(rface[(size_t)rr], i, j, k, a);
+                const int reg = rreg[(size_t)rr];
+                double pnt[3] = {(double)i, (double)j, (double)k};
+                pnt[a] -= 0.5;
+                double C[PS_RD];
+                basisRow(pnt[0] * c->dx - com[(size_t)reg * 3 + 0], pnt[1] * c->dx - com[(size_t)reg * 3 + 1],
+                         pnt[2] * c->dx - com[(size_t)reg * 3 + 2], a, C);
+                const int64_t row = nA + rr;
+                for (int p = sp[(size_t)row]; p < sp[(size_t)row + 1]; ++p) {
+                    const bool isP = sc[(size_t)p] < nP;
+                    if ((which == 0) != isP) continue;
+                    const int32_t cc = isP ? sc[(size_t)p] : (int32_t)(sc[(size_t)p] - nP);
+                    for (int n = 0; n < PS_RD; ++n) rowsM[(size_t)reg * PS_RD + n][cc] += sv[(size_t)p] * C[n];
+                }
+            }
+            std::vector<int64_t> ptr((size_t)R * PS_RD + 1, 0);
+            std::vector<int32_t> col;
+            std::vector<double> val;
+            for (size_t r = 0; r < rowsM.size(); ++r) {
+                ptr[r] = (int64_t)val.size();
+                for (auto& kv : rowsM[r]) { col.push_back(kv.first); val.push_back(kv.second); }
+            }
+            ptr[rowsM.size()] = (int64_t)val.size();
+            writeMarketSparse(pre + (which == 0 ? "Mat_JG.mtx" : "Mat_JDt.mtx"), R * PS_RD, which == 0 ? nP : nT, ptr, col, val);
+        }
+        auto diagOut = [&](const char* name, const double* dptr, int64_t n) {
+            if (!dptr) return;
+            auto v = fetch(c, dptr, n);
+            std::vector<int64_t> ptr((size_t)n + 1);
+            std::vector<int32_t> col((size_t)n);
+            for (int64_t i = 0; i <= n; ++i) ptr[(size_t)i] = i;
+            for (int64_t i = 0; i < n; ++i) col[(size_t)i] = (int32_t)i;
+            writeMarketSparse(pre + name, n, n, ptr, col, v);
+        };
+        diagOut("Mat_McInv.mtx", c->McInv.p, nA);
+        diagOut("Mat_uInv.mtx", c->uInv.p, nT);
+        if (c->P.exportComponentMatrices) { diagOut("Mat_Mc.mtx", c->Mc.p, nA); diagOut("Mat_u.mtx", c->uDiag.p, nT); }
+        auto blockOut = [&](const char* name, const double* dptr) {
+            auto v = fetch(c, dptr, R * PS_RD * PS_RD);
+            std::vector<int64_t> ptr((size_t)R * PS_RD + 1);
+            std::vector<int32_t> col((size_t)R * PS_RD * PS_RD);
+            for (int64_t r = 0; r <= R * PS_RD; ++r) ptr[(size_t)r] = r * PS_RD;
+            for (int64_t r = 0; r < R; ++r)
+                for (int m = 0; m < PS_RD; ++m)
+                    for (int n = 0; n < PS_RD; ++n) col[(size_t)((r * PS_RD + m) * PS_RD + n)] = (int32_t)(r * PS_RD + n);
+            writeMarketSparse(pre + name, R * PS_RD, R * PS_RD, ptr, col, v);
+        };
+        blockOut("Mat_Mr.mtx", c->Mr.p);
+        blockOut("Mat_JDtuDJ.mtx", c->Kv.p);
+        blockOut("Mat_Inv_Mr_plus_2JDtuDJ.mtx", c->Binv.p);
+        writeMarketVector(pre + "Vec_activeRHS.mtx", fetch(c, c->rhsA.p, nA));
+        writeMarketVector(pre + "Vec_reducedRHS.mtx", fetch(c, c->rhsR.p, R * PS_RD));
+        writeMarketVector(pre + "Vec_pressureRHS.mtx", fetch(c, c->rhsPT.p, nP));
+        writeMarketVector(pre + "Vec_stressRHS.mtx", fetch(c, c->rhsPT.p + nP, nT));
+        writeMarketVector(pre + "Vec_b.mtx", fetch(c, c->b.p, nP + nT));
+        if (c->isSolved) writeMarketVector(pre + "solutionVector.mtx", fetch(c, c->x.p, nP + nT));
+        return PS_SUCCESS;
+    })
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// The host-side mirror of the reference's `HDK_PolyStokes::Solver` (exec/HDK_PolyStokesSolver.h:27-375):
+// same stage methods, same state, but every field lives in HBM and every stage is a HIP kernel launch.
+#pragma once
+#include <map>
+
+#include "ps_common.hpp"
+
+namespace ps {
+
+struct DevCSR {
+    int64_t rows = 0, cols = 0, nnz = 0;
+    DevBuf<int32_t> ptr;   // rows+1 (nnz < 2^31 is enforced)
+    DevBuf<int32_t> col;
+    DevBuf<double> val;
+};
+
+// device-resident CG scalars (no host round trip inside the iteration)
+struct CGScalars {
+    double rsold, pAp, alpha, beta, rr, xx, rz, rre;
+    int iter;        // index of the iteration that converged (pcg.h:322-325)
+    int done;        // 1 once the stop rule fired (or rsold == 0)
+    int maxit;
+    int pad;
+    double tol2;
+};
+
+struct ArrayInfo {
+    const void* dptr;
+    int64_t count;
+    int elem;
+};
+
+}  // namespace ps
+
+struct ps_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- parameters / geometry (Solver.cpp:18-68) ----
+    ps_params P{};
+    ps::Grid g{0, 0, 0, 0};
+    double dx = 0, invDx = 0, dt = 0, invDt = 0, rho = 0;
+    bool haveInputWeights = false;
+    bool uploaded = false, isSetup = false, isSolved = false;
+
+    // ---- inputs (fp32 Houdini voxel arrays, HDK_PolyStokes.C:235-246) ----
+    ps::DevBuf<float> surface, collision, viscosity, vel[3], cvel[3];
+    ps::DevBuf<float> velOut[3], valid[3];
+
+    // ---- weights, labels, indices (Solver.h:316-335) ----
+    ps::DevBuf<float> liquidW[7], fluidW[7];
+    ps::DevBuf<int32_t> labels[7], activeIdx[7], reducedIdx[7];
+    ps::DevBuf<int32_t> faceRow[3];          // face -> row of S (-1: none)
+    ps::DevBuf<int32_t> cellScratch[3];      // layer marks / CC labels / fix flags
+    ps::DevBuf<int32_t> scanBlock;           // block sums for scans
+    ps::DevBuf<int32_t> counters;            // small device counters (flags, totals)
+
+    // ---- counts (Solver.h:272-285) ----
+    int64_t nCenter = 0, nFace[3] = {0, 0, 0}, nEdge[3] = {0, 0, 0};
+    int64_t nActiveVs = 0, nReducedVs = 0, nPressures = 0, nStresses = 0, nSystem = 0, nTotalDOFs = 0;
+    int64_t regionCount = 0;
+    int64_t nReducedRows = 0;   // reduced faces that carry at least one stencil entry
+    int64_t nRows = 0;          // nActiveVs + nReducedRows
+
+    // ---- per-region data (Solver.h:339, 705-706) ----
+    ps::DevBuf<int32_t> bbox;                // R*6: min xyz, max xyz (cells)
+    std::vector<int32_t> hbbox;
+    ps::DevBuf<double> COM, cfit, Mr, Kv, Binv, rhsR, regionScratch;
+    // work tables for per-region reductions over the region's face box (host built, small)
+    ps::DevBuf<int32_t> fbItemRegion, fbItemAxis, fbItemStart;   // one item = <=FB_CHUNK face-box positions
+    ps::DevBuf<int32_t> fbRegionItemPtr;                         // R+1
+    int64_t fbItems = 0;
+    ps::DevBuf<int32_t> fbItemCount;                             // skin faces found per item (then scanned)
+    ps::DevBuf<double> partials;                                  // items * 676 (or rows chunks * 26)
+
+    // reduced rows of S: region-contiguous, deterministic order
+    ps::DevBuf<uint32_t> rrowFace;           // packed (i,j,k,axis)
+    ps::DevBuf<int32_t> rrowRegion;
+    ps::DevBuf<int32_t> regionRowPtr;        // R+1, offsets into reduced rows
+    ps::DevBuf<int32_t> rchunkRegion, rchunkStart, rchunkEnd, regionChunkPtr;  // <=RC rows per chunk
+    int64_t nRChunks = 0;
+
+    // ---- blocks (Solver.h:337-369): S = [G Dt ; Ghat Dhat] by face row, St its transpose ----
+    ps::DevCSR S, St;
+    ps::DevBuf<double> McInv, rhsA, uInv, rhsPT, Mc, uDiag, oldVs;
+    ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
+    ps::DevBuf<double> dotPartials;
+    ps::DevBuf<ps::CGScalars> scal;
+
+    // ---- results ----
+    int solveIterations = -1;
+    double solveError = -1;
+    int usedBiCGStab = 0;
+    ps_stats lastStats{};
+
+    std::map<std::string, ps::ArrayInfo> arrays;
+    std::map<std::string, std::vector<char>> hostArrays;   // materialised-on-demand exports
+
+    // ---- stage methods: names follow exec/HDK_PolyStokesSolver.h:96-190 ----
+    void upload(const ps_params* p, const ps_fields_in* in);
+    void buildIntegrationWeightsAlt();                    // ps_grid.hip
+    void classifyCells();
+    void constructReducedRegions();
+    void constructOnlyActiveRegions();
+    void classifyFaces();
+    void classifyEdges();
+    void constructCenterReducedIndices();
+    void constructFacesReducedIndices();
+    void constructEdgesReducedIndices();
+    void constructActiveIndices();
+    void buildValidFaces();
+    void computeRegionBoxes();                            // ps_tiles.hip
+    void computeCenterOfMasses();
+    void computeLeastSquaresFits();
+    void computeReducedMassMatrices();
+    void computeReducedViscosityMatricesInteriorOnly();
+    void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
+    void constructMatrixBlocks();                         // ps_blocks.hip
+    void assembleSystemPressureStressFactored();          // ps_solve.hip
+    void constructPreconditioner();
+    int solve();
+    void recoverVelocityFromPressureStress();
+    void applySolutionToVelocity();
+    void applyOperator(const double* x, double* y, double* dotPartialsOut);   // device pointers
+
+    // orchestration (ps_context.hip)
+    int setup(ps_stats* stats);
+    int solveStage(ps_stats* stats);
+    void fillDimData(ps_stats* st) const;
+    void registerArrays();
+
+    // helpers
+    int32_t orderedIndexAssign(int s, int mode, ps::DevBuf<int32_t>& out);   // ps_grid.hip
+    int64_t exclusiveScanI32(int32_t* data, int64_t n);                       // in place; returns total
+    int32_t readCounter(int idx);
+    void zeroCounters();
+};
+
+// kernel micro-benchmark dispatch (ps_solve.hip), used by ps_bench_kernel
+void ps_bench_launch(ps_context* c, const std::string& kernel, const double* x, double* y);
+
+namespace ps {
+constexpr int FB_CHUNK = 4096;   // face-box positions per work item (per-region dense reductions)
+constexpr int RC_ROWS = 1024;    // reduced rows per chunk in the per-iteration tile kernels
+}  // namespace ps

@@ -1,0 +1,843 @@
+// Grid stages on the GPU: volume-fraction weights, cell/face/edge classification, boundary-layer
+// floods, tiling, connected reduced regions, DOF numbering.  One thread per voxel, coalesced x-fastest
+// reads; neighbour reads hit L1/L2 (each voxel is re-read by at most its 6 neighbours).
+// Reference: exec/HDK_PolyStokesSolver.cpp:238-326, exec/HDK_PolyStokesSolver_Classifier.cpp (all).
+#include <limits.h>
+
+#include "ps_context.hpp"
+
+using namespace ps;
+
+namespace {
+
+constexpr int BS = 256;
+
+__constant__ float kSampleOffset[7][3] = {
+    // Solver.h:193-222, order centre, faceX, faceY, faceZ, edgeYZ, edgeXZ, edgeXY
+    {0.5f, 0.5f, 0.5f}, {0.f, 0.5f, 0.5f}, {0.5f, 0.f, 0.5f}, {0.5f, 0.5f, 0.f},
+    {0.5f, 0.f, 0.f},   {0.f, 0.5f, 0.f},  {0.f, 0.f, 0.5f}};
+
+// SIM_RawField::getValue(pos) restated: trilinear between voxel centres, streak border, fp32,
+// lerp(a,b,t) = a + (b-a)*t, x then y then z.  The library is built with -ffp-contract=off so the
+// result is bit-identical to the CPU restatement.
+__device__ inline float sampleCenterField(const float* __restrict__ f, int nx, int ny, int nz, float px, float py, float pz) {
+    const int n[3] = {nx, ny, nz};
+    const float p[3] = {px, py, pz};
+    int i0[3], i1[3];
+    float t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float u = p[a] - 0.5f;
+        if (u < 0.f) u = 0.f;
+        if (u > (float)(n[a] - 1)) u = (float)(n[a] - 1);
+        int b = (int)u;
+        if (b >= n[a] - 1) { b = n[a] - 1; i0[a] = b; i1[a] = b; t[a] = 0.f; }
+        else { i0[a] = b; i1[a] = b + 1; t[a] = u - (float)b; }
+    }
+    const int64_t sx = 1, sy = nx, sz = (int64_t)nx * ny;
+    auto at = [&](int i, int j, int k) { return f[i * sx + j * sy + k * sz]; };
+    auto L = [](float a, float b, float tt) { return a + (b - a) * tt; };
+    const float c00 = L(at(i0[0], i0[1], i0[2]), at(i1[0], i0[1], i0[2]), t[0]);
+    const float c10 = L(at(i0[0], i1[1], i0[2]), at(i1[0], i1[1], i0[2]), t[0]);
+    const float c01 = L(at(i0[0], i0[1], i1[2]), at(i1[0], i0[1], i1[2]), t[0]);
+    const float c11 = L(at(i0[0], i1[1], i1[2]), at(i1[0], i1[1], i1[2]), t[0]);
+    const float c0 = L(c00, c10, t[1]);
+    const float c1 = L(c01, c11, t[1]);
+    return L(c0, c1, t[2]);
+}
+
+// computeSDFWeightsSampled(sdf, 2, invert=false, minweight=0): Solver.cpp:292-326 (HDK body out of tree,
+// restated: fraction of the 2x2x2 sub-samples of the voxel box whose SDF value is < 0).
+__global__ void k_sdf_weights(Grid g, int s, const float* __restrict__ sdf, int negate, float* __restrict__ dst) {
+    const int3 d = g.dims(s);
+    const int64_t n = (int64_t)d.x * d.y * d.z;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int3 q = unlin3(d, c);
+    const float cx = (float)q.x + kSampleOffset[s][0], cy = (float)q.y + kSampleOffset[s][1], cz = (float)q.z + kSampleOffset[s][2];
+    int cnt = 0;
+#pragma unroll
+    for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                float v = sampleCenterField(sdf, g.nx, g.ny, g.nz, cx + (sx ? 0.25f : -0.25f), cy + (sy ? 0.25f : -0.25f),
+                                            cz + (sz ? 0.25f : -0.25f));
+                if (negate) v = -v;
+                if (v < 0.f) ++cnt;
+            }
+    dst[c] = (float)cnt / 8.0f;
+}
+
+// Classifier.cpp:56-128
+__global__ void k_classify_cells(Grid g, Set7<const float> lw, Set7<const float> fw, int32_t* __restrict__ lab) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int3 q = unlin3(d, c);
+    bool inSolve = lw.p[0][c] > 0.f;
+    if (!inSolve) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int3 fd = g.dims(1 + a);
+#pragma unroll
+            for (int dir = 0; dir < 2; ++dir) {
+                int3 f = q;
+                addc(f, a, dir);
+                if (lw.p[1 + a][lin3(fd, f.x, f.y, f.z)] > 0.f) inSolve = true;
+            }
+        }
+    }
+    const bool inFluid = !(fw.p[0][c] == 0.f);
+    lab[c] = inSolve ? (inFluid ? PS_GENERICFLUID : PS_SOLID) : PS_UNSOLVED;
+}
+
+// buildInitialAirBoundaryLayer, Classifier.cpp:364-430.  mark = 1 for layer-0 cells.
+__global__ void k_air_layer0(Grid g, Set7<const float> lw, int32_t* __restrict__ lab, int32_t* __restrict__ mark, int setActive) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    int m = 0;
+    if (lab[c] == PS_GENERICFLUID) {
+        const int3 q = unlin3(d, c);
+        bool bnd = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int3 fd = g.dims(1 + a);
+#pragma unroll
+            for (int dir = 0; dir < 2; ++dir) {
+                int3 nb = q;
+                addc(nb, a, dir ? 1 : -1);
+                if (comp(nb, a) < 0 || comp(nb, a) >= comp(d, a)) continue;
+                int3 f = q;
+                addc(f, a, dir);
+                const int nl = lab[lin3(d, nb.x, nb.y, nb.z)];
+                // neighbours may concurrently turn GENERIC->ACTIVE; only UNSOLVED matters here
+                if (nl == PS_UNSOLVED) bnd = true;
+                if (lw.p[1 + a][lin3(fd, f.x, f.y, f.z)] < 1.f) bnd = true;
+            }
+        }
+        if (bnd) m = 1;
+    }
+    mark[c] = m;
+    if (m && setActive) lab[c] = PS_ACTIVEFLUID;
+}
+
+// buildNextLiquidBoundaryLayer (Classifier.cpp:432-508) + setActiveLayerCells (Solver.cpp:2022-2060):
+// a GENERICFLUID cell joins layer `cur+1` if a neighbour is in layer `cur` across a face with liquid > 0.
+__global__ void k_air_next(Grid g, Set7<const float> lw, int32_t* __restrict__ lab, int32_t* __restrict__ mark, int cur) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    if (lab[c] != PS_GENERICFLUID) return;
+    const int3 q = unlin3(d, c);
+    bool join = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int3 fd = g.dims(1 + a);
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            int3 nb = q;
+            addc(nb, a, dir ? 1 : -1);
+            if (comp(nb, a) < 0 || comp(nb, a) >= comp(d, a)) continue;
+            int3 f = q;
+            addc(f, a, dir);   // the face between q and nb: cellToFaceMap(nb, a, 1-dir) == cellToFaceMap(q, a, dir)
+            if (mark[lin3(d, nb.x, nb.y, nb.z)] == cur && lw.p[1 + a][lin3(fd, f.x, f.y, f.z)] > 0.f) join = true;
+        }
+    }
+    if (join) { mark[c] = cur + 1; lab[c] = PS_ACTIVEFLUID; }
+}
+
+// buildInitialSolidBoundaryLayer, Classifier.cpp:573-641.  mark = 1 -> VISITED in layer 0.
+__global__ void k_solid_layer0(Grid g, int32_t* __restrict__ lab, int32_t* __restrict__ mark, const int32_t* __restrict__ labIn) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    int m = 0;
+    const int l = labIn[c];
+    if (l == PS_GENERICFLUID || l == PS_ACTIVEFLUID) {
+        const int3 q = unlin3(d, c);
+        bool bnd = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int dir = 0; dir < 2; ++dir) {
+                int3 nb = q;
+                addc(nb, a, dir ? 1 : -1);
+                if (comp(nb, a) < 0 || comp(nb, a) >= comp(d, a)) { bnd = true; continue; }   // :617-621
+                if (labIn[lin3(d, nb.x, nb.y, nb.z)] == PS_SOLID) bnd = true;
+            }
+        if (bnd) m = 1;
+    }
+    mark[c] = m;
+    if (m) lab[c] = PS_ACTIVEFLUID;
+}
+
+// buildNextSolidBoundaryLayer, Classifier.cpp:643-703
+__global__ void k_solid_next(Grid g, Set7<const float> lw, int32_t* __restrict__ lab, int32_t* __restrict__ mark, int cur) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    if (mark[c] != 0) return;   // VISITED already
+    const int l = lab[c];
+    if (l != PS_ACTIVEFLUID && l != PS_GENERICFLUID) return;
+    const int3 q = unlin3(d, c);
+    bool join = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int3 fd = g.dims(1 + a);
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            int3 nb = q;
+            addc(nb, a, dir ? 1 : -1);
+            if (comp(nb, a) < 0 || comp(nb, a) >= comp(d, a)) continue;
+            int3 f = q;
+            addc(f, a, dir);
+            if (mark[lin3(d, nb.x, nb.y, nb.z)] == cur && lw.p[1 + a][lin3(fd, f.x, f.y, f.z)] > 0.f) join = true;
+        }
+    }
+    if (join) { mark[c] = cur + 1; lab[c] = PS_ACTIVEFLUID; }
+}
+
+// constructTiles (Classifier.cpp:705-746) + overwriteIndices GENERIC->REDUCED (:189)
+__global__ void k_tiles_and_relabel(Grid g, int32_t* __restrict__ lab, int doTile, int tileSize, int pad) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    if (lab[c] != PS_GENERICFLUID) return;
+    int out = PS_REDUCED;
+    if (doTile) {
+        const int3 q = unlin3(d, c);
+        const int mx = q.x % tileSize, my = q.y % tileSize, mz = q.z % tileSize;
+        if (mx < pad || my < pad || mz < pad) out = PS_ACTIVEFLUID;
+    }
+    lab[c] = out;
+}
+
+__global__ void k_relabel(int32_t* __restrict__ lab, int64_t n, int from, int to) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n && lab[c] == from) lab[c] = to;
+}
+__global__ void k_fill_i32(int32_t* __restrict__ a, int64_t n, int v) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) a[c] = v;
+}
+
+// findFaceLabelFromCenter, Classifier.cpp:784-832
+__global__ void k_classify_faces(Grid g, int axis, Set7<const float> lw, Set7<const float> fw, int32_t* __restrict__ lab) {
+    const int3 d = g.dims(1 + axis);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int3 q = unlin3(d, c);
+    const int3 cd = g.dims(0);
+    bool act = false;
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        int3 cc = q;
+        addc(cc, axis, dir - 1);
+        if (oob3(cd, cc.x, cc.y, cc.z)) continue;
+        if (lw.p[0][lin3(cd, cc.x, cc.y, cc.z)] > 0.f) act = true;
+    }
+    if (!act) {
+        for (int ea = 0; ea < 3 && !act; ++ea) {
+            if (ea == axis) continue;
+            const int3 ed = g.dims(4 + ea);
+            for (int dir = 0; dir < 2; ++dir) {
+                int3 e = q;
+                addc(e, 3 - axis - ea, dir);
+                if (lw.p[4 + ea][lin3(ed, e.x, e.y, e.z)] > 0.f) { act = true; break; }
+            }
+        }
+    }
+    int r = PS_UNSOLVED;
+    if (act) r = fw.p[1 + axis][c] < 0.5f ? PS_SOLID : PS_GENERICFLUID;
+    lab[c] = r;
+}
+
+__device__ inline float streakRead(const float* __restrict__ f, const int3 d, int i, int j, int k) {
+    i = i < 0 ? 0 : (i >= d.x ? d.x - 1 : i);
+    j = j < 0 ? 0 : (j >= d.y ? d.y - 1 : j);
+    k = k < 0 ? 0 : (k >= d.z ? d.z - 1 : k);
+    return f[lin3(d, i, j, k)];
+}
+
+// findEdgeLabelFromFaceAlt, Classifier.cpp:1021-1067
+__global__ void k_classify_edges(Grid g, int e, Set7<const float> lw, Set7<const float> fw, int32_t* __restrict__ lab) {
+    const int3 d = g.dims(4 + e);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int3 q = unlin3(d, c);
+    bool in = lw.p[4 + e][c] != 0.f && fw.p[4 + e][c] != 0.f;
+    if (in) {
+        const int fa = e == 0 ? 1 : 0, fb = e == 2 ? 1 : 2;
+        const int3 da = g.dims(1 + fa), db = g.dims(1 + fb);
+        int3 a2 = q; addc(a2, fb, -1);
+        int3 b2 = q; addc(b2, fa, -1);
+        in = streakRead(lw.p[1 + fa], da, q.x, q.y, q.z) != 0.f && !oob3(da, a2.x, a2.y, a2.z) &&
+             streakRead(lw.p[1 + fa], da, a2.x, a2.y, a2.z) != 0.f &&
+             streakRead(lw.p[1 + fb], db, q.x, q.y, q.z) != 0.f && !oob3(db, b2.x, b2.y, b2.z) &&
+             streakRead(lw.p[1 + fb], db, b2.x, b2.y, b2.z) != 0.f;
+    }
+    lab[c] = in ? PS_GENERICFLUID : PS_UNSOLVED;
+}
+
+// ---- connected components of REDUCED cells through faces with liquid weight > 0 -------------
+// (SIM_VolumetricConnectedComponentBuilder call site Classifier.cpp:220-229.)  Min-label propagation
+// over traversal-order indices with pointer jumping; converges to the smallest order index of the
+// component whatever the interleaving (labels only decrease).
+__global__ void k_cc_init(Grid g, const int32_t* __restrict__ lab, int32_t* __restrict__ cc) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int3 q = unlin3(d, c);
+    cc[c] = lab[c] == PS_REDUCED ? (int32_t)ijkToOrder(d, g.order, q.x, q.y, q.z) : INT_MAX;
+}
+__global__ void k_cc_step(Grid g, const int32_t* __restrict__ lab, Set7<const float> lw, int32_t* cc, int32_t* __restrict__ changed) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    if (lab[c] != PS_REDUCED) return;
+    const int3 q = unlin3(d, c);
+    const int mine = cc[c];
+    int m = mine;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int3 fd = g.dims(1 + a);
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            int3 nb = q;
+            addc(nb, a, dir ? 1 : -1);
+            if (oob3(d, nb.x, nb.y, nb.z)) continue;
+            int3 f = q;
+            addc(f, a, dir);
+            if (!(lw.p[1 + a][lin3(fd, f.x, f.y, f.z)] > 0.f)) continue;
+            const int64_t nc = lin3(d, nb.x, nb.y, nb.z);
+            if (lab[nc] != PS_REDUCED) continue;
+            const int v = cc[nc];
+            if (v < m) m = v;
+        }
+    }
+    // pointer jump through the current representative
+    const int3 rq = orderToIjk(d, g.order, m);
+    const int v2 = cc[lin3(d, rq.x, rq.y, rq.z)];
+    if (v2 < m) m = v2;
+    if (m < mine) { atomicMin(&cc[c], m); *changed = 1; }
+}
+// cell region id = rank (in traversal order) of its component's first cell
+__global__ void k_cc_assign(Grid g, const int32_t* __restrict__ lab, const int32_t* __restrict__ cc,
+                            const int32_t* __restrict__ rootRank, int32_t* __restrict__ region) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    int r = PS_UNASSIGNED;
+    if (lab[c] == PS_REDUCED) {
+        const int3 rq = orderToIjk(d, g.order, cc[c]);
+        r = rootRank[lin3(d, rq.x, rq.y, rq.z)];
+    }
+    region[c] = r;
+}
+
+// ---- fixReducedRegionBoundaries, Classifier.cpp:1073-1172 ------------------------------------
+// The reference is a serial, in-place, traversal-ordered sweep repeated to a fix point.  Within one
+// sweep, whether cell c applies its fix depends only on the fixes applied by earlier cells within
+// distance 2.  F = {cells that apply the fix in this sweep} is the unique solution of a triangular
+// system in traversal order; it is computed by iterating F <- eval(F) from F = {} until unchanged
+// (exact after at most chain-length iterations; one iteration when nothing needs fixing).
+__device__ inline bool anyEarlierFix(const Grid& g, const int3 d, const uint8_t* __restrict__ F, const int3 n, int64_t ordC) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            int3 m = n;
+            addc(m, a, dir ? 1 : -1);
+            if (oob3(d, m.x, m.y, m.z)) continue;
+            if (F[lin3(d, m.x, m.y, m.z)] && ijkToOrder(d, g.order, m.x, m.y, m.z) < ordC) return true;
+        }
+    return false;
+}
+__global__ void k_fix_eval(Grid g, const int32_t* __restrict__ lab0, const int32_t* __restrict__ reg,
+                           const uint8_t* __restrict__ Fin, uint8_t* __restrict__ Fout, int anyFin, int32_t* __restrict__ flags) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int l = lab0[c];
+    const int3 q = unlin3(d, c);
+    bool act = (l == PS_ACTIVEFLUID);
+    int64_t ordC = 0;
+    if (anyFin) ordC = ijkToOrder(d, g.order, q.x, q.y, q.z);
+    if (!act && anyFin && l == PS_REDUCED) act = anyEarlierFix(g, d, Fin, q, ordC);   // demoted earlier in this sweep
+    uint8_t out = 0;
+    if (act) {
+        bool seen = false, fix = false;
+        int first = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int dir = 0; dir < 2; ++dir) {
+                int3 nb = q;
+                addc(nb, a, dir ? 1 : -1);
+                if (oob3(d, nb.x, nb.y, nb.z)) continue;
+                const int64_t nc = lin3(d, nb.x, nb.y, nb.z);
+                if (lab0[nc] != PS_REDUCED) continue;
+                if (anyFin && anyEarlierFix(g, d, Fin, nb, ordC)) continue;   // already demoted when c is visited
+                const int r = reg[nc];
+                if (!seen) { seen = true; first = r; }
+                else if (r != first) fix = true;
+            }
+        out = fix ? 1 : 0;
+    }
+    Fout[c] = out;
+    if (out != Fin[c]) flags[0] = 1;   // changed
+    if (out) flags[1] = 1;             // any fix in this sweep
+}
+__global__ void k_fix_apply(Grid g, int32_t* __restrict__ lab, int32_t* __restrict__ reg, const uint8_t* __restrict__ F) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    if (lab[c] != PS_REDUCED) return;
+    const int3 q = unlin3(d, c);
+    bool hit = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            int3 m = q;
+            addc(m, a, dir ? 1 : -1);
+            if (oob3(d, m.x, m.y, m.z)) continue;
+            if (F[lin3(d, m.x, m.y, m.z)]) hit = true;
+        }
+    if (hit) { lab[c] = PS_ACTIVEFLUID; reg[c] = PS_UNASSIGNED; }
+}
+
+// ---- fixSmallReducedRegions, Classifier.cpp:1174-1313 -----------------------------------------
+__global__ void k_bbox_init(int32_t* __restrict__ bb, int64_t R) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    bb[r * 6 + 0] = bb[r * 6 + 1] = bb[r * 6 + 2] = INT_MAX;
+    bb[r * 6 + 3] = bb[r * 6 + 4] = bb[r * 6 + 5] = INT_MIN;
+}
+__global__ void k_bbox(Grid g, const int32_t* __restrict__ lab, const int32_t* __restrict__ reg, int32_t* bb) {
+    const int3 d = g.dims(0);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    if (lab[c] != PS_REDUCED) return;
+    const int r = reg[c];
+    const int3 q = unlin3(d, c);
+    // interior cells cannot move the box: skip the atomics unless some neighbour is outside the region
+    bool edge = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            int3 nb = q;
+            addc(nb, a, dir ? 1 : -1);
+            if (oob3(d, nb.x, nb.y, nb.z)) { edge = true; continue; }
+            const int64_t nc = lin3(d, nb.x, nb.y, nb.z);
+            if (lab[nc] != PS_REDUCED || reg[nc] != r) edge = true;
+        }
+    if (!edge) return;
+    atomicMin(&bb[r * 6 + 0], q.x); atomicMin(&bb[r * 6 + 1], q.y); atomicMin(&bb[r * 6 + 2], q.z);
+    atomicMax(&bb[r * 6 + 3], q.x); atomicMax(&bb[r * 6 + 4], q.y); atomicMax(&bb[r * 6 + 5], q.z);
+}
+__global__ void k_small_flags(const int32_t* __restrict__ bb, int64_t R, int32_t* __restrict__ keep) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    bool rem = false;
+    for (int a = 0; a < 3; ++a) {
+        const int lo = bb[r * 6 + a], hi = bb[r * 6 + 3 + a];
+        if (hi < lo) { rem = true; continue; }   // emptied region (reference overflows here; restated as removed)
+        if (hi == lo) rem = true;                 // :1236
+        if (lo > hi - 3) rem = true;              // :1239
+    }
+    keep[r] = rem ? 0 : 1;
+}
+__global__ void k_small_apply(int32_t* __restrict__ lab, int32_t* __restrict__ reg, int64_t n,
+                              const int32_t* __restrict__ keep, const int32_t* __restrict__ remap) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    if (lab[c] != PS_REDUCED) return;
+    const int r = reg[c];
+    if (!keep[r]) { lab[c] = PS_ACTIVEFLUID; reg[c] = PS_UNASSIGNED; }
+    else reg[c] = remap[r];
+}
+
+// constructFaceAxisReducedIndicesPartial, Classifier.cpp:1473-1528
+__global__ void k_face_reduced(Grid g, int axis, const int32_t* __restrict__ clab, const int32_t* __restrict__ creg,
+                               int32_t* __restrict__ flab, int32_t* __restrict__ freg) {
+    const int3 d = g.dims(1 + axis);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int3 q = unlin3(d, c);
+    const int3 cd = g.dims(0);
+    int idx = PS_UNASSIGNED;
+    int3 m = q;
+    addc(m, axis, -1);
+    if (!oob3(cd, q.x, q.y, q.z) && clab[lin3(cd, q.x, q.y, q.z)] == PS_REDUCED) idx = creg[lin3(cd, q.x, q.y, q.z)];
+    else if (!oob3(cd, m.x, m.y, m.z) && clab[lin3(cd, m.x, m.y, m.z)] == PS_REDUCED) idx = creg[lin3(cd, m.x, m.y, m.z)];
+    if (idx != PS_UNASSIGNED) { flab[c] = PS_REDUCED; freg[c] = idx; }
+}
+
+// constructEdgeAxisReducedIndicesPartial, Classifier.cpp:1534-1659
+__global__ void k_edge_reduced(Grid g, int e, Set7<const int32_t> lab, Set7<const int32_t> reg,
+                               int32_t* __restrict__ elab, int32_t* __restrict__ ereg) {
+    const int3 d = g.dims(4 + e);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int3 q = unlin3(d, c);
+    const int fa = e == 0 ? 1 : 0, fb = e == 2 ? 1 : 2;
+    const int3 da = g.dims(1 + fa), db = g.dims(1 + fb);
+    int3 a2 = q; addc(a2, fb, -1);
+    int3 b2 = q; addc(b2, fa, -1);
+    auto red = [&](int fax, const int3 fd, const int3 p) {
+        return !oob3(fd, p.x, p.y, p.z) && lab.p[1 + fax][lin3(fd, p.x, p.y, p.z)] == PS_REDUCED;
+    };
+    const bool ra1 = red(fa, da, q), ra2 = red(fa, da, a2), rb1 = red(fb, db, q), rb2 = red(fb, db, b2);
+    int label = PS_UNASSIGNED, idx = PS_UNASSIGNED;
+    if (ra1 && ra2 && rb1 && rb2) {
+        if (e == 0) idx = reg.p[2][lin3(g.dims(2), q.x, q.y - 1, q.z)];   // faceY(i,j-1,k), :1629
+        else idx = reg.p[1 + fa][lin3(da, q.x, q.y, q.z)];
+        label = PS_REDUCED;
+    } else if (ra1) { idx = reg.p[1 + fa][lin3(da, q.x, q.y, q.z)]; label = PS_BOUNDARY; }
+    else if (ra2) { idx = reg.p[1 + fa][lin3(da, a2.x, a2.y, a2.z)]; label = PS_BOUNDARY; }
+    else if (rb1) { idx = reg.p[1 + fb][lin3(db, q.x, q.y, q.z)]; label = PS_BOUNDARY; }
+    else if (rb2) { idx = reg.p[1 + fb][lin3(db, b2.x, b2.y, b2.z)]; label = PS_BOUNDARY; }
+    if (idx != PS_UNASSIGNED) { elab[c] = label; ereg[c] = idx; }
+}
+
+// buildValidFaces, Classifier.cpp:4-54
+__global__ void k_valid(const int32_t* __restrict__ lab, int64_t n, float* __restrict__ valid) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int l = lab[c];
+    valid[c] = (l == PS_UNSOLVED || l == PS_UNASSIGNED) ? 0.f : 1.f;
+}
+
+// ---- scans --------------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;                      // per thread
+constexpr int SCAN_TILE = BS * SCAN_ITEMS;         // per block
+
+__device__ inline int blockExclusiveScan(int v, int* total) {
+    __shared__ int waveSums[BS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) waveSums[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) {
+        if (i < w) base += waveSums[i];
+        tot += waveSums[i];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// flag of traversal position t for the ordered index assignment
+__device__ inline int orderedFlag(const Grid& g, const int3 d, int mode, const int32_t* __restrict__ src, int64_t t, int64_t* linOut) {
+    const int3 q = orderToIjk(d, g.order, t);
+    const int64_t c = lin3(d, q.x, q.y, q.z);
+    *linOut = c;
+    if (mode == 0) return isActiveL(src[c]) ? 1 : 0;   // serialAssignFieldIndices, Classifier.cpp:1764
+    return src[c] == (int32_t)t ? 1 : 0;               // component root (cc label == own order index)
+}
+__global__ void k_ordered_count(Grid g, int s, int mode, const int32_t* __restrict__ src, int32_t* __restrict__ blockSums) {
+    const int3 d = g.dims(s);
+    const int64_t n = (int64_t)d.x * d.y * d.z;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int cnt = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t t = base + i;
+        int64_t c;
+        if (t < n) cnt += orderedFlag(g, d, mode, src, t, &c);
+    }
+    int tot;
+    blockExclusiveScan(cnt, &tot);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
+}
+__global__ void k_ordered_assign(Grid g, int s, int mode, const int32_t* __restrict__ src, const int32_t* __restrict__ blockOffs,
+                                 int32_t* __restrict__ out) {
+    const int3 d = g.dims(s);
+    const int64_t n = (int64_t)d.x * d.y * d.z;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int fl[SCAN_ITEMS];
+    int64_t cc[SCAN_ITEMS];
+    int cnt = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t t = base + i;
+        fl[i] = 0;
+        cc[i] = 0;
+        if (t < n) fl[i] = orderedFlag(g, d, mode, src, t, &cc[i]);
+        cnt += fl[i];
+    }
+    int tot;
+    int off = blockExclusiveScan(cnt, &tot) + blockOffs[blockIdx.x];
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (fl[i]) out[cc[i]] = off++;
+}
+// single-block exclusive scan of a (short) int array, carry across tiles of 1024; total -> *total
+__global__ void k_scan_single(int32_t* __restrict__ a, int64_t n, int32_t* __restrict__ total) {
+    __shared__ int sm[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < n ? a[i] : 0;
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int t = 0;
+            if ((int)threadIdx.x >= o) t = sm[threadIdx.x - o];
+            __syncthreads();
+            sm[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = sm[threadIdx.x];
+        if (i < n) a[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void k_scan_blocksum(const int32_t* __restrict__ a, int64_t n, int32_t* __restrict__ blockSums) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int cnt = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) cnt += a[base + i];
+    int tot;
+    blockExclusiveScan(cnt, &tot);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
+}
+__global__ void k_scan_apply(int32_t* __restrict__ a, int64_t n, const int32_t* __restrict__ blockOffs) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int cnt = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? a[base + i] : 0; cnt += v[i]; }
+    int tot;
+    int off = blockExclusiveScan(cnt, &tot) + blockOffs[blockIdx.x];
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) { a[base + i] = off; off += v[i]; }
+}
+
+template <class T>
+Set7<const T> cset(DevBuf<T>* b) {
+    Set7<const T> s;
+    for (int i = 0; i < 7; ++i) s.p[i] = b[i].p;
+    return s;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+int32_t ps_context::readCounter(int idx) {
+    int32_t v = 0;
+    HIP_CHECK(hipMemcpyAsync(&v, counters.p + idx, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return v;
+}
+void ps_context::zeroCounters() { HIP_CHECK(hipMemsetAsync(counters.p, 0, 64 * sizeof(int32_t), stream)); }
+
+// In-place exclusive scan of a device int32 array; returns the total (host).
+int64_t ps_context::exclusiveScanI32(int32_t* data, int64_t n) {
+    if (n <= 0) return 0;
+    const int nb = gridFor(n, SCAN_TILE);
+    if (nb == 1) {
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, data, n, counters.p + 8);
+        return readCounter(8);
+    }
+    scanBlock.alloc((size_t)nb);
+    hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(BS), 0, stream, data, n, scanBlock.p);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nb, counters.p + 8);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(BS), 0, stream, data, n, scanBlock.p);
+    return readCounter(8);
+}
+
+// serialAssignFieldIndices (Classifier.cpp:1738-1770) as a two-level scan over traversal positions.
+int32_t ps_context::orderedIndexAssign(int s, int mode, DevBuf<int32_t>& out) {
+    const int64_t n = g.count(s);
+    const int nb = gridFor(n, SCAN_TILE);
+    scanBlock.alloc((size_t)nb);
+    const int32_t* src = mode == 0 ? labels[s].p : cellScratch[0].p;
+    hipLaunchKernelGGL(k_ordered_count, dim3(nb), dim3(BS), 0, stream, g, s, mode, src, scanBlock.p);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nb, counters.p + 8);
+    hipLaunchKernelGGL(k_ordered_assign, dim3(nb), dim3(BS), 0, stream, g, s, mode, src, scanBlock.p, out.p);
+    return readCounter(8);
+}
+
+// Solver.cpp:238-289
+void ps_context::buildIntegrationWeightsAlt() {
+    if (haveInputWeights) return;   // uploaded by the shim (HDK's own sampler output)
+    for (int s = 0; s < 7; ++s) {
+        const int64_t n = g.count(s);
+        hipLaunchKernelGGL(k_sdf_weights, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, s, surface.p, 0, liquidW[s].p);
+        hipLaunchKernelGGL(k_sdf_weights, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, s, collision.p,
+                           P.negateCollision ? 1 : 0, fluidW[s].p);
+    }
+}
+
+void ps_context::classifyCells() {
+    const int64_t n = g.count(0);
+    hipLaunchKernelGGL(k_classify_cells, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, cset(liquidW), cset(fluidW), labels[0].p);
+}
+
+// Classifier.cpp:179-190 (constructAirBoundaryLayer :291-362, constructSolidBoundaryLayer :510-571, constructTiles)
+void ps_context::constructReducedRegions() {
+    const int64_t n = g.count(0);
+    const dim3 gr(gridFor(n, BS)), bl(BS);
+    int32_t* mark = cellScratch[0].p;
+    const int L = P.activeLiquidBoundaryLayerSize, Sl = P.activeSolidBoundaryLayerSize;
+    // air: layers 0..L-2 are made ACTIVE (loop bound `layer < L-1`, :328; next built only if `layer < L-2`, :355)
+    if (L - 1 >= 1) {
+        hipLaunchKernelGGL(k_air_layer0, gr, bl, 0, stream, g, cset(liquidW), labels[0].p, mark, 1);
+        for (int layer = 0; layer < L - 2; ++layer)
+            hipLaunchKernelGGL(k_air_next, gr, bl, 0, stream, g, cset(liquidW), labels[0].p, mark, layer + 1);
+    }
+    // solid: layers 0..S-1 (:526), next built if layer < S-1 (:563)
+    if (Sl >= 1) {
+        int32_t* labIn = cellScratch[1].p;   // snapshot: layer 0 reads labels other threads are rewriting
+        HIP_CHECK(hipMemcpyAsync(labIn, labels[0].p, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_solid_layer0, gr, bl, 0, stream, g, labels[0].p, mark, labIn);
+        for (int layer = 0; layer < Sl - 1; ++layer)
+            hipLaunchKernelGGL(k_solid_next, gr, bl, 0, stream, g, cset(liquidW), labels[0].p, mark, layer + 1);
+    }
+    hipLaunchKernelGGL(k_tiles_and_relabel, gr, bl, 0, stream, g, labels[0].p, P.doTile ? 1 : 0, P.tileSize, P.tilePadding);
+}
+
+void ps_context::constructOnlyActiveRegions() {
+    const int64_t n = g.count(0);
+    hipLaunchKernelGGL(k_relabel, dim3(gridFor(n, BS)), dim3(BS), 0, stream, labels[0].p, n, (int)PS_GENERICFLUID, (int)PS_ACTIVEFLUID);
+}
+
+void ps_context::classifyFaces() {
+    for (int a = 0; a < 3; ++a) {
+        const int64_t n = g.count(1 + a);
+        hipLaunchKernelGGL(k_classify_faces, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, a, cset(liquidW), cset(fluidW), labels[1 + a].p);
+    }
+}
+void ps_context::classifyEdges() {
+    for (int e = 0; e < 3; ++e) {
+        const int64_t n = g.count(4 + e);
+        hipLaunchKernelGGL(k_classify_edges, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, e, cset(liquidW), cset(fluidW), labels[4 + e].p);
+    }
+}
+
+// Classifier.cpp:217-239
+void ps_context::constructCenterReducedIndices() {
+    const int64_t n = g.count(0);
+    const dim3 gr(gridFor(n, BS)), bl(BS);
+    int32_t* cc = cellScratch[0].p;
+    // connected components
+    hipLaunchKernelGGL(k_cc_init, gr, bl, 0, stream, g, labels[0].p, cc);
+    for (int guard = 0; guard < 100000; ++guard) {
+        zeroCounters();
+        for (int it = 0; it < 4; ++it)
+            hipLaunchKernelGGL(k_cc_step, gr, bl, 0, stream, g, labels[0].p, cset(liquidW), cc, counters.p);
+        if (!readCounter(0)) break;
+    }
+    int32_t* rootRank = cellScratch[1].p;
+    {
+        DevBuf<int32_t> view;   // non-owning alias for orderedIndexAssign's output
+        view.p = rootRank; view.n = (size_t)n;
+        regionCount = orderedIndexAssign(0, 1, view);
+        view.p = nullptr; view.n = 0;
+    }
+    hipLaunchKernelGGL(k_cc_assign, gr, bl, 0, stream, g, labels[0].p, cc, rootRank, reducedIdx[0].p);
+
+    // fixReducedRegionBoundaries (:1073-1172)
+    if (regionCount > 1) {
+        uint8_t* F0 = (uint8_t*)cellScratch[0].p;
+        uint8_t* F1 = (uint8_t*)cellScratch[1].p;
+        for (int sweep = 0; sweep < 100000; ++sweep) {
+            HIP_CHECK(hipMemsetAsync(F0, 0, (size_t)n, stream));
+            int anyF = 0;
+            bool applied = false;
+            for (int it = 0; it < 100000; ++it) {
+                zeroCounters();
+                hipLaunchKernelGGL(k_fix_eval, gr, bl, 0, stream, g, labels[0].p, reducedIdx[0].p, F0, F1, anyF, counters.p);
+                int32_t fl[2];
+                HIP_CHECK(hipMemcpyAsync(fl, counters.p, sizeof(fl), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                std::swap(F0, F1);
+                anyF = fl[1];
+                if (!fl[0]) break;
+            }
+            if (anyF) {
+                hipLaunchKernelGGL(k_fix_apply, gr, bl, 0, stream, g, labels[0].p, reducedIdx[0].p, F0);
+                applied = true;
+            }
+            if (!applied) break;
+        }
+    }
+
+    // fixSmallReducedRegions (:1174-1262)
+    if (regionCount > 0) {
+        const int64_t R = regionCount;
+        bbox.alloc((size_t)R * 6);
+        DevBuf<int32_t> keep, remap;
+        keep.alloc((size_t)R);
+        remap.alloc((size_t)R);
+        hipLaunchKernelGGL(k_bbox_init, dim3(gridFor(R, BS)), bl, 0, stream, bbox.p, R);
+        hipLaunchKernelGGL(k_bbox, gr, bl, 0, stream, g, labels[0].p, reducedIdx[0].p, bbox.p);
+        hipLaunchKernelGGL(k_small_flags, dim3(gridFor(R, BS)), bl, 0, stream, bbox.p, R, keep.p);
+        HIP_CHECK(hipMemcpyAsync(remap.p, keep.p, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        const int64_t newR = exclusiveScanI32(remap.p, R);
+        if (newR < R) {
+            hipLaunchKernelGGL(k_small_apply, gr, bl, 0, stream, labels[0].p, reducedIdx[0].p, n, keep.p, remap.p);
+            regionCount = newR;
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+}
+
+void ps_context::computeRegionBoxes() {
+    const int64_t R = regionCount;
+    hbbox.assign((size_t)R * 6, 0);
+    if (R == 0) return;
+    const int64_t n = g.count(0);
+    bbox.alloc((size_t)R * 6);
+    hipLaunchKernelGGL(k_bbox_init, dim3(gridFor(R, BS)), dim3(BS), 0, stream, bbox.p, R);
+    hipLaunchKernelGGL(k_bbox, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, labels[0].p, reducedIdx[0].p, bbox.p);
+    HIP_CHECK(hipMemcpyAsync(hbbox.data(), bbox.p, (size_t)R * 6 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void ps_context::constructFacesReducedIndices() {
+    for (int a = 0; a < 3; ++a) {
+        const int64_t n = g.count(1 + a);
+        hipLaunchKernelGGL(k_face_reduced, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, a, labels[0].p, reducedIdx[0].p,
+                           labels[1 + a].p, reducedIdx[1 + a].p);
+    }
+}
+void ps_context::constructEdgesReducedIndices() {
+    for (int e = 0; e < 3; ++e) {
+        const int64_t n = g.count(4 + e);
+        hipLaunchKernelGGL(k_edge_reduced, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, e, cset(labels), cset(reducedIdx),
+                           labels[4 + e].p, reducedIdx[4 + e].p);
+    }
+}
+
+// Classifier.cpp:257-284
+void ps_context::constructActiveIndices() {
+    for (int s = 0; s < 7; ++s) {
+        const int64_t n = g.count(s);
+        hipLaunchKernelGGL(k_relabel, dim3(gridFor(n, BS)), dim3(BS), 0, stream, labels[s].p, n, (int)PS_GENERICFLUID, (int)PS_ACTIVEFLUID);
+        const int32_t cnt = orderedIndexAssign(s, 0, activeIdx[s]);
+        if (s == 0) nCenter = cnt;
+        else if (s <= 3) nFace[s - 1] = cnt;
+        else nEdge[s - 4] = cnt;
+    }
+}
+
+void ps_context::buildValidFaces() {
+    for (int a = 0; a < 3; ++a) {
+        const int64_t n = g.count(1 + a);
+        hipLaunchKernelGGL(k_valid, dim3(gridFor(n, BS)), dim3(BS), 0, stream, labels[1 + a].p, n, valid[a].p);
+    }
+}

@@ -1,0 +1,596 @@
+// The per-iteration hot loop: y = A x for the factored pressure-stress operator and the PCG around it.
+//
+//   A = -dt [G Dt]^T McInv [G Dt] - [JG JDt]^T BInv [JG JDt] - 1/2 diag(0, uInv)
+//       (lib/include/ApplyPressureStressMatrix.h:102-179; explicit form exec/..._AssembleSystem.cpp:381-389)
+// evaluated as  s = S x;  t_f = dt McInv_f s_f (active rows),  t_f = C_f . (BInv_r sum_{g in r} C_g s_g)
+// (reduced rows, J evaluated on the fly);  y = -S^T t - 1/2 uInv x_tau.
+//
+// Kernels (all HBM-bound; fp64):
+//   k_spmv_S / k_spmv_St : CSR-stream SpMV — a 256-thread block owns 256 consecutive rows; it streams the
+//       block's contiguous (val,col) range coalesced, multiplies by the gathered x, parks the products in
+//       LDS and lets each thread reduce its own short row (<= 8 nnz) from LDS.  Epilogues fuse the
+//       diagonal scalings, the -1/2 uInv x term and the p.Ap dot partial.
+//   k_tile_gather / k_tile_solve / k_tile_expand : per-tile J^T, 26x26 BInv, J.
+//   k_cg_update_xr / k_cg_update_p : fused axpy + wavefront-shuffle dot partials.
+//   k_cg_scal1 / k_cg_scal2 : one-block reductions of the partials + the stop rule of
+//       pcg_external_matrix_A (lib/include/pcg.h:268-340); scalars stay on the device.
+#include <chrono>
+#include <cmath>
+#include <ctime>
+
+#include "ps_context.hpp"
+
+using namespace ps;
+
+namespace {
+
+constexpr int BS = 256;
+constexpr int VGRID = 2048;   // capped grid for streaming vector kernels (grid-stride)
+
+__device__ inline double waveReduceSum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// deterministic block sum (wave shuffles, then the 4 wave sums in order); result valid in thread 0
+__device__ inline double blockReduceSum(double v) {
+    __shared__ double ws[BS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = waveReduceSum(v);
+    if (lane == 0) ws[w] = v;
+    __syncthreads();
+    double s = 0.;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < BS / 64; ++i) s += ws[i];
+    }
+    __syncthreads();
+    return s;
+}
+
+// ---- CSR-stream SpMV ------------------------------------------------------------------------------
+// MODE 0: out[row] = (row < nA ? dt*McInv[row] : 1) * (S x)[row]     (operator, forward half)
+// MODE 1: out[row] = (S x)[row]                                       (velocity recovery)
+template <int MODE, int MAXNNZ>
+__global__ void __launch_bounds__(BS) k_spmv_S(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                               const double* __restrict__ x, int rows, int nA, double dt, const double* __restrict__ McInv,
+                                               double* __restrict__ out, const int* __restrict__ done) {
+    if (done && *done) return;
+    __shared__ double prod[BS * MAXNNZ];
+    const int r0 = blockIdx.x * BS;
+    const int r1 = min(r0 + BS, rows);
+    const int p0 = ptr[r0], p1 = ptr[r1];
+    for (int p = p0 + threadIdx.x; p < p1; p += BS) prod[p - p0] = val[p] * x[col[p]];
+    __syncthreads();
+    const int row = r0 + threadIdx.x;
+    if (row < rows) {
+        const int a = ptr[row] - p0, b = ptr[row + 1] - p0;
+        double s = 0.;
+        for (int q = a; q < b; ++q) s += prod[q];
+        if (MODE == 0 && row < nA) s *= dt * McInv[row];
+        out[row] = s;
+    }
+}
+// MODE 0: out[j] = -(St t)[j] - (j>=nP ? 0.5*uInv[j-nP]*xin[j] : 0);  partial[block] = sum xin[j]*out[j]
+// MODE 1: out[j] = -(St t)[j] + add[j]                                   (right-hand side b)
+template <int MODE, int MAXNNZ>
+__global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                const double* __restrict__ t, int rows, int nP, const double* __restrict__ uInv,
+                                                const double* __restrict__ xin, const double* __restrict__ add, double* __restrict__ out,
+                                                double* __restrict__ partial, const int* __restrict__ done) {
+    if (done && *done) return;
+    __shared__ double prod[BS * MAXNNZ];
+    const int r0 = blockIdx.x * BS;
+    const int r1 = min(r0 + BS, rows);
+    const int p0 = ptr[r0], p1 = ptr[r1];
+    for (int p = p0 + threadIdx.x; p < p1; p += BS) prod[p - p0] = val[p] * t[col[p]];
+    __syncthreads();
+    const int row = r0 + threadIdx.x;
+    double d = 0.;
+    if (row < rows) {
+        const int a = ptr[row] - p0, b = ptr[row + 1] - p0;
+        double s = 0.;
+        for (int q = a; q < b; ++q) s += prod[q];
+        double y;
+        if (MODE == 0) {
+            const double xv = xin[row];
+            y = -s;
+            if (row >= nP) y -= 0.5 * uInv[row - nP] * xv;
+            d = xv * y;
+        } else {
+            y = -s + add[row];
+        }
+        out[row] = y;
+    }
+    if (MODE == 0) {
+        const double bs = blockReduceSum(d);
+        if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+    }
+}
+
+// ---- per-tile reduced apply -------------------------------------------------------------------------
+__device__ inline void rowOffset(uint32_t packed, const double* __restrict__ COM, int region, double dx, double* o, int* axis) {
+    int i, j, k, a;
+    unpackFace(packed, i, j, k, a);
+    double p[3] = {(double)i, (double)j, (double)k};
+    p[a] -= 0.5;
+    o[0] = p[0] * dx - COM[(int64_t)region * 3 + 0];
+    o[1] = p[1] * dx - COM[(int64_t)region * 3 + 1];
+    o[2] = p[2] * dx - COM[(int64_t)region * 3 + 2];
+    *axis = a;
+}
+// partial w (26) of one chunk of <= RC_ROWS reduced rows:  w += C_f * s_f
+__global__ void __launch_bounds__(BS) k_tile_gather(const int32_t* __restrict__ chunkRegion, const int32_t* __restrict__ chunkStart,
+                                                    const int32_t* __restrict__ chunkEnd, const uint32_t* __restrict__ rrowFace,
+                                                    const double* __restrict__ COM, double dx, const double* __restrict__ sred,
+                                                    double* __restrict__ wpart, const int* __restrict__ done) {
+    if (done && *done) return;
+    const int ch = blockIdx.x;
+    const int r = chunkRegion[ch];
+    double w[PS_RD];
+#pragma unroll
+    for (int n = 0; n < PS_RD; ++n) w[n] = 0.;
+    for (int rr = chunkStart[ch] + threadIdx.x; rr < chunkEnd[ch]; rr += BS) {
+        double o[3];
+        int axis;
+        rowOffset(rrowFace[rr], COM, r, dx, o, &axis);
+        double c[PS_RD];
+        basisRow(o[0], o[1], o[2], axis, c);
+        const double s = sred[rr];
+#pragma unroll
+        for (int n = 0; n < PS_RD; ++n) w[n] += c[n] * s;
+    }
+    __shared__ double ws[BS / 64][PS_RD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < PS_RD; ++n) {
+        const double v = waveReduceSum(w[n]);
+        if (lane == 0) ws[wv][n] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PS_RD) {
+        double s = 0.;
+#pragma unroll
+        for (int i = 0; i < BS / 64; ++i) s += ws[i][threadIdx.x];
+        wpart[(int64_t)ch * PS_RD + threadIdx.x] = s;
+    }
+}
+// MODE 0: v = BInv w ;  MODE 1: v = BInv (invDt*rhsR - w)  (velocity recovery, Solver.cpp:509)
+// MODE 2: v = invDt * BInv rhsR  (right-hand side, AssembleSystem.cpp:448-452; no gather)
+template <int MODE>
+__global__ void __launch_bounds__(64) k_tile_solve(const int32_t* __restrict__ regionChunkPtr, const double* __restrict__ wpart,
+                                                   const double* __restrict__ Binv, const double* __restrict__ rhsR, double invDt,
+                                                   double* __restrict__ vreg, const int* __restrict__ done) {
+    if (done && *done) return;
+    __shared__ double w[PS_RD];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (lane < PS_RD) {
+        double s = 0.;
+        if (MODE != 2)
+            for (int ch = regionChunkPtr[r]; ch < regionChunkPtr[r + 1]; ++ch) s += wpart[(int64_t)ch * PS_RD + lane];
+        if (MODE == 1) s = invDt * rhsR[(int64_t)r * PS_RD + lane] - s;
+        if (MODE == 2) s = rhsR[(int64_t)r * PS_RD + lane];
+        w[lane] = s;
+    }
+    __syncthreads();
+    if (lane < PS_RD) {
+        const double* B = Binv + (int64_t)r * PS_RD * PS_RD + lane * PS_RD;
+        double s = 0.;
+#pragma unroll
+        for (int n = 0; n < PS_RD; ++n) s += B[n] * w[n];
+        if (MODE == 2) s *= invDt;
+        vreg[(int64_t)r * PS_RD + lane] = s;
+    }
+}
+// t_f = C_f . v_region(f)
+__global__ void k_tile_expand(const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, int nRr,
+                              const double* __restrict__ COM, double dx, const double* __restrict__ vreg, double* __restrict__ tred,
+                              const int* __restrict__ done) {
+    if (done && *done) return;
+    const int rr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rr >= nRr) return;
+    const int r = rrowRegion[rr];
+    double o[3];
+    int axis;
+    rowOffset(rrowFace[rr], COM, r, dx, o, &axis);
+    tred[rr] = basisDot(o[0], o[1], o[2], axis, vreg + (int64_t)r * PS_RD);
+}
+
+// ---- CG vector kernels ---------------------------------------------------------------------------
+__global__ void k_scale_rows(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+// r = b; x = 0; z = pre(r); p = z; partial rsold = r.z
+__global__ void __launch_bounds__(BS) k_cg_init(const double* __restrict__ b, const double* __restrict__ dinv, double* __restrict__ x,
+                                                double* __restrict__ r, double* __restrict__ p, int64_t n, double* __restrict__ partial) {
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double rv = b[i];
+        const double z = dinv ? dinv[i] * rv : rv;
+        x[i] = 0.; r[i] = rv; p[i] = z;
+        acc += rv * z;
+    }
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__device__ inline double sumPartials(const double* __restrict__ partial, int count) {
+    double acc = 0.;
+    for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
+    return blockReduceSum(acc);
+}
+__global__ void __launch_bounds__(BS) k_cg_scal0(CGScalars* sc, const double* __restrict__ partial, int count, double tol, int maxit) {
+    const double s = sumPartials(partial, count);
+    if (threadIdx.x == 0) {
+        sc->rsold = s; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
+        sc->done = (s == 0.) ? 1 : 0;      // deviation: b == 0 -> return at once (reference divides 0/0, pcg.h:314)
+        if (s == 0.) sc->iter = 0;
+        sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
+    }
+}
+__global__ void __launch_bounds__(BS) k_cg_scal1(CGScalars* sc, const double* __restrict__ partial, int count) {
+    if (sc->done) return;
+    const double s = sumPartials(partial, count);
+    if (threadIdx.x == 0) { sc->pAp = s; sc->alpha = sc->rsold / s; }   // pcg.h:314
+}
+// x += alpha p ; r -= alpha Ap ; partials of r.r, x.x, r.z   (pcg.h:315-319,331)
+__global__ void __launch_bounds__(BS) k_cg_update_xr(const CGScalars* __restrict__ sc, const double* __restrict__ p, const double* __restrict__ Ap,
+                                                     const double* __restrict__ dinv, double* __restrict__ x, double* __restrict__ r, int64_t n,
+                                                     double* __restrict__ partial) {
+    if (sc->done) return;
+    const double alpha = sc->alpha;
+    double arr = 0., axx = 0., arz = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double xv = x[i] + alpha * p[i];
+        const double rv = r[i] - alpha * Ap[i];
+        x[i] = xv; r[i] = rv;
+        arr += rv * rv; axx += xv * xv;
+        if (dinv) arz += rv * (dinv[i] * rv);
+    }
+    const double s0 = blockReduceSum(arr), s1 = blockReduceSum(axx), s2 = dinv ? blockReduceSum(arz) : 0.;
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s0;
+        partial[gridDim.x + blockIdx.x] = s1;
+        partial[2 * gridDim.x + blockIdx.x] = s2;
+    }
+}
+__global__ void __launch_bounds__(BS) k_cg_scal2(CGScalars* sc, const double* __restrict__ partial, int count, int jacobi, int iterIndex) {
+    if (sc->done) return;
+    const double rr = sumPartials(partial, count);
+    const double xx = sumPartials(partial + count, count);
+    const double rz = jacobi ? sumPartials(partial + 2 * count, count) : rr;
+    if (threadIdx.x == 0) {
+        sc->rr = rr; sc->xx = xx; sc->rz = rz;
+        double rre = rr;                              // pcg.h:319-325
+        if (rr / xx < rre) rre = rr / xx;
+        sc->rre = rre;
+        if (rre < sc->tol2) { sc->done = 1; sc->iter = iterIndex; }
+        else { sc->beta = rz / sc->rsold; sc->rsold = rz; }   // pcg.h:331-335
+    }
+}
+__global__ void __launch_bounds__(BS) k_cg_update_p(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                    double* __restrict__ p, int64_t n) {
+    if (sc->done) return;
+    const double beta = sc->beta;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double z = dinv ? dinv[i] * r[i] : r[i];
+        p[i] = z + beta * p[i];
+    }
+}
+
+// ---- generic vector helpers (BiCGStab fallback, rare) -----------------------------------------------
+__global__ void __launch_bounds__(BS) k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ partial) {
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) acc += a[i] * b[i];
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(BS) k_sum1(const double* __restrict__ partial, int count, double* __restrict__ out) {
+    const double s = sumPartials(partial, count);
+    if (threadIdx.x == 0) *out = s;
+}
+// out = ca*a + cb*b + cc*c  (null pointers skipped)
+__global__ void k_lin(double* __restrict__ out, double ca, const double* __restrict__ a, double cb, const double* __restrict__ b, double cc,
+                      const double* __restrict__ c, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = ca * a[i];
+        if (b) v += cb * b[i];
+        if (c) v += cc * c[i];
+        out[i] = v;
+    }
+}
+
+// ---- Jacobi diagonal (extension; reference stub Preconditioners.cpp:37-41) ------------------------
+// diag_j = -dt sum_f McInv_f S_fj^2 - sum_r q^T BInv_r q - 1/2 uInv_j,  q = sum_{f in r} C_f S_fj
+__global__ void k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int n, int nP,
+                              int nA, double dt, const double* __restrict__ McInv, const double* __restrict__ uInv,
+                              const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, const double* __restrict__ COM,
+                              double dx, const double* __restrict__ Binv, double* __restrict__ dinv) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double diag = 0.;
+    double q[PS_RD];
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;
+        const double* B = Binv + (int64_t)cur * PS_RD * PS_RD;
+        double s = 0.;
+        for (int m = 0; m < PS_RD; ++m) {
+            double t = 0.;
+            for (int k = 0; k < PS_RD; ++k) t += B[m * PS_RD + k] * q[k];
+            s += q[m] * t;
+        }
+        diag -= s;
+    };
+    for (int p = ptr[j]; p < ptr[j + 1]; ++p) {
+        const int f = col[p];
+        const double v = val[p];
+        if (f < nA) { diag += -dt * McInv[f] * v * v; continue; }
+        const int rr = f - nA;
+        const int r = rrowRegion[rr];
+        if (r != cur) {
+            flush();
+            cur = r;
+            for (int m = 0; m < PS_RD; ++m) q[m] = 0.;
+        }
+        double o[3];
+        int axis;
+        rowOffset(rrowFace[rr], COM, r, dx, o, &axis);
+        double c[PS_RD];
+        basisRow(o[0], o[1], o[2], axis, c);
+        for (int m = 0; m < PS_RD; ++m) q[m] += c[m] * v;
+    }
+    flush();
+    if (j >= nP) diag += -0.5 * uInv[j - nP];
+    dinv[j] = diag != 0. ? 1. / diag : 1.;
+}
+
+// ---- recovery and write-back ---------------------------------------------------------------------
+// u_a = dt McInv (invDt rhs_a - (G p + Dt tau))      Solver.cpp:507
+__global__ void k_recover_active(const double* __restrict__ s, const double* __restrict__ McInv, const double* __restrict__ rhsA, double dt,
+                                 double invDt, int64_t nA, double* __restrict__ ua) {
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < nA; f += (int64_t)gridDim.x * blockDim.x)
+        ua[f] = dt * McInv[f] * (invDt * rhsA[f] - s[f]);
+}
+// applySolutionToVelocity, Solver.cpp:937-1028
+__global__ void k_writeback(Grid g, int axis, const int32_t* __restrict__ lab, const int32_t* __restrict__ act, const int32_t* __restrict__ reg,
+                            int64_t faceOff, const double* __restrict__ ua, const double* __restrict__ creg, const double* __restrict__ COM,
+                            double dx, const float* __restrict__ cvel, const float* __restrict__ velIn, float* __restrict__ velOut, int apply) {
+    const int3 d = g.dims(1 + axis);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int l = lab[c];
+    float out = velIn[c];
+    if (apply && !(l == PS_UNSOLVED || l == PS_UNASSIGNED)) {
+        const int r = reg[c];
+        const int a = act[c];
+        double v = 0.;
+        if (r >= 0) {
+            const int3 q = unlin3(d, c);
+            double p[3] = {(double)q.x, (double)q.y, (double)q.z};
+            p[axis] -= 0.5;
+            const double ox = p[0] * dx - COM[(int64_t)r * 3 + 0], oy = p[1] * dx - COM[(int64_t)r * 3 + 1], oz = p[2] * dx - COM[(int64_t)r * 3 + 2];
+            double C[PS_RD];
+            basisRow(ox, oy, oz, axis, C);
+            double s = 0.;
+            for (int n = 0; n < PS_RD; ++n) s += creg[(int64_t)r * PS_RD + n] * C[n];
+            v = s;
+        } else if (a >= 0) {
+            v = ua[a + faceOff];
+        } else if (l == PS_SOLID) {
+            v = (double)cvel[c];
+        }
+        out = (float)v;
+    }
+    velOut[c] = out;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Launch {
+    ps_context* c;
+    const int* done;
+    int rowsS, rowsSt, nA, nP;
+    void spmvS(int mode, const double* x, double* out) const {
+        const dim3 gr(gridFor(rowsS, BS)), bl(BS);
+        if (rowsS == 0) return;
+        if (mode == 0)
+            hipLaunchKernelGGL((k_spmv_S<0, 8>), gr, bl, 0, c->stream, c->S.ptr.p, c->S.col.p, c->S.val.p, x, rowsS, nA, c->dt, c->McInv.p, out, done);
+        else
+            hipLaunchKernelGGL((k_spmv_S<1, 8>), gr, bl, 0, c->stream, c->S.ptr.p, c->S.col.p, c->S.val.p, x, rowsS, nA, c->dt, c->McInv.p, out, done);
+    }
+    void tiles(int mode, double* ts) const {   // ts: face-row vector; reduced part rewritten in place
+        if (c->regionCount == 0) return;
+        double* sred = ts + nA;
+        if (mode != 2 && c->nRChunks > 0)
+            hipLaunchKernelGGL(k_tile_gather, dim3((unsigned)c->nRChunks), dim3(BS), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
+                               c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, sred, c->wreg.p, done);
+        const dim3 gr((unsigned)c->regionCount), bl(64);
+        if (mode == 0)
+            hipLaunchKernelGGL(k_tile_solve<0>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
+        else if (mode == 1)
+            hipLaunchKernelGGL(k_tile_solve<1>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
+        else
+            hipLaunchKernelGGL(k_tile_solve<2>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
+        if (mode != 1 && c->nReducedRows > 0)
+            hipLaunchKernelGGL(k_tile_expand, dim3(gridFor(c->nReducedRows, BS)), dim3(BS), 0, c->stream, c->rrowFace.p, c->rrowRegion.p,
+                               (int)c->nReducedRows, c->COM.p, c->dx, c->vreg.p, sred, done);
+    }
+    void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
+        const dim3 gr(gridFor(rowsSt, BS)), bl(BS);
+        if (rowsSt == 0) return;
+        if (mode == 0)
+            hipLaunchKernelGGL((k_spmv_St<0, 6>), gr, bl, 0, c->stream, c->St.ptr.p, c->St.col.p, c->St.val.p, t, rowsSt, nP, c->uInv.p, xin, add,
+                               out, partial, done);
+        else
+            hipLaunchKernelGGL((k_spmv_St<1, 6>), gr, bl, 0, c->stream, c->St.ptr.p, c->St.col.p, c->St.val.p, t, rowsSt, nP, c->uInv.p, xin, add,
+                               out, partial, done);
+    }
+};
+Launch mk(ps_context* c, const int* done) {
+    Launch L;
+    L.c = c; L.done = done;
+    L.rowsS = (int)c->nRows; L.rowsSt = (int)c->nSystem; L.nA = (int)c->nActiveVs; L.nP = (int)c->nPressures;
+    return L;
+}
+int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
+}  // namespace
+
+// y = A x on device vectors (ApplyPressureStressMatrix::apply).  dotPartialsOut receives the per-block
+// partials of x.y (gridFor(nSystem,256) entries).
+void ps_context::applyOperator(const double* xdev, double* ydev, double* dotPartialsOut) {
+    Launch L = mk(this, nullptr);
+    L.spmvS(0, xdev, ts.p);
+    L.tiles(0, ts.p);
+    L.spmvSt(0, ts.p, xdev, nullptr, ydev, dotPartialsOut);
+}
+
+// AssembleSystem.cpp:432-470 (+ the reduced blocks of AssembleBlocks.cpp)
+void ps_context::assembleSystemPressureStressFactored() {
+    assembleReducedBlocks();
+    const int64_t n = nSystem;
+    ts.alloc((size_t)nRows + 1);
+    vreg.alloc((size_t)std::max<int64_t>(1, regionCount) * PS_RD);
+    wreg.alloc((size_t)std::max<int64_t>(1, nRChunks) * PS_RD);
+    b.alloc((size_t)n); x.alloc((size_t)n); r.alloc((size_t)n); pvec.alloc((size_t)n); Ap.alloc((size_t)n);
+    dotPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(std::max<int64_t>(n, 1), BS)) + 16);
+    scal.alloc(1);
+    // t0 = McInv rhs_a on active rows, C (invDt BInv rhs_r) on reduced rows;  b = -S^T t0 + [rhs_p; rhs_tau]
+    if (nActiveVs > 0)
+        hipLaunchKernelGGL(k_scale_rows, dim3(dotBlocks(nActiveVs)), dim3(BS), 0, stream, ts.p, McInv.p, rhsA.p, nActiveVs);
+    Launch L = mk(this, nullptr);
+    L.tiles(2, ts.p);
+    L.spmvSt(1, ts.p, nullptr, rhsPT.p, b.p, nullptr);
+    HIP_CHECK(hipMemsetAsync(x.p, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), stream));
+}
+
+// Preconditioners.cpp:4-9 (identity) / Jacobi extension
+void ps_context::constructPreconditioner() {
+    if (P.preconditioner != PS_PRE_DIAGONAL) return;
+    dinv.alloc((size_t)nSystem);
+    if (nSystem == 0) return;
+    hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 128)), dim3(128), 0, stream, St.ptr.p, St.col.p, St.val.p, (int)nSystem,
+                       (int)nPressures, (int)nActiveVs, dt, McInv.p, uInv.p, rrowFace.p, rrowRegion.p, COM.p, dx, Binv.p, dinv.p);
+}
+
+// Solver.cpp:734-812 solveSPDwithMatrixVectorPCG -> pcg_external_matrix_A (pcg.h:268-340), BiCGStab fallback (pcg.h:134-200)
+int ps_context::solve() {
+    const int64_t n = nSystem;
+    const int maxit = P.maxSolverIterations;
+    const double tol = P.tolerance;
+    usedBiCGStab = 0;
+    if (P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
+    if (n == 0) { solveIterations = 0; solveError = 0; return PS_SUCCESS; }
+    const double* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinv.p : nullptr;
+    const int vb = dotBlocks(n);
+    const int stBlocks = gridFor(n, BS);
+    CGScalars* sc = scal.p;
+    const int* done = &sc->done;
+    Launch L = mk(this, done);
+
+    hipLaunchKernelGGL(k_cg_init, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
+    hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, tol, maxit);
+    CGScalars h{};
+    const int batch = 25;
+    int it = 0;
+    bool finished = false;
+    while (it < maxit && !finished) {
+        const int upto = std::min(maxit, it + batch);
+        for (; it < upto; ++it) {
+            L.spmvS(0, pvec.p, ts.p);
+            L.tiles(0, ts.p);
+            L.spmvSt(0, ts.p, pvec.p, nullptr, Ap.p, dotPartials.p);
+            hipLaunchKernelGGL(k_cg_scal1, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, stBlocks);
+            hipLaunchKernelGGL(k_cg_update_xr, dim3(vb), dim3(BS), 0, stream, sc, pvec.p, Ap.p, dv, x.p, r.p, n, dotPartials.p);
+            hipLaunchKernelGGL(k_cg_scal2, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, dv ? 1 : 0, it);
+            hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, stream, sc, r.p, dv, pvec.p, n);
+        }
+        HIP_CHECK(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (h.done) finished = true;
+    }
+    solveIterations = h.done ? h.iter : maxit;
+    solveError = std::sqrt(h.rre);
+
+    if (solveIterations == maxit) {
+        // bicgstab_external_matrix_A (pcg.h:134-200), restarted from zero (Solver.cpp:784-799).  Rare path: host-driven.
+        usedBiCGStab = 1;
+        tmp1.alloc((size_t)n); tmp2.alloc((size_t)n); tmp3.alloc((size_t)n); tmp4.alloc((size_t)n); tmp5.alloc((size_t)n);
+        double* rhat = tmp1.p; double* v = tmp2.p; double* s = tmp3.p; double* t = tmp4.p; double* e = tmp5.p;
+        double* hvec = Ap.p;
+        auto dotH = [&](const double* a, const double* bb) {
+            hipLaunchKernelGGL(k_dot, dim3(vb), dim3(BS), 0, stream, a, bb, n, dotPartials.p);
+            hipLaunchKernelGGL(k_sum1, dim3(1), dim3(BS), 0, stream, dotPartials.p, vb, dotPartials.p + 3 * VGRID);
+            double out;
+            HIP_CHECK(hipMemcpyAsync(&out, dotPartials.p + 3 * VGRID, sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            return out;
+        };
+        auto lin = [&](double* out, double ca, const double* a, double cb, const double* bb, double cc, const double* c3) {
+            hipLaunchKernelGGL(k_lin, dim3(vb), dim3(BS), 0, stream, out, ca, a, cb, bb, cc, c3, n);
+        };
+        HIP_CHECK(hipMemsetAsync(x.p, 0, (size_t)n * sizeof(double), stream));
+        lin(r.p, 1., b.p, 0., nullptr, 0., nullptr);           // r = b - A*0
+        lin(rhat, 1., r.p, 0., nullptr, 0., nullptr);
+        HIP_CHECK(hipMemsetAsync(pvec.p, 0, (size_t)n * sizeof(double), stream));
+        HIP_CHECK(hipMemsetAsync(v, 0, (size_t)n * sizeof(double), stream));
+        double rhoCurr = 1., rhoOld = 1., alpha = 1., beta = 0., omega = 1., rre = 0.;
+        int i = 0;
+        solveIterations = maxit;
+        for (; i < maxit; ++i) {
+            rhoOld = rhoCurr;
+            rhoCurr = dotH(rhat, r.p);
+            beta = (rhoCurr / rhoOld) * (alpha / omega);
+            lin(pvec.p, 1., r.p, beta, pvec.p, -beta * omega, v);      // p = r + beta (p - omega v)
+            applyOperator(pvec.p, v, dotPartials.p);
+            alpha = rhoCurr / dotH(rhat, v);
+            lin(hvec, 1., x.p, alpha, pvec.p, 0., nullptr);            // h = x + alpha p
+            lin(s, 1., r.p, -alpha, v, 0., nullptr);                   // s = r - alpha v
+            applyOperator(s, t, dotPartials.p);
+            omega = dotH(t, s) / dotH(t, t);
+            lin(x.p, 1., hvec, omega, s, 0., nullptr);                 // x = h + omega s
+            const double xmag = std::sqrt(dotH(x.p, x.p));
+            applyOperator(x.p, e, dotPartials.p);
+            lin(e, 1., b.p, -1., e, 0., nullptr);                      // err = b - A x
+            const double rsnew = dotH(e, e);
+            rre = rsnew;
+            if (std::sqrt(rsnew) / xmag < rre) rre = std::sqrt(rsnew) / xmag;
+            if (rre < tol) { solveIterations = i; break; }
+            lin(r.p, 1., s, -omega, t, 0., nullptr);                   // r = s - omega t
+        }
+        solveError = rre;
+    }
+    return solveIterations == maxit ? PS_NOCONVERGE : PS_SUCCESS;
+}
+
+// Solver.cpp:492-510
+void ps_context::recoverVelocityFromPressureStress() {
+    recovered.alloc((size_t)(nActiveVs + nReducedVs) + 1);
+    Launch L = mk(this, nullptr);
+    L.spmvS(1, x.p, ts.p);
+    if (nActiveVs > 0)
+        hipLaunchKernelGGL(k_recover_active, dim3(dotBlocks(nActiveVs)), dim3(BS), 0, stream, ts.p, McInv.p, rhsA.p, dt, invDt, nActiveVs, recovered.p);
+    L.tiles(1, ts.p);
+    if (regionCount > 0)
+        HIP_CHECK(hipMemcpyAsync(recovered.p + nActiveVs, vreg.p, (size_t)nReducedVs * sizeof(double), hipMemcpyDeviceToDevice, stream));
+}
+
+// Solver.cpp:937-1028
+void ps_context::applySolutionToVelocity() {
+    const int64_t off[3] = {0, nFace[0], nFace[0] + nFace[1]};
+    for (int a = 0; a < 3; ++a) {
+        const int64_t n = g.count(1 + a);
+        hipLaunchKernelGGL(k_writeback, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, a, labels[1 + a].p, activeIdx[1 + a].p, reducedIdx[1 + a].p,
+                           off[a], recovered.p, recovered.p + nActiveVs, COM.p, dx, cvel[a].p, vel[a].p, velOut[a].p, 1);
+    }
+}
+
+// micro-benchmark dispatch for ps_bench_kernel (bench.py roofline object)
+void ps_bench_launch(ps_context* c, const std::string& k, const double* x, double* y) {
+    Launch L = mk(c, nullptr);
+    if (k == "spmv_S") L.spmvS(0, x, c->ts.p);
+    else if (k == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
+    else if (k == "apply") c->applyOperator(x, y, c->dotPartials.p);
+    else throw Error("unknown kernel name: " + k);
+}

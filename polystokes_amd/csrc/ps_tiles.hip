@@ -1,0 +1,465 @@
+// Per-tile dense blocks of the reduced (26-DOF divergence-free quadratic) model:
+//   centre of mass            Solver.cpp:328-372, 1274-1324
+//   least-squares fit N,rhs   Solver.cpp:374-417, 1330-1399      (c_fit = fullPivLu(N).solve(rhs))
+//   reduced mass  Mr          Solver.cpp:419-441, 1405-1482
+//   reduced viscosity K       Solver.cpp:468-490, 1484-1694      (interior stresses only)
+//   B = Mr/dt + 2K, B^-1, rhs_r = Mr c_fit     AssembleBlocks.cpp:147-244, 356-367
+//
+// All of N, Mr, K are sums of rank-1 outer products a_f (x) b_f over the faces of a region: one work
+// item = <=FB_CHUNK positions of the region's face bounding box; a 256-thread block stages 128 face
+// vectors at a time in LDS and accumulates the 26x26 block; partial blocks are then summed per region
+// in a fixed order (deterministic, no atomics).
+#include "ps_context.hpp"
+
+using namespace ps;
+
+namespace {
+
+constexpr int BS = 256;
+constexpr int FBATCH = 128;
+constexpr int OUTW = PS_RD * PS_RD + PS_RD;   // 676 block entries + 26 rhs entries
+
+enum { MODE_MASS = 0, MODE_LSQ = 1, MODE_VISC = 2 };
+
+struct TileArgs {
+    Grid g;
+    double dx, rho;
+    const int32_t* lab[7];
+    const int32_t* reg[7];
+    const float* vel[3];
+    const float* visc;
+    const double* COM;
+    const int32_t* bbox;
+    const int32_t* itemRegion;
+    const int32_t* itemAxis;
+    const int32_t* itemStart;
+};
+
+__device__ inline int labAt(const TileArgs& A, int s, const int3 d, int i, int j, int k) {
+    return oob3(d, i, j, k) ? PS_UNASSIGNED : A.lab[s][lin3(d, i, j, k)];
+}
+__device__ inline int regAt(const TileArgs& A, int s, const int3 d, int i, int j, int k) {
+    return oob3(d, i, j, k) ? PS_UNASSIGNED : A.reg[s][lin3(d, i, j, k)];
+}
+
+__device__ inline float viscSample(const TileArgs& A, float px, float py, float pz) {
+    // same restatement of SIM_RawField::getValue as ps_grid.hip::sampleCenterField
+    const int n[3] = {A.g.nx, A.g.ny, A.g.nz};
+    const float p[3] = {px, py, pz};
+    int i0[3], i1[3];
+    float t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float u = p[a] - 0.5f;
+        if (u < 0.f) u = 0.f;
+        if (u > (float)(n[a] - 1)) u = (float)(n[a] - 1);
+        int b = (int)u;
+        if (b >= n[a] - 1) { b = n[a] - 1; i0[a] = b; i1[a] = b; t[a] = 0.f; }
+        else { i0[a] = b; i1[a] = b + 1; t[a] = u - (float)b; }
+    }
+    const int64_t sy = A.g.nx, sz = (int64_t)A.g.nx * A.g.ny;
+    auto at = [&](int i, int j, int k) { return A.visc[i + j * sy + k * sz]; };
+    auto L = [](float a, float b, float tt) { return a + (b - a) * tt; };
+    const float c00 = L(at(i0[0], i0[1], i0[2]), at(i1[0], i0[1], i0[2]), t[0]);
+    const float c10 = L(at(i0[0], i1[1], i0[2]), at(i1[0], i1[1], i0[2]), t[0]);
+    const float c01 = L(at(i0[0], i0[1], i1[2]), at(i1[0], i0[1], i1[2]), t[0]);
+    const float c11 = L(at(i0[0], i1[1], i1[2]), at(i1[0], i1[1], i1[2]), t[0]);
+    return L(L(c00, c10, t[1]), L(c01, c11, t[1]), t[2]);
+}
+
+__device__ inline void faceOffset(const TileArgs& A, int axis, int i, int j, int k, int region, double* o) {
+    double p[3] = {(double)i, (double)j, (double)k};
+    p[axis] -= 0.5;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { p[q] *= A.dx; p[q] -= A.COM[(int64_t)region * 3 + q]; }
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+
+// g = sum_i contribution_i * C(adjacent face_i): the row-vector side of the viscosity outer products
+// of one reduced face (Solver.cpp:1538-1683).  Returns false if the face contributes nothing.
+__device__ void viscosityRow(const TileArgs& A, int faceAxis, int i, int j, int k, double* gv) {
+#pragma unroll
+    for (int n = 0; n < PS_RD; ++n) gv[n] = 0.;
+    const int3 cd = A.g.dims(0);
+    const int3 fd = A.g.dims(1 + faceAxis);
+    const double dx2 = A.dx * A.dx;
+    double row[PS_RD];
+    // cell-centred stresses
+    for (int divDir = 0; divDir < 2; ++divDir) {
+        int3 c = make_int3(i, j, k);
+        addc(c, faceAxis, divDir - 1);
+        if (!isReducedL(labAt(A, 0, cd, c.x, c.y, c.z))) continue;
+        if (comp(c, faceAxis) < 0 || comp(c, faceAxis) >= comp(fd, faceAxis)) continue;
+        const double divSign = divDir == 0 ? -1. : 1.;
+        const double visc = (double)viscSample(A, (float)c.x + 0.5f, (float)c.y + 0.5f, (float)c.z + 0.5f);
+        for (int gradDir = 0; gradDir < 2; ++gradDir) {
+            int3 af = c;
+            addc(af, faceAxis, gradDir);
+            const double gradSign = gradDir == 0 ? -1. : 1.;
+            const double contribution = -1. * divSign * gradSign * visc / dx2;
+            const int adj = regAt(A, 1 + faceAxis, fd, af.x, af.y, af.z);
+            if (adj < 0) continue;
+            double o[3];
+            faceOffset(A, faceAxis, af.x, af.y, af.z, adj, o);
+            basisRow(o[0], o[1], o[2], faceAxis, row);
+#pragma unroll
+            for (int n = 0; n < PS_RD; ++n) gv[n] += contribution * row[n];
+        }
+    }
+    // edge-centred stresses (pure REDUCED edges only)
+    for (int edgeAxis = 0; edgeAxis < 3; ++edgeAxis) {
+        if (edgeAxis == faceAxis) continue;
+        const int3 ed = A.g.dims(4 + edgeAxis);
+        for (int divDir = 0; divDir < 2; ++divDir) {
+            const double divSign = divDir == 0 ? -1. : 1.;
+            int3 e = make_int3(i, j, k);
+            addc(e, 3 - faceAxis - edgeAxis, divDir);
+            if (labAt(A, 4 + edgeAxis, ed, e.x, e.y, e.z) != PS_REDUCED) continue;
+            const float ox = edgeAxis == 0 ? 0.5f : 0.f, oy = edgeAxis == 1 ? 0.5f : 0.f, oz = edgeAxis == 2 ? 0.5f : 0.f;
+            const float visc = viscSample(A, (float)e.x + ox, (float)e.y + oy, (float)e.z + oz);
+            for (int gradAxis = 0; gradAxis < 3; ++gradAxis) {
+                if (gradAxis == edgeAxis) continue;
+                const int adjFaceAxis = 3 - gradAxis - edgeAxis;
+                const int3 ad = A.g.dims(1 + adjFaceAxis);
+                for (int gradDir = 0; gradDir < 2; ++gradDir) {
+                    int3 af = e;
+                    addc(af, gradAxis, gradDir - 1);
+                    const double gradSign = gradDir == 0 ? -1. : 1.;
+                    const double contribution = -0.5 * divSign * gradSign * visc / dx2;
+                    const int adj = regAt(A, 1 + adjFaceAxis, ad, af.x, af.y, af.z);
+                    if (adj < 0) continue;
+                    double o[3];
+                    faceOffset(A, adjFaceAxis, af.x, af.y, af.z, adj, o);
+                    basisRow(o[0], o[1], o[2], adjFaceAxis, row);
+#pragma unroll
+                    for (int n = 0; n < PS_RD; ++n) gv[n] += contribution * row[n];
+                }
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(BS) k_region_outer(TileArgs A, double* __restrict__ partial) {
+    __shared__ double sa[FBATCH][PS_RD];
+    __shared__ double sb[MODE == MODE_VISC ? FBATCH : 1][PS_RD];
+    __shared__ double su[FBATCH];
+    const int item = blockIdx.x;
+    const int r = A.itemRegion[item], axis = A.itemAxis[item], start = A.itemStart[item];
+    const int bx0 = A.bbox[r * 6 + 0], by0 = A.bbox[r * 6 + 1], bz0 = A.bbox[r * 6 + 2];
+    int ex = A.bbox[r * 6 + 3] - bx0 + 1, ey = A.bbox[r * 6 + 4] - by0 + 1, ez = A.bbox[r * 6 + 5] - bz0 + 1;
+    if (axis == 0) ex++; else if (axis == 1) ey++; else ez++;
+    const int total = ex * ey * ez;
+    const int end = min(start + FB_CHUNK, total);
+    const int3 fd = A.g.dims(1 + axis), cd = A.g.dims(0);
+
+    double acc[3] = {0., 0., 0.};
+    double accR = 0.;
+    const int t = threadIdx.x;
+    int em[3], en[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const int e = t + q * BS; em[q] = e / PS_RD; en[q] = e % PS_RD; }
+
+    for (int base = start; base < end; base += FBATCH) {
+        if (t < FBATCH) {
+            const int pos = base + t;
+            bool use = false;
+            double a[PS_RD];
+            double uval = 0.;
+            if (pos < end) {
+                const int li = pos % ex, lj = (pos / ex) % ey, lk = pos / (ex * ey);
+                const int i = bx0 + li, j = by0 + lj, k = bz0 + lk;
+                if (regAt(A, 1 + axis, fd, i, j, k) == r) {
+                    int3 hi = make_int3(i, j, k), lo = hi;
+                    addc(lo, axis, -1);
+                    const int lhi = labAt(A, 0, cd, hi.x, hi.y, hi.z), llo = labAt(A, 0, cd, lo.x, lo.y, lo.z);
+                    if (MODE == MODE_MASS) use = (lhi == PS_REDUCED) || (llo == PS_REDUCED && isActiveL(lhi));
+                    else if (MODE == MODE_LSQ) use = (lhi == PS_REDUCED && isActiveL(llo)) || (llo == PS_REDUCED && isActiveL(lhi));
+                    else use = true;
+                    if (use) {
+                        double o[3];
+                        faceOffset(A, axis, i, j, k, r, o);
+                        basisRow(o[0], o[1], o[2], axis, a);
+                        if (MODE == MODE_LSQ) uval = (double)A.vel[axis][lin3(fd, i, j, k)];
+                        if (MODE == MODE_VISC) {
+                            double gv[PS_RD];
+                            viscosityRow(A, axis, i, j, k, gv);
+#pragma unroll
+                            for (int n = 0; n < PS_RD; ++n) sb[t][n] = gv[n];
+                        }
+                    }
+                }
+            }
+            if (!use) {
+#pragma unroll
+                for (int n = 0; n < PS_RD; ++n) a[n] = 0.;
+                if (MODE == MODE_VISC) {
+#pragma unroll
+                    for (int n = 0; n < PS_RD; ++n) sb[t][n] = 0.;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < PS_RD; ++n) sa[t][n] = a[n];
+            su[t] = uval;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (t + q * BS < PS_RD * PS_RD) {
+                double s = acc[q];
+                if (MODE == MODE_VISC) {
+                    for (int f = 0; f < FBATCH; ++f) s += sa[f][em[q]] * sb[f][en[q]];
+                } else if (MODE == MODE_MASS) {
+                    for (int f = 0; f < FBATCH; ++f) s += (A.rho * sa[f][em[q]]) * sa[f][en[q]];
+                } else {
+                    for (int f = 0; f < FBATCH; ++f) s += sa[f][em[q]] * sa[f][en[q]];
+                }
+                acc[q] = s;
+            }
+        }
+        if (MODE == MODE_LSQ && t < PS_RD) {
+            double s = accR;
+            for (int f = 0; f < FBATCH; ++f) s += su[f] * sa[f][t];
+            accR = s;
+        }
+        __syncthreads();
+    }
+    double* out = partial + (int64_t)item * OUTW;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (t + q * BS < PS_RD * PS_RD) out[t + q * BS] = acc[q];
+    if (t < PS_RD) out[PS_RD * PS_RD + t] = accR;
+}
+
+// out[r] = sum of the region's item partials, in item order
+__global__ void k_region_sum(const double* __restrict__ partial, const int32_t* __restrict__ itemPtr,
+                             double* __restrict__ out676, double* __restrict__ out26) {
+    const int r = blockIdx.x;
+    for (int e = threadIdx.x; e < OUTW; e += blockDim.x) {
+        double s = 0.;
+        for (int it = itemPtr[r]; it < itemPtr[r + 1]; ++it) s += partial[(int64_t)it * OUTW + e];
+        if (e < PS_RD * PS_RD) out676[(int64_t)r * PS_RD * PS_RD + e] = s;
+        else if (out26) out26[(int64_t)r * PS_RD + (e - PS_RD * PS_RD)] = s;
+    }
+}
+
+// Solver.cpp:1274-1324 + :355-371.  Exact integer sums (order independent), COM = sum * (dx / count).
+__global__ void k_com(Grid g, double dx, const int32_t* __restrict__ lab, const int32_t* __restrict__ reg,
+                      const int32_t* __restrict__ bbox, double* __restrict__ COM) {
+    const int r = blockIdx.x;
+    const int3 d = g.dims(0);
+    const int bx0 = bbox[r * 6 + 0], by0 = bbox[r * 6 + 1], bz0 = bbox[r * 6 + 2];
+    const int ex = bbox[r * 6 + 3] - bx0 + 1, ey = bbox[r * 6 + 4] - by0 + 1, ez = bbox[r * 6 + 5] - bz0 + 1;
+    const int64_t total = (int64_t)ex * ey * ez;
+    unsigned long long sx = 0, sy = 0, sz = 0, cnt = 0;
+    for (int64_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
+        const int i = bx0 + (int)(pos % ex), j = by0 + (int)((pos / ex) % ey), k = bz0 + (int)(pos / ((int64_t)ex * ey));
+        const int64_t c = lin3(d, i, j, k);
+        if (isReducedL(lab[c]) && reg[c] == r) { sx += i; sy += j; sz += k; cnt++; }
+    }
+    __shared__ unsigned long long sm[4][BS];
+    sm[0][threadIdx.x] = sx; sm[1][threadIdx.x] = sy; sm[2][threadIdx.x] = sz; sm[3][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = BS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int q = 0; q < 4; ++q) sm[q][threadIdx.x] += sm[q][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) {
+        const double s = dx / (double)sm[3][0];
+        COM[(int64_t)r * 3 + threadIdx.x] = (double)sm[threadIdx.x][0] * s;
+    }
+}
+
+// c_fit = N.fullPivLu().solve(rhs)  (Solver.cpp:415).  Eigen FullPivLU semantics: column-major
+// first-maximum pivot search, rank threshold eps*26*|maxpivot|, kernel components zero.  One wave / region.
+__global__ void __launch_bounds__(64) k_lsq_solve(const double* __restrict__ N, const double* __restrict__ rhs, double* __restrict__ cfit) {
+    __shared__ double lu[PS_RD][PS_RD + 1];
+    __shared__ double c[PS_RD];
+    __shared__ int rt[PS_RD], ct[PS_RD];
+    __shared__ int s_pr, s_pc, s_nz;
+    __shared__ double s_big, s_maxpivot;
+    const int r = blockIdx.x, lane = threadIdx.x;
+    for (int e = lane; e < PS_RD * PS_RD; e += 64) lu[e / PS_RD][e % PS_RD] = N[(int64_t)r * PS_RD * PS_RD + e];
+    if (lane < PS_RD) c[lane] = rhs[(int64_t)r * PS_RD + lane];
+    if (lane == 0) { s_nz = PS_RD; s_maxpivot = 0.; }
+    __syncthreads();
+    for (int k = 0; k < PS_RD; ++k) {
+        // pivot search over rows/cols >= k, column-major order, first maximum wins
+        double best = -1.;
+        int bestIdx = 0x7fffffff;
+        const int m = PS_RD - k;
+        for (int e = lane; e < m * m; e += 64) {
+            const int jj = k + e / m, ii = k + e % m;
+            const double a = fabs(lu[ii][jj]);
+            const int idx = jj * PS_RD + ii;
+            if (a > best || (a == best && idx < bestIdx)) { best = a; bestIdx = idx; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bestIdx, o, 64);
+            if (ob > best || (ob == best && oi < bestIdx)) { best = ob; bestIdx = oi; }
+        }
+        if (lane == 0) { s_big = best; s_pc = bestIdx / PS_RD; s_pr = bestIdx % PS_RD; }
+        __syncthreads();
+        if (s_big == 0.) {
+            if (lane == 0) { s_nz = k; for (int i = k; i < PS_RD; ++i) { rt[i] = i; ct[i] = i; } }
+            __syncthreads();
+            break;
+        }
+        const int pr = s_pr, pc = s_pc;
+        if (lane == 0) { if (s_big > s_maxpivot) s_maxpivot = s_big; rt[k] = pr; ct[k] = pc; }
+        if (lane < PS_RD && pr != k) { const double tv = lu[k][lane]; lu[k][lane] = lu[pr][lane]; lu[pr][lane] = tv; }
+        __syncthreads();
+        if (lane < PS_RD && pc != k) { const double tv = lu[lane][k]; lu[lane][k] = lu[lane][pc]; lu[lane][pc] = tv; }
+        __syncthreads();
+        if (lane > k && lane < PS_RD) lu[lane][k] /= lu[k][k];
+        __syncthreads();
+        if (lane > k && lane < PS_RD) {
+            const double f = lu[lane][k];
+            for (int j = k + 1; j < PS_RD; ++j) lu[lane][j] -= f * lu[k][j];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const int n = PS_RD;
+        const double thresh = fabs(s_maxpivot) * (2.220446049250313e-16 * (double)n);
+        int rank = 0;
+        for (int i = 0; i < s_nz; ++i) rank += (fabs(lu[i][i]) > thresh);
+        double x[PS_RD];
+        for (int i = 0; i < n; ++i) x[i] = 0.;
+        if (rank > 0) {
+            for (int k = 0; k < n; ++k) { const double tv = c[k]; c[k] = c[rt[k]]; c[rt[k]] = tv; }
+            for (int i = 0; i < n; ++i) { double s = c[i]; for (int j = 0; j < i; ++j) s -= lu[i][j] * c[j]; c[i] = s; }
+            for (int i = rank - 1; i >= 0; --i) {
+                double s = c[i];
+                for (int j = i + 1; j < rank; ++j) s -= lu[i][j] * c[j];
+                c[i] = s / lu[i][i];
+            }
+            int colperm[PS_RD];
+            for (int i = 0; i < n; ++i) colperm[i] = i;
+            for (int k = 0; k < n; ++k) { const int tv = colperm[k]; colperm[k] = colperm[ct[k]]; colperm[ct[k]] = tv; }
+            for (int i = 0; i < rank; ++i) x[colperm[i]] = c[i];
+        }
+        for (int i = 0; i < n; ++i) cfit[(int64_t)r * PS_RD + i] = x[i];
+    }
+}
+
+// B = invDt*Mr + 2K; Binv = B^-1 (Eigen PartialPivLU inverse, AssembleBlocks.cpp:208-209);
+// rhs_r = Mr * c_fit (AssembleBlocks.cpp:356-367).  One wave per region.
+__global__ void __launch_bounds__(64) k_binv(double invDt, const double* __restrict__ Mr, const double* __restrict__ Kv,
+                                             const double* __restrict__ cfit, double* __restrict__ Binv, double* __restrict__ rhsR) {
+    __shared__ double lu[PS_RD][PS_RD + 1];
+    __shared__ int perm[PS_RD];
+    __shared__ int s_pr;
+    __shared__ double s_big;
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int64_t o = (int64_t)r * PS_RD * PS_RD;
+    for (int e = lane; e < PS_RD * PS_RD; e += 64) lu[e / PS_RD][e % PS_RD] = invDt * Mr[o + e] + 2. * Kv[o + e];
+    if (lane < PS_RD) {
+        perm[lane] = lane;
+        double s = 0;
+        for (int n = 0; n < PS_RD; ++n) s += Mr[o + lane * PS_RD + n] * cfit[(int64_t)r * PS_RD + n];
+        rhsR[(int64_t)r * PS_RD + lane] = s;
+    }
+    __syncthreads();
+    for (int k = 0; k < PS_RD; ++k) {
+        if (lane == 0) {
+            int pr = k;
+            double biggest = fabs(lu[k][k]);
+            for (int i = k + 1; i < PS_RD; ++i) if (fabs(lu[i][k]) > biggest) { biggest = fabs(lu[i][k]); pr = i; }
+            s_pr = pr; s_big = biggest;
+            if (biggest != 0. && pr != k) { const int tv = perm[k]; perm[k] = perm[pr]; perm[pr] = tv; }
+        }
+        __syncthreads();
+        if (s_big == 0.) continue;
+        const int pr = s_pr;
+        if (lane < PS_RD && pr != k) { const double tv = lu[k][lane]; lu[k][lane] = lu[pr][lane]; lu[pr][lane] = tv; }
+        __syncthreads();
+        if (lane > k && lane < PS_RD) {
+            lu[lane][k] /= lu[k][k];
+            const double f = lu[lane][k];
+            for (int j = k + 1; j < PS_RD; ++j) lu[lane][j] -= f * lu[k][j];
+        }
+        __syncthreads();
+    }
+    if (lane < PS_RD) {
+        double y[PS_RD];
+        for (int i = 0; i < PS_RD; ++i) y[i] = (perm[i] == lane) ? 1. : 0.;
+        for (int i = 0; i < PS_RD; ++i) { double s = y[i]; for (int j = 0; j < i; ++j) s -= lu[i][j] * y[j]; y[i] = s; }
+        for (int i = PS_RD - 1; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < PS_RD; ++j) s -= lu[i][j] * y[j]; y[i] = s / lu[i][i]; }
+        for (int i = 0; i < PS_RD; ++i) Binv[o + i * PS_RD + lane] = y[i];
+    }
+}
+
+TileArgs makeArgs(ps_context* c) {
+    TileArgs A;
+    A.g = c->g; A.dx = c->dx; A.rho = c->rho;
+    for (int s = 0; s < 7; ++s) { A.lab[s] = c->labels[s].p; A.reg[s] = c->reducedIdx[s].p; }
+    for (int a = 0; a < 3; ++a) A.vel[a] = c->vel[a].p;
+    A.visc = c->viscosity.p;
+    A.COM = c->COM.p;
+    A.bbox = c->bbox.p;
+    A.itemRegion = c->fbItemRegion.p; A.itemAxis = c->fbItemAxis.p; A.itemStart = c->fbItemStart.p;
+    return A;
+}
+
+template <int MODE>
+void runOuter(ps_context* c, double* out676, double* out26) {
+    if (c->regionCount == 0 || c->fbItems == 0) return;
+    c->partials.alloc((size_t)c->fbItems * OUTW);
+    TileArgs A = makeArgs(c);
+    hipLaunchKernelGGL(k_region_outer<MODE>, dim3((unsigned)c->fbItems), dim3(BS), 0, c->stream, A, c->partials.p);
+    hipLaunchKernelGGL(k_region_sum, dim3((unsigned)c->regionCount), dim3(BS), 0, c->stream, c->partials.p, c->fbRegionItemPtr.p, out676, out26);
+}
+
+}  // namespace
+
+// Solver.cpp:328-372.  Also builds the per-region face-box work table used by all dense reductions.
+void ps_context::computeCenterOfMasses() {
+    computeRegionBoxes();
+    const int64_t R = regionCount;
+    COM.alloc((size_t)R * 3); cfit.alloc((size_t)R * PS_RD);
+    Mr.alloc((size_t)R * PS_RD * PS_RD); Kv.alloc((size_t)R * PS_RD * PS_RD); Binv.alloc((size_t)R * PS_RD * PS_RD);
+    rhsR.alloc((size_t)R * PS_RD);
+    regionScratch.alloc((size_t)R * OUTW);
+    if (R == 0) { fbItems = 0; return; }
+    std::vector<int32_t> iR, iA, iS, ptr((size_t)R + 1, 0);
+    for (int64_t r = 0; r < R; ++r) {
+        ptr[(size_t)r] = (int32_t)iR.size();
+        for (int a = 0; a < 3; ++a) {
+            int64_t e[3];
+            for (int q = 0; q < 3; ++q) e[q] = (int64_t)hbbox[(size_t)r * 6 + 3 + q] - hbbox[(size_t)r * 6 + q] + 1;
+            e[a] += 1;
+            const int64_t total = e[0] * e[1] * e[2];
+            if (total > 0x7fffffff) throw Error("region face box too large");
+            for (int64_t st = 0; st < total; st += FB_CHUNK) { iR.push_back((int32_t)r); iA.push_back(a); iS.push_back((int32_t)st); }
+        }
+    }
+    ptr[(size_t)R] = (int32_t)iR.size();
+    fbItems = (int64_t)iR.size();
+    fbItemRegion.alloc(iR.size()); fbItemAxis.alloc(iR.size()); fbItemStart.alloc(iR.size()); fbRegionItemPtr.alloc(ptr.size());
+    fbItemCount.alloc(iR.size() + 1);
+    HIP_CHECK(hipMemcpyAsync(fbItemRegion.p, iR.data(), iR.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(fbItemAxis.p, iA.data(), iA.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(fbItemStart.p, iS.data(), iS.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(fbRegionItemPtr.p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(k_com, dim3((unsigned)R), dim3(BS), 0, stream, g, dx, labels[0].p, reducedIdx[0].p, bbox.p, COM.p);
+}
+
+void ps_context::computeLeastSquaresFits() {
+    if (regionCount == 0) return;
+    double* N = regionScratch.p;                                   // R*676
+    double* rhs = regionScratch.p + (size_t)regionCount * PS_RD * PS_RD;   // R*26
+    runOuter<MODE_LSQ>(this, N, rhs);
+    hipLaunchKernelGGL(k_lsq_solve, dim3((unsigned)regionCount), dim3(64), 0, stream, N, rhs, cfit.p);
+}
+void ps_context::computeReducedMassMatrices() { runOuter<MODE_MASS>(this, Mr.p, nullptr); }
+void ps_context::computeReducedViscosityMatricesInteriorOnly() { runOuter<MODE_VISC>(this, Kv.p, nullptr); }
+
+void ps_context::assembleReducedBlocks() {
+    if (regionCount == 0) return;
+    hipLaunchKernelGGL(k_binv, dim3((unsigned)regionCount), dim3(64), 0, stream, invDt, Mr.p, Kv.p, cfit.p, Binv.p, rhsR.p);
+}

@@ -1,0 +1,71 @@
+"""CPU-side checks of the product boundary: the C-ABI library loads, exports every symbol the public
+header declares, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "polystokes.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b(ps_[a-z_]+|polystokes_step)\s*\(", txt)
+    return sorted(set(n for n in names if n not in ("ps_allreduce_fn", "ps_halo_fn")))
+
+
+def test_library_exports_every_declared_symbol():
+    import polystokes_amd
+    L = polystokes_amd.lib()
+    syms = _header_symbols()
+    assert set(syms) == set(polystokes_amd.EXPORTED_SYMBOLS)
+    for s in syms:
+        assert hasattr(L, s), s
+    assert L.ps_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    import polystokes_amd
+    from polystokes_amd import _abi as abi
+    p = abi.Params()
+    polystokes_amd.lib().ps_params_default(ctypes.byref(p))
+    d = abi.default_params()
+    for name, _ in abi.Params._fields_:
+        assert getattr(p, name) == getattr(d, name), name
+    assert p.tolerance == 1e-3 and p.maxSolverIterations == 5000 and p.tileSize == 16 and p.tilePadding == 2
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import polystokes_amd
+    with pytest.raises(polystokes_amd.PolyStokesError) as e:
+        polystokes_amd.Solver(0)
+    assert "no HIP device" in str(e.value) or "no CPU fallback" in str(e.value)
+
+
+def test_traversal_order_roundtrip_matches_oracle(oracle_mod):
+    # host restatement of ps_common.hpp::ijkToOrder against the oracle's numbering on a ragged grid
+    from polystokes_amd import scenes
+    sc, p = scenes.cavity(20)
+    p.doReducedRegions = 0
+    sc2 = type(sc)(37, 18, 21, sc.dx, sc.dt, 1.0, [0, 0, 0], -1.0, 1.0, 1.0)
+    o = oracle_mod.Oracle()
+    o.run(sc2, p, solve=False)
+    idx = o.array("centerActiveIndices").reshape(21, 18, 37)
+
+    def order(i, j, k, d=(37, 18, 21), T=16):
+        tz, ty, tx = k // T, j // T, i // T
+        hz = T if tz * T + T <= d[2] else d[2] - tz * T
+        hy = T if ty * T + T <= d[1] else d[1] - ty * T
+        wx = T if tx * T + T <= d[0] else d[0] - tx * T
+        return (d[0] * d[1] * T * tz + d[0] * T * hz * ty + T * hy * hz * tx + (i - tx * T)
+                + wx * ((j - ty * T) + hy * (k - tz * T)))
+    rng = np.random.RandomState(0)
+    for _ in range(500):
+        i, j, k = rng.randint(37), rng.randint(18), rng.randint(21)
+        assert idx[k, j, i] == order(i, j, k)
