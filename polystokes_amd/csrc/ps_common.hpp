@@ -104,20 +104,36 @@ struct Set7 {
 
 // Polynomial basis row C_a(x), exec/HDK_PolyStokesSolver.cpp:2105-2149 (QUADRATIC_REGIONS, 26 DOF).
 __host__ __device__ inline void basisRow(const double ox, const double oy, const double oz, int axis, double* v) {
-#pragma unroll
-    for (int n = 0; n < PS_RD; ++n) v[n] = 0.;
-    if (axis == 0) {
-        v[0] = 1.; v[3] = ox; v[4] = oy; v[5] = oz;
-        v[6] = ox * ox; v[7] = ox * oy; v[8] = ox * oz; v[9] = oy * oy; v[10] = oy * oz; v[11] = oz * oz;
-    } else if (axis == 1) {
-        v[1] = 1.; v[12] = ox; v[13] = oy; v[14] = oz;
-        v[15] = ox * ox; v[16] = ox * oy; v[17] = ox * oz; v[18] = oy * oy; v[19] = oy * oz; v[20] = oz * oz;
-    } else {
-        v[2] = 1.; v[3] = -oz;
-        v[6] = -2. * ox * oz; v[7] = -1. * oy * oz; v[8] = -0.5 * oz * oz;
-        v[13] = -oz; v[16] = -1. * ox * oz; v[18] = -2. * oy * oz; v[19] = -0.5 * oz * oz;
-        v[21] = ox; v[22] = oy; v[23] = ox * ox; v[24] = ox * oy; v[25] = oy * oy;
-    }
+    const double qx[9] = {ox, oy, oz, ox * ox, ox * oy, ox * oz, oy * oy, oy * oz, oz * oz};
+    const bool a0 = axis == 0, a1 = axis == 1, a2 = axis == 2;
+    v[0] = a0 ? 1. : 0.;
+    v[1] = a1 ? 1. : 0.;
+    v[2] = a2 ? 1. : 0.;
+    const double z3 = -oz, z6 = -2. * ox * oz, z7 = -1. * oy * oz, z8 = -0.5 * oz * oz;
+    const double z16 = -1. * ox * oz, z18 = -2. * oy * oz;
+    v[3] = a0 ? qx[0] : (a2 ? z3 : 0.);
+    v[4] = a0 ? qx[1] : 0.;
+    v[5] = a0 ? qx[2] : 0.;
+    v[6] = a0 ? qx[3] : (a2 ? z6 : 0.);
+    v[7] = a0 ? qx[4] : (a2 ? z7 : 0.);
+    v[8] = a0 ? qx[5] : (a2 ? z8 : 0.);
+    v[9] = a0 ? qx[6] : 0.;
+    v[10] = a0 ? qx[7] : 0.;
+    v[11] = a0 ? qx[8] : 0.;
+    v[12] = a1 ? qx[0] : 0.;
+    v[13] = a1 ? qx[1] : (a2 ? z3 : 0.);
+    v[14] = a1 ? qx[2] : 0.;
+    v[15] = a1 ? qx[3] : 0.;
+    v[16] = a1 ? qx[4] : (a2 ? z16 : 0.);
+    v[17] = a1 ? qx[5] : 0.;
+    v[18] = a1 ? qx[6] : (a2 ? z18 : 0.);
+    v[19] = a1 ? qx[7] : (a2 ? z8 : 0.);
+    v[20] = a1 ? qx[8] : 0.;
+    v[21] = a2 ? ox : 0.;
+    v[22] = a2 ? oy : 0.;
+    v[23] = a2 ? qx[3] : 0.;
+    v[24] = a2 ? qx[4] : 0.;
+    v[25] = a2 ? qx[6] : 0.;
 }
 // dot(C_a(x), c) without materialising the row
 __host__ __device__ inline double basisDot(const double ox, const double oy, const double oz, int axis, const double* c) {
