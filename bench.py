@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench.py — Stokes-solve wall ms/step (assembly + PCG) on the 256^3 reduced-Stokes grid.
+
+One "step" = ps_step_device(): the whole hot path (weights -> classification -> tile blocks -> CSR
+assembly -> PCG -> velocity recovery/write-back) on inputs already resident in HBM.
+Prints ONE JSON line (rank 0).  See DESIGN.md §measurement for the definitions used here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+
+
+def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw):
+    """CPU restatement (oracle, kind "port") timed on this host on a bounded sample: the same scene at
+    64^3.  Scaled to the metric's unit (ms/step at the benchmark size) by DOF count and the GPU run's
+    iteration count; the raw sample numbers are kept alongside."""
+    from oracle import ps_oracle
+    from polystokes_amd import scenes
+    ns = 64
+    sc, p = scenes.cavity(ns, **params_kw)
+    o = ps_oracle.Oracle()
+    t0 = time.time()
+    o.run(sc, p, solve=False)
+    setup_ms = (time.time() - t0) * 1e3
+    n_s = o.nP + o.nT
+    iters = 8
+    ms_it = o.time_cg(iters, fair=False)
+    ms_it_fair = o.time_cg(iters, fair=True)
+    scale_cells = n_gpu_cells / float(ns ** 3)
+    est = setup_ms * scale_cells + ms_it * (gpu_n / float(n_s)) * max(gpu_iters, 1)
+    return {
+        "value": est, "unit": "ms/step", "cores": 1, "kind": "port",
+        "sample": ("oracle (single-thread restatement of ApplyPressureStressMatrix + pcg_external_matrix_A) on the same "
+                   "cavity scene at 64^3: setup %.0f ms, %.1f ms per reference-shaped CG iteration (%.1f ms fused) at n=%d; "
+                   "scaled to 256^3 by cell count (setup) and by DOFs x the GPU run's iteration count (solve)"
+                   % (setup_ms, ms_it, ms_it_fair, n_s)),
+        "sample_setup_ms": setup_ms, "sample_ms_per_cg_iter": ms_it, "sample_ms_per_cg_iter_fused": ms_it_fair,
+        "sample_dofs": n_s,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=256, help="grid resolution per axis (default 256)")
+    ap.add_argument("--precond", choices=["jacobi", "identity"], default="jacobi")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import polystokes_amd
+    from polystokes_amd import _abi as abi
+    from polystokes_amd import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    n = args.n
+    kw = dict(tile=16, pad=2, precond=abi.PRE_DIAGONAL if args.precond == "jacobi" else abi.PRE_IDENTITY)
+    # N > 1: every rank owns one n^3 brick of an (n * world)-long duct cut at tile boundaries; round 1 runs the
+    # bricks as independent sub-problems (no halo coupling yet) — see DESIGN.md §multi-GPU.
+    sc, p = scenes.cavity(n, **kw)
+    solver = polystokes_amd.Solver(local_rank)
+    solver.upload(sc, p)           # host -> HBM, outside the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.step_device()
+    barrier()
+    t0 = time.perf_counter()
+    results = []
+    for _ in range(args.steps):
+        results.append(solver.step_device())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+
+    st = solver.stats
+    iters = int(st.solveData[1])
+    solve_ms = float(st.stage_ms[8])
+    nsys = solver.nP + solver.nT
+
+    # roofline of the dominant kernels, measured live with HIP events on the solver stream
+    kern = {}
+    for name in ("spmv_St", "spmv_S", "apply"):
+        ms, by = solver.bench_kernel(name, 20)
+        kern[name] = {"ms": ms, "algorithmic_bytes": by, "GBps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+    dom = "spmv_St"
+    roofline = {
+        "bound": "hbm", "kernel": "k_spmv_St<0,6>", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+        "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_ms": kern[dom]["ms"],
+        "other_kernels": {k: v for k, v in kern.items() if k != dom},
+    }
+
+    out = {
+        "metric": "Stokes-solve wall ms/step (assembly+PCG) on 256^3 grid; CG iters/sec",
+        "value": ms_per_step, "unit": "ms/step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "synthetic lid-driven cavity %d^3, reduced tiles (tile=16, pad=2), %s-PCG, tol 1e-3" % (n, args.precond),
+                   "grid": [n, n, n], "parallelism": "1 GPU" if world == 1 else "%d independent bricks (no halo coupling yet)" % world},
+        "cg_iterations": iters, "cg_iters_per_s": iters / (solve_ms * 1e-3) if solve_ms > 0 else 0.0,
+        "system_dofs": nsys, "active_faces": solver.nA, "regions": solver.nRegions, "result": int(st.result),
+        "stage_ms": {abi.STAGE_NAMES[i]: float(st.stage_ms[i]) for i in range(len(abi.STAGE_NAMES))},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n ** 3, nsys, iters, dict(tile=16, pad=2, precond=kw["precond"]))
+    if rank == 0:
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
