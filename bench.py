@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="grid resolution per axis (default 256)")
     ap.add_argument("--precond", choices=["jacobi", "identity"], default="jacobi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--maxit", type=int, default=0, help="cap on solver iterations (profiling runs only; 0 = node default 5000)")
     args = ap.parse_args()
 
     import torch
@@ -79,6 +80,8 @@ def main():
     # N > 1: every rank owns one n^3 brick of an (n * world)-long duct cut at tile boundaries; round 1 runs the
     # bricks as independent sub-problems (no halo coupling yet) — see DESIGN.md §multi-GPU.
     sc, p = scenes.cavity(n, **kw)
+    if args.maxit > 0:
+        p.maxSolverIterations = args.maxit   # the BiCGStab fallback then runs too: use for kernel profiling only
     solver = polystokes_amd.Solver(local_rank)
     solver.upload(sc, p)           # host -> HBM, outside the timed region
 

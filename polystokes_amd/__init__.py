@@ -80,7 +80,7 @@ _DT = {(4, "i"): np.int32, (4, "f"): np.float32, (8, "f"): np.float64, (4, "u"):
 
 
 def _kind(name):
-    if name.endswith(("Labels", "Indices", ".col", ".ptr", "Region")) or name.startswith("faceRow"):
+    if name.endswith(("Labels", "Indices", ".col", ".ptr", "Region", "Perm")) or name.startswith("faceRow"):
         return "i"
     if name == "reducedRowFace":
         return "u"
@@ -204,11 +204,21 @@ class Solver:
         return int(self.stats.dimData[24])
 
     def S_matrices(self):
-        """(S, St) as scipy CSR — rows of S are face rows (active, then reduced-with-entries)."""
+        """(S, St) as scipy CSR in REFERENCE numbering — rows of S are face rows (active faces in reference
+        order, then reduced-with-entries), columns [p; tau] as in Solver.h:586-606.  On the device both are
+        stored in the block-interleaved internal numbering; `sysPerm` / `rowPerm` map reference -> internal."""
         import scipy.sparse as sp
         n = self.nP + self.nT
+        nA = self.nA
+        sys_perm, row_perm = self.array("sysPerm"), self.array("rowPerm")
         ptr, col, val = self.array("S.ptr"), self.array("S.col"), self.array("S.val")
-        S = sp.csr_matrix((val, col, ptr), shape=(len(ptr) - 1, n))
+        nrows = len(ptr) - 1
+        S = sp.csr_matrix((val, col, ptr), shape=(nrows, n))
+        rows = np.concatenate([row_perm, np.arange(nA, nrows, dtype=row_perm.dtype)])
+        S_ref = S[rows, :][:, sys_perm].tocsr()
         ptr, col, val = self.array("St.ptr"), self.array("St.col"), self.array("St.val")
-        St = sp.csr_matrix((val, col, ptr), shape=(n, S.shape[0]))
-        return S, St
+        St = sp.csr_matrix((val, col, ptr), shape=(n, nrows))
+        St_ref = St[sys_perm, :][:, rows].tocsr()
+        S_ref.sort_indices()
+        St_ref.sort_indices()
+        return S_ref, St_ref

@@ -25,6 +25,7 @@ struct BlockArgs {
     const int32_t* lab[7];
     const int32_t* act[7];
     const int32_t* reg[7];
+    const int32_t* sys[7];     // internal system numbering (sysIdx)
     const int32_t* faceRow[3];
     const float* vel[3];
     const float* cvel[3];
@@ -58,7 +59,7 @@ __device__ inline int faceEntries(const BlockArgs& A, int axis, const int3 f, in
         addc(c, axis, dir - 1);
         if (comp(c, axis) < 0 || comp(c, axis) >= comp(cd, axis)) continue;
         const int64_t cl = lin3(cd, c.x, c.y, c.z);
-        const int pidx = A.act[0][cl];
+        const int pidx = A.sys[0][cl];   // internal index of this cell's pressure (>= 0 iff the cell is ACTIVE)
         if (pidx < 0) continue;
         const double coeff = wF * (double)A.lw[0][cl] * A.invDx;
         if (coeff <= 0.) continue;
@@ -75,7 +76,7 @@ __device__ inline int faceEntries(const BlockArgs& A, int axis, const int3 f, in
         if (!isActiveL(A.lab[0][cl])) continue;
         const double coeff = wF * (double)A.lw[0][cl] * A.invDx;
         if (coeff <= 0.) continue;
-        cols[n] = (int32_t)(A.nP + stressDOF(A, A.act[0][cl], axis)); vals[n] = -1. * sign * coeff; ++n;
+        cols[n] = A.sys[0][cl] + 1 + axis; vals[n] = -1. * sign * coeff; ++n;
     }
     // edge stresses
     for (int ea = 0; ea < 3; ++ea) {
@@ -90,7 +91,7 @@ __device__ inline int faceEntries(const BlockArgs& A, int axis, const int3 f, in
             if (!isActiveL(A.lab[4 + ea][el])) continue;
             const double coeff = wF * (double)A.lw[4 + ea][el] * A.invDx;
             if (coeff <= 0.) continue;
-            cols[n] = (int32_t)(A.nP + stressDOF(A, A.act[4 + ea][el], 3 + ea)); vals[n] = -1. * sign * coeff; ++n;
+            cols[n] = A.sys[4 + ea][el]; vals[n] = -1. * sign * coeff; ++n;
         }
     }
     return n;
@@ -104,13 +105,6 @@ __device__ inline void sortEntries(int n, int32_t* cols, double* vals) {
         while (j >= 0 && cols[j] > c) { cols[j + 1] = cols[j]; vals[j + 1] = vals[j]; --j; }
         cols[j + 1] = c; vals[j + 1] = v;
     }
-}
-
-__global__ void k_face_rows_active(BlockArgs A, int axis, int32_t* __restrict__ faceRow) {
-    const int3 d = A.g.dims(1 + axis);
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (int64_t)d.x * d.y * d.z) return;
-    faceRow[c] = isActiveL(A.lab[1 + axis][c]) ? (int32_t)(A.act[1 + axis][c] + A.faceOff[axis]) : -1;
 }
 
 // reduced faces with >= 1 stencil entry, enumerated per region through its face box (same work items
@@ -332,7 +326,7 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
     const int3 d = A.g.dims(0);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
-    const int idx = A.act[0][c];
+    const int idx = A.sys[0][c];   // internal base: p, txx, tyy, tzz = idx + 0..3
     if (idx < 0) return;
     const int3 q = unlin3(d, c);
     int32_t rows[6];
@@ -348,13 +342,14 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
     for (int mode = 0; mode < 4; ++mode) {
         double rhs;
         const int n = cellColumn(A, mode, q, rows, vals, &rhs);
-        const int64_t j = mode == 0 ? idx : A.nP + stressDOF(A, idx, mode - 1);
+        const int64_t j = idx + mode;
         if (!FILL) { cnt[j] = n; continue; }
         sortRows(n, rows, vals);
         const int p0 = ptr[j];
         for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; }
         rhsPT[j] = rhs;
-        if (mode > 0) { uInv[j - A.nP] = uinvv; if (uDiag) uDiag[j - A.nP] = uv; }
+        uInv[j] = mode > 0 ? uinvv : 0.;      // full-length diagonal, zero on pressure rows
+        if (uDiag) uDiag[j] = mode > 0 ? uv : 0.;
     }
 }
 // edges: column tau_e (ConstructMatrixBlocks.cpp:651-735 for the diagonal)
@@ -365,14 +360,13 @@ __global__ void k_St_edges(BlockArgs A, int ea, int32_t* __restrict__ cnt, const
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
     if (!isActiveL(A.lab[4 + ea][c])) return;
-    const int idx = A.act[4 + ea][c];
     const int3 q = unlin3(d, c);
     int32_t rows[4];
     double vals[4];
     double rhs;
     const int n = edgeColumn(A, ea, q, rows, vals, &rhs);
-    const int64_t t = stressDOF(A, idx, 3 + ea);
-    const int64_t j = A.nP + t;
+    const int64_t j = A.sys[4 + ea][c];
+    const int64_t t = j;
     if (!FILL) { cnt[j] = n; return; }
     sortRows(n, rows, vals);
     const int p0 = ptr[j];
@@ -391,7 +385,7 @@ BlockArgs makeArgs(ps_context* c) {
     A.g = c->g; A.invDx = c->invDx; A.rho = c->rho;
     for (int s = 0; s < 7; ++s) {
         A.lw[s] = c->liquidW[s].p; A.fw[s] = c->fluidW[s].p;
-        A.lab[s] = c->labels[s].p; A.act[s] = c->activeIdx[s].p; A.reg[s] = c->reducedIdx[s].p;
+        A.lab[s] = c->labels[s].p; A.act[s] = c->activeIdx[s].p; A.reg[s] = c->reducedIdx[s].p; A.sys[s] = c->sysIdx[s].p;
     }
     for (int a = 0; a < 3; ++a) { A.faceRow[a] = c->faceRow[a].p; A.vel[a] = c->vel[a].p; A.cvel[a] = c->cvel[a].p; }
     A.visc = c->viscosity.p;
@@ -413,11 +407,8 @@ void ps_context::constructMatrixBlocks() {
     nTotalDOFs = nActiveVs + nReducedVs + nPressures + nStresses;
     if (nSystem >= 0x7fffffff || nActiveVs >= 0x7fffffff) throw Error("system too large for 32-bit DOF indices");
 
+    buildInternalNumbering();   // sysIdx[], faceRow[] (active rows), permSys, permRow
     BlockArgs A = makeArgs(this);
-    for (int a = 0; a < 3; ++a) {
-        const int64_t n = g.count(1 + a);
-        hipLaunchKernelGGL(k_face_rows_active, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, faceRow[a].p);
-    }
     // reduced rows
     nReducedRows = 0;
     if (regionCount > 0 && fbItems > 0) {
@@ -462,8 +453,8 @@ void ps_context::constructMatrixBlocks() {
 
     const bool wantExport = P.exportComponentMatrices != 0;
     McInv.alloc((size_t)nActiveVs); rhsA.alloc((size_t)nActiveVs);
-    if (wantExport) { Mc.alloc((size_t)nActiveVs); oldVs.alloc((size_t)nActiveVs); uDiag.alloc((size_t)nStresses); }
-    uInv.alloc((size_t)nStresses); rhsPT.alloc((size_t)nSystem);
+    if (wantExport) { Mc.alloc((size_t)nActiveVs); oldVs.alloc((size_t)nActiveVs); uDiag.alloc((size_t)nSystem); }
+    uInv.alloc((size_t)nSystem); rhsPT.alloc((size_t)nSystem);
 
     // S
     S.rows = nRows; S.cols = nSystem;

@@ -37,6 +37,15 @@ __global__ void k_fill32(int32_t* a, int64_t n, int32_t v) {
     if (i < n) a[i] = v;
 }
 
+__global__ void k_gather_perm8(double* __restrict__ dst, const double* __restrict__ src, const int32_t* __restrict__ perm, int64_t off, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[off + i]];
+}
+__global__ void k_scatter_perm8(double* __restrict__ dst, const double* __restrict__ src, const int32_t* __restrict__ perm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[perm[i]] = src[i];
+}
+
 const char* kSampleName[7] = {"center", "faceX", "faceY", "faceZ", "edgeYZ", "edgeXZ", "edgeXY"};
 
 }  // namespace
@@ -224,20 +233,31 @@ void ps_context::registerArrays() {
     reg("reducedViscosityMatrices", Kv.p, R * PS_RD * PS_RD, 8);
     reg("Inv_Mr_plus_2JDtuDJ", Binv.p, R * PS_RD * PS_RD, 8);
     reg("reducedRHSVector", rhsR.p, R * PS_RD, 8);
-    reg("McInv", McInv.p, nActiveVs, 8);
-    reg("activeRHSVector", rhsA.p, nActiveVs, 8);
-    reg("uInv", uInv.p, nStresses, 8);
+    auto regp = [&](const std::string& n, const void* p, int64_t c, const int32_t* perm, int64_t off) {
+        ArrayInfo a{p, c, 8};
+        a.perm = perm; a.permOffset = off;
+        arrays[n] = a;
+    };
+    // vectors are stored in the internal (block-interleaved) numbering; these views are in reference order
+    regp("McInv", McInv.p, nActiveVs, permRow.p, 0);
+    regp("activeRHSVector", rhsA.p, nActiveVs, permRow.p, 0);
+    regp("uInv", uInv.p, nStresses, permSys.p, nPressures);
     if (P.exportComponentMatrices) {
-        reg("Mc", Mc.p, nActiveVs, 8);
-        reg("oldActiveVs", oldVs.p, nActiveVs, 8);
-        reg("u", uDiag.p, nStresses, 8);
+        regp("Mc", Mc.p, nActiveVs, permRow.p, 0);
+        regp("oldActiveVs", oldVs.p, nActiveVs, permRow.p, 0);
+        regp("u", uDiag.p, nStresses, permSys.p, nPressures);
     }
-    reg("pressureRHSVector", rhsPT.p, nPressures, 8);
-    reg("stressRHSVector", rhsPT.p ? rhsPT.p + nPressures : nullptr, nStresses, 8);
-    reg("b", b.p, nSystem, 8);
-    reg("solutionVector", x.p, nSystem, 8);
-    if (P.preconditioner == PS_PRE_DIAGONAL) reg("dinv", dinv.p, nSystem, 8);
-    if (isSolved) reg("recoveredVelocity", recovered.p, nActiveVs + nReducedVs, 8);
+    regp("pressureRHSVector", rhsPT.p, nPressures, permSys.p, 0);
+    regp("stressRHSVector", rhsPT.p, nStresses, permSys.p, nPressures);
+    regp("b", b.p, nSystem, permSys.p, 0);
+    regp("solutionVector", x.p, nSystem, permSys.p, 0);
+    if (P.preconditioner == PS_PRE_DIAGONAL) regp("dinv", dinv.p, nSystem, permSys.p, 0);
+    if (isSolved) {
+        regp("recoveredActiveVelocity", recovered.p, nActiveVs, permRow.p, 0);
+        reg("recoveredReducedVelocity", recovered.p ? recovered.p + nActiveVs : nullptr, nReducedVs, 8);
+    }
+    reg("sysPerm", permSys.p, nSystem, 4);
+    reg("rowPerm", permRow.p, nActiveVs, 4);
     reg("S.ptr", S.ptr.p, S.rows + 1, 4); reg("S.col", S.col.p, S.nnz, 4); reg("S.val", S.val.p, S.nnz, 8);
     reg("St.ptr", St.ptr.p, St.rows + 1, 4); reg("St.col", St.col.p, St.nnz, 4); reg("St.val", St.val.p, St.nnz, 8);
     reg("reducedRowFace", rrowFace.p, nReducedRows, 4);
@@ -406,9 +426,12 @@ int32_t ps_apply_operator(ps_context* c, const double* x, double* y) {
         HIP_CHECK(hipSetDevice(c->device));
         const size_t n = (size_t)c->nSystem;
         c->tmp1.alloc(n); c->tmp2.alloc(n);
-        HIP_CHECK(hipMemcpyAsync(c->tmp1.p, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->tmp3.alloc(n);
+        HIP_CHECK(hipMemcpyAsync(c->tmp3.p, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scatter_perm8, dim3(gridFor((int64_t)n, 256)), dim3(256), 0, c->stream, c->tmp1.p, c->tmp3.p, c->permSys.p, (int64_t)n);
         c->applyOperator(c->tmp1.p, c->tmp2.p, c->dotPartials.p);
-        HIP_CHECK(hipMemcpyAsync(y, c->tmp2.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(k_gather_perm8, dim3(gridFor((int64_t)n, 256)), dim3(256), 0, c->stream, c->tmp3.p, c->tmp2.p, c->permSys.p, (int64_t)0, (int64_t)n);
+        HIP_CHECK(hipMemcpyAsync(y, c->tmp3.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
         return PS_SUCCESS;
     })
@@ -430,7 +453,15 @@ int32_t ps_read_array(ps_context* c, const char* name, void* dst, int64_t dst_by
         if (dst_bytes < need) throw Error("destination too small");
         if (need > 0) {
             HIP_CHECK(hipSetDevice(c->device));
-            HIP_CHECK(hipMemcpyAsync(dst, it->second.dptr, (size_t)need, hipMemcpyDeviceToHost, c->stream));
+            const void* src = it->second.dptr;
+            if (it->second.perm) {
+                const int64_t n = it->second.count;
+                c->tmp3.alloc((size_t)n);
+                hipLaunchKernelGGL(k_gather_perm8, dim3(gridFor(n, 256)), dim3(256), 0, c->stream, c->tmp3.p, (const double*)it->second.dptr,
+                                   it->second.perm, it->second.permOffset, n);
+                src = c->tmp3.p;
+            }
+            HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)need, hipMemcpyDeviceToHost, c->stream));
             HIP_CHECK(hipStreamSynchronize(c->stream));
         }
         return PS_SUCCESS;
@@ -460,10 +491,10 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
         if (avg_ms) *avg_ms = (double)ms / (double)iters;
         if (algorithmic_bytes) {
             // CSR with fp64 values, int32 columns, int32 row pointers:
-            // 12 nnz + 4 (rows+1) + 8 rows (y) + 8 cols (x read once)
+            // 12 nnz + 4 (rows+1) + 8 rows (y) + 8 cols (x read once) + fused diagonal / x reads of the epilogue
             const double nnz = (double)c->S.nnz, rowsS = (double)c->nRows, rowsT = (double)c->nSystem;
             const double bS = 12. * nnz + 4. * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
-            const double bT = 12. * nnz + 4. * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * (double)c->nStresses;
+            const double bT = 12. * nnz + 4. * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * rowsT;
             if (k == "spmv_S") *algorithmic_bytes = bS;
             else if (k == "spmv_St") *algorithmic_bytes = bT;
             else if (k == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);
@@ -503,17 +534,28 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
         auto rface = fetch(c, c->rrowFace.p, c->nReducedRows);
         auto rreg = fetch(c, c->rrowRegion.p, c->nReducedRows);
         auto com = fetch(c, c->COM.p, R * 3);
+        // device storage is in the internal block-interleaved numbering; files are written in reference order
+        auto permRow = fetch(c, c->permRow.p, nA);
+        auto permSys = fetch(c, c->permSys.p, nP + nT);
+        std::vector<int32_t> invSys((size_t)(nP + nT));
+        for (int64_t i = 0; i < nP + nT; ++i) invSys[(size_t)permSys[(size_t)i]] = (int32_t)i;
         // G, Dt
         for (int which = 0; which < 2; ++which) {
             std::vector<int64_t> ptr((size_t)nA + 1, 0);
             std::vector<int32_t> col;
             std::vector<double> val;
+            std::vector<std::pair<int32_t, double>> ent;
             for (int64_t r = 0; r < nA; ++r) {
                 ptr[(size_t)r] = (int64_t)val.size();
-                for (int p = sp[(size_t)r]; p < sp[(size_t)r + 1]; ++p) {
-                    const bool isP = sc[(size_t)p] < nP;
-                    if ((which == 0) == isP) { col.push_back(isP ? sc[(size_t)p] : (int32_t)(sc[(size_t)p] - nP)); val.push_back(sv[(size_t)p]); }
+                const int row = permRow[(size_t)r];
+                ent.clear();
+                for (int p = sp[(size_t)row]; p < sp[(size_t)row + 1]; ++p) {
+                    const int32_t rc = invSys[(size_t)sc[(size_t)p]];
+                    const bool isP = rc < nP;
+                    if ((which == 0) == isP) ent.push_back({isP ? rc : (int32_t)(rc - nP), sv[(size_t)p]});
                 }
+                std::sort(ent.begin(), ent.end());
+                for (auto& e : ent) { col.push_back(e.first); val.push_back(e.second); }
             }
             ptr[(size_t)nA] = (int64_t)val.size();
             writeMarketSparse(pre + (which == 0 ? "Mat_G.mtx" : "Mat_Dt.mtx"), nA, which == 0 ? nP : nT, ptr, col, val);
@@ -532,9 +574,10 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
                          pnt[2] * c->dx - com[(size_t)reg * 3 + 2], a, C);
                 const int64_t row = nA + rr;
                 for (int p = sp[(size_t)row]; p < sp[(size_t)row + 1]; ++p) {
-                    const bool isP = sc[(size_t)p] < nP;
+                    const int32_t rc = invSys[(size_t)sc[(size_t)p]];
+                    const bool isP = rc < nP;
                     if ((which == 0) != isP) continue;
-                    const int32_t cc = isP ? sc[(size_t)p] : (int32_t)(sc[(size_t)p] - nP);
+                    const int32_t cc = isP ? rc : (int32_t)(rc - nP);
                     for (int n = 0; n < PS_RD; ++n) rowsM[(size_t)reg * PS_RD + n][cc] += sv[(size_t)p] * C[n];
                 }
             }
@@ -548,18 +591,29 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
             ptr[rowsM.size()] = (int64_t)val.size();
             writeMarketSparse(pre + (which == 0 ? "Mat_JG.mtx" : "Mat_JDt.mtx"), R * PS_RD, which == 0 ? nP : nT, ptr, col, val);
         }
-        auto diagOut = [&](const char* name, const double* dptr, int64_t n) {
-            if (!dptr) return;
-            auto v = fetch(c, dptr, n);
+        auto refRows = [&](const double* dptr) {   // active-row vector -> reference order
+            auto v = fetch(c, dptr, nA);
+            std::vector<double> o((size_t)nA);
+            for (int64_t i = 0; i < nA; ++i) o[(size_t)i] = v[(size_t)permRow[(size_t)i]];
+            return o;
+        };
+        auto refSys = [&](const double* dptr, int64_t off, int64_t n) {   // system vector slice -> reference order
+            auto v = fetch(c, dptr, nP + nT);
+            std::vector<double> o((size_t)n);
+            for (int64_t i = 0; i < n; ++i) o[(size_t)i] = v[(size_t)permSys[(size_t)(off + i)]];
+            return o;
+        };
+        auto diagOut = [&](const char* name, const std::vector<double>& v) {
+            const int64_t n = (int64_t)v.size();
             std::vector<int64_t> ptr((size_t)n + 1);
             std::vector<int32_t> col((size_t)n);
             for (int64_t i = 0; i <= n; ++i) ptr[(size_t)i] = i;
             for (int64_t i = 0; i < n; ++i) col[(size_t)i] = (int32_t)i;
             writeMarketSparse(pre + name, n, n, ptr, col, v);
         };
-        diagOut("Mat_McInv.mtx", c->McInv.p, nA);
-        diagOut("Mat_uInv.mtx", c->uInv.p, nT);
-        if (c->P.exportComponentMatrices) { diagOut("Mat_Mc.mtx", c->Mc.p, nA); diagOut("Mat_u.mtx", c->uDiag.p, nT); }
+        diagOut("Mat_McInv.mtx", refRows(c->McInv.p));
+        diagOut("Mat_uInv.mtx", refSys(c->uInv.p, nP, nT));
+        if (c->P.exportComponentMatrices) { diagOut("Mat_Mc.mtx", refRows(c->Mc.p)); diagOut("Mat_u.mtx", refSys(c->uDiag.p, nP, nT)); }
         auto blockOut = [&](const char* name, const double* dptr) {
             auto v = fetch(c, dptr, R * PS_RD * PS_RD);
             std::vector<int64_t> ptr((size_t)R * PS_RD + 1);
@@ -573,12 +627,12 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
         blockOut("Mat_Mr.mtx", c->Mr.p);
         blockOut("Mat_JDtuDJ.mtx", c->Kv.p);
         blockOut("Mat_Inv_Mr_plus_2JDtuDJ.mtx", c->Binv.p);
-        writeMarketVector(pre + "Vec_activeRHS.mtx", fetch(c, c->rhsA.p, nA));
+        writeMarketVector(pre + "Vec_activeRHS.mtx", refRows(c->rhsA.p));
         writeMarketVector(pre + "Vec_reducedRHS.mtx", fetch(c, c->rhsR.p, R * PS_RD));
-        writeMarketVector(pre + "Vec_pressureRHS.mtx", fetch(c, c->rhsPT.p, nP));
-        writeMarketVector(pre + "Vec_stressRHS.mtx", fetch(c, c->rhsPT.p + nP, nT));
-        writeMarketVector(pre + "Vec_b.mtx", fetch(c, c->b.p, nP + nT));
-        if (c->isSolved) writeMarketVector(pre + "solutionVector.mtx", fetch(c, c->x.p, nP + nT));
+        writeMarketVector(pre + "Vec_pressureRHS.mtx", refSys(c->rhsPT.p, 0, nP));
+        writeMarketVector(pre + "Vec_stressRHS.mtx", refSys(c->rhsPT.p, nP, nT));
+        writeMarketVector(pre + "Vec_b.mtx", refSys(c->b.p, 0, nP + nT));
+        if (c->isSolved) writeMarketVector(pre + "solutionVector.mtx", refSys(c->x.p, 0, nP + nT));
         return PS_SUCCESS;
     })
 }

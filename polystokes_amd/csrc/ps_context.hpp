@@ -28,6 +28,8 @@ struct ArrayInfo {
     const void* dptr;
     int64_t count;
     int elem;
+    const int32_t* perm = nullptr;   // optional: out[i] = src[perm[permOffset + i]] (reference order view)
+    int64_t permOffset = 0;
 };
 
 }  // namespace ps
@@ -51,7 +53,13 @@ struct ps_context {
     // ---- weights, labels, indices (Solver.h:316-335) ----
     ps::DevBuf<float> liquidW[7], fluidW[7];
     ps::DevBuf<int32_t> labels[7], activeIdx[7], reducedIdx[7];
-    ps::DevBuf<int32_t> faceRow[3];          // face -> row of S (-1: none)
+    ps::DevBuf<int32_t> faceRow[3];          // face -> internal row of S (-1: none)
+    // Internal (solver) numbering: DOFs and face rows interleaved by 16^3 spatial block so that the SpMV
+    // gathers stay in L2.  sysIdx[0]: cell -> base (p, txx, tyy, tzz = base+0..3); sysIdx[4..6]: edge -> index.
+    // permSys[ref system index] = internal index; permRow[ref active-face index] = internal row.
+    ps::DevBuf<int32_t> sysIdx[7];
+    ps::DevBuf<int32_t> permSys, permRow;
+    ps::DevBuf<int64_t> ilSegStart;          // interleaved-scan segment table (host built)
     ps::DevBuf<int32_t> cellScratch[3];      // layer marks / CC labels / fix flags
     ps::DevBuf<int32_t> scanBlock;           // block sums for scans
     ps::DevBuf<int32_t> counters;            // small device counters (flags, totals)
@@ -85,7 +93,7 @@ struct ps_context {
     ps::DevCSR S, St;
     ps::DevBuf<double> McInv, rhsA, uInv, rhsPT, Mc, uDiag, oldVs;
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
-    ps::DevBuf<double> dotPartials;
+    ps::DevBuf<double> dotPartials, dotPartials2;
     ps::DevBuf<ps::CGScalars> scal;
 
     // ---- results ----
@@ -132,6 +140,8 @@ struct ps_context {
 
     // helpers
     int32_t orderedIndexAssign(int s, int mode, ps::DevBuf<int32_t>& out);   // ps_grid.hip
+    int64_t interleavedIndexAssign(int ngroups, const int* samples, const int* weights, int32_t* const* outs);
+    void buildInternalNumbering();                                            // ps_grid.hip
     int64_t exclusiveScanI32(int32_t* data, int64_t n);                       // in place; returns total
     int32_t readCounter(int idx);
     void zeroCounters();

@@ -626,6 +626,80 @@ __global__ void k_scan_apply(int32_t* __restrict__ a, int64_t n, const int32_t* 
         if (base + i < n) { a[base + i] = off; off += v[i]; }
 }
 
+
+// ---- internal (solver) numbering: interleaved by 16^3 spatial block ------------------------------------
+// Virtual sequence: for block b (lattice order), for group g: the voxels of grid sample[g] that fall in
+// block b, x-fastest.  An active voxel takes weight[g] consecutive indices.
+struct ILDesc {
+    int ngroups;
+    int sample[4];
+    int weight[4];
+    int LBx, LBy, LBz;
+    int64_t total;
+    const int64_t* segStart;   // LB^3 * ngroups + 1
+    int nseg;
+};
+__device__ inline bool ilDecode(const ILDesc& D, const Grid& g, int64_t u, int* grp, int64_t* lin) {
+    if (u >= D.total) return false;
+    int lo = 0, hi = D.nseg;   // largest s with segStart[s] <= u
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (D.segStart[mid] <= u) lo = mid; else hi = mid;
+    }
+    const int b = lo / D.ngroups, gg = lo % D.ngroups;
+    const int64_t local = u - D.segStart[lo];
+    const int bx = b % D.LBx, by = (b / D.LBx) % D.LBy, bz = b / (D.LBx * D.LBy);
+    const int3 d = g.dims(D.sample[gg]);
+    const int ex = min(16, d.x - 16 * bx), ey = min(16, d.y - 16 * by);
+    const int li = (int)(local % ex), lj = (int)((local / ex) % ey), lk = (int)(local / ((int64_t)ex * ey));
+    *grp = gg;
+    *lin = lin3(d, 16 * bx + li, 16 * by + lj, 16 * bz + lk);
+    return true;
+}
+__global__ void k_il_count(ILDesc D, Grid g, Set7<const int32_t> lab, int32_t* __restrict__ blockSums) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int cnt = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        int grp; int64_t c;
+        if (ilDecode(D, g, base + i, &grp, &c) && isActiveL(lab.p[D.sample[grp]][c])) cnt += D.weight[grp];
+    }
+    int tot;
+    blockExclusiveScan(cnt, &tot);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
+}
+__global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int32_t* __restrict__ blockOffs, Set7<int32_t> outs) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int w[SCAN_ITEMS], gr[SCAN_ITEMS];
+    int64_t cc[SCAN_ITEMS];
+    int cnt = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        w[i] = 0; gr[i] = 0; cc[i] = 0;
+        if (ilDecode(D, g, base + i, &gr[i], &cc[i]) && isActiveL(lab.p[D.sample[gr[i]]][cc[i]])) w[i] = D.weight[gr[i]];
+        cnt += w[i];
+    }
+    int tot;
+    int off = blockExclusiveScan(cnt, &tot) + blockOffs[blockIdx.x];
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (w[i]) { outs.p[D.sample[gr[i]]][cc[i]] = off; off += w[i]; }
+}
+// permSys[reference index] = internal index  (reference layout: Solver.h:586-606)
+__global__ void k_perm_cells(Grid g, const int32_t* __restrict__ act, const int32_t* __restrict__ sys, int64_t nP, int64_t nC,
+                             int32_t* __restrict__ perm) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.count(0)) return;
+    const int q = act[c];
+    if (q < 0) return;
+    const int b = sys[c];
+    perm[q] = b; perm[nP + q] = b + 1; perm[nP + nC + q] = b + 2; perm[nP + 2 * nC + q] = b + 3;
+}
+__global__ void k_perm_simple(const int32_t* __restrict__ act, const int32_t* __restrict__ internal, int64_t n, int64_t refOffset,
+                              int32_t* __restrict__ perm) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int q = act[c];
+    if (q >= 0) perm[refOffset + q] = internal[c];
+}
+
 template <class T>
 Set7<const T> cset(DevBuf<T>* b) {
     Set7<const T> s;
@@ -833,6 +907,82 @@ void ps_context::constructActiveIndices() {
         else if (s <= 3) nFace[s - 1] = cnt;
         else nEdge[s - 4] = cnt;
     }
+}
+
+
+int64_t ps_context::interleavedIndexAssign(int ngroups, const int* samples, const int* weights, int32_t* const* outs) {
+    ILDesc D;
+    D.ngroups = ngroups;
+    for (int q = 0; q < 4; ++q) { D.sample[q] = q < ngroups ? samples[q] : 0; D.weight[q] = q < ngroups ? weights[q] : 0; }
+    D.LBx = (g.nx + 1 + 15) / 16; D.LBy = (g.ny + 1 + 15) / 16; D.LBz = (g.nz + 1 + 15) / 16;
+    const int nb = D.LBx * D.LBy * D.LBz;
+    std::vector<int64_t> seg((size_t)nb * ngroups + 1);
+    int64_t run = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int bx = b % D.LBx, by = (b / D.LBx) % D.LBy, bz = b / (D.LBx * D.LBy);
+        for (int q = 0; q < ngroups; ++q) {
+            const int3 d = g.dims(samples[q]);
+            const int64_t ex = std::max(0, std::min(16, d.x - 16 * bx)), ey = std::max(0, std::min(16, d.y - 16 * by)),
+                          ez = std::max(0, std::min(16, d.z - 16 * bz));
+            seg[(size_t)b * ngroups + q] = run;
+            run += ex * ey * ez;
+        }
+    }
+    seg.back() = run;
+    // empty segments share their start with the next one; the search returns the LAST index with start <= u,
+    // which is the non-empty segment that contains u (u < total).
+    D.total = run;
+    D.nseg = (int)seg.size() - 1;
+    ilSegStart.alloc(seg.size());
+    HIP_CHECK(hipMemcpyAsync(ilSegStart.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    D.segStart = ilSegStart.p;
+    const int nbk = gridFor(run, SCAN_TILE);
+    scanBlock.alloc((size_t)nbk);
+    Set7<int32_t> o;
+    for (int q = 0; q < 7; ++q) o.p[q] = nullptr;
+    for (int q = 0; q < ngroups; ++q) o.p[samples[q]] = outs[q];
+    hipLaunchKernelGGL(k_il_count, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nbk, counters.p + 8);
+    hipLaunchKernelGGL(k_il_assign, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p, o);
+    return readCounter(8);
+}
+
+// Internal numbering of system DOFs and active face rows (see ps_context.hpp).  With PS_ORDER_LINEAR the
+// same interleaving is used: it is an internal layout, the reference numbering stays in activeIdx[].
+void ps_context::buildInternalNumbering() {
+    const int64_t nC = nCenter, nPq = nCenter;
+    const int64_t nSys = 4 * nCenter + nEdge[0] + nEdge[1] + nEdge[2];
+    const int64_t nAct = nFace[0] + nFace[1] + nFace[2];
+    for (int s : {0, 4, 5, 6}) {
+        sysIdx[s].alloc((size_t)g.count(s));
+        hipLaunchKernelGGL(k_fill_i32, dim3(gridFor(g.count(s), BS)), dim3(BS), 0, stream, sysIdx[s].p, g.count(s), -1);
+    }
+    for (int a = 0; a < 3; ++a)
+        hipLaunchKernelGGL(k_fill_i32, dim3(gridFor(g.count(1 + a), BS)), dim3(BS), 0, stream, faceRow[a].p, g.count(1 + a), -1);
+    {
+        const int samples[4] = {0, 4, 5, 6}, weights[4] = {4, 1, 1, 1};
+        int32_t* outs[4] = {sysIdx[0].p, sysIdx[4].p, sysIdx[5].p, sysIdx[6].p};
+        const int64_t tot = interleavedIndexAssign(4, samples, weights, outs);
+        if (tot != nSys) throw Error("internal numbering: system DOF count mismatch");
+    }
+    {
+        const int samples[3] = {1, 2, 3}, weights[3] = {1, 1, 1};
+        int32_t* outs[3] = {faceRow[0].p, faceRow[1].p, faceRow[2].p};
+        const int64_t tot = interleavedIndexAssign(3, samples, weights, outs);
+        if (tot != nAct) throw Error("internal numbering: face row count mismatch");
+    }
+    permSys.alloc((size_t)nSys);
+    permRow.alloc((size_t)nAct);
+    hipLaunchKernelGGL(k_perm_cells, dim3(gridFor(g.count(0), BS)), dim3(BS), 0, stream, g, activeIdx[0].p, sysIdx[0].p, nPq, nC, permSys.p);
+    const int64_t eoff[3] = {nPq + 3 * nC, nPq + 3 * nC + nEdge[0], nPq + 3 * nC + nEdge[0] + nEdge[1]};
+    for (int e = 0; e < 3; ++e)
+        hipLaunchKernelGGL(k_perm_simple, dim3(gridFor(g.count(4 + e), BS)), dim3(BS), 0, stream, activeIdx[4 + e].p, sysIdx[4 + e].p,
+                           g.count(4 + e), eoff[e], permSys.p);
+    const int64_t foff[3] = {0, nFace[0], nFace[0] + nFace[1]};
+    for (int a = 0; a < 3; ++a)
+        hipLaunchKernelGGL(k_perm_simple, dim3(gridFor(g.count(1 + a), BS)), dim3(BS), 0, stream, activeIdx[1 + a].p, faceRow[a].p,
+                           g.count(1 + a), foff[a], permRow.p);
 }
 
 void ps_context::buildValidFaces() {
