@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=256, help="grid resolution per axis (default 256)")
+    ap.add_argument("--res", dest="n", type=int, default=256, help="grid resolution per axis (default 256)")
     ap.add_argument("--precond", choices=["jacobi", "identity"], default="jacobi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--maxit", type=int, default=0, help="cap on solver iterations (profiling runs only; 0 = node default 5000)")
@@ -77,13 +77,24 @@ def main():
 
     n = args.n
     kw = dict(tile=16, pad=2, precond=abi.PRE_DIAGONAL if args.precond == "jacobi" else abi.PRE_IDENTITY)
-    # N > 1: every rank owns one n^3 brick of an (n * world)-long duct cut at tile boundaries; round 1 runs the
-    # bricks as independent sub-problems (no halo coupling yet) — see DESIGN.md §multi-GPU.
-    sc, p = scenes.cavity(n, **kw)
+    solver = polystokes_amd.Solver(local_rank)
+    if world == 1:
+        sc, p = scenes.cavity(n, **kw)
+        slab = None
+    else:
+        # weak scaling: the n x n x (n*world) cavity cut into z-slabs of n layers, one per GPU, coupled through the
+        # one-layer halo exchange + scalar all-reduces over RCCL
+        sc, p, slab = scenes.cavity_slab(n, world, rank, **kw)
     if args.maxit > 0:
         p.maxSolverIterations = args.maxit   # the BiCGStab fallback then runs too: use for kernel profiling only
-    solver = polystokes_amd.Solver(local_rank)
     solver.upload(sc, p)           # host -> HBM, outside the timed region
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.tensor(list(polystokes_amd.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        solver.set_slab(slab)
+        solver.comm_init(bytes(uid.cpu().tolist()), rank, world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -110,6 +121,12 @@ def main():
     iters = int(st.solveData[1])
     solve_ms = float(st.stage_ms[8])
     nsys = solver.nP + solver.nT
+    if dist is not None:   # whole-job DOF count (owned DOFs only would need the owned range; local systems include the halo)
+        t = torch.tensor([float(nsys)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        nsys_total = int(t.item())
+    else:
+        nsys_total = nsys
 
     # roofline of the dominant kernels, measured live with HIP events on the solver stream
     kern = {}
@@ -130,9 +147,9 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "synthetic lid-driven cavity %d^3, reduced tiles (tile=16, pad=2), %s-PCG, tol 1e-3" % (n, args.precond),
-                   "grid": [n, n, n], "parallelism": "1 GPU" if world == 1 else "%d independent bricks (no halo coupling yet)" % world},
+                   "grid": [n, n, n * world], "parallelism": "1 GPU" if world == 1 else "%d z-slabs, RCCL halo exchange + all-reduce" % world},
         "cg_iterations": iters, "cg_iters_per_s": iters / (solve_ms * 1e-3) if solve_ms > 0 else 0.0,
-        "system_dofs": nsys, "active_faces": solver.nA, "regions": solver.nRegions, "result": int(st.result),
+        "system_dofs": nsys_total, "dof_iterations_per_s": nsys_total * iters / (solve_ms * 1e-3) if solve_ms > 0 else 0.0, "active_faces": solver.nA, "regions": solver.nRegions, "result": int(st.result),
         "stage_ms": {abi.STAGE_NAMES[i]: float(st.stage_ms[i]) for i in range(len(abi.STAGE_NAMES))},
         "roofline": roofline,
     }

@@ -191,12 +191,32 @@ int32_t ps_export_stats(ps_context* ctx, const ps_stats* stats, const char* pref
 int32_t ps_bench_kernel(ps_context* ctx, const char* kernel, int32_t iters, double* avg_ms,
                         double* algorithmic_bytes);
 
-/* Multi-GPU: slab decomposition over z in multiples of the tile size.  The host harness gives each
- * rank its slab (plus halo) as an ordinary ps_fields_in; these hooks let torch.distributed (RCCL)
- * carry the two per-iteration exchanges.  See DESIGN.md §multi-GPU. */
-typedef void (*ps_allreduce_fn)(double* device_buf, int32_t count, void* user);
-typedef void (*ps_halo_fn)(double* device_vec, void* user);
-int32_t ps_set_collectives(ps_context* ctx, ps_allreduce_fn allreduce, ps_halo_fn halo, void* user);
+/* ---- Multi-GPU (not in the reference, which is single-process) -------------------------
+ * Slab decomposition along z, cut at multiples of lcm(16, tileSize).  Each rank is given (as an ordinary
+ * ps_fields_in) its slab plus one halo tile per interior side, and is told which local cell layers it owns.
+ * Per operator apply the ranks exchange the one-cell layer of x their rows touch across each cut and the y
+ * contributions their rows make to the neighbour's layer; CG scalars are all-reduced. */
+typedef struct ps_slab {
+    int32_t rank, world;
+    int32_t zLoOwned, zHiOwned;     /* owned cell layers [zLo, zHi) in LOCAL grid coordinates (multiples of 16) */
+    int32_t hasLower, hasUpper;     /* a neighbouring rank exists below / above */
+} ps_slab;
+int32_t ps_set_slab(ps_context* ctx, const ps_slab* slab);            /* after ps_upload_fields, before setup */
+
+/* One process per GPU: RCCL communicator on the solver stream.  Rank 0 calls ps_comm_unique_id and hands the
+ * 128 bytes to the other ranks (bench.py broadcasts them with torch.distributed); every rank then calls
+ * ps_comm_init_rccl.  ps_step_device / ps_setup_device / ps_solve_device then run the distributed solve. */
+int32_t ps_comm_unique_id(void* id128);
+int32_t ps_comm_init_rccl(ps_context* ctx, const void* id128, int32_t rank, int32_t world);
+int32_t ps_comm_selftest(ps_context* ctx);   /* all-reduce + grouped send/recv on the communicator */
+
+/* Several ranks inside ONE process on one GPU (device-to-device copies instead of RCCL): used to test the
+ * distributed algorithm on a single-GPU box.  Same kernels, same exchange lists, same reduction order. */
+typedef struct ps_group ps_group;
+ps_group* ps_group_create(int32_t device, int32_t world);
+void ps_group_destroy(ps_group* g);
+ps_context* ps_group_rank(ps_group* g, int32_t rank);                 /* upload fields / set slab per rank */
+int32_t ps_group_step(ps_group* g, ps_stats* stats);                  /* setup on every rank + distributed solve */
 
 #ifdef __cplusplus
 }

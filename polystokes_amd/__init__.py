@@ -22,7 +22,9 @@ EXPORTED_SYMBOLS = [
     "ps_abi_version", "ps_context_create", "ps_context_destroy", "ps_last_error", "ps_params_default",
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
     "polystokes_step", "ps_apply_operator", "ps_query_array", "ps_read_array",
-    "ps_export_component_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_collectives",
+    "ps_export_component_matrices", "ps_export_stats", "ps_bench_kernel",
+    "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest",
+    "ps_group_create", "ps_group_destroy", "ps_group_rank", "ps_group_step",
 ]
 
 
@@ -72,6 +74,21 @@ def lib():
         L.ps_export_stats.restype = C.c_int32
         L.ps_bench_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ps_bench_kernel.restype = C.c_int32
+        L.ps_set_slab.argtypes = [C.c_void_p, C.POINTER(_abi.SlabStruct)]
+        L.ps_set_slab.restype = C.c_int32
+        L.ps_comm_unique_id.argtypes = [C.c_void_p]
+        L.ps_comm_unique_id.restype = C.c_int32
+        L.ps_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.ps_comm_init_rccl.restype = C.c_int32
+        L.ps_comm_selftest.argtypes = [C.c_void_p]
+        L.ps_comm_selftest.restype = C.c_int32
+        L.ps_group_create.argtypes = [C.c_int32, C.c_int32]
+        L.ps_group_create.restype = C.c_void_p
+        L.ps_group_destroy.argtypes = [C.c_void_p]
+        L.ps_group_rank.argtypes = [C.c_void_p, C.c_int32]
+        L.ps_group_rank.restype = C.c_void_p
+        L.ps_group_step.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.ps_group_step.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -81,6 +98,10 @@ _DT = {(4, "i"): np.int32, (4, "f"): np.float32, (8, "f"): np.float64, (4, "u"):
 
 def _kind(name):
     if name.endswith(("Labels", "Indices", ".col", ".ptr", "Region", "Perm")) or name.startswith("faceRow"):
+        return "i"
+    if name in ("ownedX", "ownedY", "ownedZ"):
+        return "f"
+    if False:
         return "i"
     if name == "reducedRowFace":
         return "u"
@@ -95,9 +116,10 @@ class Solver:
     """Thin object wrapper over a `ps_context` — the counterpart of `HDK_PolyStokes::Solver`
     (exec/HDK_PolyStokesSolver.h:27) as seen through the C ABI."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _handle=None):
         self.L = lib()
-        h = self.L.ps_context_create(device)
+        self._owned = _handle is None
+        h = self.L.ps_context_create(device) if _handle is None else _handle
         if not h:
             raise PolyStokesError(self.L.ps_last_error(None).decode())
         self.h = C.c_void_p(h)
@@ -106,8 +128,20 @@ class Solver:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.ps_context_destroy(self.h)
+            if self._owned:
+                self.L.ps_context_destroy(self.h)
             self.h = None
+
+    def set_slab(self, slab):
+        st = _abi.SlabStruct(slab.rank, slab.world, slab.zLoOwned, slab.zHiOwned, slab.hasLower, slab.hasUpper)
+        self._check(self.L.ps_set_slab(self.h, C.byref(st)))
+
+    def comm_selftest(self):
+        self._check(self.L.ps_comm_selftest(self.h))
+
+    def comm_init(self, uid_bytes, rank, world):
+        buf = C.create_string_buffer(bytes(uid_bytes), 128)
+        self._check(self.L.ps_comm_init_rccl(self.h, buf, rank, world))
 
     def __del__(self):
         try:
@@ -222,3 +256,67 @@ class Solver:
         S_ref.sort_indices()
         St_ref.sort_indices()
         return S_ref, St_ref
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, the harness broadcasts it)."""
+    buf = C.create_string_buffer(128)
+    if lib().ps_comm_unique_id(buf) != 1:
+        raise PolyStokesError("ncclGetUniqueId failed")
+    return bytes(buf.raw)
+
+
+class Group:
+    """`world` ranks inside one process on one GPU (device copies instead of RCCL): the distributed algorithm
+    on a single-GPU box.  Same kernels, exchange lists and reduction order as the one-process-per-GPU path."""
+
+    def __init__(self, world, device=0):
+        self.L = lib()
+        g = self.L.ps_group_create(device, world)
+        if not g:
+            raise PolyStokesError(self.L.ps_last_error(None).decode())
+        self.g = C.c_void_p(g)
+        self.world = world
+        self.ranks = [Solver(device, _handle=self.L.ps_group_rank(self.g, r)) for r in range(world)]
+        self.stats = Stats()
+
+    def step(self):
+        rc = self.L.ps_group_step(self.g, C.byref(self.stats))
+        if rc == _abi.FAILED:
+            raise PolyStokesError(self.L.ps_last_error(self.ranks[0].h).decode())
+        for r in self.ranks:
+            r.stats = self.stats
+        return rc
+
+    def solve_scene(self, scene, params):
+        """Partition `scene` into slabs, run the distributed step, merge the owned faces into global arrays."""
+        from . import partition
+        slabs = [partition.make_slab(scene.nz, self.world, r, params.tileSize) for r in range(self.world)]
+        for r, sl in enumerate(slabs):
+            self.ranks[r].upload(partition.local_scene(scene, sl), params)
+            self.ranks[r].set_slab(sl)
+        rc = self.step()
+        sh = _abi.grid_shapes(scene.nx, scene.ny, scene.nz)
+        vel = [np.array(scene.vel[a], copy=True) for a in range(3)]
+        valid = [np.zeros(sh["face" + "XYZ"[a]], np.float32) for a in range(3)]
+        for r, sl in enumerate(slabs):
+            lv, lval = self.ranks[r].download()
+            for a in range(3):
+                owned = self.ranks[r].array("owned" + "XYZ"[a])
+                partition.merge_faces(vel[a], lv[a], owned, sl, a)
+                partition.merge_faces(valid[a], lval[a], owned, sl, a)
+        self.vel, self.valid, self.slabs = vel, valid, slabs
+        return rc
+
+    def close(self):
+        if getattr(self, "g", None):
+            for r in self.ranks:
+                r.h = None
+            self.L.ps_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

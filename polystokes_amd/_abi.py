@@ -64,6 +64,11 @@ class Stats(C.Structure):
     ]
 
 
+class SlabStruct(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("zLoOwned", C.c_int32), ("zHiOwned", C.c_int32),
+                ("hasLower", C.c_int32), ("hasUpper", C.c_int32)]
+
+
 def default_params(**kw):
     """Defaults of the reference's PRM template (exec/HDK_PolyStokes.C:88-208)."""
     p = Params()

@@ -31,6 +31,8 @@ struct BlockArgs {
     const float* cvel[3];
     const float* visc;
     int64_t nCenter, nEdge0, nEdge1, nP, nA, faceOff[3];
+    Own own;
+    const int32_t* regionOwned;   // null: all owned
 };
 
 __device__ inline int64_t stressDOF(const BlockArgs& A, int64_t idx, int type) {   // Solver.h:586-606
@@ -143,6 +145,10 @@ __global__ void __launch_bounds__(BS) k_skin(BlockArgs A, const int32_t* __restr
                                              int32_t* __restrict__ faceRow2, uint32_t* __restrict__ rrowFace, int32_t* __restrict__ rrowRegion) {
     const int item = blockIdx.x;
     const int r = itemRegion[item], axis = itemAxis[item], start = itemStart[item];
+    if (A.regionOwned && !A.regionOwned[r]) {   // tile of another rank (halo): no rows here
+        if (!ASSIGN && threadIdx.x == 0) itemCount[item] = 0;
+        return;
+    }
     const int bx0 = bbox[r * 6 + 0], by0 = bbox[r * 6 + 1], bz0 = bbox[r * 6 + 2];
     int ex = bbox[r * 6 + 3] - bx0 + 1, ey = bbox[r * 6 + 4] - by0 + 1, ez = bbox[r * 6 + 5] - bz0 + 1;
     if (axis == 0) ex++; else if (axis == 1) ey++; else ez++;
@@ -338,6 +344,7 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
         const double invVisc = clampd(1. / visc, 0., 1.e10);
         uinvv = invVisc * clampd(vw, 1.e-2, 1.);
         uv = visc * clampd(1. / vw, 0., 1.e2);
+        if (!A.own.layer(q.z)) uinvv = 0.;   // the -1/2 uInv x term belongs to the owner of the DOF
     }
     for (int mode = 0; mode < 4; ++mode) {
         double rhs;
@@ -376,7 +383,7 @@ __global__ void k_St_edges(BlockArgs A, int ea, int32_t* __restrict__ cnt, const
     const float ox = ea == 0 ? 0.5f : 0.f, oy = ea == 1 ? 0.5f : 0.f, oz = ea == 2 ? 0.5f : 0.f;
     const double visc = (double)viscAt(A, (float)q.x + ox, (float)q.y + oy, (float)q.z + oz);
     const double invVisc = clampd(1. / visc, 0., 1e10);
-    uInv[t] = 2. * invVisc * vw;
+    uInv[t] = A.own.sample(4 + ea, q.z) ? 2. * invVisc * vw : 0.;
     if (uDiag) uDiag[t] = 0.5 * visc * clampd(1. / vw, 0., 1.e2);
 }
 
@@ -392,6 +399,8 @@ BlockArgs makeArgs(ps_context* c) {
     A.nCenter = c->nCenter; A.nEdge0 = c->nEdge[0]; A.nEdge1 = c->nEdge[1];
     A.nP = c->nPressures; A.nA = c->nActiveVs;
     A.faceOff[0] = 0; A.faceOff[1] = c->nFace[0]; A.faceOff[2] = c->nFace[0] + c->nFace[1];
+    A.own = c->own();
+    A.regionOwned = (c->slabEnabled && c->regionCount > 0) ? c->regionOwned.p : nullptr;
     return A;
 }
 
@@ -408,6 +417,7 @@ void ps_context::constructMatrixBlocks() {
     if (nSystem >= 0x7fffffff || nActiveVs >= 0x7fffffff) throw Error("system too large for 32-bit DOF indices");
 
     buildInternalNumbering();   // sysIdx[], faceRow[] (active rows), permSys, permRow
+    buildHaloLists();
     BlockArgs A = makeArgs(this);
     // reduced rows
     nReducedRows = 0;

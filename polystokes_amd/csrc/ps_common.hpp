@@ -102,6 +102,16 @@ struct Set7 {
     T* p[7];
 };
 
+// Slab ownership (multi-GPU): which entities of the local (slab + halo) grid this rank owns.  Cells, X/Y faces and
+// XY edges live IN a cell layer k; Z faces and YZ/XZ edges live ON a plane k (the plane below layer k); the plane on a
+// cut belongs to the rank above it, the top plane of the whole domain to the last rank.
+struct Own {
+    int enabled, zLo, zHi, hasUpper;
+    __host__ __device__ bool layer(int k) const { return !enabled || (k >= zLo && k < zHi); }
+    __host__ __device__ bool plane(int k) const { return !enabled || (k >= zLo && k < zHi) || (k == zHi && !hasUpper); }
+    __host__ __device__ bool sample(int s, int k) const { return (s == 3 || s == 4 || s == 5) ? plane(k) : layer(k); }
+};
+
 // Polynomial basis row C_a(x), exec/HDK_PolyStokesSolver.cpp:2105-2149 (QUADRATIC_REGIONS, 26 DOF).
 __host__ __device__ inline void basisRow(const double ox, const double oy, const double oz, int axis, double* v) {
     const double qx[9] = {ox, oy, oz, ox * ox, ox * oy, ox * oz, oy * oy, oy * oz, oz * oz};

@@ -267,6 +267,7 @@ void ps_context::registerArrays() {
         reg(std::string("vel") + ax[a], velOut[a].p, g.count(1 + a), 4);
         reg(std::string("valid") + ax[a], valid[a].p, g.count(1 + a), 4);
         reg(std::string("faceRow") + ax[a], faceRow[a].p, g.count(1 + a), 4);
+        if (slabEnabled && isSolved) reg(std::string("owned") + ax[a], ownedFace[a].p, g.count(1 + a), 4);
     }
 }
 
@@ -350,7 +351,7 @@ void ps_context_destroy(ps_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    hipStream_t s = c->stream;
+    hipStream_t s = c->ownsStream ? c->stream : nullptr;
     delete c;
     if (s) (void)hipStreamDestroy(s);
 }
@@ -384,6 +385,10 @@ int32_t ps_solve_device(ps_context* c, ps_stats* st) {
 int32_t ps_step_device(ps_context* c, ps_stats* st) {
     if (!c) return PS_FAILED;
     PS_TRY(c, {
+        if (c->slabEnabled) {
+            if (!c->rcclComm) throw Error("a slab is set but no communicator: call ps_comm_init_rccl (or use ps_group_step)");
+            return ps_dist_step_single(c, st);
+        }
         const int rc = c->setup(nullptr);
         if (rc != PS_SUCCESS) return rc;
         return c->solveStage(st);
@@ -502,11 +507,6 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
         }
         return PS_SUCCESS;
     })
-}
-
-int32_t ps_set_collectives(ps_context* c, ps_allreduce_fn, ps_halo_fn, void*) {
-    if (c) c->err = "multi-GPU domain decomposition is not implemented in this build";
-    return PS_FAILED;
 }
 
 int32_t ps_export_stats(ps_context* c, const ps_stats* st, const char* prefix) {

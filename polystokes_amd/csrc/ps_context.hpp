@@ -96,6 +96,26 @@ struct ps_context {
     ps::DevBuf<double> dotPartials, dotPartials2;
     ps::DevBuf<ps::CGScalars> scal;
 
+    // ---- multi-GPU (slab decomposition; ps_dist.hip) ----
+    bool slabEnabled = false;
+    ps_slab slab{};
+    int64_t ownLo = 0, ownHi = 0;            // owned DOF range in the internal numbering (contiguous: whole 16-layer blocks)
+    ps::DevBuf<int32_t> regionOwned;         // R flags
+    // exchange lists (internal system indices, canonical x-fastest order): the neighbour's layer my rows touch
+    // (halo) and my layer the neighbour's rows touch (own), below and above
+    ps::DevBuf<int32_t> listLowHalo, listLowOwn, listUpHalo, listUpOwn;
+    int64_t nLowHalo = 0, nLowOwn = 0, nUpHalo = 0, nUpOwn = 0;
+    ps::DevBuf<double> sendLo, sendUp, recvLo, recvUp, redbuf;
+    void* rcclComm = nullptr;                // ncclComm_t when one process per GPU
+    bool ownsStream = true;
+    ps::DevBuf<float> ownedFace[3];          // 1 where this rank is responsible for the output face
+    ps::Own own() const {
+        ps::Own o;
+        o.enabled = slabEnabled ? 1 : 0; o.zLo = slab.zLoOwned; o.zHi = slab.zHiOwned; o.hasUpper = slab.hasUpper;
+        return o;
+    }
+    void buildHaloLists();                   // ps_grid.hip
+
     // ---- results ----
     int solveIterations = -1;
     double solveError = -1;
@@ -141,6 +161,8 @@ struct ps_context {
     // helpers
     int32_t orderedIndexAssign(int s, int mode, ps::DevBuf<int32_t>& out);   // ps_grid.hip
     int64_t interleavedIndexAssign(int ngroups, const int* samples, const int* weights, int32_t* const* outs);
+    int64_t interleavedIndexAssignEx(int ngroups, const int* samples, const int* weights, int32_t* const* outs, bool ownFilter,
+                                     int64_t* ownedRange);
     void buildInternalNumbering();                                            // ps_grid.hip
     int64_t exclusiveScanI32(int32_t* data, int64_t n);                       // in place; returns total
     int32_t readCounter(int idx);
@@ -149,6 +171,7 @@ struct ps_context {
 
 // kernel micro-benchmark dispatch (ps_solve.hip), used by ps_bench_kernel
 void ps_bench_launch(ps_context* c, const std::string& kernel, const double* x, double* y);
+int ps_dist_step_single(ps_context* c, ps_stats* stats);   // ps_solve.hip: distributed step of one RCCL rank
 
 namespace ps {
 constexpr int FB_CHUNK = 4096;   // face-box positions per work item (per-region dense reductions)

@@ -638,7 +638,20 @@ struct ILDesc {
     int64_t total;
     const int64_t* segStart;   // LB^3 * ngroups + 1
     int nseg;
+    Own own;
+    int ownFilter;             // 1: only owned voxels are numbered (face rows); 0: every active voxel (DOFs)
+    int64_t probe[2];          // virtual positions whose running prefix is reported in counters[10], [11]
 };
+__device__ inline bool ilFlag(const ILDesc& D, const Grid& g, const Set7<const int32_t>& lab, int grp, int64_t c) {
+    const int s = D.sample[grp];
+    if (!isActiveL(lab.p[s][c])) return false;
+    if (D.ownFilter) {
+        const int3 d = g.dims(s);
+        const int k = (int)(c / ((int64_t)d.x * d.y));
+        if (!D.own.sample(s, k)) return false;
+    }
+    return true;
+}
 __device__ inline bool ilDecode(const ILDesc& D, const Grid& g, int64_t u, int* grp, int64_t* lin) {
     if (u >= D.total) return false;
     int lo = 0, hi = D.nseg;   // largest s with segStart[s] <= u
@@ -661,26 +674,30 @@ __global__ void k_il_count(ILDesc D, Grid g, Set7<const int32_t> lab, int32_t* _
     int cnt = 0;
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         int grp; int64_t c;
-        if (ilDecode(D, g, base + i, &grp, &c) && isActiveL(lab.p[D.sample[grp]][c])) cnt += D.weight[grp];
+        if (ilDecode(D, g, base + i, &grp, &c) && ilFlag(D, g, lab, grp, c)) cnt += D.weight[grp];
     }
     int tot;
     blockExclusiveScan(cnt, &tot);
     if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
 }
-__global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int32_t* __restrict__ blockOffs, Set7<int32_t> outs) {
+__global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int32_t* __restrict__ blockOffs, Set7<int32_t> outs,
+                            int32_t* __restrict__ probeOut) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int w[SCAN_ITEMS], gr[SCAN_ITEMS];
     int64_t cc[SCAN_ITEMS];
     int cnt = 0;
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         w[i] = 0; gr[i] = 0; cc[i] = 0;
-        if (ilDecode(D, g, base + i, &gr[i], &cc[i]) && isActiveL(lab.p[D.sample[gr[i]]][cc[i]])) w[i] = D.weight[gr[i]];
+        if (ilDecode(D, g, base + i, &gr[i], &cc[i]) && ilFlag(D, g, lab, gr[i], cc[i])) w[i] = D.weight[gr[i]];
         cnt += w[i];
     }
     int tot;
     int off = blockExclusiveScan(cnt, &tot) + blockOffs[blockIdx.x];
-    for (int i = 0; i < SCAN_ITEMS; ++i)
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i == D.probe[0]) probeOut[0] = off;
+        if (base + i == D.probe[1]) probeOut[1] = off;
         if (w[i]) { outs.p[D.sample[gr[i]]][cc[i]] = off; off += w[i]; }
+    }
 }
 // permSys[reference index] = internal index  (reference layout: Solver.h:586-606)
 __global__ void k_perm_cells(Grid g, const int32_t* __restrict__ act, const int32_t* __restrict__ sys, int64_t nP, int64_t nC,
@@ -911,8 +928,15 @@ void ps_context::constructActiveIndices() {
 
 
 int64_t ps_context::interleavedIndexAssign(int ngroups, const int* samples, const int* weights, int32_t* const* outs) {
+    return interleavedIndexAssignEx(ngroups, samples, weights, outs, false, nullptr);
+}
+int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, const int* weights, int32_t* const* outs, bool ownFilter,
+                                             int64_t* ownedRange) {
     ILDesc D;
     D.ngroups = ngroups;
+    D.own = own();
+    D.ownFilter = ownFilter ? 1 : 0;
+    D.probe[0] = D.probe[1] = -1;
     for (int q = 0; q < 4; ++q) { D.sample[q] = q < ngroups ? samples[q] : 0; D.weight[q] = q < ngroups ? weights[q] : 0; }
     D.LBx = (g.nx + 1 + 15) / 16; D.LBy = (g.ny + 1 + 15) / 16; D.LBz = (g.nz + 1 + 15) / 16;
     const int nb = D.LBx * D.LBy * D.LBz;
@@ -933,6 +957,12 @@ int64_t ps_context::interleavedIndexAssign(int ngroups, const int* samples, cons
     // which is the non-empty segment that contains u (u < total).
     D.total = run;
     D.nseg = (int)seg.size() - 1;
+    if (ownedRange) {   // owned DOFs = whole lattice blocks bz in [zLo/16, hasUpper ? zHi/16 : LBz): a contiguous index range
+        const int b0 = slabEnabled ? slab.zLoOwned / 16 : 0;
+        const int b1 = (slabEnabled && slab.hasUpper) ? slab.zHiOwned / 16 : D.LBz;
+        D.probe[0] = seg[(size_t)b0 * D.LBx * D.LBy * ngroups];
+        D.probe[1] = seg[(size_t)b1 * D.LBx * D.LBy * ngroups];
+    }
     ilSegStart.alloc(seg.size());
     HIP_CHECK(hipMemcpyAsync(ilSegStart.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -944,8 +974,13 @@ int64_t ps_context::interleavedIndexAssign(int ngroups, const int* samples, cons
     for (int q = 0; q < ngroups; ++q) o.p[samples[q]] = outs[q];
     hipLaunchKernelGGL(k_il_count, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nbk, counters.p + 8);
-    hipLaunchKernelGGL(k_il_assign, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p, o);
-    return readCounter(8);
+    hipLaunchKernelGGL(k_il_assign, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p, o, counters.p + 10);
+    const int64_t total = readCounter(8);
+    if (ownedRange) {
+        ownedRange[0] = D.probe[0] >= run ? total : readCounter(10);
+        ownedRange[1] = D.probe[1] >= run ? total : readCounter(11);
+    }
+    return total;
 }
 
 // Internal numbering of system DOFs and active face rows (see ps_context.hpp).  With PS_ORDER_LINEAR the
@@ -963,17 +998,21 @@ void ps_context::buildInternalNumbering() {
     {
         const int samples[4] = {0, 4, 5, 6}, weights[4] = {4, 1, 1, 1};
         int32_t* outs[4] = {sysIdx[0].p, sysIdx[4].p, sysIdx[5].p, sysIdx[6].p};
-        const int64_t tot = interleavedIndexAssign(4, samples, weights, outs);
+        int64_t range[2] = {0, 0};
+        const int64_t tot = interleavedIndexAssignEx(4, samples, weights, outs, false, range);
         if (tot != nSys) throw Error("internal numbering: system DOF count mismatch");
+        ownLo = range[0]; ownHi = range[1];
     }
     {
         const int samples[3] = {1, 2, 3}, weights[3] = {1, 1, 1};
         int32_t* outs[3] = {faceRow[0].p, faceRow[1].p, faceRow[2].p};
-        const int64_t tot = interleavedIndexAssign(3, samples, weights, outs);
-        if (tot != nAct) throw Error("internal numbering: face row count mismatch");
+        const int64_t tot = interleavedIndexAssignEx(3, samples, weights, outs, slabEnabled, nullptr);
+        if (!slabEnabled && tot != nAct) throw Error("internal numbering: face row count mismatch");
+        nActiveVs = tot;   // with a slab: only the owned active faces get a row
     }
     permSys.alloc((size_t)nSys);
     permRow.alloc((size_t)nAct);
+    if (slabEnabled) HIP_CHECK(hipMemsetAsync(permRow.p, 0, (size_t)std::max<int64_t>(nAct, 1) * sizeof(int32_t), stream));
     hipLaunchKernelGGL(k_perm_cells, dim3(gridFor(g.count(0), BS)), dim3(BS), 0, stream, g, activeIdx[0].p, sysIdx[0].p, nPq, nC, permSys.p);
     const int64_t eoff[3] = {nPq + 3 * nC, nPq + 3 * nC + nEdge[0], nPq + 3 * nC + nEdge[0] + nEdge[1]};
     for (int e = 0; e < 3; ++e)
@@ -983,6 +1022,48 @@ void ps_context::buildInternalNumbering() {
     for (int a = 0; a < 3; ++a)
         hipLaunchKernelGGL(k_perm_simple, dim3(gridFor(g.count(1 + a), BS)), dim3(BS), 0, stream, activeIdx[1 + a].p, faceRow[a].p,
                            g.count(1 + a), foff[a], permRow.p);
+}
+
+// Exchange lists for the slab decomposition, built on the host from one-layer slices of sysIdx.
+void ps_context::buildHaloLists() {
+    nLowHalo = nLowOwn = nUpHalo = nUpOwn = 0;
+    if (!slabEnabled) return;
+    const int zLo = slab.zLoOwned, zHi = slab.zHiOwned;
+    auto slice = [&](int s, int k, std::vector<int32_t>& out) {
+        const int3 d = g.dims(s);
+        out.assign((size_t)d.x * d.y, -1);
+        if (k < 0 || k >= d.z) return;
+        HIP_CHECK(hipMemcpyAsync(out.data(), sysIdx[s].p + (int64_t)d.x * d.y * k, out.size() * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    };
+    auto cellsOf = [&](int k, std::vector<int32_t>& list) {
+        std::vector<int32_t> sl;
+        slice(0, k, sl);
+        for (int32_t b : sl) if (b >= 0) { list.push_back(b); list.push_back(b + 1); list.push_back(b + 2); list.push_back(b + 3); }
+    };
+    auto edgesOf = [&](int s, int k, std::vector<int32_t>& list) {
+        std::vector<int32_t> sl;
+        slice(s, k, sl);
+        for (int32_t b : sl) if (b >= 0) list.push_back(b);
+    };
+    std::vector<int32_t> lowHalo, lowOwn, upHalo, upOwn;
+    if (slab.hasLower) {
+        cellsOf(zLo - 1, lowHalo);                                   // their top layer, touched by my z-faces on plane zLo
+        cellsOf(zLo, lowOwn); edgesOf(4, zLo, lowOwn); edgesOf(5, zLo, lowOwn);   // mine, touched by their rows
+    }
+    if (slab.hasUpper) {
+        cellsOf(zHi, upHalo); edgesOf(4, zHi, upHalo); edgesOf(5, zHi, upHalo);   // theirs, touched by my rows
+        cellsOf(zHi - 1, upOwn);                                     // mine, touched by their z-faces on plane zHi
+    }
+    auto up = [&](const std::vector<int32_t>& h, DevBuf<int32_t>& d, int64_t& n) {
+        n = (int64_t)h.size();
+        d.alloc(h.size());
+        if (n) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, stream));
+    };
+    up(lowHalo, listLowHalo, nLowHalo); up(lowOwn, listLowOwn, nLowOwn); up(upHalo, listUpHalo, nUpHalo); up(upOwn, listUpOwn, nUpOwn);
+    const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo, nLowOwn), std::max(nUpHalo, nUpOwn)) + 1;
+    sendLo.alloc(mx); sendUp.alloc(mx); recvLo.alloc(mx); recvUp.alloc(mx);
+    HIP_CHECK(hipStreamSynchronize(stream));
 }
 
 void ps_context::buildValidFaces() {

@@ -425,6 +425,19 @@ void ps_context::computeCenterOfMasses() {
     rhsR.alloc((size_t)R * PS_RD);
     regionScratch.alloc((size_t)R * OUTW);
     if (R == 0) { fbItems = 0; return; }
+    if (slabEnabled) {   // a tile is owned iff all of its cells are in my layers; cuts are tile aligned
+        std::vector<int32_t> ro((size_t)R, 1);
+        for (int64_t r = 0; r < R; ++r) {
+            const int zmin = hbbox[(size_t)r * 6 + 2], zmax = hbbox[(size_t)r * 6 + 5];
+            const bool inside = zmin >= slab.zLoOwned && zmax < slab.zHiOwned;
+            const bool outside = zmax < slab.zLoOwned || zmin >= slab.zHiOwned;
+            if (!inside && !outside) throw Error("a reduced region straddles a slab cut (cuts must be tile aligned; doTile required)");
+            ro[(size_t)r] = inside ? 1 : 0;
+        }
+        regionOwned.alloc((size_t)R);
+        HIP_CHECK(hipMemcpyAsync(regionOwned.p, ro.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
     std::vector<int32_t> iR, iA, iS, ptr((size_t)R + 1, 0);
     for (int64_t r = 0; r < R; ++r) {
         ptr[(size_t)r] = (int32_t)iR.size();

@@ -122,3 +122,18 @@ def droplet(n=24, tile=8, pad=2, radius=0.33):
     surface = np.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) - radius
     sc = Scene(n, n, n, dx, dt, 1000.0, [0.0, 0.0, 0.0], surface, np.float32(10.0), 50.0, name=f"droplet{n}")
     return sc, default_params(tileSize=tile, tilePadding=pad)
+
+
+def cavity_slab(n, world, rank, tile=16, pad=2, precond=1):
+    """Rank-local piece of the weak-scaling cavity n x n x (n*world) (lid on the global top plane), generated
+    directly without materialising the global grid.  Returns (local Scene, params, Slab)."""
+    from . import partition
+    dx, dt = 1.0 / n, 1.0e-2
+    sl = partition.make_slab(n * world, world, rank, tile)
+    nzl = sl.nz_local
+    velx = np.zeros((nzl, n, n + 1), dtype=np.float32)
+    top = n * world - 1 - sl.g0          # local index of the global lid layer
+    if 0 <= top < nzl:
+        velx[top, :, :] = 1.0
+    sc = Scene(n, n, nzl, dx, dt, 1.0, [velx, 0.0, 0.0], np.float32(-1.0), np.float32(1.0), 1.0, name=f"cavity{n}x{world}.r{rank}")
+    return sc, default_params(tileSize=tile, tilePadding=pad, preconditioner=precond), sl

@@ -1,0 +1,71 @@
+"""Distributed (slab) solve on ONE GPU: `world` ranks in one process exchanging halos by device copies.
+Checks the distributed algorithm (ownership, exchange lists, reduction order) against the single-domain solve."""
+import numpy as np
+import pytest
+
+from polystokes_amd import _abi as abi
+from polystokes_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _tall_cavity(nx, nz, precond=abi.PRE_IDENTITY, tile=16):
+    sc0, p = scenes.cavity(nx, tile=tile, precond=precond)
+    velx = np.zeros((nz, nx, nx + 1), np.float32)
+    velx[nz - 1] = 1.0
+    velx[nz // 2, :, : nx // 2] = -0.5          # something to do near the cut as well
+    sc = abi.Scene(nx, nx, nz, sc0.dx, sc0.dt, 1.0, [velx, 0.0, 0.0], -1.0, 1.0, 1.0, name=f"tall{nx}x{nz}")
+    return sc, p
+
+
+def _tall_coil(n, nz):
+    # liquid column + pool with a free surface crossing the cuts, solid floor
+    sc0, p = scenes.coil(n)
+    rep = lambda a, extra=0: np.concatenate([a] * (nz // n) + ([a[-1:]] if extra and False else []), axis=0)
+    z, y, x = np.meshgrid((np.arange(nz) + 0.5) * sc0.dx, (np.arange(n) + 0.5) * sc0.dx, (np.arange(n) + 0.5) * sc0.dx, indexing="ij")
+    r = 0.2
+    col = np.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2) - r          # column along z
+    surface = np.minimum(col, z - 0.3)                           # pool below z = 0.3
+    collision = z - 2 * sc0.dx
+    sc = abi.Scene(n, n, nz, sc0.dx, sc0.dt, 1000.0, [0.0, 0.0, -1.0], surface, collision, 100.0, name=f"tallcoil{n}x{nz}")
+    return sc, p
+
+
+@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w4_tile8"])
+def test_group_matches_single_domain(case):
+    import polystokes_amd
+    if case == "cavity_w2":
+        (sc, p), world = _tall_cavity(32, 64), 2
+    elif case == "cavity_w3_jacobi":
+        (sc, p), world = _tall_cavity(24, 96, precond=abi.PRE_DIAGONAL), 3
+    elif case == "coil_w2":
+        (sc, p), world = _tall_coil(32, 64), 2
+    else:
+        (sc, p), world = _tall_cavity(24, 64, tile=8), 4
+    single = polystokes_amd.Solver(0)
+    rc1 = single.step(sc, p)
+    grp = polystokes_amd.Group(world)
+    rc2 = grp.solve_scene(sc, p)
+    assert rc1 == rc2 == abi.SUCCESS
+    it1, it2 = single.stats.solveData[1], grp.stats.solveData[1]
+    assert abs(it1 - it2) <= max(2, 0.02 * it1), (it1, it2)
+    # every owned label equals the global classification
+    lab = single.array("centerLabels").reshape(sc.nz, sc.ny, sc.nx)
+    for r, sl in enumerate(grp.slabs):
+        ll = grp.ranks[r].array("centerLabels").reshape(sl.nz_local, sc.ny, sc.nx)
+        assert np.array_equal(ll[sl.zLoOwned:sl.zHiOwned], lab[sl.z0:sl.z1]), (case, r)
+    for a in range(3):
+        assert np.array_equal(grp.valid[a], single.valid[a]), case
+        scale = max(np.abs(single.vel[a]).max(), 1e-30)
+        assert np.abs(grp.vel[a] - single.vel[a]).max() <= 20 * p.tolerance * scale, case
+    grp.close()
+    single.close()
+
+
+def test_rccl_entry_points_world1():
+    """dlopen'ed RCCL on the solver stream: communicator init, all-reduce, grouped send/recv (to self)."""
+    import polystokes_amd
+    s = polystokes_amd.Solver(0)
+    s.comm_init(polystokes_amd.comm_unique_id(), 0, 1)
+    s.comm_selftest()
+    s.close()

@@ -1,0 +1,81 @@
+"""world_size-2 (and 3) gloo test of the host-side slab decomposition on CPU: every rank builds its slab (+halo)
+from the global scene, runs the CPU oracle's classification on it and must reproduce the global labels, indices'
+counts and weights inside its owned range; owned counts all-reduce to the global counts."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from polystokes_amd import _abi as abi
+from polystokes_amd import partition, scenes
+
+
+def _scene():
+    sc0, p = scenes.coil(32)
+    nz, n = 64, 32
+    z, y, x = np.meshgrid((np.arange(nz) + 0.5) * sc0.dx, (np.arange(n) + 0.5) * sc0.dx, (np.arange(n) + 0.5) * sc0.dx, indexing="ij")
+    col = np.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2) - 0.2
+    surface = np.minimum(col, z - 0.3)
+    sc = abi.Scene(n, n, nz, sc0.dx, sc0.dt, 1000.0, [0.0, 0.0, -1.0], surface, z - 2 * sc0.dx, 100.0)
+    return sc, p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ps_oracle
+        sc, p = _scene()
+        og = ps_oracle.Oracle()
+        og.run(sc, p, solve=False)
+        sl = partition.make_slab(sc.nz, world, rank, p.tileSize)
+        loc = partition.local_scene(sc, sl)
+        ol = ps_oracle.Oracle()
+        ol.run(loc, p, solve=False)
+        ok = True
+        own_active = 0
+        for name, extra in (("centerLabels", 0), ("faceXLabels", 0), ("faceYLabels", 0), ("edgeXYLabels", 0),
+                            ("centerLiquidWeights", 0), ("faceZLabels", 0), ("edgeYZLabels", 0)):
+            g = og.array(name)
+            l = ol.array(name)
+            plane = g.size // (sc.nz + (1 if name.startswith(("faceZ", "edgeYZ", "edgeXZ")) else 0))
+            g = g.reshape(-1, plane)
+            l = l.reshape(-1, plane)
+            a, b = sl.zLoOwned, sl.zHiOwned
+            ok = ok and np.array_equal(l[a:b], g[sl.z0:sl.z1])
+            if name == "centerLabels":
+                own_active = int((l[a:b] == abi.ACTIVEFLUID).sum())
+        t = torch.tensor([own_active, int(ok)], dtype=torch.int64)
+        dist.all_reduce(t)
+        total_active = int((og.array("centerLabels") == abi.ACTIVEFLUID).sum())
+        q.put((rank, int(t[0]) == total_active, int(t[1]) == world))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slabs_reproduce_global_classification(world, oracle_mod):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(60)
+    assert all(a and b for _, a, b in res), res
+
+
+def test_slab_ranges_and_alignment():
+    assert partition.slab_ranges(256, 8, 16) == [(32 * r, 32 * (r + 1)) for r in range(8)]
+    assert partition.slab_ranges(80, 2, 16) == [(0, 48), (48, 80)]
+    assert partition.alignment(16) == 16 and partition.alignment(8) == 16 and partition.alignment(12) == 48
+    with pytest.raises(ValueError):
+        partition.slab_ranges(32, 4, 16)
+    sl = partition.make_slab(96, 3, 1, 16)
+    assert (sl.z0, sl.z1, sl.g0, sl.zLoOwned, sl.zHiOwned, sl.hasLower, sl.hasUpper, sl.nz_local) == (32, 64, 16, 16, 48, 1, 1, 64)
