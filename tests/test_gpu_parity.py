@@ -187,3 +187,73 @@ def test_noconverge_falls_back_to_bicgstab(gpu, oracle_mod):
     rc = gpu.step(sc, p)
     assert o.stats.usedBiCGStab == 1 and gpu.stats.usedBiCGStab == 1
     assert rc == o.result
+
+
+def test_export_component_matrices_roundtrip(gpu, oracle_mod, tmp_path):
+    """exportComponentMatrices / exportStats (Solver.cpp:543-606): MatrixMarket files with the reference's names,
+    read back with scipy and compared with the oracle's blocks (reference numbering)."""
+    import scipy.io
+    sc, p = scenes.blob(seed=7)
+    p.exportComponentMatrices = 1
+    o = oracle_mod.Oracle()
+    o.run(sc, p)
+    rc = gpu.step(sc, p)
+    assert rc == o.result
+    pre = str(tmp_path) + "/frame0001."
+    gpu.export_component_matrices(pre)
+    gpu.export_stats(pre)
+    for nm in ("G", "Dt", "JG", "JDt"):
+        M = scipy.io.mmread(pre + "Mat_%s.mtx" % nm).tocsr()
+        Mo = o.csr(nm)
+        assert M.shape == Mo.shape
+        d = abs(M - Mo)
+        assert (d.max() if d.nnz else 0.0) <= 1e-12 * max(abs(Mo).max(), 1e-300), nm
+    for nm, arr in (("Mat_McInv", "McInv"), ("Mat_uInv", "uInv"), ("Mat_Mc", "Mc"), ("Mat_u", "u")):
+        M = scipy.io.mmread(pre + nm + ".mtx").tocsr()
+        assert relerr(M.diagonal(), o.array(arr)) < 1e-13, nm
+    for nm, arr in (("Vec_activeRHS", "activeRHSVector"), ("Vec_pressureRHS", "pressureRHSVector"),
+                    ("Vec_stressRHS", "stressRHSVector"), ("Vec_b", "b")):
+        v = scipy.io.mmread(pre + nm + ".mtx").ravel()
+        assert relerr(v, o.array(arr)) < 1e-9, nm
+    dd = scipy.io.mmread(pre + "dimData.mtx").ravel()
+    assert list(dd) == list(o.stats.dimData)
+    sd = scipy.io.mmread(pre + "solveData.mtx").ravel()
+    assert sd[1] == gpu.stats.solveData[1]
+    head = open(pre + "Mat_G.mtx").readline()
+    assert head.startswith("%%MatrixMarket matrix coordinate  real general")     # MarketIO.h header text
+    assert open(pre + "Vec_b.mtx").readline().startswith("%%MatrixMarket matrix array real general")
+
+
+def test_no_liquid_and_all_solid(gpu, oracle_mod):
+    """Edge cases: an empty domain (no liquid anywhere) and liquid entirely inside a solid."""
+    n = 20
+    for surface, collision in ((1.0, 1.0), (-1.0, -1.0)):
+        sc = abi.Scene(n, n, n, 1.0 / n, 0.01, 1.0, [0.3, 0.0, 0.0], np.float32(surface), np.float32(collision), 1.0)
+        p = abi.default_params()
+        o = oracle_mod.Oracle()
+        ro = o.run(sc, p)
+        rg = gpu.step(sc, p)
+        assert rg == ro
+        assert list(gpu.stats.dimData) == list(o.stats.dimData)
+        for a in range(3):
+            assert np.array_equal(gpu.valid[a].ravel(), o.array("valid" + "XYZ"[a]))
+            assert np.array_equal(gpu.vel[a].ravel(), o.array("vel" + "XYZ"[a]))
+
+
+def test_input_weights_are_used_verbatim(gpu, oracle_mod):
+    """The shim may hand over the 14 volume-fraction fields sampled by HDK itself (ps_fields_in.weights)."""
+    sc, p = scenes.blob(seed=8)
+    o = oracle_mod.Oracle()
+    o.run(sc, p, solve=False)
+    w = [o.array(s + "LiquidWeights") for s in abi.SAMPLE_NAMES] + [o.array(s + "FluidWeights") for s in abi.SAMPLE_NAMES]
+    # hand them in under a different SDF: the result must follow the weights, not the SDF
+    sh = abi.grid_shapes(sc.nx, sc.ny, sc.nz)
+    sc2 = abi.Scene(sc.nx, sc.ny, sc.nz, sc.dx, sc.dt, sc.density, sc.vel, np.float32(5.0), np.float32(5.0), sc.viscosity,
+                    collisionvel=sc.collisionvel, weights=[w[i].reshape(sh[abi.SAMPLE_NAMES[i % 7]]) for i in range(14)])
+    o2 = oracle_mod.Oracle()
+    o2.run(sc2, p)
+    rc = gpu.step(sc2, p)
+    assert rc == o2.result
+    assert np.array_equal(gpu.array("centerLabels"), o.array("centerLabels"))
+    assert np.array_equal(gpu.array("edgeXZActiveIndices"), o2.array("edgeXZActiveIndices"))
+    assert abs(gpu.stats.solveData[1] - o2.stats.solveData[1]) <= 2
