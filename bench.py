@@ -129,15 +129,27 @@ def main():
         nsys_total = nsys
 
     # roofline of the dominant kernels, measured live with HIP events on the solver stream
+    coded = bool(solver.array("valuesCoded")[0])
     kern = {}
-    for name in ("spmv_St", "spmv_S", "apply"):
+    names = ["spmv_St", "spmv_S", "apply"] + (["spmv_St_fp64", "spmv_S_fp64"] if coded else [])
+    for name in names:
         ms, by = solver.bench_kernel(name, 20)
-        kern[name] = {"ms": ms, "algorithmic_bytes": by, "GBps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+        kern[name] = {"ms": ms, "algorithmic_bytes": by, "GBps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                      "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0}
     dom = "spmv_St"
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tp) and n == 256 and world == 1:
+        try:
+            traffic = json.load(open(tp)).get("k_spmv_St", {}).get("traffic_bytes_per_launch")
+        except Exception:
+            traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "k_spmv_St<0,6>", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+        "bound": "hbm", "kernel": "k_spmv_St_pipe<0,6,%s>" % ("int8-coded values" if coded else "fp64 values"),
+        "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": kern[dom]["frac"], "traffic": traffic,
         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_ms": kern[dom]["ms"],
+        "value_format": "int32 col + int8 value code (5 B/nnz, lossless)" if coded else "int32 col + fp64 value (12 B/nnz)",
         "other_kernels": {k: v for k, v in kern.items() if k != dom},
     }
 

@@ -33,7 +33,16 @@ struct BlockArgs {
     int64_t nCenter, nEdge0, nEdge1, nP, nA, faceOff[3];
     Own own;
     const int32_t* regionOwned;   // null: all owned
+    double valScale;              // invDx / 64
+    int32_t* codeFail;            // set to 1 if some value is not code * valScale
 };
+
+__device__ inline int8_t encodeVal(const BlockArgs& A, double v) {
+    const double q = v / A.valScale;
+    const double r = rint(q);
+    if (!(fabs(r) <= 127.) || r * A.valScale != v) { *A.codeFail = 1; return 0; }
+    return (int8_t)(int)r;
+}
 
 __device__ inline int64_t stressDOF(const BlockArgs& A, int64_t idx, int type) {   // Solver.h:586-606
     switch (type) {
@@ -190,7 +199,7 @@ __global__ void k_S_count(BlockArgs A, int axis, int32_t* __restrict__ rowCount)
 }
 // fill S; for active rows also the diagonal mass terms and rhs (ConstructMatrixBlocks.cpp:362-391)
 __global__ void k_S_fill(BlockArgs A, int axis, const int32_t* __restrict__ ptr, int32_t* __restrict__ col, double* __restrict__ val,
-                         double* __restrict__ McInv, double* __restrict__ rhsA, double* __restrict__ Mc, double* __restrict__ oldVs) {
+                         int8_t* __restrict__ code, double* __restrict__ McInv, double* __restrict__ rhsA, double* __restrict__ Mc, double* __restrict__ oldVs) {
     const int3 d = A.g.dims(1 + axis);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
@@ -201,7 +210,7 @@ __global__ void k_S_fill(BlockArgs A, int axis, const int32_t* __restrict__ ptr,
     const int n = faceEntries(A, axis, unlin3(d, c), cols, vals);
     sortEntries(n, cols, vals);
     const int p0 = ptr[row];
-    for (int q = 0; q < n; ++q) { col[p0 + q] = cols[q]; val[p0 + q] = vals[q]; }
+    for (int q = 0; q < n; ++q) { col[p0 + q] = cols[q]; val[p0 + q] = vals[q]; code[p0 + q] = encodeVal(A, vals[q]); }
     if (row < A.nA) {
         double volume = (double)A.fw[1 + axis][c] * (double)A.lw[1 + axis][c];
         const double lo = 0.1 * 0.1;   // MINWEIGHT * MINWEIGHT, :365
@@ -328,7 +337,7 @@ __device__ inline void sortRows(int n, int32_t* rows, double* vals) {
 // and the stress diagonals uInv (/u) (ConstructMatrixBlocks.cpp:737-867).
 template <bool FILL>
 __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t* __restrict__ ptr, int32_t* __restrict__ col,
-                           double* __restrict__ val, double* __restrict__ rhsPT, double* __restrict__ uInv, double* __restrict__ uDiag) {
+                           double* __restrict__ val, int8_t* __restrict__ code, double* __restrict__ rhsPT, double* __restrict__ uInv, double* __restrict__ uDiag) {
     const int3 d = A.g.dims(0);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
@@ -353,7 +362,7 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
         if (!FILL) { cnt[j] = n; continue; }
         sortRows(n, rows, vals);
         const int p0 = ptr[j];
-        for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; }
+        for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; code[p0 + k] = encodeVal(A, vals[k]); }
         rhsPT[j] = rhs;
         uInv[j] = mode > 0 ? uinvv : 0.;      // full-length diagonal, zero on pressure rows
         if (uDiag) uDiag[j] = mode > 0 ? uv : 0.;
@@ -362,7 +371,7 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
 // edges: column tau_e (ConstructMatrixBlocks.cpp:651-735 for the diagonal)
 template <bool FILL>
 __global__ void k_St_edges(BlockArgs A, int ea, int32_t* __restrict__ cnt, const int32_t* __restrict__ ptr, int32_t* __restrict__ col,
-                           double* __restrict__ val, double* __restrict__ rhsPT, double* __restrict__ uInv, double* __restrict__ uDiag) {
+                           double* __restrict__ val, int8_t* __restrict__ code, double* __restrict__ rhsPT, double* __restrict__ uInv, double* __restrict__ uDiag) {
     const int3 d = A.g.dims(4 + ea);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
@@ -377,7 +386,7 @@ __global__ void k_St_edges(BlockArgs A, int ea, int32_t* __restrict__ cnt, const
     if (!FILL) { cnt[j] = n; return; }
     sortRows(n, rows, vals);
     const int p0 = ptr[j];
-    for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; }
+    for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; code[p0 + k] = encodeVal(A, vals[k]); }
     rhsPT[j] = rhs;
     const double vw = clampd((double)A.fw[4 + ea][c], 0.1, 1.0) * (double)A.lw[4 + ea][c];
     const float ox = ea == 0 ? 0.5f : 0.f, oy = ea == 1 ? 0.5f : 0.f, oz = ea == 2 ? 0.5f : 0.f;
@@ -400,6 +409,8 @@ BlockArgs makeArgs(ps_context* c) {
     A.nP = c->nPressures; A.nA = c->nActiveVs;
     A.faceOff[0] = 0; A.faceOff[1] = c->nFace[0]; A.faceOff[2] = c->nFace[0] + c->nFace[1];
     A.own = c->own();
+    A.valScale = c->valScale;
+    A.codeFail = c->counters.p + 20;
     A.regionOwned = (c->slabEnabled && c->regionCount > 0) ? c->regionOwned.p : nullptr;
     return A;
 }
@@ -416,6 +427,8 @@ void ps_context::constructMatrixBlocks() {
     nTotalDOFs = nActiveVs + nReducedVs + nPressures + nStresses;
     if (nSystem >= 0x7fffffff || nActiveVs >= 0x7fffffff) throw Error("system too large for 32-bit DOF indices");
 
+    valScale = invDx / 64.;
+    HIP_CHECK(hipMemsetAsync(counters.p + 20, 0, sizeof(int32_t), stream));
     buildInternalNumbering();   // sysIdx[], faceRow[] (active rows), permSys, permRow
     buildHaloLists();
     BlockArgs A = makeArgs(this);
@@ -483,10 +496,10 @@ void ps_context::constructMatrixBlocks() {
         if (tot < 0) throw Error("nnz(S) overflows 32-bit row pointers");
         S.nnz = tot;
     }
-    S.col.alloc((size_t)S.nnz); S.val.alloc((size_t)S.nnz);
+    S.col.alloc((size_t)S.nnz); S.val.alloc((size_t)S.nnz); S.code.alloc((size_t)S.nnz);
     for (int a = 0; a < 3; ++a) {
         const int64_t n = g.count(1 + a);
-        hipLaunchKernelGGL(k_S_fill, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, S.ptr.p, S.col.p, S.val.p, McInv.p, rhsA.p,
+        hipLaunchKernelGGL(k_S_fill, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, S.ptr.p, S.col.p, S.val.p, S.code.p, McInv.p, rhsA.p,
                            wantExport ? Mc.p : (double*)nullptr, wantExport ? oldVs.p : (double*)nullptr);
     }
     // St
@@ -496,21 +509,30 @@ void ps_context::constructMatrixBlocks() {
     {
         const int64_t n = g.count(0);
         hipLaunchKernelGGL(k_St_cells<false>, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, St.ptr.p, (const int32_t*)nullptr,
-                           (int32_t*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+                           (int32_t*)nullptr, (double*)nullptr, (int8_t*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr);
         for (int e = 0; e < 3; ++e) {
             const int64_t ne = g.count(4 + e);
             hipLaunchKernelGGL(k_St_edges<false>, dim3(gridFor(ne, BS)), dim3(BS), 0, stream, A, e, St.ptr.p, (const int32_t*)nullptr,
-                               (int32_t*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+                               (int32_t*)nullptr, (double*)nullptr, (int8_t*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr);
         }
         St.nnz = exclusiveScanI32(St.ptr.p, nSystem + 1);
         if (St.nnz != S.nnz) throw Error("internal: nnz(S^T) != nnz(S)");
-        St.col.alloc((size_t)St.nnz); St.val.alloc((size_t)St.nnz);
-        hipLaunchKernelGGL(k_St_cells<true>, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, (int32_t*)nullptr, St.ptr.p, St.col.p, St.val.p,
+        St.col.alloc((size_t)St.nnz); St.val.alloc((size_t)St.nnz); St.code.alloc((size_t)St.nnz);
+        hipLaunchKernelGGL(k_St_cells<true>, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, (int32_t*)nullptr, St.ptr.p, St.col.p, St.val.p, St.code.p,
                            rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
         for (int e = 0; e < 3; ++e) {
             const int64_t ne = g.count(4 + e);
             hipLaunchKernelGGL(k_St_edges<true>, dim3(gridFor(ne, BS)), dim3(BS), 0, stream, A, e, (int32_t*)nullptr, St.ptr.p, St.col.p,
-                               St.val.p, rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
+                               St.val.p, St.code.p, rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
         }
+    }
+    {
+        const char* e = getenv("PS_FORCE_FP64_VALUES");
+        forceFp64Values = e && atoi(e) != 0;
+        const bool ok = readCounter(20) == 0;
+        S.packed = St.packed = ok && !forceFp64Values;
+        const int32_t flag = S.packed ? 1 : 0;
+        HIP_CHECK(hipMemcpyAsync(counters.p + 21, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
     }
 }

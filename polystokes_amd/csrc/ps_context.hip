@@ -256,6 +256,7 @@ void ps_context::registerArrays() {
         regp("recoveredActiveVelocity", recovered.p, nActiveVs, permRow.p, 0);
         reg("recoveredReducedVelocity", recovered.p ? recovered.p + nActiveVs : nullptr, nReducedVs, 8);
     }
+    reg("valuesCoded", counters.p + 21, 1, 4);
     reg("sysPerm", permSys.p, nSystem, 4);
     reg("rowPerm", permRow.p, nActiveVs, 4);
     reg("S.ptr", S.ptr.p, S.rows + 1, 4); reg("S.col", S.col.p, S.nnz, 4); reg("S.val", S.val.p, S.nnz, 8);
@@ -498,11 +499,14 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             // CSR with fp64 values, int32 columns, int32 row pointers:
             // 12 nnz + 4 (rows+1) + 8 rows (y) + 8 cols (x read once) + fused diagonal / x reads of the epilogue
             const double nnz = (double)c->S.nnz, rowsS = (double)c->nRows, rowsT = (double)c->nSystem;
-            const double bS = 12. * nnz + 4. * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
-            const double bT = 12. * nnz + 4. * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * rowsT;
-            if (k == "spmv_S") *algorithmic_bytes = bS;
-            else if (k == "spmv_St") *algorithmic_bytes = bT;
-            else if (k == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);
+            const bool fp64 = k.size() > 5 && k.compare(k.size() - 5, 5, "_fp64") == 0;
+            const std::string kb = fp64 ? k.substr(0, k.size() - 5) : k;
+            const double perNnz = (c->S.packed && !fp64) ? 5. : 12.;   // int32 column + (int8 value code | fp64 value)
+            const double bS = perNnz * nnz + 4. * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
+            const double bT = perNnz * nnz + 4. * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * rowsT;
+            if (kb == "spmv_S") *algorithmic_bytes = bS;
+            else if (kb == "spmv_St") *algorithmic_bytes = bT;
+            else if (kb == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);
             else *algorithmic_bytes = 0;
         }
         return PS_SUCCESS;

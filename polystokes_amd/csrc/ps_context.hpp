@@ -12,6 +12,11 @@ struct DevCSR {
     DevBuf<int32_t> ptr;   // rows+1 (nnz < 2^31 is enforced)
     DevBuf<int32_t> col;
     DevBuf<double> val;
+    // Lossless value coding: every stencil value is code * scale with an integer |code| <= 127 whenever the volume
+    // fractions are multiples of 1/8 (the 2x2x2 sampler): val = +-(wF*wL)/dx = +-(8wF * 8wL) * (1/(64 dx)).
+    // The fill kernels verify code*scale == val bit for bit; if any entry fails, the SpMV streams `val` instead.
+    DevBuf<int8_t> code;
+    bool packed = false;
 };
 
 // device-resident CG scalars (no host round trip inside the iteration)
@@ -43,6 +48,8 @@ struct ps_context {
     ps_params P{};
     ps::Grid g{0, 0, 0, 0};
     double dx = 0, invDx = 0, dt = 0, invDt = 0, rho = 0;
+    double valScale = 0;      // invDx / 64
+    bool forceFp64Values = false;   // env PS_FORCE_FP64_VALUES=1: never use the coded values (A/B and fallback testing)
     bool haveInputWeights = false;
     bool uploaded = false, isSetup = false, isSolved = false;
 

@@ -51,92 +51,262 @@ __device__ inline double blockReduceSum(double v) {
 // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its
 // 4 MiB L2).  Give each XCD one contiguous range of row blocks so that the x / t entries gathered by neighbouring
 // row blocks (same 16^3 spatial block in the interleaved numbering) are fetched into ONE L2 instead of eight.
+__device__ int g_swizzle = 0;   // experiment switch (PS_SWIZZLE=1): XCD-contiguous row-block mapping
 __device__ inline int xcdSwizzle(int b, int nb) {
-    const int q = nb >> 3, rem = nb & 7;
-    const int xcd = b & 7, idx = b >> 3;
-    return xcd * q + min(xcd, rem) + idx;
+    // g_swizzle = G > 1: within every chunk of 8*G consecutive row blocks, XCD k (= b % 8) gets the G consecutive
+    // logical blocks [k*G, (k+1)*G) — neighbouring row blocks share an L2 while all XCDs stream the same region.
+    const int G = g_swizzle;
+    const int chunk = 8 * G;
+    const int base = (b / chunk) * chunk;
+    if (base + chunk > nb) return b;   // ragged tail: identity
+    const int l = b - base;
+    return base + (l & 7) * G + (l >> 3);
 }
 
 // Streaming phase of the CSR-stream SpMV: the block's contiguous nnz range [p0,p1) (<= BS*MAXNNZ entries)
 // is read with a fixed-trip, fully unrolled loop so that all MAXNNZ (col,val) loads of a thread — and then
 // all MAXNNZ gathers — are in flight together (memory-level parallelism instead of a dependent chain).
-template <int MAXNNZ>
-__device__ inline void streamProducts(const int32_t* __restrict__ col, const double* __restrict__ val, const double* __restrict__ x,
-                                      int p0, int p1, double* __restrict__ prod) {
-    int c[MAXNNZ];
-    double v[MAXNNZ];
+template <int SLOTS, bool PACKED>
+__device__ inline void streamProducts(const int32_t* __restrict__ col, const double* __restrict__ val, const int8_t* __restrict__ code,
+                                      double scale, const double* __restrict__ x, int p0, int p1, double* __restrict__ prod) {
+    int c[SLOTS];
+    double v[SLOTS];
 #pragma unroll
-    for (int u = 0; u < MAXNNZ; ++u) {
+    for (int u = 0; u < SLOTS; ++u) {
         const int p = p0 + threadIdx.x + u * BS;
         const bool ok = p < p1;
         c[u] = ok ? __builtin_nontemporal_load(col + p) : -1;
-        v[u] = ok ? __builtin_nontemporal_load(val + p) : 0.;
+        if (PACKED) v[u] = ok ? (double)__builtin_nontemporal_load(code + p) * scale : 0.;   // exact: see DevCSR::code
+        else v[u] = ok ? __builtin_nontemporal_load(val + p) : 0.;
     }
-    double xv[MAXNNZ];
+    double xv[SLOTS];
 #pragma unroll
-    for (int u = 0; u < MAXNNZ; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.;
+    for (int u = 0; u < SLOTS; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.;
 #pragma unroll
-    for (int u = 0; u < MAXNNZ; ++u)
+    for (int u = 0; u < SLOTS; ++u)
         if (c[u] >= 0) prod[threadIdx.x + u * BS] = v[u] * xv[u];
 }
 
 // ---- CSR-stream SpMV ------------------------------------------------------------------------------
+// A block owns BS*RPT consecutive rows (thread t: rows r0 + t + q*BS, q < RPT).  RPT > 1 puts more independent
+// loads in flight per lane (the coded-value stream is only 5 B/nnz, so latency, not bytes, is what has to be hidden).
 // MODE 0: out[row] = (row < nA ? dt*McInv[row] : 1) * (S x)[row]     (operator, forward half)
 // MODE 1: out[row] = (S x)[row]                                       (velocity recovery)
-template <int MODE, int MAXNNZ>
+template <int MODE, int MAXNNZ, bool PACKED, int RPT>
 __global__ void __launch_bounds__(BS) k_spmv_S(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                               const double* __restrict__ x, int rows, int nA, double dt, const double* __restrict__ McInv,
-                                               double* __restrict__ out, const int* __restrict__ done) {
+                                               const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
+                                               double dt, const double* __restrict__ McInv, double* __restrict__ out,
+                                               const int* __restrict__ done) {
     if (done && *done) return;
-    __shared__ double prod[BS * MAXNNZ];
-    const int r0 = blockIdx.x * BS;   // plain mapping: the XCD-contiguous swizzle measured 4-12 % slower here
-    const int r1 = min(r0 + BS, rows);
+    __shared__ double prod[BS * MAXNNZ * RPT];
+    const int r0 = blockIdx.x * (BS * RPT);
+    const int r1 = min(r0 + BS * RPT, rows);
     const int p0 = ptr[r0], p1 = ptr[r1];
-    streamProducts<MAXNNZ>(col, val, x, p0, p1, prod);
+    // per-row loads that do not depend on the stream: issue them first
+    int pa[RPT], pb[RPT];
+    double sc[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int row = r0 + threadIdx.x + q * BS;
+        const bool ok = row < rows;
+        pa[q] = ok ? ptr[row] : 0;
+        pb[q] = ok ? ptr[row + 1] : 0;
+        sc[q] = (MODE == 0 && ok && row < nA) ? dt * McInv[row] : 1.;
+    }
+    streamProducts<MAXNNZ * RPT, PACKED>(col, val, code, scale, x, p0, p1, prod);
     __syncthreads();
-    const int row = r0 + threadIdx.x;
-    if (row < rows) {
-        const int a = ptr[row] - p0, b = ptr[row + 1] - p0;
-        double s = 0.;
-        for (int q = a; q < b; ++q) s += prod[q];
-        if (MODE == 0 && row < nA) s *= dt * McInv[row];
-        out[row] = s;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int row = r0 + threadIdx.x + q * BS;
+        if (row < rows) {
+            double s = 0.;
+            for (int e = pa[q] - p0; e < pb[q] - p0; ++e) s += prod[e];
+            out[row] = s * sc[q];
+        }
     }
 }
-// MODE 0: out[j] = -(St t)[j] - (j>=nP ? 0.5*uInv[j-nP]*xin[j] : 0);  partial[block] = sum xin[j]*out[j]
+// MODE 0: out[j] = -(St t)[j] - 0.5*uInv[j]*xin[j];  partial[block] = sum xin[j]*out[j]
 // MODE 1: out[j] = -(St t)[j] + add[j]                                   (right-hand side b)
-template <int MODE, int MAXNNZ>
+template <int MODE, int MAXNNZ, bool PACKED, int RPT>
 __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                const double* __restrict__ t, int rows, int nP, const double* __restrict__ uInv,
-                                                const double* __restrict__ xin, const double* __restrict__ add, double* __restrict__ out,
-                                                double* __restrict__ partial, const int* __restrict__ done) {
+                                                const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
+                                                const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
+                                                double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done) {
     if (done && *done) return;
-    __shared__ double prod[BS * MAXNNZ];
-    const int r0 = blockIdx.x * BS;   // plain mapping: the XCD-contiguous swizzle measured 4-12 % slower here
-    const int r1 = min(r0 + BS, rows);
+    __shared__ double prod[BS * MAXNNZ * RPT];
+    const int r0 = blockIdx.x * (BS * RPT);
+    const int r1 = min(r0 + BS * RPT, rows);
     const int p0 = ptr[r0], p1 = ptr[r1];
-    streamProducts<MAXNNZ>(col, val, t, p0, p1, prod);
+    int pa[RPT], pb[RPT];
+    double e0[RPT], e1[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int row = r0 + threadIdx.x + q * BS;
+        const bool ok = row < rows;
+        pa[q] = ok ? ptr[row] : 0;
+        pb[q] = ok ? ptr[row + 1] : 0;
+        if (MODE == 0) { e0[q] = ok ? xin[row] : 0.; e1[q] = ok ? uInv[row] : 0.; }   // uInv is full length (0 on pressure rows)
+        else { e0[q] = ok ? add[row] : 0.; e1[q] = 0.; }
+    }
+    streamProducts<MAXNNZ * RPT, PACKED>(col, val, code, scale, t, p0, p1, prod);
     __syncthreads();
-    const int row = r0 + threadIdx.x;
     double d = 0.;
-    if (row < rows) {
-        const int a = ptr[row] - p0, b = ptr[row + 1] - p0;
-        double s = 0.;
-        for (int q = a; q < b; ++q) s += prod[q];
-        double y;
-        if (MODE == 0) {
-            const double xv = xin[row];
-            y = -s;
-            y -= 0.5 * uInv[row] * xv;   // uInv is full length (0 on pressure rows)
-            d = xv * y;
-        } else {
-            y = -s + add[row];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int row = r0 + threadIdx.x + q * BS;
+        if (row < rows) {
+            double s = 0.;
+            for (int e = pa[q] - p0; e < pb[q] - p0; ++e) s += prod[e];
+            double y;
+            if (MODE == 0) {
+                y = -s;
+                y -= 0.5 * e1[q] * e0[q];
+                d += e0[q] * y;
+            } else {
+                y = -s + e0[q];
+            }
+            out[row] = y;
         }
-        out[row] = y;
     }
     if (MODE == 0) {
         const double bs = blockReduceSum(d);
         if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+    }
+}
+
+
+// ---- software-pipelined persistent variants ---------------------------------------------------------
+// PMC (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 85 %) shows the one-shot kernels above are latency bound: every block walks
+// three dependent memory round trips (row-pointer bounds -> (col,code) stream -> gather) at the occupancy cap of
+// 8 waves/SIMD.  Here a block loops over row chunks (grid = #CUs x 8) and, while the gathers / LDS reduction of
+// chunk i are in flight, the (col,code) stream of chunk i+1 is already loading into a second register set and the
+// bounds of chunk i+2 are being fetched.
+template <bool PACKED> struct RawVal { using type = double; };
+template <> struct RawVal<true> { using type = int; };   // the int8 code, widened: 1 VGPR instead of 2 in the prefetch set
+template <int SLOTS, bool PACKED>
+__device__ inline void loadStream(const int32_t* __restrict__ col, const double* __restrict__ val, const int8_t* __restrict__ code,
+                                  int p0, int p1, int (&c)[SLOTS], typename RawVal<PACKED>::type (&v)[SLOTS]) {
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int p = p0 + threadIdx.x + u * BS;
+        const bool ok = p < p1;
+        c[u] = ok ? __builtin_nontemporal_load(col + p) : -1;
+        if constexpr (PACKED) v[u] = ok ? (int)__builtin_nontemporal_load(code + p) : 0;
+        else v[u] = ok ? __builtin_nontemporal_load(val + p) : 0.;
+    }
+}
+template <bool PACKED>
+__device__ inline double rawToVal(typename RawVal<PACKED>::type r, double scale) {
+    if constexpr (PACKED) return (double)r * scale;   // exact: see DevCSR::code
+    else return r;
+}
+template <int MODE, int MAXNNZ, bool PACKED>
+__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                    const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
+                                                    double dt, const double* __restrict__ McInv, double* __restrict__ out,
+                                                    const int* __restrict__ done, int nChunks) {
+    if (done && *done) return;
+    __shared__ double prod[BS * MAXNNZ];
+    int chunk = blockIdx.x;
+    if (chunk >= nChunks) return;
+    int r0 = chunk * BS;
+    int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
+    int c[MAXNNZ];
+    typename RawVal<PACKED>::type v[MAXNNZ];
+    loadStream<MAXNNZ, PACKED>(col, val, code, p0, p1, c, v);
+    int nchunk = chunk + gridDim.x;
+    int np0 = 0, np1 = 0;
+    if (nchunk < nChunks) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
+    while (true) {
+        const int row = r0 + threadIdx.x;
+        const bool ok = row < rows;
+        const int pa = ok ? ptr[row] : 0, pb = ok ? ptr[row + 1] : 0;
+        const double sc = (MODE == 0 && ok && row < nA) ? dt * McInv[row] : 1.;
+        double xv[MAXNNZ];
+#pragma unroll
+        for (int u = 0; u < MAXNNZ; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.;
+        const bool hasNext = nchunk < nChunks;
+        int c2[MAXNNZ];
+        typename RawVal<PACKED>::type v2[MAXNNZ];
+        if (hasNext) loadStream<MAXNNZ, PACKED>(col, val, code, np0, np1, c2, v2);
+        const int nn = nchunk + gridDim.x;
+        int nnp0 = 0, nnp1 = 0;
+        if (nn < nChunks) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
+#pragma unroll
+        for (int u = 0; u < MAXNNZ; ++u)
+            if (c[u] >= 0) prod[threadIdx.x + u * BS] = rawToVal<PACKED>(v[u], scale) * xv[u];
+        __syncthreads();
+        if (ok) {
+            double s = 0.;
+            for (int e = pa - p0; e < pb - p0; ++e) s += prod[e];
+            out[row] = s * sc;
+        }
+        __syncthreads();
+        if (!hasNext) break;
+        chunk = nchunk; r0 = chunk * BS; p0 = np0; p1 = np1;
+#pragma unroll
+        for (int u = 0; u < MAXNNZ; ++u) { c[u] = c2[u]; v[u] = v2[u]; }
+        nchunk = nn; np0 = nnp0; np1 = nnp1;
+    }
+}
+template <int MODE, int MAXNNZ, bool PACKED>
+__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                     const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
+                                                     const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
+                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done, int nChunks) {
+    if (done && *done) return;
+    __shared__ double prod[BS * MAXNNZ];
+    int chunk = blockIdx.x;
+    if (chunk >= nChunks) return;
+    int r0 = chunk * BS;
+    int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
+    int c[MAXNNZ];
+    typename RawVal<PACKED>::type v[MAXNNZ];
+    loadStream<MAXNNZ, PACKED>(col, val, code, p0, p1, c, v);
+    int nchunk = chunk + gridDim.x;
+    int np0 = 0, np1 = 0;
+    if (nchunk < nChunks) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
+    while (true) {
+        const int row = r0 + threadIdx.x;
+        const bool ok = row < rows;
+        const int pa = ok ? ptr[row] : 0, pb = ok ? ptr[row + 1] : 0;
+        double e0, e1 = 0.;
+        if (MODE == 0) { e0 = ok ? xin[row] : 0.; e1 = ok ? uInv[row] : 0.; }
+        else e0 = ok ? add[row] : 0.;
+        double xv[MAXNNZ];
+#pragma unroll
+        for (int u = 0; u < MAXNNZ; ++u) xv[u] = c[u] >= 0 ? t[c[u]] : 0.;
+        const bool hasNext = nchunk < nChunks;
+        int c2[MAXNNZ];
+        typename RawVal<PACKED>::type v2[MAXNNZ];
+        if (hasNext) loadStream<MAXNNZ, PACKED>(col, val, code, np0, np1, c2, v2);
+        const int nn = nchunk + gridDim.x;
+        int nnp0 = 0, nnp1 = 0;
+        if (nn < nChunks) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
+#pragma unroll
+        for (int u = 0; u < MAXNNZ; ++u)
+            if (c[u] >= 0) prod[threadIdx.x + u * BS] = rawToVal<PACKED>(v[u], scale) * xv[u];
+        __syncthreads();
+        double d = 0.;
+        if (ok) {
+            double s = 0.;
+            for (int e = pa - p0; e < pb - p0; ++e) s += prod[e];
+            double y;
+            if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; d = e0 * y; }
+            else y = -s + e0;
+            out[row] = y;
+        }
+        if (MODE == 0) {
+            const double bs = blockReduceSum(d);   // two barriers inside: also protects the LDS reuse
+            if (threadIdx.x == 0) partial[chunk] = bs;
+        } else {
+            __syncthreads();
+        }
+        if (!hasNext) break;
+        chunk = nchunk; r0 = chunk * BS; p0 = np0; p1 = np1;
+#pragma unroll
+        for (int u = 0; u < MAXNNZ; ++u) { c[u] = c2[u]; v[u] = v2[u]; }
+        nchunk = nn; np0 = nnp0; np1 = nnp1;
     }
 }
 
@@ -433,13 +603,32 @@ struct Launch {
     ps_context* c;
     const int* done;
     int rowsS, rowsSt, nA, nP;
+    int rptS, rptT;   // rows per thread
+    template <int RPT>
+    void spmvS_(int mode, const double* x, double* out) const {
+        const dim3 gr(gridFor(rowsS, BS * RPT)), bl(BS);
+        const ps::DevCSR& M = c->S;
+#define PS_LAUNCH_S(MODE_, PK_) hipLaunchKernelGGL((k_spmv_S<MODE_, 8, PK_, RPT>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
+                                                   c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done)
+        if (mode == 0) { if (M.packed) PS_LAUNCH_S(0, true); else PS_LAUNCH_S(0, false); }
+        else { if (M.packed) PS_LAUNCH_S(1, true); else PS_LAUNCH_S(1, false); }
+#undef PS_LAUNCH_S
+    }
+    int pipeGrid;   // 0: one-shot kernels; >0: persistent software-pipelined kernels with this many blocks
     void spmvS(int mode, const double* x, double* out) const {
-        const dim3 gr(gridFor(rowsS, BS)), bl(BS);
         if (rowsS == 0) return;
-        if (mode == 0)
-            hipLaunchKernelGGL((k_spmv_S<0, 8>), gr, bl, 0, c->stream, c->S.ptr.p, c->S.col.p, c->S.val.p, x, rowsS, nA, c->dt, c->McInv.p, out, done);
-        else
-            hipLaunchKernelGGL((k_spmv_S<1, 8>), gr, bl, 0, c->stream, c->S.ptr.p, c->S.col.p, c->S.val.p, x, rowsS, nA, c->dt, c->McInv.p, out, done);
+        if (pipeGrid > 0 && c->S.packed) {   // fp64 values: the one-shot kernel is faster (register pressure of the prefetch set)
+            const int nChunks = gridFor(rowsS, BS);
+            const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
+            const ps::DevCSR& M = c->S;
+#define PS_LAUNCH_SP(MODE_, PK_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, 8, PK_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
+                                                    c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks)
+            if (mode == 0) { if (M.packed) PS_LAUNCH_SP(0, true); else PS_LAUNCH_SP(0, false); }
+            else { if (M.packed) PS_LAUNCH_SP(1, true); else PS_LAUNCH_SP(1, false); }
+#undef PS_LAUNCH_SP
+            return;
+        }
+        if (rptS == 4) spmvS_<4>(mode, x, out); else if (rptS == 2) spmvS_<2>(mode, x, out); else spmvS_<1>(mode, x, out);
     }
     void tiles(int mode, double* ts) const {   // ts: face-row vector; reduced part rewritten in place
         if (c->regionCount == 0) return;
@@ -458,21 +647,44 @@ struct Launch {
             hipLaunchKernelGGL(k_tile_expand, dim3(gridFor(c->nReducedRows, BS)), dim3(BS), 0, c->stream, c->rrowFace.p, c->rrowRegion.p,
                                (int)c->nReducedRows, c->COM.p, c->dx, c->vreg.p, sred, done);
     }
-    void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
-        const dim3 gr(gridFor(rowsSt, BS)), bl(BS);
-        if (rowsSt == 0) return;
-        if (mode == 0)
-            hipLaunchKernelGGL((k_spmv_St<0, 6>), gr, bl, 0, c->stream, c->St.ptr.p, c->St.col.p, c->St.val.p, t, rowsSt, nP, c->uInv.p, xin, add,
-                               out, partial, done);
-        else
-            hipLaunchKernelGGL((k_spmv_St<1, 6>), gr, bl, 0, c->stream, c->St.ptr.p, c->St.col.p, c->St.val.p, t, rowsSt, nP, c->uInv.p, xin, add,
-                               out, partial, done);
+    template <int RPT>
+    void spmvSt_(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
+        const dim3 gr(gridFor(rowsSt, BS * RPT)), bl(BS);
+        const ps::DevCSR& M = c->St;
+#define PS_LAUNCH_T(MODE_, PK_) hipLaunchKernelGGL((k_spmv_St<MODE_, 6, PK_, RPT>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
+                                                   c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done)
+        if (mode == 0) { if (M.packed) PS_LAUNCH_T(0, true); else PS_LAUNCH_T(0, false); }
+        else { if (M.packed) PS_LAUNCH_T(1, true); else PS_LAUNCH_T(1, false); }
+#undef PS_LAUNCH_T
     }
+    void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
+        if (rowsSt == 0) return;
+        if (pipeGrid > 0 && c->St.packed) {
+            const int nChunks = gridFor(rowsSt, BS);
+            const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
+            const ps::DevCSR& M = c->St;
+#define PS_LAUNCH_TP(MODE_, PK_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, 6, PK_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
+                                                    c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done, nChunks)
+            if (mode == 0) { if (M.packed) PS_LAUNCH_TP(0, true); else PS_LAUNCH_TP(0, false); }
+            else { if (M.packed) PS_LAUNCH_TP(1, true); else PS_LAUNCH_TP(1, false); }
+#undef PS_LAUNCH_TP
+            return;
+        }
+        if (rptT == 4) spmvSt_<4>(mode, t, xin, add, out, partial); else if (rptT == 2) spmvSt_<2>(mode, t, xin, add, out, partial);
+        else spmvSt_<1>(mode, t, xin, add, out, partial);
+    }
+    int stBlocks() const { return (pipeGrid > 0 && c->St.packed) ? gridFor(rowsSt, BS) : gridFor(rowsSt, BS * rptT); }   // number of p.Ap partials the St kernel writes
 };
 Launch mk(ps_context* c, const int* done) {
     Launch L;
     L.c = c; L.done = done;
     L.rowsS = (int)c->nRows; L.rowsSt = (int)c->nSystem; L.nA = (int)c->nActiveVs; L.nP = (int)c->nPressures;
+    static int rS = -1, rT = -1, pg = 0;
+    if (rS < 0) {
+        const char* a = getenv("PS_RPT_S"); const char* b = getenv("PS_RPT_ST"); const char* g = getenv("PS_PIPE_GRID");
+        rS = a ? atoi(a) : 1; rT = b ? atoi(b) : 1; pg = g ? atoi(g) : 4096;   // persistent pipelined kernels by default
+    }
+    L.rptS = rS; L.rptT = rT; L.pipeGrid = pg;
     return L;
 }
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
@@ -527,10 +739,10 @@ int ps_context::solve() {
     if (n == 0) { solveIterations = 0; solveError = 0; return PS_SUCCESS; }
     const double* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinv.p : nullptr;
     const int vb = dotBlocks(n);
-    const int stBlocks = gridFor(n, BS);
     CGScalars* sc = scal.p;
     const int* done = &sc->done;
     Launch L = mk(this, done);
+    const int stBlocks = L.stBlocks();
 
     hipLaunchKernelGGL(k_cg_init, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
     hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, tol, maxit);
@@ -631,11 +843,24 @@ void ps_context::applySolutionToVelocity() {
 
 // micro-benchmark dispatch for ps_bench_kernel (bench.py roofline object)
 void ps_bench_launch(ps_context* c, const std::string& k, const double* x, double* y) {
+    static int once = 0;
+    if (!once) {
+        once = 1;
+        const char* e = getenv("PS_SWIZZLE");
+        const int v = e ? atoi(e) : 0;
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_swizzle), &v, sizeof(int)));
+    }
     Launch L = mk(c, nullptr);
-    if (k == "spmv_S") L.spmvS(0, x, c->ts.p);
-    else if (k == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
-    else if (k == "apply") c->applyOperator(x, y, c->dotPartials.p);
-    else throw Error("unknown kernel name: " + k);
+    // "<name>_fp64": the same kernel streaming the fp64 value array instead of the int8 codes (A/B of the two formats)
+    const bool fp64 = k.size() > 5 && k.compare(k.size() - 5, 5, "_fp64") == 0;
+    const std::string base = fp64 ? k.substr(0, k.size() - 5) : k;
+    const bool keepS = c->S.packed, keepT = c->St.packed;
+    if (fp64) { c->S.packed = false; c->St.packed = false; }
+    if (base == "spmv_S") L.spmvS(0, x, c->ts.p);
+    else if (base == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
+    else if (base == "apply") c->applyOperator(x, y, c->dotPartials.p);
+    else { c->S.packed = keepS; c->St.packed = keepT; throw Error("unknown kernel name: " + k); }
+    c->S.packed = keepS; c->St.packed = keepT;
 }
 
 // =====================================================================================================
@@ -887,10 +1112,10 @@ struct Dist {
             Loc& l = loc[q];
             l.lo = c->ownLo; l.n = c->ownHi - c->ownLo;
             l.vb = dotBlocks(std::max<int64_t>(l.n, 1));
-            l.stBlocks = gridFor(std::max<int64_t>(c->nSystem, 1), BS);
             l.dv = jac ? c->dinv.p + l.lo : nullptr;
             l.sc = c->scal.p;
             l.L = mk(c, &l.sc->done);
+            l.stBlocks = l.L.stBlocks();
             c->usedBiCGStab = 0;
         }
         // r = b, x = 0, p = z on the owned range; rsold = sum over ranks of r.z
