@@ -1,0 +1,92 @@
+"""BASELINE-size checks (256^3 cavity, tile 16 / pad 2) through size-independent properties: the oracle cannot run
+this size in seconds, so the HIP path is checked against closed forms and against its own invariants."""
+import numpy as np
+import pytest
+
+from polystokes_amd import _abi as abi
+from polystokes_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+N = 256
+
+
+@pytest.fixture(scope="module")
+def big():
+    import polystokes_amd
+    sc, p = scenes.cavity(N, precond=abi.PRE_DIAGONAL)
+    s = polystokes_amd.Solver(0)
+    s.upload(sc, p)
+    s.setup()
+    yield sc, p, s
+    s.close()
+
+
+def test_closed_form_dof_counts(big):
+    sc, p, s = big
+    T, P, S = 16, 2, 2
+    # per axis: tiles of 14 reduced cells, the last tile loses S layers to the domain-boundary solid layer (first tile's
+    # boundary layer coincides with its padding)
+    red_axis = (N // T) * (T - P) - S
+    dd = s.stats.dimData
+    assert dd[24] == (N // T) ** 3                                   # one region per tile
+    assert dd[0] == N ** 3 - red_axis ** 3                           # active cells = pressures
+    lab = s.array("centerLabels")
+    assert (lab == abi.REDUCED).sum() == red_axis ** 3
+    assert dd[12] == dd[0] and dd[13] == 3 * dd[0] + dd[4] + dd[5] + dd[6]
+    # active + reduced faces tile the whole face grid (all-liquid box: no UNSOLVED / SOLID faces)
+    fl = s.array("faceXLabels")
+    assert (fl == abi.ACTIVEFLUID).sum() + (fl == abi.REDUCED).sum() == (N + 1) * N * N
+    assert (fl == abi.ACTIVEFLUID).sum() == dd[1]
+    # indices are permutations
+    for nm, cnt in (("centerActiveIndices", dd[0]), ("faceZActiveIndices", dd[3]), ("edgeXZActiveIndices", dd[5])):
+        idx = s.array(nm)
+        v = idx[idx >= 0]
+        assert len(v) == cnt and v.min() == 0 and v.max() == cnt - 1 and len(np.unique(v)) == cnt
+
+
+def test_tile_blocks_closed_forms(big):
+    sc, p, s = big
+    Mr = s.array("reducedMassMatrices").reshape(-1, 26, 26)
+    com = s.array("reducedRegionCOM").reshape(-1, 3)
+    # first tile: full 14^3 block, Mr[a,a] = rho * s^2 (s+1); COM = mean integer coordinate * dx
+    for a in range(3):
+        assert Mr[0, a, a] == pytest.approx(14 * 14 * 15, rel=1e-14)
+    np.testing.assert_allclose(com[0], 8.5 * sc.dx, rtol=1e-15)
+    assert np.abs(Mr - np.transpose(Mr, (0, 2, 1))).max() <= 1e-9 * np.abs(Mr).max()
+    Bi = s.array("Inv_Mr_plus_2JDtuDJ").reshape(-1, 26, 26)
+    K = s.array("reducedViscosityMatrices").reshape(-1, 26, 26)
+    for r in (0, 17, 4095):
+        B = Mr[r] / sc.dt + 2 * K[r]
+        assert np.abs(Bi[r] @ B - np.eye(26)).max() < 1e-7
+        assert np.abs(K[r][:, :3]).max() < 1e-6 * np.abs(K[r]).max()      # rigid translations carry no viscous stress
+
+
+def test_operator_symmetric_negative_definite(big):
+    sc, p, s = big
+    n = s.nP + s.nT
+    rng = np.random.RandomState(3)
+    x, y = rng.randn(n), rng.randn(n)
+    Ax, Ay = s.apply(x), s.apply(y)
+    assert abs(x @ Ay - y @ Ax) <= 1e-9 * abs(x @ Ay)
+    assert x @ Ax < 0 and y @ Ay < 0
+    # linearity
+    z = s.apply(2.0 * x - 3.0 * y)
+    assert np.abs(z - (2.0 * Ax - 3.0 * Ay)).max() <= 1e-9 * np.abs(Ax).max()
+
+
+def test_solution_satisfies_reference_stop_rule(big):
+    sc, p, s = big
+    rc = s.solve()
+    assert rc == abi.SUCCESS
+    x, b = s.array("solutionVector"), s.array("b")
+    r = b - s.apply(x)
+    rre = min(r @ r, (r @ r) / (x @ x))                    # pcg.h:319-325
+    assert rre < p.tolerance ** 2 * 1.001
+    assert s.stats.solveData[0] == pytest.approx(np.sqrt(rre), rel=1e-5)
+    assert 0 < s.stats.solveData[1] < p.maxSolverIterations
+    vel, valid = s.download()
+    assert all(np.all(v == 1.0) for v in valid)
+    assert all(np.isfinite(v).all() for v in vel)
+    # the one-cell lid impulse is smeared out by the viscous solve but still drives the top more than the bottom
+    assert vel[0][N - 1].mean() > 10 * abs(vel[0][0]).mean() and abs(vel[0]).max() <= 1.0
