@@ -231,6 +231,94 @@ __global__ void __launch_bounds__(BS) k_region_outer(TileArgs A, double* __restr
     if (t < PS_RD) out[PS_RD * PS_RD + t] = accR;
 }
 
+
+// ---- MFMA variant -------------------------------------------------------------------------------------
+// The 26x26 (+1 rhs column) block of a region is  M = sum_f a_f b_f^T : a GEMM with the faces as the K dimension.
+// v_mfma_f64_16x16x4_f64: A operand lane l holds A[row l&15][k = l>>4], B operand lane l holds B[k = l>>4][col l&15],
+// result reg q of lane l is D[row (l>>4) + 4q][col l&15] (cdna_hip_programming.md, f64 layout).
+// M is padded to 32x32 = 2x2 MFMA tiles; wave w of the block owns tile (w>>1, w&1) and walks all 128 staged faces
+// (32 k-steps), so no cross-wave reduction is needed.  Threads t and t+128 produce a_f and b_f of face t.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int MPAD = 32;
+
+template <int MODE>
+__global__ void __launch_bounds__(BS) k_region_outer_mfma(TileArgs A, double* __restrict__ partial) {
+    __shared__ double sa[FBATCH][MPAD];
+    __shared__ double sb[FBATCH][MPAD];
+    const int item = blockIdx.x;
+    const int r = A.itemRegion[item], axis = A.itemAxis[item], start = A.itemStart[item];
+    const int bx0 = A.bbox[r * 6 + 0], by0 = A.bbox[r * 6 + 1], bz0 = A.bbox[r * 6 + 2];
+    int ex = A.bbox[r * 6 + 3] - bx0 + 1, ey = A.bbox[r * 6 + 4] - by0 + 1, ez = A.bbox[r * 6 + 5] - bz0 + 1;
+    if (axis == 0) ex++; else if (axis == 1) ey++; else ez++;
+    const int total = ex * ey * ez;
+    const int end = min(start + FB_CHUNK, total);
+    const int3 fd = A.g.dims(1 + axis), cd = A.g.dims(0);
+    const int t = threadIdx.x;
+    const int ft = t & (FBATCH - 1);      // staged face handled by this thread
+    const bool doB = t >= FBATCH;         // second half of the block produces the b vectors
+    const int wave = t >> 6, lane = t & 63;
+    const int ti = wave >> 1, tj = wave & 1;
+    double4_t acc = {0., 0., 0., 0.};
+
+    for (int base = start; base < end; base += FBATCH) {
+        const int pos = base + ft;
+        bool use = false;
+        int i = 0, j = 0, k = 0;
+        if (pos < end) {
+            const int li = pos % ex, lj = (pos / ex) % ey, lk = pos / (ex * ey);
+            i = bx0 + li; j = by0 + lj; k = bz0 + lk;
+            if (regAt(A, 1 + axis, fd, i, j, k) == r) {
+                int3 hi = make_int3(i, j, k), lo = hi;
+                addc(lo, axis, -1);
+                const int lhi = labAt(A, 0, cd, hi.x, hi.y, hi.z), llo = labAt(A, 0, cd, lo.x, lo.y, lo.z);
+                if (MODE == MODE_MASS) use = (lhi == PS_REDUCED) || (llo == PS_REDUCED && isActiveL(lhi));
+                else if (MODE == MODE_LSQ) use = (lhi == PS_REDUCED && isActiveL(llo)) || (llo == PS_REDUCED && isActiveL(lhi));
+                else use = true;
+            }
+        }
+        double vec[MPAD];
+#pragma unroll
+        for (int n = 0; n < MPAD; ++n) vec[n] = 0.;
+        if (use) {
+            if (!doB || MODE != MODE_VISC) {
+                double o[3];
+                faceOffset(A, axis, i, j, k, r, o);
+                basisRow(o[0], o[1], o[2], axis, vec);
+                if (MODE == MODE_MASS && !doB) {
+#pragma unroll
+                    for (int n = 0; n < PS_RD; ++n) vec[n] *= A.rho;
+                }
+                if (MODE == MODE_LSQ && doB) vec[PS_RD] = (double)A.vel[axis][lin3(fd, i, j, k)];   // rhs column: sum_f C_f u_f
+            } else {
+                viscosityRow(A, axis, i, j, k, vec);
+            }
+        }
+        double* dst = doB ? sb[ft] : sa[ft];
+#pragma unroll
+        for (int n = 0; n < MPAD; ++n) dst[n] = vec[n];
+        __syncthreads();
+        // 32 k-steps of 4 faces; lane l: A[m = 16 ti + (l&15)][face 4 ks + (l>>4)], B[face][n = 16 tj + (l&15)]
+#pragma unroll 8
+        for (int ks = 0; ks < FBATCH / 4; ++ks) {
+            const int f = 4 * ks + (lane >> 4);
+            const double av = sa[f][16 * ti + (lane & 15)];
+            const double bv = sb[f][16 * tj + (lane & 15)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double* out = partial + (int64_t)item * OUTW;
+    const int n = 16 * tj + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = 16 * ti + (lane >> 4) + 4 * q;
+        if (m < PS_RD) {
+            if (n < PS_RD) out[m * PS_RD + n] = acc[q];
+            else if (n == PS_RD) out[PS_RD * PS_RD + m] = acc[q];   // LSQ right-hand side (zero in the other modes)
+        }
+    }
+}
+
 // out[r] = sum of the region's item partials, in item order
 __global__ void k_region_sum(const double* __restrict__ partial, const int32_t* __restrict__ itemPtr,
                              double* __restrict__ out676, double* __restrict__ out26) {
@@ -410,7 +498,9 @@ void runOuter(ps_context* c, double* out676, double* out26) {
     if (c->regionCount == 0 || c->fbItems == 0) return;
     c->partials.alloc((size_t)c->fbItems * OUTW);
     TileArgs A = makeArgs(c);
-    hipLaunchKernelGGL(k_region_outer<MODE>, dim3((unsigned)c->fbItems), dim3(BS), 0, c->stream, A, c->partials.p);
+    static const bool useMfma = !(getenv("PS_TILE_VALU") && atoi(getenv("PS_TILE_VALU")) != 0);
+    if (useMfma) hipLaunchKernelGGL(k_region_outer_mfma<MODE>, dim3((unsigned)c->fbItems), dim3(BS), 0, c->stream, A, c->partials.p);
+    else hipLaunchKernelGGL(k_region_outer<MODE>, dim3((unsigned)c->fbItems), dim3(BS), 0, c->stream, A, c->partials.p);
     hipLaunchKernelGGL(k_region_sum, dim3((unsigned)c->regionCount), dim3(BS), 0, c->stream, c->partials.p, c->fbRegionItemPtr.p, out676, out26);
 }
 
