@@ -257,3 +257,39 @@ def test_input_weights_are_used_verbatim(gpu, oracle_mod):
     assert np.array_equal(gpu.array("centerLabels"), o.array("centerLabels"))
     assert np.array_equal(gpu.array("edgeXZActiveIndices"), o2.array("edgeXZActiveIndices"))
     assert abs(gpu.stats.solveData[1] - o2.stats.solveData[1]) <= 2
+
+
+def test_exported_system_solved_independently(gpu, tmp_path):
+    """North-star parity route: export the component matrices as .mtx (the reference's file set), rebuild the explicit
+    operator A = -dt [G Dt]^T McInv [G Dt] - [JG JDt]^T BInv [JG JDt] - 1/2 diag(0,uInv) (AssembleSystem.cpp:381-389)
+    with scipy — no oracle, no product code — solve A x = b directly and compare with the HIP PCG solution."""
+    import scipy.io
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    sc, p = scenes.blob(20, 18, 22, seed=9, tile=8)
+    p.tolerance = 1e-9
+    p.maxSolverIterations = 20000
+    rc = gpu.step(sc, p)
+    assert rc == abi.SUCCESS
+    pre = str(tmp_path) + "/sys."
+    gpu.export_component_matrices(pre)
+    rd = lambda n: scipy.io.mmread(pre + n + ".mtx")
+    G, Dt, JG, JDt = (rd("Mat_" + n).tocsr() for n in ("G", "Dt", "JG", "JDt"))
+    McInv, uInv, BInv = rd("Mat_McInv").tocsr(), rd("Mat_uInv").tocsr(), rd("Mat_Inv_Mr_plus_2JDtuDJ").tocsr()
+    b = np.asarray(rd("Vec_b")).ravel()
+    nP, nT = G.shape[1], Dt.shape[1]
+    C = sp.hstack([G, Dt]).tocsr()
+    J = sp.hstack([JG, JDt]).tocsr()
+    U = sp.block_diag([sp.csr_matrix((nP, nP)), uInv]).tocsr()
+    A = (-sc.dt * (C.T @ McInv @ C) - J.T @ BInv @ J - 0.5 * U).tocsc()
+    assert abs(A - A.T).max() <= 1e-10 * abs(A).max()
+    x = np.asarray(rd("solutionVector")).ravel()
+    # DOFs with an empty row (e.g. a pressure cell whose centre liquid weight is 0, so every G coefficient is skipped,
+    # ConstructMatrixBlocks.cpp:414) are decoupled: b is 0 there and CG leaves x at 0
+    keep = np.diff(A.tocsr().indptr) > 0
+    assert np.all(b[~keep] == 0) and np.all(x[~keep] == 0)
+    Ak = A.tocsr()[keep][:, keep].tocsc()
+    x_ref = np.zeros_like(b)
+    x_ref[keep] = spla.spsolve(Ak, b[keep])
+    assert np.linalg.norm(x - x_ref) <= 1e-5 * np.linalg.norm(x_ref)
+    assert np.linalg.norm(A @ x - b) <= 1e-7 * np.linalg.norm(b)
