@@ -654,19 +654,18 @@ __device__ inline bool ilFlag(const ILDesc& D, const Grid& g, const Set7<const i
 }
 __device__ inline bool ilDecode(const ILDesc& D, const Grid& g, int64_t u, int* grp, int64_t* lin) {
     if (u >= D.total) return false;
-    int lo = 0, hi = D.nseg;   // largest s with segStart[s] <= u
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (D.segStart[mid] <= u) lo = mid; else hi = mid;
-    }
-    const int b = lo / D.ngroups, gg = lo % D.ngroups;
-    const int64_t local = u - D.segStart[lo];
+    // position = ((block * 4096 + local voxel) * ngroups + group): the groups of ONE voxel index are adjacent, so the
+    // 3 face rows (resp. the 7 DOFs) hanging off a cell are contiguous and a row block re-uses the lines it gathers
+    const int64_t per = (int64_t)4096 * D.ngroups;
+    const int b = (int)(u / per);
+    const int rem = (int)(u - (int64_t)b * per);
+    const int v = rem / D.ngroups, gg = rem - v * D.ngroups;
     const int bx = b % D.LBx, by = (b / D.LBx) % D.LBy, bz = b / (D.LBx * D.LBy);
+    const int i = 16 * bx + (v & 15), j = 16 * by + ((v >> 4) & 15), k = 16 * bz + (v >> 8);
     const int3 d = g.dims(D.sample[gg]);
-    const int ex = min(16, d.x - 16 * bx), ey = min(16, d.y - 16 * by);
-    const int li = (int)(local % ex), lj = (int)((local / ex) % ey), lk = (int)(local / ((int64_t)ex * ey));
+    if (i >= d.x || j >= d.y || k >= d.z) return false;
     *grp = gg;
-    *lin = lin3(d, 16 * bx + li, 16 * by + lj, 16 * bz + lk);
+    *lin = lin3(d, i, j, k);
     return true;
 }
 __global__ void k_il_count(ILDesc D, Grid g, Set7<const int32_t> lab, int32_t* __restrict__ blockSums) {
@@ -939,34 +938,17 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     D.probe[0] = D.probe[1] = -1;
     for (int q = 0; q < 4; ++q) { D.sample[q] = q < ngroups ? samples[q] : 0; D.weight[q] = q < ngroups ? weights[q] : 0; }
     D.LBx = (g.nx + 1 + 15) / 16; D.LBy = (g.ny + 1 + 15) / 16; D.LBz = (g.nz + 1 + 15) / 16;
-    const int nb = D.LBx * D.LBy * D.LBz;
-    std::vector<int64_t> seg((size_t)nb * ngroups + 1);
-    int64_t run = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int bx = b % D.LBx, by = (b / D.LBx) % D.LBy, bz = b / (D.LBx * D.LBy);
-        for (int q = 0; q < ngroups; ++q) {
-            const int3 d = g.dims(samples[q]);
-            const int64_t ex = std::max(0, std::min(16, d.x - 16 * bx)), ey = std::max(0, std::min(16, d.y - 16 * by)),
-                          ez = std::max(0, std::min(16, d.z - 16 * bz));
-            seg[(size_t)b * ngroups + q] = run;
-            run += ex * ey * ez;
-        }
-    }
-    seg.back() = run;
-    // empty segments share their start with the next one; the search returns the LAST index with start <= u,
-    // which is the non-empty segment that contains u (u < total).
+    const int64_t per = (int64_t)4096 * ngroups;
+    const int64_t run = (int64_t)D.LBx * D.LBy * D.LBz * per;
     D.total = run;
-    D.nseg = (int)seg.size() - 1;
+    D.nseg = 0;
+    D.segStart = nullptr;
     if (ownedRange) {   // owned DOFs = whole lattice blocks bz in [zLo/16, hasUpper ? zHi/16 : LBz): a contiguous index range
         const int b0 = slabEnabled ? slab.zLoOwned / 16 : 0;
         const int b1 = (slabEnabled && slab.hasUpper) ? slab.zHiOwned / 16 : D.LBz;
-        D.probe[0] = seg[(size_t)b0 * D.LBx * D.LBy * ngroups];
-        D.probe[1] = seg[(size_t)b1 * D.LBx * D.LBy * ngroups];
+        D.probe[0] = (int64_t)b0 * D.LBx * D.LBy * per;
+        D.probe[1] = (int64_t)b1 * D.LBx * D.LBy * per;
     }
-    ilSegStart.alloc(seg.size());
-    HIP_CHECK(hipMemcpyAsync(ilSegStart.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    D.segStart = ilSegStart.p;
     const int nbk = gridFor(run, SCAN_TILE);
     scanBlock.alloc((size_t)nbk);
     Set7<int32_t> o;
