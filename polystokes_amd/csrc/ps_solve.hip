@@ -25,7 +25,7 @@ using namespace ps;
 namespace {
 
 constexpr int BS = 256;
-constexpr int VGRID = 2048;   // capped grid for streaming vector kernels (grid-stride)
+constexpr int VGRID = 1024;   // capped grid for streaming vector kernels (grid-stride); 4 blocks per CU measured best
 
 __device__ inline double waveReduceSum(double v) {
 #pragma unroll
@@ -334,18 +334,35 @@ __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ 
     double w[PS_RD];
 #pragma unroll
     for (int n = 0; n < PS_RD; ++n) w[n] = 0.;
-    const int e = chunkEnd[ch];
-    for (int rr = chunkStart[ch] + threadIdx.x; rr < e; rr += 64) {
+    const int e = chunkEnd[ch], b0 = chunkStart[ch];
+    // rows are ordered (region, axis, position), so a wave almost always sees one face axis: accumulate only the
+    // 10 / 10 / 14 non-zero entries of that axis' basis row (wave-uniform branch), generic path otherwise
+    for (int rr = b0 + threadIdx.x; rr < e; rr += 64) {
         int i, j, k, axis;
         unpackFace(rrowFace[rr], i, j, k, axis);
         const double s = sred[rr];
         const double ox = ((double)i - (axis == 0 ? 0.5 : 0.)) * dx - cx;
         const double oy = ((double)j - (axis == 1 ? 0.5 : 0.)) * dx - cy;
         const double oz = ((double)k - (axis == 2 ? 0.5 : 0.)) * dx - cz;
-        double c[PS_RD];
-        basisRow(ox, oy, oz, axis, c);
+        const int a0 = __builtin_amdgcn_readfirstlane(axis);
+        if (__all(axis == a0)) {
+            if (a0 == 0) {
+                w[0] += s; w[3] += ox * s; w[4] += oy * s; w[5] += oz * s;
+                w[6] += ox * ox * s; w[7] += ox * oy * s; w[8] += ox * oz * s; w[9] += oy * oy * s; w[10] += oy * oz * s; w[11] += oz * oz * s;
+            } else if (a0 == 1) {
+                w[1] += s; w[12] += ox * s; w[13] += oy * s; w[14] += oz * s;
+                w[15] += ox * ox * s; w[16] += ox * oy * s; w[17] += ox * oz * s; w[18] += oy * oy * s; w[19] += oy * oz * s; w[20] += oz * oz * s;
+            } else {
+                w[2] += s; w[3] += (-oz) * s; w[6] += (-2. * ox * oz) * s; w[7] += (-1. * oy * oz) * s; w[8] += (-0.5 * oz * oz) * s;
+                w[13] += (-oz) * s; w[16] += (-1. * ox * oz) * s; w[18] += (-2. * oy * oz) * s; w[19] += (-0.5 * oz * oz) * s;
+                w[21] += ox * s; w[22] += oy * s; w[23] += ox * ox * s; w[24] += ox * oy * s; w[25] += oy * oy * s;
+            }
+        } else {
+            double c[PS_RD];
+            basisRow(ox, oy, oz, axis, c);
 #pragma unroll
-        for (int n = 0; n < PS_RD; ++n) w[n] += c[n] * s;
+            for (int n = 0; n < PS_RD; ++n) w[n] += c[n] * s;
+        }
     }
 #pragma unroll
     for (int n = 0; n < PS_RD; ++n) {
@@ -380,18 +397,39 @@ __global__ void __launch_bounds__(64) k_tile_solve(const int32_t* __restrict__ r
         vreg[(int64_t)r * PS_RD + lane] = s;
     }
 }
-// t_f = C_f . v_region(f)
-__global__ void k_tile_expand(const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, int nRr,
-                              const double* __restrict__ COM, double dx, const double* __restrict__ vreg, double* __restrict__ tred,
-                              const int* __restrict__ done) {
+// t_f = C_f . v_region(f).  One block per chunk of <= RC_ROWS rows of ONE region: the 26 coefficients are block-uniform
+// (scalar loads), each thread expands RC_ROWS/256 rows.
+__global__ void __launch_bounds__(BS) k_tile_expand(const int32_t* __restrict__ chunkRegion, const int32_t* __restrict__ chunkStart,
+                                                    const int32_t* __restrict__ chunkEnd, const uint32_t* __restrict__ rrowFace,
+                                                    const double* __restrict__ COM, double dx, const double* __restrict__ vreg,
+                                                    double* __restrict__ tred, const int* __restrict__ done) {
     if (done && *done) return;
-    const int rr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rr >= nRr) return;
-    const int r = rrowRegion[rr];
-    double o[3];
-    int axis;
-    rowOffset(rrowFace[rr], COM, r, dx, o, &axis);
-    tred[rr] = basisDot(o[0], o[1], o[2], axis, vreg + (int64_t)r * PS_RD);
+    const int ch = blockIdx.x;
+    const int r = chunkRegion[ch];
+    const int b0 = chunkStart[ch], e = chunkEnd[ch];
+    const double cx = COM[(int64_t)r * 3 + 0], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
+    double v[PS_RD];
+#pragma unroll
+    for (int n = 0; n < PS_RD; ++n) v[n] = vreg[(int64_t)r * PS_RD + n];
+    constexpr int PER = RC_ROWS / BS;
+    uint32_t fq[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int rr = b0 + threadIdx.x + q * BS;
+        fq[q] = rr < e ? rrowFace[rr] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int rr = b0 + threadIdx.x + q * BS;
+        if (rr < e) {
+            int i, j, k, axis;
+            unpackFace(fq[q], i, j, k, axis);
+            const double ox = ((double)i - (axis == 0 ? 0.5 : 0.)) * dx - cx;
+            const double oy = ((double)j - (axis == 1 ? 0.5 : 0.)) * dx - cy;
+            const double oz = ((double)k - (axis == 2 ? 0.5 : 0.)) * dx - cz;
+            tred[rr] = basisDot(ox, oy, oz, axis, v);
+        }
+    }
 }
 
 // ---- CG vector kernels ---------------------------------------------------------------------------
@@ -442,14 +480,28 @@ __global__ void __launch_bounds__(BS) k_cg_scal1(CGScalars* sc, const double* __
     const double s = sumPartials(partial, count);
     if (threadIdx.x == 0) { sc->pAp = s; sc->alpha = sc->rsold / s; }   // pcg.h:314
 }
-// x += alpha p ; r -= alpha Ap ; partials of r.r, x.x, r.z   (pcg.h:315-319,331)
+// x += alpha p ; r -= alpha Ap ; partials of r.r, x.x, r.z   (pcg.h:315-319,331).  16-byte (double2) accesses.
 __global__ void __launch_bounds__(BS) k_cg_update_xr(const CGScalars* __restrict__ sc, const double* __restrict__ p, const double* __restrict__ Ap,
                                                      const double* __restrict__ dinv, double* __restrict__ x, double* __restrict__ r, int64_t n,
                                                      double* __restrict__ partial) {
     if (sc->done) return;
     const double alpha = sc->alpha;
     double arr = 0., axx = 0., arz = 0.;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+    const bool vec = ((((uintptr_t)p | (uintptr_t)Ap | (uintptr_t)x | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* p2 = (const double2*)p; const double2* A2 = (const double2*)Ap; const double2* d2 = (const double2*)dinv;
+    double2* x2 = (double2*)x; double2* r2 = (double2*)r;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        const double2 pv = p2[i], av = A2[i];
+        double2 xv = x2[i], rv = r2[i];
+        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
+        rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
+        x2[i] = xv; r2[i] = rv;
+        arr += rv.x * rv.x; arr += rv.y * rv.y;
+        axx += xv.x * xv.x; axx += xv.y * xv.y;
+        if (dinv) { const double2 dv = d2[i]; arz += rv.x * (dv.x * rv.x); arz += rv.y * (dv.y * rv.y); }
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double xv = x[i] + alpha * p[i];
         const double rv = r[i] - alpha * Ap[i];
         x[i] = xv; r[i] = rv;
@@ -481,7 +533,18 @@ __global__ void __launch_bounds__(BS) k_cg_update_p(const CGScalars* __restrict_
                                                     double* __restrict__ p, int64_t n) {
     if (sc->done) return;
     const double beta = sc->beta;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* r2 = (const double2*)r; const double2* d2 = (const double2*)dinv;
+    double2* p2 = (double2*)p;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        double2 z = r2[i];
+        if (dinv) { const double2 dv = d2[i]; z.x = dv.x * z.x; z.y = dv.y * z.y; }
+        double2 pv = p2[i];
+        pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
+        p2[i] = pv;
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double z = dinv ? dinv[i] * r[i] : r[i];
         p[i] = z + beta * p[i];
     }
@@ -643,9 +706,9 @@ struct Launch {
             hipLaunchKernelGGL(k_tile_solve<1>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
         else
             hipLaunchKernelGGL(k_tile_solve<2>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
-        if (mode != 1 && c->nReducedRows > 0)
-            hipLaunchKernelGGL(k_tile_expand, dim3(gridFor(c->nReducedRows, BS)), dim3(BS), 0, c->stream, c->rrowFace.p, c->rrowRegion.p,
-                               (int)c->nReducedRows, c->COM.p, c->dx, c->vreg.p, sred, done);
+        if (mode != 1 && c->nRChunks > 0)
+            hipLaunchKernelGGL(k_tile_expand, dim3((unsigned)c->nRChunks), dim3(BS), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
+                               c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, c->vreg.p, sred, done);
     }
     template <int RPT>
     void spmvSt_(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
@@ -859,6 +922,23 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
     if (base == "spmv_S") L.spmvS(0, x, c->ts.p);
     else if (base == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
     else if (base == "apply") c->applyOperator(x, y, c->dotPartials.p);
+    else if (base == "cg_update_xr" || base == "cg_update_p") {
+        // streaming vector kernels on scratch vectors (alpha = beta = 0 keeps them finite over many launches)
+        static ps::DevBuf<CGScalars> scratch;
+        scratch.alloc(1);
+        CGScalars h{};
+        HIP_CHECK(hipMemcpyAsync(scratch.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        const int64_t n = c->nSystem;
+        const char* e = getenv("PS_VGRID");
+        const int vb = e ? atoi(e) : dotBlocks(n);
+        const double* dv = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinv.p : nullptr;
+        c->tmp4.alloc((size_t)n); c->tmp5.alloc((size_t)n);
+        c->dotPartials.alloc((size_t)3 * std::max(vb, VGRID) + 16);
+        if (base == "cg_update_xr")
+            hipLaunchKernelGGL(k_cg_update_xr, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, y, dv, c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);
+        else
+            hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, dv, c->tmp4.p, n);
+    }
     else { c->S.packed = keepS; c->St.packed = keepT; throw Error("unknown kernel name: " + k); }
     c->S.packed = keepS; c->St.packed = keepT;
 }
