@@ -48,21 +48,6 @@ __device__ inline double blockReduceSum(double v) {
     return s;
 }
 
-// XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its
-// 4 MiB L2).  Give each XCD one contiguous range of row blocks so that the x / t entries gathered by neighbouring
-// row blocks (same 16^3 spatial block in the interleaved numbering) are fetched into ONE L2 instead of eight.
-__device__ int g_swizzle = 0;   // experiment switch (PS_SWIZZLE=1): XCD-contiguous row-block mapping
-__device__ inline int xcdSwizzle(int b, int nb) {
-    // g_swizzle = G > 1: within every chunk of 8*G consecutive row blocks, XCD k (= b % 8) gets the G consecutive
-    // logical blocks [k*G, (k+1)*G) — neighbouring row blocks share an L2 while all XCDs stream the same region.
-    const int G = g_swizzle;
-    const int chunk = 8 * G;
-    const int base = (b / chunk) * chunk;
-    if (base + chunk > nb) return b;   // ragged tail: identity
-    const int l = b - base;
-    return base + (l & 7) * G + (l >> 3);
-}
-
 // Streaming phase of the CSR-stream SpMV: the block's contiguous nnz range [p0,p1) (<= BS*MAXNNZ entries)
 // is read with a fixed-trip, fully unrolled loop so that all MAXNNZ (col,val) loads of a thread — and then
 // all MAXNNZ gathers — are in flight together (memory-level parallelism instead of a dependent chain).
@@ -88,16 +73,17 @@ __device__ inline void streamProducts(const int32_t* __restrict__ col, const dou
 }
 
 // ---- CSR-stream SpMV ------------------------------------------------------------------------------
-// A block owns BS*RPT consecutive rows (thread t: rows r0 + t + q*BS, q < RPT).  RPT > 1 puts more independent
-// loads in flight per lane (the coded-value stream is only 5 B/nnz, so latency, not bytes, is what has to be hidden).
+// One-shot variant: a block owns BS consecutive rows.  (More rows per thread was tried: 2 and 4 rows per thread are
+// 5-100 % slower — registers and LDS cost more occupancy than the extra loads in flight buy.)
 // MODE 0: out[row] = (row < nA ? dt*McInv[row] : 1) * (S x)[row]     (operator, forward half)
 // MODE 1: out[row] = (S x)[row]                                       (velocity recovery)
-template <int MODE, int MAXNNZ, bool PACKED, int RPT>
+template <int MODE, int MAXNNZ, bool PACKED>
 __global__ void __launch_bounds__(BS) k_spmv_S(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
                                                const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
                                                double dt, const double* __restrict__ McInv, double* __restrict__ out,
                                                const int* __restrict__ done) {
     if (done && *done) return;
+    constexpr int RPT = 1;
     __shared__ double prod[BS * MAXNNZ * RPT];
     const int r0 = blockIdx.x * (BS * RPT);
     const int r1 = min(r0 + BS * RPT, rows);
@@ -127,12 +113,13 @@ __global__ void __launch_bounds__(BS) k_spmv_S(const int32_t* __restrict__ ptr, 
 }
 // MODE 0: out[j] = -(St t)[j] - 0.5*uInv[j]*xin[j];  partial[block] = sum xin[j]*out[j]
 // MODE 1: out[j] = -(St t)[j] + add[j]                                   (right-hand side b)
-template <int MODE, int MAXNNZ, bool PACKED, int RPT>
+template <int MODE, int MAXNNZ, bool PACKED>
 __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
                                                 const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
                                                 const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
                                                 double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done) {
     if (done && *done) return;
+    constexpr int RPT = 1;
     __shared__ double prod[BS * MAXNNZ * RPT];
     const int r0 = blockIdx.x * (BS * RPT);
     const int r1 = min(r0 + BS * RPT, rows);
@@ -666,12 +653,10 @@ struct Launch {
     ps_context* c;
     const int* done;
     int rowsS, rowsSt, nA, nP;
-    int rptS, rptT;   // rows per thread
-    template <int RPT>
     void spmvS_(int mode, const double* x, double* out) const {
-        const dim3 gr(gridFor(rowsS, BS * RPT)), bl(BS);
+        const dim3 gr(gridFor(rowsS, BS)), bl(BS);
         const ps::DevCSR& M = c->S;
-#define PS_LAUNCH_S(MODE_, PK_) hipLaunchKernelGGL((k_spmv_S<MODE_, 8, PK_, RPT>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
+#define PS_LAUNCH_S(MODE_, PK_) hipLaunchKernelGGL((k_spmv_S<MODE_, 8, PK_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
                                                    c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done)
         if (mode == 0) { if (M.packed) PS_LAUNCH_S(0, true); else PS_LAUNCH_S(0, false); }
         else { if (M.packed) PS_LAUNCH_S(1, true); else PS_LAUNCH_S(1, false); }
@@ -691,7 +676,7 @@ struct Launch {
 #undef PS_LAUNCH_SP
             return;
         }
-        if (rptS == 4) spmvS_<4>(mode, x, out); else if (rptS == 2) spmvS_<2>(mode, x, out); else spmvS_<1>(mode, x, out);
+        spmvS_(mode, x, out);
     }
     void tiles(int mode, double* ts) const {   // ts: face-row vector; reduced part rewritten in place
         if (c->regionCount == 0) return;
@@ -710,11 +695,10 @@ struct Launch {
             hipLaunchKernelGGL(k_tile_expand, dim3((unsigned)c->nRChunks), dim3(BS), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
                                c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, c->vreg.p, sred, done);
     }
-    template <int RPT>
     void spmvSt_(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
-        const dim3 gr(gridFor(rowsSt, BS * RPT)), bl(BS);
+        const dim3 gr(gridFor(rowsSt, BS)), bl(BS);
         const ps::DevCSR& M = c->St;
-#define PS_LAUNCH_T(MODE_, PK_) hipLaunchKernelGGL((k_spmv_St<MODE_, 6, PK_, RPT>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
+#define PS_LAUNCH_T(MODE_, PK_) hipLaunchKernelGGL((k_spmv_St<MODE_, 6, PK_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
                                                    c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done)
         if (mode == 0) { if (M.packed) PS_LAUNCH_T(0, true); else PS_LAUNCH_T(0, false); }
         else { if (M.packed) PS_LAUNCH_T(1, true); else PS_LAUNCH_T(1, false); }
@@ -733,21 +717,20 @@ struct Launch {
 #undef PS_LAUNCH_TP
             return;
         }
-        if (rptT == 4) spmvSt_<4>(mode, t, xin, add, out, partial); else if (rptT == 2) spmvSt_<2>(mode, t, xin, add, out, partial);
-        else spmvSt_<1>(mode, t, xin, add, out, partial);
+        spmvSt_(mode, t, xin, add, out, partial);
     }
-    int stBlocks() const { return (pipeGrid > 0 && c->St.packed) ? gridFor(rowsSt, BS) : gridFor(rowsSt, BS * rptT); }   // number of p.Ap partials the St kernel writes
+    int stBlocks() const { return gridFor(rowsSt, BS); }   // number of p.Ap partials the St kernel writes
 };
 Launch mk(ps_context* c, const int* done) {
     Launch L;
     L.c = c; L.done = done;
     L.rowsS = (int)c->nRows; L.rowsSt = (int)c->nSystem; L.nA = (int)c->nActiveVs; L.nP = (int)c->nPressures;
-    static int rS = -1, rT = -1, pg = 0;
-    if (rS < 0) {
-        const char* a = getenv("PS_RPT_S"); const char* b = getenv("PS_RPT_ST"); const char* g = getenv("PS_PIPE_GRID");
-        rS = a ? atoi(a) : 1; rT = b ? atoi(b) : 1; pg = g ? atoi(g) : 4096;   // persistent pipelined kernels by default
+    static int pg = -1;
+    if (pg < 0) {
+        const char* g = getenv("PS_PIPE_GRID");   // A/B switch: 0 = one-shot kernels
+        pg = g ? atoi(g) : 4096;                   // persistent pipelined kernels, 16 blocks per CU, by default
     }
-    L.rptS = rS; L.rptT = rT; L.pipeGrid = pg;
+    L.pipeGrid = pg;
     return L;
 }
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
@@ -906,13 +889,6 @@ void ps_context::applySolutionToVelocity() {
 
 // micro-benchmark dispatch for ps_bench_kernel (bench.py roofline object)
 void ps_bench_launch(ps_context* c, const std::string& k, const double* x, double* y) {
-    static int once = 0;
-    if (!once) {
-        once = 1;
-        const char* e = getenv("PS_SWIZZLE");
-        const int v = e ? atoi(e) : 0;
-        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_swizzle), &v, sizeof(int)));
-    }
     Launch L = mk(c, nullptr);
     // "<name>_fp64": the same kernel streaming the fp64 value array instead of the int8 codes (A/B of the two formats)
     const bool fp64 = k.size() > 5 && k.compare(k.size() - 5, 5, "_fp64") == 0;

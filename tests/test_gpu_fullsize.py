@@ -90,3 +90,35 @@ def test_solution_satisfies_reference_stop_rule(big):
     assert all(np.isfinite(v).all() for v in vel)
     # the one-cell lid impulse is smeared out by the viscous solve but still drives the top more than the bottom
     assert vel[0][N - 1].mean() > 10 * abs(vel[0][0]).mean() and abs(vel[0]).max() <= 1.0
+
+
+def test_config2_coil_128_properties():
+    """BASELINE config 2 stand-in at its real size (128^3 coil, tile 16 / pad 2): free surface, solid floor, air."""
+    import polystokes_amd
+    sc, p = scenes.coil(128)
+    s = polystokes_amd.Solver(0)
+    s.upload(sc, p)
+    s.setup()
+    n = s.nP + s.nT
+    dd = s.stats.dimData
+    assert dd[24] > 50 and dd[0] > 1e5                      # many tiles, many active cells
+    lab = s.array("centerLabels")
+    assert set(np.unique(lab)) <= {abi.UNSOLVED, abi.ACTIVEFLUID, abi.SOLID, abi.REDUCED}
+    for nm, cnt in (("centerActiveIndices", dd[0]), ("faceYActiveIndices", dd[2]), ("edgeXYActiveIndices", dd[6])):
+        idx = s.array(nm)
+        v = idx[idx >= 0]
+        assert len(v) == cnt and len(np.unique(v)) == cnt
+    rng = np.random.RandomState(4)
+    x, y = rng.randn(n), rng.randn(n)
+    Ax, Ay = s.apply(x), s.apply(y)
+    assert abs(x @ Ay - y @ Ax) <= 1e-9 * abs(x @ Ay) and x @ Ax < 0
+    rc = s.solve()
+    assert rc == abi.SUCCESS
+    xs, b = s.array("solutionVector"), s.array("b")
+    r = b - s.apply(xs)
+    assert min(r @ r, (r @ r) / (xs @ xs)) < p.tolerance ** 2 * 1.001
+    vel, valid = s.download()
+    assert all(np.isfinite(v).all() for v in vel)
+    # air faces are invalid, liquid faces valid
+    assert 0 < valid[1].mean() < 1
+    s.close()
