@@ -163,6 +163,12 @@ int32_t ps_setup_device(ps_context* ctx, ps_stats* stats);
 /* solve() + recover + write-back on an already set-up context (HDK_PolyStokes.C:518-583). */
 int32_t ps_solve_device(ps_context* ctx, ps_stats* stats);
 
+/* UT_Interrupt equivalent (the reference polls boss->opInterrupt() in its sweeps, e.g. Classifier.cpp:73,386): the
+ * callback is polled between batches of CG iterations; a non-zero return stops the solve, which then reports
+ * PS_INCOMPLETE and leaves the velocity untouched.  Pass NULL to clear. */
+typedef int32_t (*ps_interrupt_fn)(void* user);
+int32_t ps_set_interrupt(ps_context* ctx, ps_interrupt_fn cb, void* user);
+
 /* Device -> host copy of vel / valid. */
 int32_t ps_download_fields(ps_context* ctx, ps_fields_out* out);
 

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "ps_abi_version", "ps_context_create", "ps_context_destroy", "ps_last_error", "ps_params_default",
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
     "polystokes_step", "ps_apply_operator", "ps_query_array", "ps_read_array",
-    "ps_export_component_matrices", "ps_export_stats", "ps_bench_kernel",
+    "ps_export_component_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt",
     "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest",
     "ps_group_create", "ps_group_destroy", "ps_group_rank", "ps_group_step",
 ]
@@ -74,6 +74,8 @@ def lib():
         L.ps_export_stats.restype = C.c_int32
         L.ps_bench_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ps_bench_kernel.restype = C.c_int32
+        L.ps_set_interrupt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ps_set_interrupt.restype = C.c_int32
         L.ps_set_slab.argtypes = [C.c_void_p, C.POINTER(_abi.SlabStruct)]
         L.ps_set_slab.restype = C.c_int32
         L.ps_comm_unique_id.argtypes = [C.c_void_p]
@@ -133,6 +135,15 @@ class Solver:
             if self._owned:
                 self.L.ps_context_destroy(self.h)
             self.h = None
+
+    def set_interrupt(self, fn):
+        """fn() -> truthy stops the solve at the next CG batch boundary (UT_Interrupt equivalent)."""
+        if fn is None:
+            self._cb = None
+            self._check(self.L.ps_set_interrupt(self.h, None, None))
+            return
+        self._cb = C.CFUNCTYPE(C.c_int32, C.c_void_p)(lambda user: 1 if fn() else 0)
+        self._check(self.L.ps_set_interrupt(self.h, C.cast(self._cb, C.c_void_p), None))
 
     def set_slab(self, slab):
         st = _abi.SlabStruct(slab.rank, slab.world, slab.zLoOwned, slab.zHiOwned, slab.hasLower, slab.hasUpper)

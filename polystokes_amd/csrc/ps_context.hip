@@ -192,7 +192,7 @@ int ps_context::solveStage(ps_stats* stats) {
     }
     T.mark(1);
     buildValidFaces();
-    const bool apply = P.doSolve && result != PS_UNSUPPORTED_SOLVER && (result == PS_SUCCESS || P.keepNonConvergedResults);
+    const bool apply = P.doSolve && result != PS_UNSUPPORTED_SOLVER && result != PS_INCOMPLETE && (result == PS_SUCCESS || P.keepNonConvergedResults);
     if (apply) {
         recoverVelocityFromPressureStress();
         T.mark(2);
@@ -394,6 +394,12 @@ int32_t ps_step_device(ps_context* c, ps_stats* st) {
         if (rc != PS_SUCCESS) return rc;
         return c->solveStage(st);
     })
+}
+int32_t ps_set_interrupt(ps_context* c, ps_interrupt_fn cb, void* user) {
+    if (!c) return PS_FAILED;
+    c->interruptCb = cb;
+    c->interruptUser = user;
+    return PS_SUCCESS;
 }
 int32_t ps_download_fields(ps_context* c, ps_fields_out* out) {
     if (!c || !out) return PS_FAILED;

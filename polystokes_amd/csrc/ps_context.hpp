@@ -123,6 +123,10 @@ struct ps_context {
     }
     void buildHaloLists();                   // ps_grid.hip
 
+    ps_interrupt_fn interruptCb = nullptr;   // polled between CG batches (UT_Interrupt equivalent)
+    void* interruptUser = nullptr;
+    bool interrupted = false;
+
     // ---- results ----
     int solveIterations = -1;
     double solveError = -1;

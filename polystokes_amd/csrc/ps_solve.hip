@@ -191,19 +191,28 @@ template <int MODE, int MAXNNZ, bool PACKED>
 __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
                                                     const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
                                                     double dt, const double* __restrict__ McInv, double* __restrict__ out,
-                                                    const int* __restrict__ done, int nChunks) {
+                                                    const int* __restrict__ done, int nChunks, int xcdAware) {
     if (done && *done) return;
     __shared__ double prod[BS * MAXNNZ];
-    int chunk = blockIdx.x;
-    if (chunk >= nChunks) return;
+    // chunk walk: plain (chunk = block, block + grid, ...) or XCD-aware: blocks b, b+8, ... share an XCD (and its L2), so
+    // XCD x walks its own contiguous eighth of the chunks and the lines gathered by neighbouring chunks stay in ONE L2
+    int chunk, stride, chunkEnd;
+    if (xcdAware) {
+        const int per = (nChunks + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        chunk = xcd * per + (blockIdx.x >> 3);
+        stride = gridDim.x >> 3;
+        chunkEnd = min(nChunks, (xcd + 1) * per);
+    } else { chunk = blockIdx.x; stride = gridDim.x; chunkEnd = nChunks; }
+    if (chunk >= chunkEnd) return;
     int r0 = chunk * BS;
     int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
     int c[MAXNNZ];
     typename RawVal<PACKED>::type v[MAXNNZ];
     loadStream<MAXNNZ, PACKED>(col, val, code, p0, p1, c, v);
-    int nchunk = chunk + gridDim.x;
+    int nchunk = chunk + stride;
     int np0 = 0, np1 = 0;
-    if (nchunk < nChunks) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
+    if (nchunk < chunkEnd) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
     while (true) {
         const int row = r0 + threadIdx.x;
         const bool ok = row < rows;
@@ -212,13 +221,13 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
         double xv[MAXNNZ];
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.;
-        const bool hasNext = nchunk < nChunks;
+        const bool hasNext = nchunk < chunkEnd;
         int c2[MAXNNZ];
         typename RawVal<PACKED>::type v2[MAXNNZ];
         if (hasNext) loadStream<MAXNNZ, PACKED>(col, val, code, np0, np1, c2, v2);
-        const int nn = nchunk + gridDim.x;
+        const int nn = nchunk + stride;
         int nnp0 = 0, nnp1 = 0;
-        if (nn < nChunks) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
+        if (nn < chunkEnd) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u)
             if (c[u] >= 0) prod[threadIdx.x + u * BS] = rawToVal<PACKED>(v[u], scale) * xv[u];
@@ -240,19 +249,27 @@ template <int MODE, int MAXNNZ, bool PACKED>
 __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
                                                      const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
-                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done, int nChunks) {
+                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done, int nChunks,
+                                                     int xcdAware) {
     if (done && *done) return;
     __shared__ double prod[BS * MAXNNZ];
-    int chunk = blockIdx.x;
-    if (chunk >= nChunks) return;
+    int chunk, stride, chunkEnd;
+    if (xcdAware) {
+        const int per = (nChunks + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        chunk = xcd * per + (blockIdx.x >> 3);
+        stride = gridDim.x >> 3;
+        chunkEnd = min(nChunks, (xcd + 1) * per);
+    } else { chunk = blockIdx.x; stride = gridDim.x; chunkEnd = nChunks; }
+    if (chunk >= chunkEnd) return;
     int r0 = chunk * BS;
     int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
     int c[MAXNNZ];
     typename RawVal<PACKED>::type v[MAXNNZ];
     loadStream<MAXNNZ, PACKED>(col, val, code, p0, p1, c, v);
-    int nchunk = chunk + gridDim.x;
+    int nchunk = chunk + stride;
     int np0 = 0, np1 = 0;
-    if (nchunk < nChunks) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
+    if (nchunk < chunkEnd) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
     while (true) {
         const int row = r0 + threadIdx.x;
         const bool ok = row < rows;
@@ -263,13 +280,13 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__
         double xv[MAXNNZ];
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u) xv[u] = c[u] >= 0 ? t[c[u]] : 0.;
-        const bool hasNext = nchunk < nChunks;
+        const bool hasNext = nchunk < chunkEnd;
         int c2[MAXNNZ];
         typename RawVal<PACKED>::type v2[MAXNNZ];
         if (hasNext) loadStream<MAXNNZ, PACKED>(col, val, code, np0, np1, c2, v2);
-        const int nn = nchunk + gridDim.x;
+        const int nn = nchunk + stride;
         int nnp0 = 0, nnp1 = 0;
-        if (nn < nChunks) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
+        if (nn < chunkEnd) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u)
             if (c[u] >= 0) prod[threadIdx.x + u * BS] = rawToVal<PACKED>(v[u], scale) * xv[u];
@@ -663,6 +680,7 @@ struct Launch {
 #undef PS_LAUNCH_S
     }
     int pipeGrid;   // 0: one-shot kernels; >0: persistent software-pipelined kernels with this many blocks
+    int xcdAware;   // pipelined kernels: each XCD walks a contiguous eighth of the row chunks
     void spmvS(int mode, const double* x, double* out) const {
         if (rowsS == 0) return;
         if (pipeGrid > 0 && c->S.packed) {   // fp64 values: the one-shot kernel is faster (register pressure of the prefetch set)
@@ -670,7 +688,7 @@ struct Launch {
             const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
             const ps::DevCSR& M = c->S;
 #define PS_LAUNCH_SP(MODE_, PK_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, 8, PK_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
-                                                    c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks)
+                                                    c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware)
             if (mode == 0) { if (M.packed) PS_LAUNCH_SP(0, true); else PS_LAUNCH_SP(0, false); }
             else { if (M.packed) PS_LAUNCH_SP(1, true); else PS_LAUNCH_SP(1, false); }
 #undef PS_LAUNCH_SP
@@ -711,7 +729,7 @@ struct Launch {
             const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
             const ps::DevCSR& M = c->St;
 #define PS_LAUNCH_TP(MODE_, PK_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, 6, PK_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
-                                                    c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done, nChunks)
+                                                    c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware)
             if (mode == 0) { if (M.packed) PS_LAUNCH_TP(0, true); else PS_LAUNCH_TP(0, false); }
             else { if (M.packed) PS_LAUNCH_TP(1, true); else PS_LAUNCH_TP(1, false); }
 #undef PS_LAUNCH_TP
@@ -731,6 +749,9 @@ Launch mk(ps_context* c, const int* done) {
         pg = g ? atoi(g) : 4096;                   // persistent pipelined kernels, 16 blocks per CU, by default
     }
     L.pipeGrid = pg;
+    static int xa = -1;
+    if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 0; }
+    L.xcdAware = (xa && (pg % 8) == 0) ? 1 : 0;
     return L;
 }
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
@@ -781,6 +802,7 @@ int ps_context::solve() {
     const int maxit = P.maxSolverIterations;
     const double tol = P.tolerance;
     usedBiCGStab = 0;
+    interrupted = false;
     if (P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
     if (n == 0) { solveIterations = 0; solveError = 0; return PS_SUCCESS; }
     const double* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinv.p : nullptr;
@@ -811,7 +833,9 @@ int ps_context::solve() {
         HIP_CHECK(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         if (h.done) finished = true;
+        if (!finished && interruptCb && interruptCb(interruptUser)) { interrupted = true; break; }
     }
+    if (interrupted) { solveIterations = it; solveError = std::sqrt(h.rre); return PS_INCOMPLETE; }
     solveIterations = h.done ? h.iter : maxit;
     solveError = std::sqrt(h.rre);
 

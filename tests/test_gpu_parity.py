@@ -293,3 +293,18 @@ def test_exported_system_solved_independently(gpu, tmp_path):
     x_ref[keep] = spla.spsolve(Ak, b[keep])
     assert np.linalg.norm(x - x_ref) <= 1e-5 * np.linalg.norm(x_ref)
     assert np.linalg.norm(A @ x - b) <= 1e-7 * np.linalg.norm(b)
+
+
+def test_interrupt_callback_stops_the_solve(gpu):
+    sc, p = scenes.cavity(32)
+    calls = []
+    gpu.set_interrupt(lambda: calls.append(1) or len(calls) >= 2)
+    try:
+        rc = gpu.step(sc, p)
+    finally:
+        gpu.set_interrupt(None)
+    assert rc == abi.INCOMPLETE and len(calls) == 2
+    assert 25 <= gpu.stats.solveData[1] <= 75
+    for a in range(3):
+        assert np.array_equal(gpu.vel[a], sc.vel[a])       # velocity untouched
+    assert gpu.step(sc, p) == abi.SUCCESS                   # and the context is reusable afterwards
