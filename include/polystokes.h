@@ -192,6 +192,13 @@ int32_t ps_read_array(ps_context* ctx, const char* name, void* dst, int64_t dst_
 int32_t ps_export_component_matrices(ps_context* ctx, const char* prefix);
 int32_t ps_export_stats(ps_context* ctx, const ps_stats* stats, const char* prefix);
 
+/* Solve a component set exported by exportComponentMatrices() (Solver.cpp:543-566: <prefix>Mat_G.mtx, Mat_Dt, Mat_JG,
+ * Mat_JDt, Mat_McInv, Mat_uInv, Mat_Inv_Mr_plus_2JDtuDJ, Vec_b) with the same PCG (params: tolerance,
+ * maxSolverIterations, preconditioner); the operator is applied literally as in ApplyPressureStressMatrix.h:102-179.
+ * x_out receives [p; tau] (length nPressures + nStresses, reference numbering).  `dt` is dimData entry 27. */
+int32_t ps_solve_exported_system(ps_context* ctx, const char* prefix, const ps_params* params, double dt, double* x_out,
+                                 int64_t x_len, ps_stats* stats);
+
 /* Micro-benchmark hooks used by bench.py for the roofline object: run `iters` launches of the
  * dominant kernel(s) on the solver stream bracketed by HIP events, return avg ms per launch. */
 int32_t ps_bench_kernel(ps_context* ctx, const char* kernel, int32_t iters, double* avg_ms,

@@ -308,3 +308,32 @@ def test_interrupt_callback_stops_the_solve(gpu):
     for a in range(3):
         assert np.array_equal(gpu.vel[a], sc.vel[a])       # velocity untouched
     assert gpu.step(sc, p) == abi.SUCCESS                   # and the context is reusable afterwards
+
+
+@pytest.mark.parametrize("precond", [abi.PRE_IDENTITY, abi.PRE_DIAGONAL])
+def test_exported_system_import_and_solve(gpu, tmp_path, precond):
+    """ps_solve_exported_system: read back the .mtx component set (the reference's exportComponentMatrices file set,
+    Solver.cpp:543-566) and run the same PCG on it with general CSR SpMVs.  Must agree with the in-memory solve: same
+    iteration count (the operator is the same up to summation order) and the same solution."""
+    import scipy.io
+    sc, p = scenes.blob(20, 18, 22, seed=9, tile=8)
+    p.tolerance = 1e-8
+    p.maxSolverIterations = 20000
+    p.preconditioner = precond
+    assert gpu.step(sc, p) == abi.SUCCESS
+    its = gpu.stats.solveData[1]
+    pre = str(tmp_path) + "/sys."
+    gpu.export_component_matrices(pre)
+    x_mem = np.asarray(scipy.io.mmread(pre + "solutionVector.mtx")).ravel()
+    n = x_mem.size
+    assert n == int(gpu.stats.dimData[21])
+    rc, x = gpu.solve_exported_system(pre, p, sc.dt, n)
+    assert rc == abi.SUCCESS
+    assert abs(gpu.stats.solveData[1] - its) <= 2
+    assert int(gpu.stats.dimData[21]) == n and int(gpu.stats.dimData[24]) > 0
+    assert np.linalg.norm(x - x_mem) <= 1e-6 * np.linalg.norm(x_mem)
+
+
+def test_exported_system_import_errors(gpu, tmp_path):
+    with pytest.raises(RuntimeError, match="cannot open"):
+        gpu.solve_exported_system(str(tmp_path) + "/nothing.", abi.default_params(), 0.1, 4)
