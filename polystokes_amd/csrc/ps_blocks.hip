@@ -448,23 +448,40 @@ void ps_context::constructMatrixBlocks() {
         HIP_CHECK(hipMemcpyAsync(itemOff.data(), fbItemCount.p, itemOff.size() * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(itemPtr.data(), fbRegionItemPtr.p, itemPtr.size() * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        std::vector<int32_t> rptr((size_t)regionCount + 1), cR, cS, cE, cptr((size_t)regionCount + 1);
+        std::vector<int32_t> rptr((size_t)regionCount + 1), cR, cS, cE, cA, cptr((size_t)regionCount + 1);
         for (int64_t r = 0; r <= regionCount; ++r) rptr[(size_t)r] = itemOff[(size_t)itemPtr[(size_t)r]];
         for (int64_t r = 0; r < regionCount; ++r) {
             cptr[(size_t)r] = (int32_t)cR.size();
-            for (int32_t s0 = rptr[(size_t)r]; s0 < rptr[(size_t)r + 1]; s0 += RC_ROWS) {
-                cR.push_back((int32_t)r); cS.push_back(s0); cE.push_back(std::min(s0 + RC_ROWS, rptr[(size_t)r + 1]));
+            // rows are ordered (region, axis, position): cut every axis run into equal pieces of <= RC_ROWS rows
+            int32_t it = itemPtr[(size_t)r];
+            const int32_t itEnd = itemPtr[(size_t)r + 1];
+            while (it < itEnd) {
+                const int32_t a = fbItemAxisHost[(size_t)it];
+                int32_t it2 = it;
+                while (it2 < itEnd && fbItemAxisHost[(size_t)it2] == a) ++it2;
+                const int32_t lo = itemOff[(size_t)it], hi = itemOff[(size_t)it2];
+                const int32_t len = hi - lo;
+                if (len > 0) {
+                    const int32_t pieces = (len + RC_ROWS - 1) / RC_ROWS;
+                    for (int32_t q = 0; q < pieces; ++q) {
+                        cR.push_back((int32_t)r); cA.push_back(a);
+                        cS.push_back(lo + (int32_t)((int64_t)len * q / pieces));
+                        cE.push_back(lo + (int32_t)((int64_t)len * (q + 1) / pieces));
+                    }
+                }
+                it = it2;
             }
         }
         cptr[(size_t)regionCount] = (int32_t)cR.size();
         nRChunks = (int64_t)cR.size();
-        regionRowPtr.alloc(rptr.size()); rchunkRegion.alloc(cR.size()); rchunkStart.alloc(cS.size()); rchunkEnd.alloc(cE.size());
+        regionRowPtr.alloc(rptr.size()); rchunkRegion.alloc(cR.size()); rchunkStart.alloc(cS.size()); rchunkEnd.alloc(cE.size()); rchunkAxis.alloc(cA.size());
         regionChunkPtr.alloc(cptr.size());
         HIP_CHECK(hipMemcpyAsync(regionRowPtr.p, rptr.data(), rptr.size() * 4, hipMemcpyHostToDevice, stream));
         if (nRChunks) {
             HIP_CHECK(hipMemcpyAsync(rchunkRegion.p, cR.data(), cR.size() * 4, hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(rchunkStart.p, cS.data(), cS.size() * 4, hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(rchunkEnd.p, cE.data(), cE.size() * 4, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(rchunkAxis.p, cA.data(), cA.size() * 4, hipMemcpyHostToDevice, stream));
         }
         HIP_CHECK(hipMemcpyAsync(regionChunkPtr.p, cptr.data(), cptr.size() * 4, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

@@ -85,6 +85,7 @@ struct ps_context {
     // work tables for per-region reductions over the region's face box (host built, small)
     ps::DevBuf<int32_t> fbItemRegion, fbItemAxis, fbItemStart;   // one item = <=FB_CHUNK face-box positions
     ps::DevBuf<int32_t> fbRegionItemPtr;                         // R+1
+    std::vector<int32_t> fbItemAxisHost;                         // host copy of fbItemAxis (axis-pure row chunks)
     int64_t fbItems = 0;
     ps::DevBuf<int32_t> fbItemCount;                             // skin faces found per item (then scanned)
     ps::DevBuf<double> partials;                                  // items * 676 (or rows chunks * 26)
@@ -93,7 +94,7 @@ struct ps_context {
     ps::DevBuf<uint32_t> rrowFace;           // packed (i,j,k,axis)
     ps::DevBuf<int32_t> rrowRegion;
     ps::DevBuf<int32_t> regionRowPtr;        // R+1, offsets into reduced rows
-    ps::DevBuf<int32_t> rchunkRegion, rchunkStart, rchunkEnd, regionChunkPtr;  // <=RC rows per chunk
+    ps::DevBuf<int32_t> rchunkRegion, rchunkStart, rchunkEnd, rchunkAxis, regionChunkPtr;  // <=RC rows of ONE face axis per chunk
     int64_t nRChunks = 0;
 
     // ---- blocks (Solver.h:337-369): S = [G Dt ; Ghat Dhat] by face row, St its transpose ----
@@ -186,5 +187,5 @@ int ps_dist_step_single(ps_context* c, ps_stats* stats);   // ps_solve.hip: dist
 
 namespace ps {
 constexpr int FB_CHUNK = 4096;   // face-box positions per work item (per-region dense reductions)
-constexpr int RC_ROWS = 1024;    // reduced rows per chunk in the per-iteration tile kernels
+constexpr int RC_ROWS = 512;     // reduced rows per chunk in the per-iteration tile kernels
 }  // namespace ps

@@ -1043,7 +1043,7 @@ void ps_context::buildHaloLists() {
         if (n) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, stream));
     };
     up(lowHalo, listLowHalo, nLowHalo); up(lowOwn, listLowOwn, nLowOwn); up(upHalo, listUpHalo, nUpHalo); up(upOwn, listUpOwn, nUpOwn);
-    const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo, nLowOwn), std::max(nUpHalo, nUpOwn)) + 1;
+    const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo, nLowOwn), std::max(nUpHalo, nUpOwn)) + 2;   // >= 2: Dist::checkLists ships two counters through these buffers
     sendLo.alloc(mx); sendUp.alloc(mx); recvLo.alloc(mx); recvUp.alloc(mx);
     HIP_CHECK(hipStreamSynchronize(stream));
 }

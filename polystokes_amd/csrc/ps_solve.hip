@@ -168,6 +168,19 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 // 8 waves/SIMD.  Here a block loops over row chunks (grid = #CUs x 8) and, while the gathers / LDS reduction of
 // chunk i are in flight, the (col,code) stream of chunk i+1 is already loading into a second register set and the
 // bounds of chunk i+2 are being fetched.
+// chunk walk of a persistent block.  Plain: chunk = block + it * grid.  Grouped (G = xcdAware > 0): workgroups b, b+8, ...
+// run on XCD b & 7 (verified with s_getreg HW_REG_XCC_ID), so runs of G consecutive chunks are dealt to the XCDs round
+// robin — rows that gather the same lines of x (k-plane neighbours, a few chunks apart) then share ONE L2, while
+// the chip as a whole still sweeps one compact window of memory.
+struct ChunkWalk {
+    int G, x, l, per;
+    __device__ ChunkWalk(int g) : G(g), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3) {}
+    __device__ int at(int it) const {
+        if (G <= 0) return blockIdx.x + it * gridDim.x;
+        const int q = l + it * per;
+        return ((q / G) * 8 + x) * G + q % G;
+    }
+};
 template <bool PACKED> struct RawVal { using type = double; };
 template <> struct RawVal<true> { using type = int; };   // the int8 code, widened: 1 VGPR instead of 2 in the prefetch set
 template <int SLOTS, bool PACKED>
@@ -196,21 +209,17 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
     __shared__ double prod[BS * MAXNNZ];
     // chunk walk: plain (chunk = block, block + grid, ...) or XCD-aware: blocks b, b+8, ... share an XCD (and its L2), so
     // XCD x walks its own contiguous eighth of the chunks and the lines gathered by neighbouring chunks stay in ONE L2
-    int chunk, stride, chunkEnd;
-    if (xcdAware) {
-        const int per = (nChunks + 7) >> 3;
-        const int xcd = blockIdx.x & 7;
-        chunk = xcd * per + (blockIdx.x >> 3);
-        stride = gridDim.x >> 3;
-        chunkEnd = min(nChunks, (xcd + 1) * per);
-    } else { chunk = blockIdx.x; stride = gridDim.x; chunkEnd = nChunks; }
+    const ChunkWalk W(xcdAware);
+    const int chunkEnd = nChunks;
+    int it = 0;
+    int chunk = W.at(0);
     if (chunk >= chunkEnd) return;
     int r0 = chunk * BS;
     int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
     int c[MAXNNZ];
     typename RawVal<PACKED>::type v[MAXNNZ];
     loadStream<MAXNNZ, PACKED>(col, val, code, p0, p1, c, v);
-    int nchunk = chunk + stride;
+    int nchunk = W.at(1);
     int np0 = 0, np1 = 0;
     if (nchunk < chunkEnd) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
     while (true) {
@@ -225,7 +234,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
         int c2[MAXNNZ];
         typename RawVal<PACKED>::type v2[MAXNNZ];
         if (hasNext) loadStream<MAXNNZ, PACKED>(col, val, code, np0, np1, c2, v2);
-        const int nn = nchunk + stride;
+        const int nn = W.at(it + 2);
         int nnp0 = 0, nnp1 = 0;
         if (nn < chunkEnd) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
 #pragma unroll
@@ -243,6 +252,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u) { c[u] = c2[u]; v[u] = v2[u]; }
         nchunk = nn; np0 = nnp0; np1 = nnp1;
+        ++it;
     }
 }
 template <int MODE, int MAXNNZ, bool PACKED>
@@ -253,21 +263,17 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__
                                                      int xcdAware) {
     if (done && *done) return;
     __shared__ double prod[BS * MAXNNZ];
-    int chunk, stride, chunkEnd;
-    if (xcdAware) {
-        const int per = (nChunks + 7) >> 3;
-        const int xcd = blockIdx.x & 7;
-        chunk = xcd * per + (blockIdx.x >> 3);
-        stride = gridDim.x >> 3;
-        chunkEnd = min(nChunks, (xcd + 1) * per);
-    } else { chunk = blockIdx.x; stride = gridDim.x; chunkEnd = nChunks; }
+    const ChunkWalk W(xcdAware);
+    const int chunkEnd = nChunks;
+    int it = 0;
+    int chunk = W.at(0);
     if (chunk >= chunkEnd) return;
     int r0 = chunk * BS;
     int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
     int c[MAXNNZ];
     typename RawVal<PACKED>::type v[MAXNNZ];
     loadStream<MAXNNZ, PACKED>(col, val, code, p0, p1, c, v);
-    int nchunk = chunk + stride;
+    int nchunk = W.at(1);
     int np0 = 0, np1 = 0;
     if (nchunk < chunkEnd) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
     while (true) {
@@ -284,7 +290,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__
         int c2[MAXNNZ];
         typename RawVal<PACKED>::type v2[MAXNNZ];
         if (hasNext) loadStream<MAXNNZ, PACKED>(col, val, code, np0, np1, c2, v2);
-        const int nn = nchunk + stride;
+        const int nn = W.at(it + 2);
         int nnp0 = 0, nnp1 = 0;
         if (nn < chunkEnd) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
 #pragma unroll
@@ -311,6 +317,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u) { c[u] = c2[u]; v[u] = v2[u]; }
         nchunk = nn; np0 = nnp0; np1 = nnp1;
+        ++it;
     }
 }
 
@@ -325,54 +332,69 @@ __device__ inline void rowOffset(uint32_t packed, const double* __restrict__ COM
     o[2] = p[2] * dx - COM[(int64_t)region * 3 + 2];
     *axis = a;
 }
-// partial w (26) of one chunk of <= RC_ROWS reduced rows:  w += C_f * s_f.  One wavefront per chunk: each lane
-// accumulates RC_ROWS/64 rows in registers, then 26 wave-shuffle reductions; no LDS, no barrier.
+// partial w (26) of one chunk of <= RC_ROWS reduced rows of ONE face axis:  w += C_f * s_f.  One wavefront per chunk:
+// all RC_ROWS/64 (face, s) pairs of a lane are requested up front (independent loads in flight together), then only
+// the 10 / 10 / 14 non-zero entries of that axis' basis row (buildConversionCoefficients, Solver.cpp:2112-2145) are
+// accumulated in registers and wave-shuffle reduced; no LDS, no barrier.
+template <int AXIS>
+__device__ inline void tileGatherAxis(int b0, int e, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx,
+                                      double cx, double cy, double cz, double* __restrict__ wout) {
+    constexpr int PER = RC_ROWS / 64;
+    constexpr int NW = AXIS == 2 ? 14 : 10;
+    uint32_t fq[PER];
+    double sq[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int rr = b0 + threadIdx.x + q * 64;
+        const bool ok = rr < e;
+        fq[q] = ok ? __builtin_nontemporal_load(rrowFace + rr) : 0u;
+        sq[q] = ok ? __builtin_nontemporal_load(sred + rr) : 0.;     // 0 for the lanes past the end: contributes nothing
+    }
+    double w[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) w[n] = 0.;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        int i, j, k, axis;
+        unpackFace(fq[q], i, j, k, axis);
+        const double s = sq[q];
+        const double ox = ((double)i - (AXIS == 0 ? 0.5 : 0.)) * dx - cx;
+        const double oy = ((double)j - (AXIS == 1 ? 0.5 : 0.)) * dx - cy;
+        const double oz = ((double)k - (AXIS == 2 ? 0.5 : 0.)) * dx - cz;
+        if (AXIS != 2) {    // x-row: entries 0,3..11 ; y-row: entries 1,12..20
+            w[0] += s; w[1] += ox * s; w[2] += oy * s; w[3] += oz * s;
+            w[4] += ox * ox * s; w[5] += ox * oy * s; w[6] += ox * oz * s; w[7] += oy * oy * s; w[8] += oy * oz * s; w[9] += oz * oz * s;
+        } else {            // z-row: entries 2,3,6,7,8,13,16,18,19,21..25
+            w[0] += s; w[1] += (-oz) * s; w[2] += (-2. * ox * oz) * s; w[3] += (-1. * oy * oz) * s; w[4] += (-0.5 * oz * oz) * s;
+            w[5] += (-oz) * s; w[6] += (-1. * ox * oz) * s; w[7] += (-2. * oy * oz) * s; w[8] += (-0.5 * oz * oz) * s;
+            w[9] += ox * s; w[10] += oy * s; w[11] += ox * ox * s; w[12] += ox * oy * s; w[13] += oy * oy * s;
+        }
+    }
+    constexpr int slotX[10] = {0, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+    constexpr int slotY[10] = {1, 12, 13, 14, 15, 16, 17, 18, 19, 20};
+    constexpr int slotZ[14] = {2, 3, 6, 7, 8, 13, 16, 18, 19, 21, 22, 23, 24, 25};
+    // lane n < 26 ends up holding entry n of the chunk's partial w (0 for the entries this axis never touches): one store
+    double mine = 0.;
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        const double v = __shfl(waveReduceSum(w[n]), 0);
+        if ((int)threadIdx.x == (AXIS == 0 ? slotX[n] : (AXIS == 1 ? slotY[n] : slotZ[n]))) mine = v;
+    }
+    if (threadIdx.x < PS_RD) wout[threadIdx.x] = mine;
+}
 __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ chunkRegion, const int32_t* __restrict__ chunkStart,
-                                                    const int32_t* __restrict__ chunkEnd, const uint32_t* __restrict__ rrowFace,
-                                                    const double* __restrict__ COM, double dx, const double* __restrict__ sred,
-                                                    double* __restrict__ wpart, const int* __restrict__ done) {
+                                                    const int32_t* __restrict__ chunkEnd, const int32_t* __restrict__ chunkAxis,
+                                                    const uint32_t* __restrict__ rrowFace, const double* __restrict__ COM, double dx,
+                                                    const double* __restrict__ sred, double* __restrict__ wpart, const int* __restrict__ done) {
     if (done && *done) return;
     const int ch = blockIdx.x;
     const int r = chunkRegion[ch];
     const double cx = COM[(int64_t)r * 3 + 0], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
-    double w[PS_RD];
-#pragma unroll
-    for (int n = 0; n < PS_RD; ++n) w[n] = 0.;
-    const int e = chunkEnd[ch], b0 = chunkStart[ch];
-    // rows are ordered (region, axis, position), so a wave almost always sees one face axis: accumulate only the
-    // 10 / 10 / 14 non-zero entries of that axis' basis row (wave-uniform branch), generic path otherwise
-    for (int rr = b0 + threadIdx.x; rr < e; rr += 64) {
-        int i, j, k, axis;
-        unpackFace(rrowFace[rr], i, j, k, axis);
-        const double s = sred[rr];
-        const double ox = ((double)i - (axis == 0 ? 0.5 : 0.)) * dx - cx;
-        const double oy = ((double)j - (axis == 1 ? 0.5 : 0.)) * dx - cy;
-        const double oz = ((double)k - (axis == 2 ? 0.5 : 0.)) * dx - cz;
-        const int a0 = __builtin_amdgcn_readfirstlane(axis);
-        if (__all(axis == a0)) {
-            if (a0 == 0) {
-                w[0] += s; w[3] += ox * s; w[4] += oy * s; w[5] += oz * s;
-                w[6] += ox * ox * s; w[7] += ox * oy * s; w[8] += ox * oz * s; w[9] += oy * oy * s; w[10] += oy * oz * s; w[11] += oz * oz * s;
-            } else if (a0 == 1) {
-                w[1] += s; w[12] += ox * s; w[13] += oy * s; w[14] += oz * s;
-                w[15] += ox * ox * s; w[16] += ox * oy * s; w[17] += ox * oz * s; w[18] += oy * oy * s; w[19] += oy * oz * s; w[20] += oz * oz * s;
-            } else {
-                w[2] += s; w[3] += (-oz) * s; w[6] += (-2. * ox * oz) * s; w[7] += (-1. * oy * oz) * s; w[8] += (-0.5 * oz * oz) * s;
-                w[13] += (-oz) * s; w[16] += (-1. * ox * oz) * s; w[18] += (-2. * oy * oz) * s; w[19] += (-0.5 * oz * oz) * s;
-                w[21] += ox * s; w[22] += oy * s; w[23] += ox * ox * s; w[24] += ox * oy * s; w[25] += oy * oy * s;
-            }
-        } else {
-            double c[PS_RD];
-            basisRow(ox, oy, oz, axis, c);
-#pragma unroll
-            for (int n = 0; n < PS_RD; ++n) w[n] += c[n] * s;
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < PS_RD; ++n) {
-        const double v = waveReduceSum(w[n]);
-        if (threadIdx.x == 0) wpart[(int64_t)ch * PS_RD + n] = v;
-    }
+    const int e = chunkEnd[ch], b0 = chunkStart[ch], axis = chunkAxis[ch];
+    double* wout = wpart + (int64_t)ch * PS_RD;
+    if (axis == 0) tileGatherAxis<0>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
+    else if (axis == 1) tileGatherAxis<1>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
+    else tileGatherAxis<2>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
 }
 // MODE 0: v = BInv w ;  MODE 1: v = BInv (invDt*rhsR - w)  (velocity recovery, Solver.cpp:509)
 // MODE 2: v = invDt * BInv rhsR  (right-hand side, AssembleSystem.cpp:448-452; no gather)
@@ -701,7 +723,7 @@ struct Launch {
         double* sred = ts + nA;
         if (mode != 2 && c->nRChunks > 0)
             hipLaunchKernelGGL(k_tile_gather, dim3((unsigned)c->nRChunks), dim3(64), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
-                               c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, sred, c->wreg.p, done);
+                               c->rchunkEnd.p, c->rchunkAxis.p, c->rrowFace.p, c->COM.p, c->dx, sred, c->wreg.p, done);
         const dim3 gr((unsigned)c->regionCount), bl(64);
         if (mode == 0)
             hipLaunchKernelGGL(k_tile_solve<0>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
@@ -751,7 +773,7 @@ Launch mk(ps_context* c, const int* done) {
     L.pipeGrid = pg;
     static int xa = -1;
     if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 0; }
-    L.xcdAware = (xa && (pg % 8) == 0) ? 1 : 0;
+    L.xcdAware = (xa > 0 && (pg % 8) == 0) ? xa : 0;
     return L;
 }
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
@@ -922,6 +944,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
     if (base == "spmv_S") L.spmvS(0, x, c->ts.p);
     else if (base == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
     else if (base == "apply") c->applyOperator(x, y, c->dotPartials.p);
+    else if (base == "tiles") L.tiles(0, c->ts.p);
     else if (base == "cg_update_xr" || base == "cg_update_p") {
         // streaming vector kernels on scratch vectors (alpha = beta = 0 keeps them finite over many launches)
         static ps::DevBuf<CGScalars> scratch;

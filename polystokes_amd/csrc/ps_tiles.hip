@@ -542,6 +542,7 @@ void ps_context::computeCenterOfMasses() {
     }
     ptr[(size_t)R] = (int32_t)iR.size();
     fbItems = (int64_t)iR.size();
+    fbItemAxisHost = iA;
     fbItemRegion.alloc(iR.size()); fbItemAxis.alloc(iR.size()); fbItemStart.alloc(iR.size()); fbRegionItemPtr.alloc(ptr.size());
     fbItemCount.alloc(iR.size() + 1);
     HIP_CHECK(hipMemcpyAsync(fbItemRegion.p, iR.data(), iR.size() * 4, hipMemcpyHostToDevice, stream));

@@ -69,3 +69,36 @@ def test_rccl_entry_points_world1():
     s.comm_init(polystokes_amd.comm_unique_id(), 0, 1)
     s.comm_selftest()
     s.close()
+
+
+def test_bench_weak_scaling_pieces_match_the_global_cavity():
+    """The rank-local scenes bench.py --gpus N feeds (scenes.cavity_slab), run as a 2-rank group, reproduce the
+    single-domain solve of the global n x n x 2n cavity."""
+    import polystokes_amd
+    from polystokes_amd import partition
+    n, world = 32, 2
+    sc0, p = scenes.cavity(n, precond=abi.PRE_DIAGONAL)
+    velx = np.zeros((n * world, n, n + 1), np.float32)
+    velx[n * world - 1] = 1.0
+    glob = abi.Scene(n, n, n * world, sc0.dx, sc0.dt, 1.0, [velx, 0.0, 0.0], np.float32(-1.0), np.float32(1.0), 1.0)
+    single = polystokes_amd.Solver(0)
+    assert single.step(glob, p) == abi.SUCCESS
+    grp = polystokes_amd.Group(world)
+    slabs = []
+    for r in range(world):
+        sc, pr, sl = scenes.cavity_slab(n, world, r, precond=abi.PRE_DIAGONAL)
+        grp.ranks[r].upload(sc, pr)
+        grp.ranks[r].set_slab(sl)
+        slabs.append(sl)
+    assert grp.step() == abi.SUCCESS
+    it1, it2 = single.stats.solveData[1], grp.stats.solveData[1]
+    assert abs(it1 - it2) <= max(2, 0.02 * it1), (it1, it2)
+    for r, sl in enumerate(slabs):
+        lv, lval = grp.ranks[r].download()
+        for a in range(3):
+            own = grp.ranks[r].array("owned" + "XYZ"[a]).reshape(lv[a].shape) > 0
+            ref = single.vel[a][sl.g0:sl.g0 + lv[a].shape[0]]
+            scale = max(np.abs(single.vel[a]).max(), 1e-30)
+            assert np.abs(lv[a][own] - ref[own]).max() <= 20 * p.tolerance * scale
+    grp.close()
+    single.close()

@@ -79,3 +79,29 @@ def test_slab_ranges_and_alignment():
         partition.slab_ranges(32, 4, 16)
     sl = partition.make_slab(96, 3, 1, 16)
     assert (sl.z0, sl.z1, sl.g0, sl.zLoOwned, sl.zHiOwned, sl.hasLower, sl.hasUpper, sl.nz_local) == (32, 64, 16, 16, 48, 1, 1, 64)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cavity_slab_is_the_cut_of_the_global_weak_scaling_cavity(world):
+    """bench.py --gpus N builds each rank's piece directly (scenes.cavity_slab); it must be exactly the slab that
+    partition.local_scene cuts out of the global n x n x (n*world) cavity with the lid on the global top plane."""
+    from polystokes_amd import _abi as abi
+    from polystokes_amd import partition, scenes
+    n = 32
+    sc0, p0 = scenes.cavity(n)
+    velx = np.zeros((n * world, n, n + 1), np.float32)
+    velx[n * world - 1] = 1.0
+    glob = abi.Scene(n, n, n * world, sc0.dx, sc0.dt, 1.0, [velx, 0.0, 0.0], np.float32(-1.0), np.float32(1.0), 1.0)
+    for rank in range(world):
+        sc, p, sl = scenes.cavity_slab(n, world, rank)
+        ref = partition.local_scene(glob, partition.make_slab(n * world, world, rank, p.tileSize))
+        assert (sc.nx, sc.ny, sc.nz) == (ref.nx, ref.ny, ref.nz)
+        assert (sl.z0, sl.z1, sl.g0, sl.nz_local, sl.zLoOwned, sl.zHiOwned) == (rank * n, (rank + 1) * n, max(0, rank * n - 16),
+                                                                              n + 16 * ((rank > 0) + (rank < world - 1)),
+                                                                              16 * (rank > 0), 16 * (rank > 0) + n)
+        assert sc.dx == ref.dx and sc.dt == ref.dt and sc.density == ref.density
+        for a in range(3):
+            assert np.array_equal(sc.vel[a], ref.vel[a]) and np.array_equal(sc.collisionvel[a], ref.collisionvel[a])
+        for f in ("surface", "collision", "viscosity"):
+            assert np.array_equal(getattr(sc, f), getattr(ref, f))
+        assert p.tileSize == p0.tileSize and p.tilePadding == p0.tilePadding
