@@ -415,7 +415,69 @@ BlockArgs makeArgs(ps_context* c) {
     return A;
 }
 
+// 16-bit windowed columns of one 256-row chunk (one block per chunk).  Greedy cover of the chunk's column set by
+// windows [base, base + 4096): base = smallest column not yet covered (block min), at most 16 windows; a chunk that
+// needs more raises *fail and the SpMVs keep the 32-bit columns.  The block-interleaved numbering keeps the
+// columns of a chunk in a handful of short runs (own voxels, the j/k neighbours, the 6 neighbouring blocks, skin rows
+// of adjacent tiles), so 16 windows are plenty.
+__global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, int rows,
+                                                    uint16_t* __restrict__ col16, int32_t* __restrict__ winBase, int32_t* __restrict__ fail) {
+    __shared__ int red[BS / 64];
+    __shared__ int bmin;
+    const int chunk = blockIdx.x;
+    const int r0 = chunk * BS;
+    const int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
+    constexpr int SL = 8;                               // <= 8 entries per row: <= 2048 entries per chunk
+    int c[SL];
+    bool open[SL];
+#pragma unroll
+    for (int u = 0; u < SL; ++u) {
+        const int p = p0 + threadIdx.x + u * BS;
+        open[u] = p < p1;
+        c[u] = open[u] ? col[p] : 0x7fffffff;
+    }
+    if (p1 - p0 > SL * BS) { if (threadIdx.x == 0) *fail = 1; return; }
+    for (int w = 0; w < 16; ++w) {
+        int m = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < SL; ++u) if (open[u]) m = min(m, c[u]);
+        for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_down(m, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) { int b = red[0]; for (int q = 1; q < BS / 64; ++q) b = min(b, red[q]); bmin = b; }
+        __syncthreads();
+        const int base = bmin;
+        __syncthreads();
+        if (threadIdx.x == 0) winBase[(int64_t)chunk * 16 + w] = base == 0x7fffffff ? 0 : base;
+        if (base == 0x7fffffff) continue;               // block-uniform: nothing left, remaining windows get base 0
+#pragma unroll
+        for (int u = 0; u < SL; ++u)
+            if (open[u] && c[u] - base < 4096) {
+                col16[p0 + threadIdx.x + u * BS] = (uint16_t)((w << 12) | (c[u] - base));
+                open[u] = false;
+            }
+    }
+    bool left = false;
+#pragma unroll
+    for (int u = 0; u < SL; ++u) left |= open[u];
+    if (left) *fail = 1;
+}
+
 }  // namespace
+
+// SpMV column compression (see k_col16_build); decided per matrix, like the value coding
+void ps_context::buildCol16(ps::DevCSR& M, int slot) {
+    M.col16ok = false;
+    const char* e = getenv("PS_COL32");
+    if (!M.packed || M.rows == 0 || M.nnz == 0 || (e && atoi(e) != 0)) return;
+    const int nChunks = gridFor(M.rows, BS);
+    M.col16.alloc((size_t)M.nnz);
+    M.winBase.alloc((size_t)nChunks * 16);
+    HIP_CHECK(hipMemsetAsync(counters.p + slot, 0, sizeof(int32_t), stream));
+    hipLaunchKernelGGL(k_col16_build, dim3((unsigned)nChunks), dim3(BS), 0, stream, M.ptr.p, M.col.p, (int)M.rows, M.col16.p, M.winBase.p,
+                       counters.p + slot);
+    M.col16ok = readCounter(slot) == 0;
+}
 
 // ConstructMatrixBlocks.cpp:9-292
 void ps_context::constructMatrixBlocks() {
@@ -550,6 +612,11 @@ void ps_context::constructMatrixBlocks() {
         S.packed = St.packed = ok && !forceFp64Values;
         const int32_t flag = S.packed ? 1 : 0;
         HIP_CHECK(hipMemcpyAsync(counters.p + 21, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        buildCol16(S, 22);
+        buildCol16(St, 23);
+        const int32_t c16 = (S.col16ok ? 1 : 0) | (St.col16ok ? 2 : 0);
+        HIP_CHECK(hipMemcpyAsync(counters.p + 24, &c16, sizeof(c16), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 }

@@ -257,6 +257,7 @@ void ps_context::registerArrays() {
         reg("recoveredReducedVelocity", recovered.p ? recovered.p + nActiveVs : nullptr, nReducedVs, 8);
     }
     reg("valuesCoded", counters.p + 21, 1, 4);
+    reg("columns16", counters.p + 24, 1, 4);
     reg("sysPerm", permSys.p, nSystem, 4);
     reg("rowPerm", permRow.p, nActiveVs, 4);
     reg("S.ptr", S.ptr.p, S.rows + 1, 4); reg("S.col", S.col.p, S.nnz, 4); reg("S.val", S.val.p, S.nnz, 8);
@@ -507,9 +508,13 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             const double nnz = (double)c->S.nnz, rowsS = (double)c->nRows, rowsT = (double)c->nSystem;
             const bool fp64 = k.size() > 5 && k.compare(k.size() - 5, 5, "_fp64") == 0;
             const std::string kb = fp64 ? k.substr(0, k.size() - 5) : k;
-            const double perNnz = (c->S.packed && !fp64) ? 5. : 12.;   // int32 column + (int8 value code | fp64 value)
-            const double bS = perNnz * nnz + 4. * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
-            const double bT = perNnz * nnz + 4. * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * rowsT;
+            // int32 column + fp64 value | int32 column + int8 value code | 16-bit windowed column + int8 code (+ 64 B of
+            // window bases per 256-row chunk)
+            const bool coded = c->S.packed && !fp64;
+            const double perNnzS = coded ? (c->S.col16ok ? 3. : 5.) : 12., perNnzT = coded ? (c->St.col16ok ? 3. : 5.) : 12.;
+            const double winS = (coded && c->S.col16ok) ? 0.25 * (double)c->nRows : 0., winT = (coded && c->St.col16ok) ? 0.25 * (double)c->nSystem : 0.;
+            const double bS = winS + perNnzS * nnz + 4. * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
+            const double bT = winT + perNnzT * nnz + 4. * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * rowsT;
             if (kb == "spmv_S") *algorithmic_bytes = bS;
             else if (kb == "spmv_St") *algorithmic_bytes = bT;
             else if (kb == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);

@@ -17,6 +17,11 @@ struct DevCSR {
     // The fill kernels verify code*scale == val bit for bit; if any entry fails, the SpMV streams `val` instead.
     DevBuf<int8_t> code;
     bool packed = false;
+    // 16-bit windowed columns (only with `packed`): per 256-row chunk up to 16 windows of 4096 columns;
+    // col = winBase[chunk*16 + (c16 >> 12)] + (c16 & 4095).  Used only if EVERY chunk fits (col16ok).
+    DevBuf<uint16_t> col16;
+    DevBuf<int32_t> winBase;
+    bool col16ok = false;
 };
 
 // device-resident CG scalars (no host round trip inside the iteration)
@@ -157,6 +162,7 @@ struct ps_context {
     void computeReducedViscosityMatricesInteriorOnly();
     void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
     void constructMatrixBlocks();                         // ps_blocks.hip
+    void buildCol16(ps::DevCSR& M, int counterSlot);       // ps_blocks.hip
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();
     int solve();

@@ -183,16 +183,26 @@ struct ChunkWalk {
 };
 template <bool PACKED> struct RawVal { using type = double; };
 template <> struct RawVal<true> { using type = int; };   // the int8 code, widened: 1 VGPR instead of 2 in the prefetch set
-template <int SLOTS, bool PACKED>
-__device__ inline void loadStream(const int32_t* __restrict__ col, const double* __restrict__ val, const int8_t* __restrict__ code,
-                                  int p0, int p1, int (&c)[SLOTS], typename RawVal<PACKED>::type (&v)[SLOTS]) {
+template <int SLOTS, bool PACKED, bool C16>
+__device__ inline void loadStream(const int32_t* __restrict__ col, const uint16_t* __restrict__ col16, const double* __restrict__ val,
+                                  const int8_t* __restrict__ code, int p0, int p1, int (&c)[SLOTS], typename RawVal<PACKED>::type (&v)[SLOTS]) {
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         const int p = p0 + threadIdx.x + u * BS;
         const bool ok = p < p1;
-        c[u] = ok ? __builtin_nontemporal_load(col + p) : -1;
+        if constexpr (C16) c[u] = ok ? (int)__builtin_nontemporal_load(col16 + p) : -1;
+        else c[u] = ok ? __builtin_nontemporal_load(col + p) : -1;
         if constexpr (PACKED) v[u] = ok ? (int)__builtin_nontemporal_load(code + p) : 0;
         else v[u] = ok ? __builtin_nontemporal_load(val + p) : 0.;
+    }
+}
+// 16-bit windowed column -> column: window base (held by lane `window` of every 16-lane group) + 12-bit offset
+template <bool C16>
+__device__ inline int resolveCol(int raw, int myBase) {
+    if constexpr (!C16) return raw;
+    else {
+        const int b = __shfl(myBase, (raw >> 12) & 15, 16);   // executed by all lanes
+        return raw >= 0 ? b + (raw & 4095) : -1;
     }
 }
 template <bool PACKED>
@@ -200,8 +210,9 @@ __device__ inline double rawToVal(typename RawVal<PACKED>::type r, double scale)
     if constexpr (PACKED) return (double)r * scale;   // exact: see DevCSR::code
     else return r;
 }
-template <int MODE, int MAXNNZ, bool PACKED>
-__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+template <int MODE, int MAXNNZ, bool PACKED, bool C16>
+__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const uint16_t* __restrict__ col16,
+                                                    const int32_t* __restrict__ winBase, const double* __restrict__ val,
                                                     const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
                                                     double dt, const double* __restrict__ McInv, double* __restrict__ out,
                                                     const int* __restrict__ done, int nChunks, int xcdAware) {
@@ -218,7 +229,9 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
     int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
     int c[MAXNNZ];
     typename RawVal<PACKED>::type v[MAXNNZ];
-    loadStream<MAXNNZ, PACKED>(col, val, code, p0, p1, c, v);
+    loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, p0, p1, c, v);
+    int myBase = 0, nBase = 0;
+    if constexpr (C16) myBase = winBase[chunk * 16 + (threadIdx.x & 15)];
     int nchunk = W.at(1);
     int np0 = 0, np1 = 0;
     if (nchunk < chunkEnd) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
@@ -229,11 +242,14 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
         const double sc = (MODE == 0 && ok && row < nA) ? dt * McInv[row] : 1.;
         double xv[MAXNNZ];
 #pragma unroll
-        for (int u = 0; u < MAXNNZ; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.;
+        for (int u = 0; u < MAXNNZ; ++u) { const int cc = resolveCol<C16>(c[u], myBase); xv[u] = cc >= 0 ? x[cc] : 0.; }
         const bool hasNext = nchunk < chunkEnd;
         int c2[MAXNNZ];
         typename RawVal<PACKED>::type v2[MAXNNZ];
-        if (hasNext) loadStream<MAXNNZ, PACKED>(col, val, code, np0, np1, c2, v2);
+        if (hasNext) {
+            loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, np0, np1, c2, v2);
+            if constexpr (C16) nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
+        }
         const int nn = W.at(it + 2);
         int nnp0 = 0, nnp1 = 0;
         if (nn < chunkEnd) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
@@ -252,11 +268,13 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u) { c[u] = c2[u]; v[u] = v2[u]; }
         nchunk = nn; np0 = nnp0; np1 = nnp1;
+        myBase = nBase;
         ++it;
     }
 }
-template <int MODE, int MAXNNZ, bool PACKED>
-__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+template <int MODE, int MAXNNZ, bool PACKED, bool C16>
+__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const uint16_t* __restrict__ col16,
+                                                     const int32_t* __restrict__ winBase, const double* __restrict__ val,
                                                      const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
                                                      double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done, int nChunks,
@@ -272,7 +290,9 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__
     int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
     int c[MAXNNZ];
     typename RawVal<PACKED>::type v[MAXNNZ];
-    loadStream<MAXNNZ, PACKED>(col, val, code, p0, p1, c, v);
+    loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, p0, p1, c, v);
+    int myBase = 0, nBase = 0;
+    if constexpr (C16) myBase = winBase[chunk * 16 + (threadIdx.x & 15)];
     int nchunk = W.at(1);
     int np0 = 0, np1 = 0;
     if (nchunk < chunkEnd) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
@@ -285,11 +305,14 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__
         else e0 = ok ? add[row] : 0.;
         double xv[MAXNNZ];
 #pragma unroll
-        for (int u = 0; u < MAXNNZ; ++u) xv[u] = c[u] >= 0 ? t[c[u]] : 0.;
+        for (int u = 0; u < MAXNNZ; ++u) { const int cc = resolveCol<C16>(c[u], myBase); xv[u] = cc >= 0 ? t[cc] : 0.; }
         const bool hasNext = nchunk < chunkEnd;
         int c2[MAXNNZ];
         typename RawVal<PACKED>::type v2[MAXNNZ];
-        if (hasNext) loadStream<MAXNNZ, PACKED>(col, val, code, np0, np1, c2, v2);
+        if (hasNext) {
+            loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, np0, np1, c2, v2);
+            if constexpr (C16) nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
+        }
         const int nn = W.at(it + 2);
         int nnp0 = 0, nnp1 = 0;
         if (nn < chunkEnd) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
@@ -317,6 +340,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u) { c[u] = c2[u]; v[u] = v2[u]; }
         nchunk = nn; np0 = nnp0; np1 = nnp1;
+        myBase = nBase;
         ++it;
     }
 }
@@ -709,10 +733,10 @@ struct Launch {
             const int nChunks = gridFor(rowsS, BS);
             const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
             const ps::DevCSR& M = c->S;
-#define PS_LAUNCH_SP(MODE_, PK_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, 8, PK_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
-                                                    c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware)
-            if (mode == 0) { if (M.packed) PS_LAUNCH_SP(0, true); else PS_LAUNCH_SP(0, false); }
-            else { if (M.packed) PS_LAUNCH_SP(1, true); else PS_LAUNCH_SP(1, false); }
+#define PS_LAUNCH_SP(MODE_, C16_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, 8, true, C16_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.col16.p, \
+                                                     M.winBase.p, M.val.p, M.code.p, c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware)
+            if (mode == 0) { if (M.col16ok) PS_LAUNCH_SP(0, true); else PS_LAUNCH_SP(0, false); }
+            else { if (M.col16ok) PS_LAUNCH_SP(1, true); else PS_LAUNCH_SP(1, false); }
 #undef PS_LAUNCH_SP
             return;
         }
@@ -750,10 +774,11 @@ struct Launch {
             const int nChunks = gridFor(rowsSt, BS);
             const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
             const ps::DevCSR& M = c->St;
-#define PS_LAUNCH_TP(MODE_, PK_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, 6, PK_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.val.p, M.code.p, \
-                                                    c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware)
-            if (mode == 0) { if (M.packed) PS_LAUNCH_TP(0, true); else PS_LAUNCH_TP(0, false); }
-            else { if (M.packed) PS_LAUNCH_TP(1, true); else PS_LAUNCH_TP(1, false); }
+#define PS_LAUNCH_TP(MODE_, C16_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, 6, true, C16_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.col16.p, \
+                                                     M.winBase.p, M.val.p, M.code.p, c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done, \
+                                                     nChunks, xcdAware)
+            if (mode == 0) { if (M.col16ok) PS_LAUNCH_TP(0, true); else PS_LAUNCH_TP(0, false); }
+            else { if (M.col16ok) PS_LAUNCH_TP(1, true); else PS_LAUNCH_TP(1, false); }
 #undef PS_LAUNCH_TP
             return;
         }
