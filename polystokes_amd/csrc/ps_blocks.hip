@@ -463,11 +463,35 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
     if (left) *fail = 1;
 }
 
+__global__ void k_len8_build(const int32_t* __restrict__ ptr, int rows, int nChunks, uint8_t* __restrict__ len8, int32_t* __restrict__ chunkPtr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) len8[i] = (uint8_t)(ptr[i + 1] - ptr[i]);
+    if (i <= nChunks) chunkPtr[i] = ptr[min(i * BS, rows)];
+}
+__global__ void k_chunk_max(const int32_t* __restrict__ ptr, int rows, int c0, int c1, int32_t* __restrict__ out) {
+    const int ch = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < c1) atomicMax(out, ptr[min(ch * BS + BS, rows)] - ptr[ch * BS]);
+}
 }  // namespace
-
-// SpMV column compression (see k_col16_build); decided per matrix, like the value coding
-void ps_context::buildCol16(ps::DevCSR& M, int slot) {
+// SpMV stream compression (see k_col16_build); decided per matrix, like the value coding.  splitRow: rows before it
+// (active faces) and behind it (skin rows) get their own launch with their own number of entry slots.
+void ps_context::buildCol16(ps::DevCSR& M, int slot, int64_t splitRow) {
     M.col16ok = false;
+    M.splitChunk = 0x7fffffff; M.slotsA = M.slotsB = 8;
+    if (M.rows > 0 && M.nnz > 0) {
+        const int nCh = gridFor(M.rows, BS);
+        M.splitChunk = (int)std::min<int64_t>(nCh, (splitRow + BS - 1) / BS);
+        int* mx[2] = {&M.slotsA, &M.slotsB};
+        const int lo[2] = {0, M.splitChunk}, hi[2] = {M.splitChunk, nCh};
+        for (int q = 0; q < 2; ++q) {
+            if (hi[q] <= lo[q]) continue;
+            HIP_CHECK(hipMemsetAsync(counters.p + 25, 0, sizeof(int32_t), stream));
+            hipLaunchKernelGGL(k_chunk_max, dim3(gridFor(hi[q] - lo[q], BS)), dim3(BS), 0, stream, M.ptr.p, (int)M.rows, lo[q], hi[q], counters.p + 25);
+            *mx[q] = std::max(1, (readCounter(25) + BS - 1) / BS);
+        }
+        if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] stream slots: rows %lld nnz %lld split chunk %d of %d, slots %d / %d\n",
+                                               (long long)M.rows, (long long)M.nnz, M.splitChunk, nCh, M.slotsA, M.slotsB);
+    }
     const char* e = getenv("PS_COL32");
     if (!M.packed || M.rows == 0 || M.nnz == 0 || (e && atoi(e) != 0)) return;
     const int nChunks = gridFor(M.rows, BS);
@@ -476,6 +500,8 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot) {
     HIP_CHECK(hipMemsetAsync(counters.p + slot, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(k_col16_build, dim3((unsigned)nChunks), dim3(BS), 0, stream, M.ptr.p, M.col.p, (int)M.rows, M.col16.p, M.winBase.p,
                        counters.p + slot);
+    M.len8.alloc((size_t)M.rows); M.chunkPtr.alloc((size_t)nChunks + 1);
+    hipLaunchKernelGGL(k_len8_build, dim3(gridFor(M.rows + 1, BS)), dim3(BS), 0, stream, M.ptr.p, (int)M.rows, nChunks, M.len8.p, M.chunkPtr.p);
     M.col16ok = readCounter(slot) == 0;
 }
 
@@ -613,8 +639,8 @@ void ps_context::constructMatrixBlocks() {
         const int32_t flag = S.packed ? 1 : 0;
         HIP_CHECK(hipMemcpyAsync(counters.p + 21, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        buildCol16(S, 22);
-        buildCol16(St, 23);
+        buildCol16(S, 22, nActiveVs);
+        buildCol16(St, 23, nSystem);
         const int32_t c16 = (S.col16ok ? 1 : 0) | (St.col16ok ? 2 : 0);
         HIP_CHECK(hipMemcpyAsync(counters.p + 24, &c16, sizeof(c16), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

@@ -513,8 +513,9 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             const bool coded = c->S.packed && !fp64;
             const double perNnzS = coded ? (c->S.col16ok ? 3. : 5.) : 12., perNnzT = coded ? (c->St.col16ok ? 3. : 5.) : 12.;
             const double winS = (coded && c->S.col16ok) ? 0.25 * (double)c->nRows : 0., winT = (coded && c->St.col16ok) ? 0.25 * (double)c->nSystem : 0.;
-            const double bS = winS + perNnzS * nnz + 4. * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
-            const double bT = winT + perNnzT * nnz + 4. * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * rowsT;
+            const double ptrS = (coded && c->S.col16ok) ? 1. : 4., ptrT = (coded && c->St.col16ok) ? 1. : 4.;   // row length byte | row pointer
+            const double bS = winS + perNnzS * nnz + ptrS * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
+            const double bT = winT + perNnzT * nnz + ptrT * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * rowsT;
             if (kb == "spmv_S") *algorithmic_bytes = bS;
             else if (kb == "spmv_St") *algorithmic_bytes = bT;
             else if (kb == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);

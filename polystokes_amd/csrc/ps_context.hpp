@@ -21,7 +21,11 @@ struct DevCSR {
     // col = winBase[chunk*16 + (c16 >> 12)] + (c16 & 4095).  Used only if EVERY chunk fits (col16ok).
     DevBuf<uint16_t> col16;
     DevBuf<int32_t> winBase;
+    DevBuf<int32_t> chunkPtr;    // with col16: ptr[256 * chunk] (nChunks + 1 entries) ...
+    DevBuf<uint8_t> len8;        // ... and one row-length byte per row instead of the 4-byte row pointer
     bool col16ok = false;
+    // entry slots per thread (= ceil(fullest chunk / 256)) of the chunk ranges [0, splitChunk) and [splitChunk, nChunks)
+    int splitChunk = 0x7fffffff, slotsA = 8, slotsB = 8;
 };
 
 // device-resident CG scalars (no host round trip inside the iteration)
@@ -162,7 +166,7 @@ struct ps_context {
     void computeReducedViscosityMatricesInteriorOnly();
     void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
     void constructMatrixBlocks();                         // ps_blocks.hip
-    void buildCol16(ps::DevCSR& M, int counterSlot);       // ps_blocks.hip
+    void buildCol16(ps::DevCSR& M, int counterSlot, int64_t splitRow);   // ps_blocks.hip
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();
     int solve();

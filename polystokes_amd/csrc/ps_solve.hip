@@ -205,6 +205,19 @@ __device__ inline int resolveCol(int raw, int myBase) {
         return raw >= 0 ? b + (raw & 4095) : -1;
     }
 }
+// entry range of chunk ch: from the per-chunk pointers of the compressed format, or from the CSR row pointers
+template <bool C16>
+__device__ inline void chunkBounds(const int32_t* __restrict__ ptr, const int32_t* __restrict__ chunkPtr, int ch, int rows, int& a, int& b) {
+    if constexpr (C16) { a = chunkPtr[ch]; b = chunkPtr[ch + 1]; }
+    else { a = ptr[ch * BS]; b = ptr[min(ch * BS + BS, rows)]; }
+}
+// position of this thread's row inside the chunk's entry range.  Compressed format: one length byte per row, prefix-summed
+// across the block (wave shuffles + the 4 wave totals through LDS; call on both sides of the caller's barrier).
+__device__ inline int waveInclusiveScan(int v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if ((int)(threadIdx.x & 63) >= o) v += t; }
+    return v;
+}
 template <bool PACKED>
 __device__ inline double rawToVal(typename RawVal<PACKED>::type r, double scale) {
     if constexpr (PACKED) return (double)r * scale;   // exact: see DevCSR::code
@@ -212,10 +225,11 @@ __device__ inline double rawToVal(typename RawVal<PACKED>::type r, double scale)
 }
 template <int MODE, int MAXNNZ, bool PACKED, bool C16>
 __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const uint16_t* __restrict__ col16,
-                                                    const int32_t* __restrict__ winBase, const double* __restrict__ val,
+                                                    const int32_t* __restrict__ winBase, const int32_t* __restrict__ chunkPtr,
+                                                    const uint8_t* __restrict__ len8, const double* __restrict__ val,
                                                     const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
                                                     double dt, const double* __restrict__ McInv, double* __restrict__ out,
-                                                    const int* __restrict__ done, int nChunks, int xcdAware) {
+                                                    const int* __restrict__ done, int chunkBegin, int nChunks, int xcdAware) {
     if (done && *done) return;
     __shared__ double prod[BS * MAXNNZ];
     // chunk walk: plain (chunk = block, block + grid, ...) or XCD-aware: blocks b, b+8, ... share an XCD (and its L2), so
@@ -223,22 +237,26 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
     const ChunkWalk W(xcdAware);
     const int chunkEnd = nChunks;
     int it = 0;
-    int chunk = W.at(0);
+    int chunk = chunkBegin + W.at(0);   // this launch covers chunks [chunkBegin, nChunks)
     if (chunk >= chunkEnd) return;
     int r0 = chunk * BS;
-    int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
+    int p0, p1;
+    chunkBounds<C16>(ptr, chunkPtr, chunk, rows, p0, p1);
+    __shared__ int wtot[BS / 64];
     int c[MAXNNZ];
     typename RawVal<PACKED>::type v[MAXNNZ];
     loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, p0, p1, c, v);
     int myBase = 0, nBase = 0;
     if constexpr (C16) myBase = winBase[chunk * 16 + (threadIdx.x & 15)];
-    int nchunk = W.at(1);
+    int nchunk = chunkBegin + W.at(1);
     int np0 = 0, np1 = 0;
-    if (nchunk < chunkEnd) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
+    if (nchunk < chunkEnd) chunkBounds<C16>(ptr, chunkPtr, nchunk, rows, np0, np1);
     while (true) {
         const int row = r0 + threadIdx.x;
         const bool ok = row < rows;
-        const int pa = ok ? ptr[row] : 0, pb = ok ? ptr[row + 1] : 0;
+        int ea = 0, eb = 0, incl = 0;      // this row's entries are prod[ea .. eb)
+        if constexpr (C16) eb = ok ? (int)len8[row] : 0;
+        else { ea = ok ? ptr[row] - p0 : 0; eb = ok ? ptr[row + 1] - p0 : 0; }
         const double sc = (MODE == 0 && ok && row < nA) ? dt * McInv[row] : 1.;
         double xv[MAXNNZ];
 #pragma unroll
@@ -250,16 +268,25 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
             loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, np0, np1, c2, v2);
             if constexpr (C16) nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
-        const int nn = W.at(it + 2);
+        const int nn = chunkBegin + W.at(it + 2);
         int nnp0 = 0, nnp1 = 0;
-        if (nn < chunkEnd) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
+        if (nn < chunkEnd) chunkBounds<C16>(ptr, chunkPtr, nn, rows, nnp0, nnp1);
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u)
             if (c[u] >= 0) prod[threadIdx.x + u * BS] = rawToVal<PACKED>(v[u], scale) * xv[u];
+        if constexpr (C16) {
+            incl = waveInclusiveScan(eb);
+            if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        }
         __syncthreads();
+        if constexpr (C16) {
+            int off = 0;
+            for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) off += wtot[q];
+            ea = off + incl - eb; eb = off + incl;
+        }
         if (ok) {
             double s = 0.;
-            for (int e = pa - p0; e < pb - p0; ++e) s += prod[e];
+            for (int e = ea; e < eb; ++e) s += prod[e];
             out[row] = s * sc;
         }
         __syncthreads();
@@ -274,32 +301,37 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ 
 }
 template <int MODE, int MAXNNZ, bool PACKED, bool C16>
 __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const uint16_t* __restrict__ col16,
-                                                     const int32_t* __restrict__ winBase, const double* __restrict__ val,
+                                                     const int32_t* __restrict__ winBase, const int32_t* __restrict__ chunkPtr,
+                                                     const uint8_t* __restrict__ len8, const double* __restrict__ val,
                                                      const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
-                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done, int nChunks,
-                                                     int xcdAware) {
+                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done, int chunkBegin,
+                                                     int nChunks, int xcdAware) {
     if (done && *done) return;
     __shared__ double prod[BS * MAXNNZ];
     const ChunkWalk W(xcdAware);
     const int chunkEnd = nChunks;
     int it = 0;
-    int chunk = W.at(0);
+    int chunk = chunkBegin + W.at(0);   // this launch covers chunks [chunkBegin, nChunks)
     if (chunk >= chunkEnd) return;
     int r0 = chunk * BS;
-    int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
+    int p0, p1;
+    chunkBounds<C16>(ptr, chunkPtr, chunk, rows, p0, p1);
+    __shared__ int wtot[BS / 64];
     int c[MAXNNZ];
     typename RawVal<PACKED>::type v[MAXNNZ];
     loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, p0, p1, c, v);
     int myBase = 0, nBase = 0;
     if constexpr (C16) myBase = winBase[chunk * 16 + (threadIdx.x & 15)];
-    int nchunk = W.at(1);
+    int nchunk = chunkBegin + W.at(1);
     int np0 = 0, np1 = 0;
-    if (nchunk < chunkEnd) { np0 = ptr[nchunk * BS]; np1 = ptr[min(nchunk * BS + BS, rows)]; }
+    if (nchunk < chunkEnd) chunkBounds<C16>(ptr, chunkPtr, nchunk, rows, np0, np1);
     while (true) {
         const int row = r0 + threadIdx.x;
         const bool ok = row < rows;
-        const int pa = ok ? ptr[row] : 0, pb = ok ? ptr[row + 1] : 0;
+        int ea = 0, eb = 0, incl = 0;      // this row's entries are prod[ea .. eb)
+        if constexpr (C16) eb = ok ? (int)len8[row] : 0;
+        else { ea = ok ? ptr[row] - p0 : 0; eb = ok ? ptr[row + 1] - p0 : 0; }
         double e0, e1 = 0.;
         if (MODE == 0) { e0 = ok ? xin[row] : 0.; e1 = ok ? uInv[row] : 0.; }
         else e0 = ok ? add[row] : 0.;
@@ -313,17 +345,26 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__
             loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, np0, np1, c2, v2);
             if constexpr (C16) nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
-        const int nn = W.at(it + 2);
+        const int nn = chunkBegin + W.at(it + 2);
         int nnp0 = 0, nnp1 = 0;
-        if (nn < chunkEnd) { nnp0 = ptr[nn * BS]; nnp1 = ptr[min(nn * BS + BS, rows)]; }
+        if (nn < chunkEnd) chunkBounds<C16>(ptr, chunkPtr, nn, rows, nnp0, nnp1);
 #pragma unroll
         for (int u = 0; u < MAXNNZ; ++u)
             if (c[u] >= 0) prod[threadIdx.x + u * BS] = rawToVal<PACKED>(v[u], scale) * xv[u];
+        if constexpr (C16) {
+            incl = waveInclusiveScan(eb);
+            if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        }
         __syncthreads();
+        if constexpr (C16) {
+            int off = 0;
+            for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) off += wtot[q];
+            ea = off + incl - eb; eb = off + incl;
+        }
         double d = 0.;
         if (ok) {
             double s = 0.;
-            for (int e = pa - p0; e < pb - p0; ++e) s += prod[e];
+            for (int e = ea; e < eb; ++e) s += prod[e];
             double y;
             if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; d = e0 * y; }
             else y = -s + e0;
@@ -731,12 +772,22 @@ struct Launch {
         if (rowsS == 0) return;
         if (pipeGrid > 0 && c->S.packed) {   // fp64 values: the one-shot kernel is faster (register pressure of the prefetch set)
             const int nChunks = gridFor(rowsS, BS);
-            const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
             const ps::DevCSR& M = c->S;
-#define PS_LAUNCH_SP(MODE_, C16_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, 8, true, C16_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.col16.p, \
-                                                     M.winBase.p, M.val.p, M.code.p, c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware)
-            if (mode == 0) { if (M.col16ok) PS_LAUNCH_SP(0, true); else PS_LAUNCH_SP(0, false); }
-            else { if (M.col16ok) PS_LAUNCH_SP(1, true); else PS_LAUNCH_SP(1, false); }
+            // entry slots per thread = what the fullest chunk needs
+            auto go = [&](int c0, int c1, int slots) {
+                if (c1 <= c0) return;
+                const dim3 gr(std::min(c1 - c0, pipeGrid)), bl(BS);
+#define PS_LAUNCH_SP(MODE_, SL_, C16_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, SL_, true, C16_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.col16.p, \
+                                                     M.winBase.p, M.chunkPtr.p, M.len8.p, M.val.p, M.code.p, c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done, \
+                                                     c0, c1, xcdAware)
+                if (!M.col16ok) { if (mode == 0) PS_LAUNCH_SP(0, 8, false); else PS_LAUNCH_SP(1, 8, false); }
+                else if (slots <= 4) { if (mode == 0) PS_LAUNCH_SP(0, 4, true); else PS_LAUNCH_SP(1, 4, true); }
+                else if (slots <= 6) { if (mode == 0) PS_LAUNCH_SP(0, 6, true); else PS_LAUNCH_SP(1, 6, true); }
+                else { if (mode == 0) PS_LAUNCH_SP(0, 8, true); else PS_LAUNCH_SP(1, 8, true); }
+            };
+            // (two launches — active-face rows / skin rows, each with its own slot count — measured slower than one: 0.405 vs
+            // 0.376 ms at 256^3 with 8 / 6 slots; the second launch's ramp costs more than the empty slots)
+            go(0, nChunks, std::max(M.slotsA, M.slotsB));
 #undef PS_LAUNCH_SP
             return;
         }
@@ -774,11 +825,12 @@ struct Launch {
             const int nChunks = gridFor(rowsSt, BS);
             const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
             const ps::DevCSR& M = c->St;
-#define PS_LAUNCH_TP(MODE_, C16_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, 6, true, C16_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.col16.p, \
-                                                     M.winBase.p, M.val.p, M.code.p, c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done, \
-                                                     nChunks, xcdAware)
-            if (mode == 0) { if (M.col16ok) PS_LAUNCH_TP(0, true); else PS_LAUNCH_TP(0, false); }
-            else { if (M.col16ok) PS_LAUNCH_TP(1, true); else PS_LAUNCH_TP(1, false); }
+#define PS_LAUNCH_TP(MODE_, SL_, C16_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, SL_, true, C16_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.col16.p, \
+                                                     M.winBase.p, M.chunkPtr.p, M.len8.p, M.val.p, M.code.p, c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done, \
+                                                     0, nChunks, xcdAware)
+            if (!M.col16ok) { if (mode == 0) PS_LAUNCH_TP(0, 6, false); else PS_LAUNCH_TP(1, 6, false); }
+            else if (M.slotsA <= 4) { if (mode == 0) PS_LAUNCH_TP(0, 4, true); else PS_LAUNCH_TP(1, 4, true); }
+            else { if (mode == 0) PS_LAUNCH_TP(0, 6, true); else PS_LAUNCH_TP(1, 6, true); }
 #undef PS_LAUNCH_TP
             return;
         }
