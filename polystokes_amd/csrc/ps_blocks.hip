@@ -415,28 +415,42 @@ BlockArgs makeArgs(ps_context* c) {
     return A;
 }
 
-// 16-bit windowed columns of one 256-row chunk (one block per chunk).  Greedy cover of the chunk's column set by
-// windows [base, base + 4096): base = smallest column not yet covered (block min), at most 16 windows; a chunk that
-// needs more raises *fail and the SpMVs keep the 32-bit columns.  The block-interleaved numbering keeps the
-// columns of a chunk in a handful of short runs (own voxels, the j/k neighbours, the 6 neighbouring blocks, skin rows
-// of adjacent tiles), so 16 windows are plenty.
-__global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, int rows,
-                                                    uint16_t* __restrict__ col16, int32_t* __restrict__ winBase, int32_t* __restrict__ fail) {
+// Compressed SpMV stream, step 1: entries per chunk rounded up to a multiple of 4 (scanned into the chunk starts)
+__global__ void k_chunk_len4(const int32_t* __restrict__ ptr, int rows, int nChunks, int32_t* __restrict__ len4, int32_t* __restrict__ maxLen) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch > nChunks) return;
+    int n = 0;
+    if (ch < nChunks) { n = ptr[min(ch * BS + BS, rows)] - ptr[ch * BS]; atomicMax(maxLen, n); }
+    len4[ch] = (n + 3) & ~3;
+}
+// step 2, one block per chunk: 16-bit windowed columns.  Greedy cover of the chunk's column set by windows
+// [base, base + 4096): base = smallest column not yet covered (block min), at most 16 windows; a chunk that needs more
+// raises *fail and the SpMVs keep the 32-bit CSR.  The block-interleaved numbering keeps the columns of a chunk in a
+// handful of short runs (own voxels, the j/k neighbours, the 6 neighbouring blocks, skin rows of adjacent tiles), so 16
+// windows are plenty.  Also copies the value codes to the aligned layout and writes the row-length bytes.
+__global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const int8_t* __restrict__ code,
+                                                    int rows, const int32_t* __restrict__ start4, uint16_t* __restrict__ col16,
+                                                    int8_t* __restrict__ code4, int32_t* __restrict__ winBase, int2* __restrict__ chunkRange,
+                                                    uint8_t* __restrict__ len8, int32_t* __restrict__ fail) {
     __shared__ int red[BS / 64];
     __shared__ int bmin;
     const int chunk = blockIdx.x;
     const int r0 = chunk * BS;
     const int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
+    const int q0 = start4[chunk], q1 = start4[chunk + 1];          // q1 - q0 = (p1 - p0) rounded up to 4
+    if (threadIdx.x == 0) chunkRange[chunk] = make_int2(q0, q0 + (p1 - p0));
+    if (r0 + (int)threadIdx.x < rows) len8[r0 + threadIdx.x] = (uint8_t)(ptr[r0 + threadIdx.x + 1] - ptr[r0 + threadIdx.x]);
     constexpr int SL = 8;                               // <= 8 entries per row: <= 2048 entries per chunk
+    if (p1 - p0 > SL * BS) { if (threadIdx.x == 0) *fail = 1; return; }
     int c[SL];
     bool open[SL];
 #pragma unroll
     for (int u = 0; u < SL; ++u) {
-        const int p = p0 + threadIdx.x + u * BS;
-        open[u] = p < p1;
-        c[u] = open[u] ? col[p] : 0x7fffffff;
+        const int i = threadIdx.x + u * BS;
+        open[u] = p0 + i < p1;
+        c[u] = open[u] ? col[p0 + i] : 0x7fffffff;
+        if (q0 + i < q1) { code4[q0 + i] = open[u] ? code[p0 + i] : (int8_t)0; if (!open[u]) col16[q0 + i] = 0; }   // incl. the padding
     }
-    if (p1 - p0 > SL * BS) { if (threadIdx.x == 0) *fail = 1; return; }
     for (int w = 0; w < 16; ++w) {
         int m = 0x7fffffff;
 #pragma unroll
@@ -453,7 +467,7 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < SL; ++u)
             if (open[u] && c[u] - base < 4096) {
-                col16[p0 + threadIdx.x + u * BS] = (uint16_t)((w << 12) | (c[u] - base));
+                col16[q0 + threadIdx.x + u * BS] = (uint16_t)((w << 12) | (c[u] - base));
                 open[u] = false;
             }
     }
@@ -462,47 +476,34 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
     for (int u = 0; u < SL; ++u) left |= open[u];
     if (left) *fail = 1;
 }
-
-__global__ void k_len8_build(const int32_t* __restrict__ ptr, int rows, int nChunks, uint8_t* __restrict__ len8, int32_t* __restrict__ chunkPtr) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows) len8[i] = (uint8_t)(ptr[i + 1] - ptr[i]);
-    if (i <= nChunks) chunkPtr[i] = ptr[min(i * BS, rows)];
-}
-__global__ void k_chunk_max(const int32_t* __restrict__ ptr, int rows, int c0, int c1, int32_t* __restrict__ out) {
-    const int ch = c0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch < c1) atomicMax(out, ptr[min(ch * BS + BS, rows)] - ptr[ch * BS]);
-}
 }  // namespace
-// SpMV stream compression (see k_col16_build); decided per matrix, like the value coding.  splitRow: rows before it
-// (active faces) and behind it (skin rows) get their own launch with their own number of entry slots.
-void ps_context::buildCol16(ps::DevCSR& M, int slot, int64_t splitRow) {
+
+// Compressed SpMV stream (DevCSR::col16 ...); decided per matrix, like the value coding.  PS_COL32=1 keeps the CSR kernels.
+void ps_context::buildCol16(ps::DevCSR& M, int slot) {
     M.col16ok = false;
-    M.splitChunk = 0x7fffffff; M.slotsA = M.slotsB = 8;
-    if (M.rows > 0 && M.nnz > 0) {
-        const int nCh = gridFor(M.rows, BS);
-        M.splitChunk = (int)std::min<int64_t>(nCh, (splitRow + BS - 1) / BS);
-        int* mx[2] = {&M.slotsA, &M.slotsB};
-        const int lo[2] = {0, M.splitChunk}, hi[2] = {M.splitChunk, nCh};
-        for (int q = 0; q < 2; ++q) {
-            if (hi[q] <= lo[q]) continue;
-            HIP_CHECK(hipMemsetAsync(counters.p + 25, 0, sizeof(int32_t), stream));
-            hipLaunchKernelGGL(k_chunk_max, dim3(gridFor(hi[q] - lo[q], BS)), dim3(BS), 0, stream, M.ptr.p, (int)M.rows, lo[q], hi[q], counters.p + 25);
-            *mx[q] = std::max(1, (readCounter(25) + BS - 1) / BS);
-        }
-        if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] stream slots: rows %lld nnz %lld split chunk %d of %d, slots %d / %d\n",
-                                               (long long)M.rows, (long long)M.nnz, M.splitChunk, nCh, M.slotsA, M.slotsB);
-    }
     const char* e = getenv("PS_COL32");
     if (!M.packed || M.rows == 0 || M.nnz == 0 || (e && atoi(e) != 0)) return;
     const int nChunks = gridFor(M.rows, BS);
-    M.col16.alloc((size_t)M.nnz);
-    M.winBase.alloc((size_t)nChunks * 16);
+    DevBuf<int32_t> start4;
+    start4.alloc((size_t)nChunks + 1);
+    HIP_CHECK(hipMemsetAsync(counters.p + 25, 0, sizeof(int32_t), stream));
+    hipLaunchKernelGGL(k_chunk_len4, dim3(gridFor(nChunks + 1, BS)), dim3(BS), 0, stream, M.ptr.p, (int)M.rows, nChunks, start4.p, counters.p + 25);
+    const int64_t total4 = exclusiveScanI32(start4.p, nChunks + 1);
+    if (total4 < 0) return;                                           // would overflow 32 bits: keep the CSR kernels
+    const int maxLen = readCounter(25);
+    M.nv = std::max(1, (maxLen + 4 * BS - 1) / (4 * BS));
+    if (M.nv > 2) return;
+    // the kernels address everything through 32-bit buffer descriptors: every array they touch must stay below 4 GiB
+    if ((uint64_t)std::max(M.rows, M.cols) * 8 >= 0xffffffffull || (uint64_t)total4 * 2 >= 0xffffffffull) return;
+    M.streamLen = total4;
+    M.col16.alloc((size_t)total4 + 8); M.code4.alloc((size_t)total4 + 8);
+    M.winBase.alloc((size_t)nChunks * 16); M.chunkRange.alloc((size_t)nChunks); M.len8.alloc((size_t)M.rows);
     HIP_CHECK(hipMemsetAsync(counters.p + slot, 0, sizeof(int32_t), stream));
-    hipLaunchKernelGGL(k_col16_build, dim3((unsigned)nChunks), dim3(BS), 0, stream, M.ptr.p, M.col.p, (int)M.rows, M.col16.p, M.winBase.p,
-                       counters.p + slot);
-    M.len8.alloc((size_t)M.rows); M.chunkPtr.alloc((size_t)nChunks + 1);
-    hipLaunchKernelGGL(k_len8_build, dim3(gridFor(M.rows + 1, BS)), dim3(BS), 0, stream, M.ptr.p, (int)M.rows, nChunks, M.len8.p, M.chunkPtr.p);
+    hipLaunchKernelGGL(k_col16_build, dim3((unsigned)nChunks), dim3(BS), 0, stream, M.ptr.p, M.col.p, M.code.p, (int)M.rows, start4.p, M.col16.p,
+                       M.code4.p, M.winBase.p, M.chunkRange.p, M.len8.p, counters.p + slot);
     M.col16ok = readCounter(slot) == 0;
+    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] compressed stream: rows %lld nnz %lld, fullest chunk %d (nv %d), ok %d\n",
+                                           (long long)M.rows, (long long)M.nnz, maxLen, M.nv, (int)M.col16ok);
 }
 
 // ConstructMatrixBlocks.cpp:9-292
@@ -639,8 +640,8 @@ void ps_context::constructMatrixBlocks() {
         const int32_t flag = S.packed ? 1 : 0;
         HIP_CHECK(hipMemcpyAsync(counters.p + 21, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        buildCol16(S, 22, nActiveVs);
-        buildCol16(St, 23, nSystem);
+        buildCol16(S, 22);
+        buildCol16(St, 23);
         const int32_t c16 = (S.col16ok ? 1 : 0) | (St.col16ok ? 2 : 0);
         HIP_CHECK(hipMemcpyAsync(counters.p + 24, &c16, sizeof(c16), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

@@ -17,15 +17,18 @@ struct DevCSR {
     // The fill kernels verify code*scale == val bit for bit; if any entry fails, the SpMV streams `val` instead.
     DevBuf<int8_t> code;
     bool packed = false;
-    // 16-bit windowed columns (only with `packed`): per 256-row chunk up to 16 windows of 4096 columns;
-    // col = winBase[chunk*16 + (c16 >> 12)] + (c16 & 4095).  Used only if EVERY chunk fits (col16ok).
+    // Compressed stream of the persistent SpMV kernels (only with `packed`, and only if EVERY chunk fits: col16ok).
+    // Per 256-row chunk: a 4-entry-aligned run [chunkRange.x, chunkRange.y) of (col16, code4) entries in CSR order;
+    // col = winBase[chunk*16 + (c16 >> 12)] + (c16 & 4095) (up to 16 windows of 4096 columns per chunk);
+    // len8 = entries per row.  nv = ceil(fullest chunk / 1024) = 4-entry groups per lane.
     DevBuf<uint16_t> col16;
+    DevBuf<int8_t> code4;
     DevBuf<int32_t> winBase;
-    DevBuf<int32_t> chunkPtr;    // with col16: ptr[256 * chunk] (nChunks + 1 entries) ...
-    DevBuf<uint8_t> len8;        // ... and one row-length byte per row instead of the 4-byte row pointer
+    DevBuf<int2> chunkRange;
+    DevBuf<uint8_t> len8;
     bool col16ok = false;
-    // entry slots per thread (= ceil(fullest chunk / 256)) of the chunk ranges [0, splitChunk) and [splitChunk, nChunks)
-    int splitChunk = 0x7fffffff, slotsA = 8, slotsB = 8;
+    int nv = 2;
+    int64_t streamLen = 0;       // entries of col16 / code4 (multiple of 4)
 };
 
 // device-resident CG scalars (no host round trip inside the iteration)
@@ -166,7 +169,7 @@ struct ps_context {
     void computeReducedViscosityMatricesInteriorOnly();
     void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
     void constructMatrixBlocks();                         // ps_blocks.hip
-    void buildCol16(ps::DevCSR& M, int counterSlot, int64_t splitRow);   // ps_blocks.hip
+    void buildCol16(ps::DevCSR& M, int counterSlot);      // ps_blocks.hip
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();
     int solve();

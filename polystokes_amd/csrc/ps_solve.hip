@@ -162,12 +162,17 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 }
 
 
-// ---- software-pipelined persistent variants ---------------------------------------------------------
+// ---- persistent, software-pipelined kernels on the compressed stream -----------------------------------
 // PMC (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 85 %) shows the one-shot kernels above are latency bound: every block walks
-// three dependent memory round trips (row-pointer bounds -> (col,code) stream -> gather) at the occupancy cap of
-// 8 waves/SIMD.  Here a block loops over row chunks (grid = #CUs x 8) and, while the gathers / LDS reduction of
-// chunk i are in flight, the (col,code) stream of chunk i+1 is already loading into a second register set and the
-// bounds of chunk i+2 are being fetched.
+// three dependent memory round trips (row-pointer bounds -> (col,val) stream -> gather) at the occupancy cap of
+// 8 waves/SIMD.  Here a block loops over row chunks (grid = #CUs x 16) and, while the gathers / LDS reduction of
+// chunk i are in flight, the stream of chunk i+1 is already loading into a second register set and the bounds of
+// chunk i+2 are being fetched.  They read the compressed form of the matrix built by ps_context::buildCol16:
+//   * per 256-row chunk a 4-entry-aligned run of (16-bit windowed column, int8 value code): 3 B per entry, fetched as
+//     one 8-byte + one 4-byte load per lane for 4 consecutive entries,
+//   * 16 window bases and an (begin, end) pair per chunk, one row-length byte per row (prefix-summed in the block)
+// and reproduce the fp64 CSR product bit for bit (same values, same summation order within a row).
+//
 // chunk walk of a persistent block.  Plain: chunk = block + it * grid.  Grouped (G = xcdAware > 0): workgroups b, b+8, ...
 // run on XCD b & 7 (verified with s_getreg HW_REG_XCC_ID), so runs of G consecutive chunks are dealt to the XCDs round
 // robin — rows that gather the same lines of x (k-plane neighbours, a few chunks apart) then share ONE L2, while
@@ -181,208 +186,202 @@ struct ChunkWalk {
         return ((q / G) * 8 + x) * G + q % G;
     }
 };
-template <bool PACKED> struct RawVal { using type = double; };
-template <> struct RawVal<true> { using type = int; };   // the int8 code, widened: 1 VGPR instead of 2 in the prefetch set
-template <int SLOTS, bool PACKED, bool C16>
-__device__ inline void loadStream(const int32_t* __restrict__ col, const uint16_t* __restrict__ col16, const double* __restrict__ val,
-                                  const int8_t* __restrict__ code, int p0, int p1, int (&c)[SLOTS], typename RawVal<PACKED>::type (&v)[SLOTS]) {
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// Every access of the loop body goes through a buffer descriptor (buffer_load/store ... offen): 32-bit byte offsets
+// instead of 64-bit address arithmetic, and hardware bounds checking (a load past `bytes` returns 0, a store is dropped),
+// so the body has NO branches: lanes past the end of a chunk / of the rows load and multiply harmless values into LDS
+// slots no row reads.  (Arrays must be < 4 GiB: checked by ps_context::buildCol16.)
+__device__ inline __amdgpu_buffer_rsrc_t bufRsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ inline double bufLoadF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, 0));
+}
+__device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, 0);
+}
+// one lane's share of a chunk's stream: NV groups of 4 consecutive entries (non-temporal: read once)
+template <int NV> struct Stream4 { u32x2 c[NV]; unsigned v[NV]; };
+template <int NV>
+__device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, int p0, int p1, Stream4<NV>& s) {
 #pragma unroll
-    for (int u = 0; u < SLOTS; ++u) {
-        const int p = p0 + threadIdx.x + u * BS;
-        const bool ok = p < p1;
-        if constexpr (C16) c[u] = ok ? (int)__builtin_nontemporal_load(col16 + p) : -1;
-        else c[u] = ok ? __builtin_nontemporal_load(col + p) : -1;
-        if constexpr (PACKED) v[u] = ok ? (int)__builtin_nontemporal_load(code + p) : 0;
-        else v[u] = ok ? __builtin_nontemporal_load(val + p) : 0.;
+    for (int w = 0; w < NV; ++w) {
+        const unsigned first = (unsigned)p0 + 4u * (threadIdx.x + w * BS);     // p0 is a multiple of 4
+        // groups past the end of the chunk: offset 0xffffffff is out of range -> zeros without a memory access
+        // (zeros decode to window 0 / offset 0 / value 0, like the padding inside the last group)
+        const bool in = (int)first < p1;
+        s.c[w] = __builtin_amdgcn_raw_buffer_load_b64(rCol, in ? (int)(first * 2u) : -1, 0, 2);
+        s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, 2);
     }
 }
-// 16-bit windowed column -> column: window base (held by lane `window` of every 16-lane group) + 12-bit offset
-template <bool C16>
-__device__ inline int resolveCol(int raw, int myBase) {
-    if constexpr (!C16) return raw;
-    else {
-        const int b = __shfl(myBase, (raw >> 12) & 15, 16);   // executed by all lanes
-        return raw >= 0 ? b + (raw & 4095) : -1;
-    }
+__device__ inline unsigned streamCol(u32x2 c, int j, int myBase) {   // window base (lane `window` of every 16-lane group) + 12-bit offset
+    const unsigned w = j < 2 ? c.x : c.y;
+    const unsigned raw = (w >> (16 * (j & 1))) & 0xffffu;
+    return (unsigned)__shfl(myBase, (int)(raw >> 12), 16) + (raw & 4095u);
 }
-// entry range of chunk ch: from the per-chunk pointers of the compressed format, or from the CSR row pointers
-template <bool C16>
-__device__ inline void chunkBounds(const int32_t* __restrict__ ptr, const int32_t* __restrict__ chunkPtr, int ch, int rows, int& a, int& b) {
-    if constexpr (C16) { a = chunkPtr[ch]; b = chunkPtr[ch + 1]; }
-    else { a = ptr[ch * BS]; b = ptr[min(ch * BS + BS, rows)]; }
+__device__ inline double streamVal(unsigned v, int j, double scale) {   // exact: see DevCSR::code
+    return (double)((int)(v << (24 - 8 * j)) >> 24) * scale;
 }
-// position of this thread's row inside the chunk's entry range.  Compressed format: one length byte per row, prefix-summed
-// across the block (wave shuffles + the 4 wave totals through LDS; call on both sides of the caller's barrier).
+// inclusive prefix sum over the 64 lanes with DPP moves (VALU only, no LDS round trips): Hillis-Steele inside each row of
+// 16 lanes (row_shr 1,2,4,8; lanes without a source keep 0), then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
 __device__ inline int waveInclusiveScan(int v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if ((int)(threadIdx.x & 63) >= o) v += t; }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
-template <bool PACKED>
-__device__ inline double rawToVal(typename RawVal<PACKED>::type r, double scale) {
-    if constexpr (PACKED) return (double)r * scale;   // exact: see DevCSR::code
-    else return r;
-}
-template <int MODE, int MAXNNZ, bool PACKED, bool C16>
-__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const uint16_t* __restrict__ col16,
-                                                    const int32_t* __restrict__ winBase, const int32_t* __restrict__ chunkPtr,
-                                                    const uint8_t* __restrict__ len8, const double* __restrict__ val,
-                                                    const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
-                                                    double dt, const double* __restrict__ McInv, double* __restrict__ out,
+// Both kernels: gathers of the current chunk, prefetch of the next, products to LDS (entry e of the chunk at
+// prod[(e & 3) * PL + (e >> 2)]: conflict-free writes), row offsets from the length bytes (wave scans + 4 wave totals).
+template <int MODE, int NV>
+__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
+                                                    const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
+                                                    const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
+                                                    int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
                                                     const int* __restrict__ done, int chunkBegin, int nChunks, int xcdAware) {
     if (done && *done) return;
-    __shared__ double prod[BS * MAXNNZ];
-    // chunk walk: plain (chunk = block, block + grid, ...) or XCD-aware: blocks b, b+8, ... share an XCD (and its L2), so
-    // XCD x walks its own contiguous eighth of the chunks and the lines gathered by neighbouring chunks stay in ONE L2
+    constexpr int PL = BS * NV;
+    __shared__ double prod[4 * PL];
+    __shared__ __align__(16) int wtot[BS / 64];
+    static_assert(BS == 256, "four waves per block");
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
+                                 rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
+                                 rOut = bufRsrc(out, (size_t)rows * 8);
     const ChunkWalk W(xcdAware);
-    const int chunkEnd = nChunks;
     int it = 0;
     int chunk = chunkBegin + W.at(0);   // this launch covers chunks [chunkBegin, nChunks)
-    if (chunk >= chunkEnd) return;
-    int r0 = chunk * BS;
-    int p0, p1;
-    chunkBounds<C16>(ptr, chunkPtr, chunk, rows, p0, p1);
-    __shared__ int wtot[BS / 64];
-    int c[MAXNNZ];
-    typename RawVal<PACKED>::type v[MAXNNZ];
-    loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, p0, p1, c, v);
-    int myBase = 0, nBase = 0;
-    if constexpr (C16) myBase = winBase[chunk * 16 + (threadIdx.x & 15)];
+    if (chunk >= nChunks) return;
+    int2 pr = chunkRange[chunk];
+    Stream4<NV> cur, nxt;
+    loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
+    int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = chunkBegin + W.at(1);
-    int np0 = 0, np1 = 0;
-    if (nchunk < chunkEnd) chunkBounds<C16>(ptr, chunkPtr, nchunk, rows, np0, np1);
+    int2 npr = {0, 0};
+    if (nchunk < nChunks) npr = chunkRange[nchunk];
     while (true) {
-        const int row = r0 + threadIdx.x;
-        const bool ok = row < rows;
-        int ea = 0, eb = 0, incl = 0;      // this row's entries are prod[ea .. eb)
-        if constexpr (C16) eb = ok ? (int)len8[row] : 0;
-        else { ea = ok ? ptr[row] - p0 : 0; eb = ok ? ptr[row + 1] - p0 : 0; }
-        const double sc = (MODE == 0 && ok && row < nA) ? dt * McInv[row] : 1.;
-        double xv[MAXNNZ];
+        const unsigned row = (unsigned)chunk * BS + threadIdx.x;
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
+        double sc = 1.;
+        if (MODE == 0) { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
+        double xv[4 * NV];
 #pragma unroll
-        for (int u = 0; u < MAXNNZ; ++u) { const int cc = resolveCol<C16>(c[u], myBase); xv[u] = cc >= 0 ? x[cc] : 0.; }
-        const bool hasNext = nchunk < chunkEnd;
-        int c2[MAXNNZ];
-        typename RawVal<PACKED>::type v2[MAXNNZ];
+        for (int w = 0; w < NV; ++w) {
+            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufLoadF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
+        }
+        const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, np0, np1, c2, v2);
-            if constexpr (C16) nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
+            loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
+            nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = chunkBegin + W.at(it + 2);
-        int nnp0 = 0, nnp1 = 0;
-        if (nn < chunkEnd) chunkBounds<C16>(ptr, chunkPtr, nn, rows, nnp0, nnp1);
+        int2 nnpr = {0, 0};
+        if (nn < nChunks) nnpr = chunkRange[nn];
 #pragma unroll
-        for (int u = 0; u < MAXNNZ; ++u)
-            if (c[u] >= 0) prod[threadIdx.x + u * BS] = rawToVal<PACKED>(v[u], scale) * xv[u];
-        if constexpr (C16) {
-            incl = waveInclusiveScan(eb);
-            if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        for (int w = 0; w < NV; ++w) {
+            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = streamVal(cur.v[w], j, scale) * xv[4 * w + j];
         }
+        const int incl = waveInclusiveScan(len);
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
         __syncthreads();
-        if constexpr (C16) {
-            int off = 0;
-            for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) off += wtot[q];
-            ea = off + incl - eb; eb = off + incl;
-        }
-        if (ok) {
+        {
+            const int4 wt = *reinterpret_cast<const int4*>(wtot);
+            const int wv = threadIdx.x >> 6;
+            const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
             double s = 0.;
-            for (int e = ea; e < eb; ++e) s += prod[e];
-            out[row] = s * sc;
+            for (int e = ea; e < ea + len; ++e) s += prod[(e & 3) * PL + (e >> 2)];
+            bufStoreF64(rOut, row * 8u, s * sc);                             // dropped past the last row
         }
         __syncthreads();
         if (!hasNext) break;
-        chunk = nchunk; r0 = chunk * BS; p0 = np0; p1 = np1;
-#pragma unroll
-        for (int u = 0; u < MAXNNZ; ++u) { c[u] = c2[u]; v[u] = v2[u]; }
-        nchunk = nn; np0 = nnp0; np1 = nnp1;
-        myBase = nBase;
+        chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
+        nchunk = nn; npr = nnpr;
         ++it;
     }
 }
-template <int MODE, int MAXNNZ, bool PACKED, bool C16>
-__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const uint16_t* __restrict__ col16,
-                                                     const int32_t* __restrict__ winBase, const int32_t* __restrict__ chunkPtr,
-                                                     const uint8_t* __restrict__ len8, const double* __restrict__ val,
-                                                     const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
+template <int MODE, int NV>
+__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
+                                                     const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
+                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
-                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done, int chunkBegin,
-                                                     int nChunks, int xcdAware) {
+                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done,
+                                                     int chunkBegin, int nChunks, int xcdAware) {
     if (done && *done) return;
-    __shared__ double prod[BS * MAXNNZ];
+    constexpr int PL = BS * NV;
+    __shared__ double prod[4 * PL];
+    __shared__ __align__(16) int wtot[BS / 64];
+    static_assert(BS == 256, "four waves per block");
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
+                                 rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
+                                 rE0 = bufRsrc(MODE == 0 ? xin : add, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
+                                 rOut = bufRsrc(out, (size_t)rows * 8);
     const ChunkWalk W(xcdAware);
-    const int chunkEnd = nChunks;
     int it = 0;
-    int chunk = chunkBegin + W.at(0);   // this launch covers chunks [chunkBegin, nChunks)
-    if (chunk >= chunkEnd) return;
-    int r0 = chunk * BS;
-    int p0, p1;
-    chunkBounds<C16>(ptr, chunkPtr, chunk, rows, p0, p1);
-    __shared__ int wtot[BS / 64];
-    int c[MAXNNZ];
-    typename RawVal<PACKED>::type v[MAXNNZ];
-    loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, p0, p1, c, v);
-    int myBase = 0, nBase = 0;
-    if constexpr (C16) myBase = winBase[chunk * 16 + (threadIdx.x & 15)];
+    int chunk = chunkBegin + W.at(0);
+    if (chunk >= nChunks) { if (MODE == 0 && threadIdx.x == 0) partial[blockIdx.x] = 0.; return; }
+    double dacc = 0.;
+    int2 pr = chunkRange[chunk];
+    Stream4<NV> cur, nxt;
+    loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
+    int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = chunkBegin + W.at(1);
-    int np0 = 0, np1 = 0;
-    if (nchunk < chunkEnd) chunkBounds<C16>(ptr, chunkPtr, nchunk, rows, np0, np1);
+    int2 npr = {0, 0};
+    if (nchunk < nChunks) npr = chunkRange[nchunk];
     while (true) {
-        const int row = r0 + threadIdx.x;
-        const bool ok = row < rows;
-        int ea = 0, eb = 0, incl = 0;      // this row's entries are prod[ea .. eb)
-        if constexpr (C16) eb = ok ? (int)len8[row] : 0;
-        else { ea = ok ? ptr[row] - p0 : 0; eb = ok ? ptr[row + 1] - p0 : 0; }
-        double e0, e1 = 0.;
-        if (MODE == 0) { e0 = ok ? xin[row] : 0.; e1 = ok ? uInv[row] : 0.; }
-        else e0 = ok ? add[row] : 0.;
-        double xv[MAXNNZ];
+        const unsigned row = (unsigned)chunk * BS + threadIdx.x;
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
+        const double e0 = bufLoadF64(rE0, row * 8u);                                       // x (MODE 0) / the vector added (MODE 1)
+        double e1 = 0.;
+        if (MODE == 0) e1 = bufLoadF64(rE1, row * 8u);
+        double xv[4 * NV];
 #pragma unroll
-        for (int u = 0; u < MAXNNZ; ++u) { const int cc = resolveCol<C16>(c[u], myBase); xv[u] = cc >= 0 ? t[cc] : 0.; }
-        const bool hasNext = nchunk < chunkEnd;
-        int c2[MAXNNZ];
-        typename RawVal<PACKED>::type v2[MAXNNZ];
+        for (int w = 0; w < NV; ++w) {
+            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufLoadF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
+        }
+        const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream<MAXNNZ, PACKED, C16>(col, col16, val, code, np0, np1, c2, v2);
-            if constexpr (C16) nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
+            loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
+            nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = chunkBegin + W.at(it + 2);
-        int nnp0 = 0, nnp1 = 0;
-        if (nn < chunkEnd) chunkBounds<C16>(ptr, chunkPtr, nn, rows, nnp0, nnp1);
+        int2 nnpr = {0, 0};
+        if (nn < nChunks) nnpr = chunkRange[nn];
 #pragma unroll
-        for (int u = 0; u < MAXNNZ; ++u)
-            if (c[u] >= 0) prod[threadIdx.x + u * BS] = rawToVal<PACKED>(v[u], scale) * xv[u];
-        if constexpr (C16) {
-            incl = waveInclusiveScan(eb);
-            if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        for (int w = 0; w < NV; ++w) {
+            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = streamVal(cur.v[w], j, scale) * xv[4 * w + j];
         }
+        const int incl = waveInclusiveScan(len);
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
         __syncthreads();
-        if constexpr (C16) {
-            int off = 0;
-            for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) off += wtot[q];
-            ea = off + incl - eb; eb = off + incl;
-        }
-        double d = 0.;
-        if (ok) {
+        {
+            const int4 wt = *reinterpret_cast<const int4*>(wtot);
+            const int wv = threadIdx.x >> 6;
+            const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
             double s = 0.;
-            for (int e = ea; e < eb; ++e) s += prod[e];
+            for (int e = ea; e < ea + len; ++e) s += prod[(e & 3) * PL + (e >> 2)];
             double y;
-            if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; d = e0 * y; }
+            if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
             else y = -s + e0;
-            out[row] = y;
+            bufStoreF64(rOut, row * 8u, y);
         }
-        if (MODE == 0) {
-            const double bs = blockReduceSum(d);   // two barriers inside: also protects the LDS reuse
-            if (threadIdx.x == 0) partial[chunk] = bs;
-        } else {
-            __syncthreads();
-        }
+        __syncthreads();    // protects the LDS reuse
         if (!hasNext) break;
-        chunk = nchunk; r0 = chunk * BS; p0 = np0; p1 = np1;
-#pragma unroll
-        for (int u = 0; u < MAXNNZ; ++u) { c[u] = c2[u]; v[u] = v2[u]; }
-        nchunk = nn; np0 = nnp0; np1 = nnp1;
-        myBase = nBase;
+        chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
+        nchunk = nn; npr = nnpr;
         ++it;
+    }
+    if (MODE == 0) {
+        const double bs = blockReduceSum(dacc);
+        if (threadIdx.x == 0) partial[blockIdx.x] = bs;   // gridDim.x partials (Launch::stBlocks)
     }
 }
 
@@ -770,24 +769,14 @@ struct Launch {
     int xcdAware;   // pipelined kernels: each XCD walks a contiguous eighth of the row chunks
     void spmvS(int mode, const double* x, double* out) const {
         if (rowsS == 0) return;
-        if (pipeGrid > 0 && c->S.packed) {   // fp64 values: the one-shot kernel is faster (register pressure of the prefetch set)
+        const ps::DevCSR& M = c->S;
+        if (pipeGrid > 0 && M.col16ok) {
             const int nChunks = gridFor(rowsS, BS);
-            const ps::DevCSR& M = c->S;
-            // entry slots per thread = what the fullest chunk needs
-            auto go = [&](int c0, int c1, int slots) {
-                if (c1 <= c0) return;
-                const dim3 gr(std::min(c1 - c0, pipeGrid)), bl(BS);
-#define PS_LAUNCH_SP(MODE_, SL_, C16_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, SL_, true, C16_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.col16.p, \
-                                                     M.winBase.p, M.chunkPtr.p, M.len8.p, M.val.p, M.code.p, c->valScale, x, rowsS, nA, c->dt, c->McInv.p, out, done, \
-                                                     c0, c1, xcdAware)
-                if (!M.col16ok) { if (mode == 0) PS_LAUNCH_SP(0, 8, false); else PS_LAUNCH_SP(1, 8, false); }
-                else if (slots <= 4) { if (mode == 0) PS_LAUNCH_SP(0, 4, true); else PS_LAUNCH_SP(1, 4, true); }
-                else if (slots <= 6) { if (mode == 0) PS_LAUNCH_SP(0, 6, true); else PS_LAUNCH_SP(1, 6, true); }
-                else { if (mode == 0) PS_LAUNCH_SP(0, 8, true); else PS_LAUNCH_SP(1, 8, true); }
-            };
-            // (two launches — active-face rows / skin rows, each with its own slot count — measured slower than one: 0.405 vs
-            // 0.376 ms at 256^3 with 8 / 6 slots; the second launch's ramp costs more than the empty slots)
-            go(0, nChunks, std::max(M.slotsA, M.slotsB));
+            const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
+#define PS_LAUNCH_SP(MODE_, NV_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
+                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, 0, nChunks, xcdAware)
+            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP(0, 1); else PS_LAUNCH_SP(1, 1); }
+            else { if (mode == 0) PS_LAUNCH_SP(0, 2); else PS_LAUNCH_SP(1, 2); }
 #undef PS_LAUNCH_SP
             return;
         }
@@ -821,22 +810,23 @@ struct Launch {
     }
     void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
         if (rowsSt == 0) return;
-        if (pipeGrid > 0 && c->St.packed) {
+        const ps::DevCSR& M = c->St;
+        if (pipeGrid > 0 && M.col16ok) {
             const int nChunks = gridFor(rowsSt, BS);
             const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
-            const ps::DevCSR& M = c->St;
-#define PS_LAUNCH_TP(MODE_, SL_, C16_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, SL_, true, C16_>), gr, bl, 0, c->stream, M.ptr.p, M.col.p, M.col16.p, \
-                                                     M.winBase.p, M.chunkPtr.p, M.len8.p, M.val.p, M.code.p, c->valScale, t, rowsSt, nP, c->uInv.p, xin, add, out, partial, done, \
-                                                     0, nChunks, xcdAware)
-            if (!M.col16ok) { if (mode == 0) PS_LAUNCH_TP(0, 6, false); else PS_LAUNCH_TP(1, 6, false); }
-            else if (M.slotsA <= 4) { if (mode == 0) PS_LAUNCH_TP(0, 4, true); else PS_LAUNCH_TP(1, 4, true); }
-            else { if (mode == 0) PS_LAUNCH_TP(0, 6, true); else PS_LAUNCH_TP(1, 6, true); }
+#define PS_LAUNCH_TP(MODE_, NV_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
+                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, 0, nChunks, xcdAware)
+            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP(0, 1); else PS_LAUNCH_TP(1, 1); }
+            else { if (mode == 0) PS_LAUNCH_TP(0, 2); else PS_LAUNCH_TP(1, 2); }
 #undef PS_LAUNCH_TP
             return;
         }
         spmvSt_(mode, t, xin, add, out, partial);
     }
-    int stBlocks() const { return gridFor(rowsSt, BS); }   // number of p.Ap partials the St kernel writes
+    int stBlocks() const {   // number of p.Ap partials the St kernel writes: one per block
+        const int nChunks = gridFor(rowsSt, BS);
+        return (pipeGrid > 0 && c->St.col16ok) ? std::min(nChunks, pipeGrid) : nChunks;
+    }
 };
 Launch mk(ps_context* c, const int* done) {
     Launch L;
@@ -923,8 +913,12 @@ int ps_context::solve() {
             L.spmvS(0, pvec.p, ts.p);
             L.tiles(0, ts.p);
             L.spmvSt(0, ts.p, pvec.p, nullptr, Ap.p, dotPartials.p);
-            hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, stream, sc, dotPartials.p, stBlocks, dotPartials2.p);
-            hipLaunchKernelGGL(k_cg_scal1, dim3(1), dim3(BS), 0, stream, sc, dotPartials2.p, RED_BLOCKS);
+            if (stBlocks <= 8192) {   // persistent St kernel: one partial per block, few enough for one reducing block
+                hipLaunchKernelGGL(k_cg_scal1, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, stBlocks);
+            } else {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, stream, sc, dotPartials.p, stBlocks, dotPartials2.p);
+                hipLaunchKernelGGL(k_cg_scal1, dim3(1), dim3(BS), 0, stream, sc, dotPartials2.p, RED_BLOCKS);
+            }
             hipLaunchKernelGGL(k_cg_update_xr, dim3(vb), dim3(BS), 0, stream, sc, pvec.p, Ap.p, dv, x.p, r.p, n, dotPartials.p);
             hipLaunchKernelGGL(k_cg_scal2, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, dv ? 1 : 0, it);
             hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, stream, sc, r.p, dv, pvec.p, n);
@@ -1323,8 +1317,12 @@ struct Dist {
                     l.L.spmvS(0, c->pvec.p, c->ts.p);
                     l.L.tiles(0, c->ts.p);
                     l.L.spmvSt(0, c->ts.p, c->pvec.p, nullptr, c->Ap.p, c->dotPartials.p);
-                    hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, c->stream, l.sc, c->dotPartials.p, l.stBlocks, c->dotPartials2.p);
-                    hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials2.p, RED_BLOCKS, 0, 1, c->redbuf.p);
+                    if (l.stBlocks <= 8192) {
+                        hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials.p, l.stBlocks, 0, 1, c->redbuf.p);
+                    } else {
+                        hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, c->stream, l.sc, c->dotPartials.p, l.stBlocks, c->dotPartials2.p);
+                        hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials2.p, RED_BLOCKS, 0, 1, c->redbuf.p);
+                    }
                 }
                 exchangeAddY(&ps_context::Ap);
                 allreduce(1);
