@@ -233,6 +233,17 @@ __device__ inline int waveInclusiveScan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
+// sum of the row's products prod[ea .. ea+len) in entry order; all (<= ML) LDS reads are issued up front
+template <int ML, int PL>
+__device__ inline double rowSum(const double* prod, int ea, int len) {
+    double v[ML];
+#pragma unroll
+    for (int k = 0; k < ML; ++k) { const int e = min(ea + k, 4 * PL - 1); v[k] = prod[(e & 3) * PL + (e >> 2)]; }
+    double s = 0.;
+#pragma unroll
+    for (int k = 0; k < ML; ++k) s = k < len ? s + v[k] : s;
+    return s;
+}
 // Both kernels: gathers of the current chunk, prefetch of the next, products to LDS (entry e of the chunk at
 // prod[(e & 3) * PL + (e >> 2)]: conflict-free writes), row offsets from the length bytes (wave scans + 4 wave totals).
 template <int MODE, int NV>
@@ -293,8 +304,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
             const int4 wt = *reinterpret_cast<const int4*>(wtot);
             const int wv = threadIdx.x >> 6;
             const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
-            double s = 0.;
-            for (int e = ea; e < ea + len; ++e) s += prod[(e & 3) * PL + (e >> 2)];
+            const double s = rowSum<8, PL>(prod, ea, len);
             bufStoreF64(rOut, row * 8u, s * sc);                             // dropped past the last row
         }
         __syncthreads();
@@ -366,8 +376,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             const int4 wt = *reinterpret_cast<const int4*>(wtot);
             const int wv = threadIdx.x >> 6;
             const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
-            double s = 0.;
-            for (int e = ea; e < ea + len; ++e) s += prod[(e & 3) * PL + (e >> 2)];
+            const double s = rowSum<6, PL>(prod, ea, len);
             double y;
             if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
             else y = -s + e0;
