@@ -37,8 +37,9 @@ struct CGScalars {
     int iter;        // index of the iteration that converged (pcg.h:322-325)
     int done;        // 1 once the stop rule fired (or rsold == 0)
     int maxit;
-    int pad;
+    int pend;        // the stop test of iteration `pendIter` waits for ||x||^2 of the x it updated (deferred-x step)
     double tol2;
+    int pendIter, pad;
 };
 
 struct ArrayInfo {
@@ -113,7 +114,7 @@ struct ps_context {
     ps::DevCSR S, St;
     ps::DevBuf<double> McInv, rhsA, uInv, rhsPT, Mc, uDiag, oldVs;
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
-    ps::DevBuf<double> dotPartials, dotPartials2;
+    ps::DevBuf<double> dotPartials, dotPartials2, dotPartials3;
     ps::DevBuf<ps::CGScalars> scal;
 
     // ---- multi-GPU (slab decomposition; ps_dist.hip) ----

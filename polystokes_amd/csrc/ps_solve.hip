@@ -560,6 +560,7 @@ __global__ void __launch_bounds__(BS) k_cg_scal0(CGScalars* sc, const double* __
         sc->done = (s == 0.) ? 1 : 0;      // deviation: b == 0 -> return at once (reference divides 0/0, pcg.h:314)
         if (s == 0.) sc->iter = 0;
         sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
+        sc->pend = 0; sc->pendIter = 0;
     }
 }
 // stage A of the p.Ap reduction: RED_BLOCKS blocks each sum a contiguous slice of the SpMV block partials
@@ -647,6 +648,107 @@ __global__ void __launch_bounds__(BS) k_cg_update_p(const CGScalars* __restrict_
         const double z = dinv ? dinv[i] * r[i] : r[i];
         p[i] = z + beta * p[i];
     }
+}
+
+// ---- PCG step with the x update deferred into the p update (10 vector passes per iteration instead of 11) ----------
+// pcg.h:311-335 updates x and r together, tests min(rr, rr/xx) < tol^2, then forms beta and the new p.  Here r is updated
+// first (k_cg_update_r: reads Ap, r, dinv), beta follows, and ONE kernel then does x += alpha p, p = z + beta p
+// (k_cg_update_xp: p is read once for both) and sums ||x||^2 of the updated x.  The stop test of that iteration — same
+// rr, same xx, same iteration index — is evaluated by the next scalar kernel (k_cg_alpha of the following iteration, or
+// k_cg_check before the host polls); if it fires, every later kernel is a no-op, and x already holds the iterate the
+// reference would return.  The extra work is one unused p update, and one unused operator apply when the test fires at
+// the start of an iteration.
+__device__ inline void pendingStopTest(CGScalars* sc, double xx) {
+    const double rr = sc->rr;
+    sc->xx = xx;
+    double rre = rr;                                   // pcg.h:319-325
+    if (rr / xx < rre) rre = rr / xx;
+    sc->rre = rre;
+    sc->pend = 0;
+    if (rre < sc->tol2) { sc->done = 1; sc->iter = sc->pendIter; }
+}
+__global__ void __launch_bounds__(BS) k_cg_alpha(CGScalars* sc, const double* __restrict__ pApPartial, int count, const double* __restrict__ xxPartial,
+                                                 int vb) {
+    if (sc->done) return;
+    const int pend = sc->pend;                         // block-uniform
+    const double xx = pend ? sumPartials(xxPartial, vb) : 0.;
+    const double s = sumPartials(pApPartial, count);
+    if (threadIdx.x == 0) {
+        if (pend) pendingStopTest(sc, xx);
+        if (!sc->done) { sc->pAp = s; sc->alpha = sc->rsold / s; }   // pcg.h:314
+    }
+}
+__global__ void __launch_bounds__(BS) k_cg_check(CGScalars* sc, const double* __restrict__ xxPartial, int vb) {
+    if (sc->done || !sc->pend) return;
+    const double xx = sumPartials(xxPartial, vb);
+    if (threadIdx.x == 0) pendingStopTest(sc, xx);
+}
+// r -= alpha Ap ; partials of r.r and r.z
+__global__ void __launch_bounds__(BS) k_cg_update_r(const CGScalars* __restrict__ sc, const double* __restrict__ Ap, const double* __restrict__ dinv,
+                                                    double* __restrict__ r, int64_t n, double* __restrict__ partial) {
+    if (sc->done) return;
+    const double alpha = sc->alpha;
+    double arr = 0., arz = 0.;
+    const bool vec = ((((uintptr_t)Ap | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* A2 = (const double2*)Ap; const double2* d2 = (const double2*)dinv;
+    double2* r2 = (double2*)r;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        const double2 av = A2[i];
+        double2 rv = r2[i];
+        rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
+        r2[i] = rv;
+        arr += rv.x * rv.x; arr += rv.y * rv.y;
+        if (dinv) { const double2 dv = d2[i]; arz += rv.x * (dv.x * rv.x); arz += rv.y * (dv.y * rv.y); }
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double rv = r[i] - alpha * Ap[i];
+        r[i] = rv;
+        arr += rv * rv;
+        if (dinv) arz += rv * (dinv[i] * rv);
+    }
+    const double s0 = blockReduceSum(arr), s2 = dinv ? blockReduceSum(arz) : 0.;
+    if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s2; }
+}
+__device__ inline void cgBeta(CGScalars* sc, double rr, double rz, int iterIndex) {
+    sc->rr = rr; sc->rz = rz;
+    sc->beta = rz / sc->rsold; sc->rsold = rz;         // pcg.h:331-335
+    sc->pend = 1; sc->pendIter = iterIndex;
+}
+__global__ void __launch_bounds__(BS) k_cg_beta(CGScalars* sc, const double* __restrict__ partial, int count, int jacobi, int iterIndex) {
+    if (sc->done) return;
+    const double rr = sumPartials(partial, count);
+    const double rz = jacobi ? sumPartials(partial + count, count) : rr;
+    if (threadIdx.x == 0) cgBeta(sc, rr, rz, iterIndex);
+}
+// x += alpha p ; p = z + beta p (z = D^-1 r) ; partials of x.x
+__global__ void __launch_bounds__(BS) k_cg_update_xp(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                     double* __restrict__ x, double* __restrict__ p, int64_t n, double* __restrict__ partial) {
+    if (sc->done) return;
+    const double alpha = sc->alpha, beta = sc->beta;
+    double axx = 0.;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x | (uintptr_t)dinv) & 15) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* r2 = (const double2*)r; const double2* d2 = (const double2*)dinv;
+    double2* p2 = (double2*)p; double2* x2 = (double2*)x;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        double2 z = r2[i];
+        if (dinv) { const double2 dv = d2[i]; z.x = dv.x * z.x; z.y = dv.y * z.y; }
+        double2 pv = p2[i], xv = x2[i];
+        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
+        pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
+        x2[i] = xv; p2[i] = pv;
+        axx += xv.x * xv.x; axx += xv.y * xv.y;
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double z = dinv ? dinv[i] * r[i] : r[i];
+        const double pv = p[i];
+        const double xv = x[i] + alpha * pv;
+        x[i] = xv; p[i] = z + beta * pv;
+        axx += xv * xv;
+    }
+    const double s1 = blockReduceSum(axx);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s1;
 }
 
 // ---- generic vector helpers (BiCGStab fallback, rare) -----------------------------------------------
@@ -875,6 +977,7 @@ void ps_context::assembleSystemPressureStressFactored() {
     dotPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(std::max<int64_t>(n, 1), BS)) + 16);
     scal.alloc(1);
     dotPartials2.alloc(RED_BLOCKS);
+    dotPartials3.alloc(VGRID);
     // t0 = McInv rhs_a on active rows, C (invDt BInv rhs_r) on reduced rows;  b = -S^T t0 + [rhs_p; rhs_tau]
     if (nActiveVs > 0)
         hipLaunchKernelGGL(k_scale_rows, dim3(dotBlocks(nActiveVs)), dim3(BS), 0, stream, ts.p, McInv.p, rhsA.p, nActiveVs);
@@ -910,6 +1013,7 @@ int ps_context::solve() {
     Launch L = mk(this, done);
     const int stBlocks = L.stBlocks();
 
+    HIP_CHECK(hipMemsetAsync(dotPartials3.p, 0, VGRID * sizeof(double), stream));
     hipLaunchKernelGGL(k_cg_init, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
     hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, tol, maxit);
     CGScalars h{};
@@ -922,16 +1026,18 @@ int ps_context::solve() {
             L.spmvS(0, pvec.p, ts.p);
             L.tiles(0, ts.p);
             L.spmvSt(0, ts.p, pvec.p, nullptr, Ap.p, dotPartials.p);
-            if (stBlocks <= 8192) {   // persistent St kernel: one partial per block, few enough for one reducing block
-                hipLaunchKernelGGL(k_cg_scal1, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, stBlocks);
-            } else {
+            const double* pApPart = dotPartials.p;
+            int pApCount = stBlocks;
+            if (stBlocks > 8192) {   // one-shot St kernel: one partial per 256 rows, reduced in two stages
                 hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, stream, sc, dotPartials.p, stBlocks, dotPartials2.p);
-                hipLaunchKernelGGL(k_cg_scal1, dim3(1), dim3(BS), 0, stream, sc, dotPartials2.p, RED_BLOCKS);
+                pApPart = dotPartials2.p; pApCount = RED_BLOCKS;
             }
-            hipLaunchKernelGGL(k_cg_update_xr, dim3(vb), dim3(BS), 0, stream, sc, pvec.p, Ap.p, dv, x.p, r.p, n, dotPartials.p);
-            hipLaunchKernelGGL(k_cg_scal2, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, dv ? 1 : 0, it);
-            hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, stream, sc, r.p, dv, pvec.p, n);
+            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BS), 0, stream, sc, pApPart, pApCount, dotPartials3.p, vb);
+            hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, stream, sc, Ap.p, dv, r.p, n, dotPartials.p);
+            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, dv ? 1 : 0, it);
+            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, stream, sc, r.p, dv, x.p, pvec.p, n, dotPartials3.p);
         }
+        hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BS), 0, stream, sc, dotPartials3.p, vb);
         HIP_CHECK(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         if (h.done) finished = true;
@@ -1025,7 +1131,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
     else if (base == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
     else if (base == "apply") c->applyOperator(x, y, c->dotPartials.p);
     else if (base == "tiles") L.tiles(0, c->ts.p);
-    else if (base == "cg_update_xr" || base == "cg_update_p") {
+    else if (base == "cg_update_xr" || base == "cg_update_p" || base == "cg_update_r" || base == "cg_update_xp") {
         // streaming vector kernels on scratch vectors (alpha = beta = 0 keeps them finite over many launches)
         static ps::DevBuf<CGScalars> scratch;
         scratch.alloc(1);
@@ -1039,8 +1145,12 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         c->dotPartials.alloc((size_t)3 * std::max(vb, VGRID) + 16);
         if (base == "cg_update_xr")
             hipLaunchKernelGGL(k_cg_update_xr, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, y, dv, c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);
-        else
+        else if (base == "cg_update_p")
             hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, dv, c->tmp4.p, n);
+        else if (base == "cg_update_r")
+            hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, c->stream, scratch.p, y, dv, c->tmp5.p, n, c->dotPartials.p);
+        else
+            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, dv, c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);
     }
     else { c->S.packed = keepS; c->St.packed = keepT; throw Error("unknown kernel name: " + k); }
     c->S.packed = keepS; c->St.packed = keepT;
@@ -1090,21 +1200,20 @@ __global__ void k_dscal0(CGScalars* sc, const double* __restrict__ red, double t
     sc->done = (s == 0.) ? 1 : 0;
     if (s == 0.) sc->iter = 0;
     sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
+    sc->pend = 0; sc->pendIter = 0;
 }
-__global__ void k_dscal1(CGScalars* sc, const double* __restrict__ red) {
+__global__ void k_dalpha(CGScalars* sc, const double* __restrict__ red) {   // red = {p.Ap, ||x||^2} summed over the ranks
     if (sc->done) return;
-    sc->pAp = red[0];
-    sc->alpha = sc->rsold / red[0];
+    if (sc->pend) pendingStopTest(sc, red[1]);
+    if (!sc->done) { sc->pAp = red[0]; sc->alpha = sc->rsold / red[0]; }
 }
-__global__ void k_dscal2(CGScalars* sc, const double* __restrict__ red, int jacobi, int iterIndex) {
+__global__ void k_dbeta(CGScalars* sc, const double* __restrict__ red, int jacobi, int iterIndex) {   // red = {r.r, r.z}
     if (sc->done) return;
-    const double rr = red[0], xx = red[1], rz = jacobi ? red[2] : red[0];
-    sc->rr = rr; sc->xx = xx; sc->rz = rz;
-    double rre = rr;
-    if (rr / xx < rre) rre = rr / xx;
-    sc->rre = rre;
-    if (rre < sc->tol2) { sc->done = 1; sc->iter = iterIndex; }
-    else { sc->beta = rz / sc->rsold; sc->rsold = rz; }
+    cgBeta(sc, red[0], jacobi ? red[1] : red[0], iterIndex);
+}
+__global__ void k_dcheck(CGScalars* sc, const double* __restrict__ red) {    // red = {||x||^2}
+    if (sc->done || !sc->pend) return;
+    pendingStopTest(sc, red[0]);
 }
 __global__ void k_invert_diag(double* __restrict__ d, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1306,6 +1415,7 @@ struct Dist {
             ps_context* c = R[q];
             Loc& l = loc[q];
             HIP_CHECK(hipMemsetAsync(c->pvec.p, 0, (size_t)std::max<int64_t>(c->nSystem, 1) * 8, c->stream));
+            HIP_CHECK(hipMemsetAsync(c->dotPartials3.p, 0, VGRID * sizeof(double), c->stream));
             hipLaunchKernelGGL(k_cg_init, dim3(l.vb), dim3(BS), 0, c->stream, c->b.p + l.lo, l.dv, c->x.p + l.lo, c->r.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials.p);
             hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)nullptr, c->dotPartials.p, l.vb, 0, 1, c->redbuf.p);
         }
@@ -1332,24 +1442,30 @@ struct Dist {
                         hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, c->stream, l.sc, c->dotPartials.p, l.stBlocks, c->dotPartials2.p);
                         hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials2.p, RED_BLOCKS, 0, 1, c->redbuf.p);
                     }
+                    // ||x||^2 of the x updated last iteration rides along (pending stop test, see k_cg_alpha)
+                    hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials3.p, l.vb, 0, 1, c->redbuf.p + 1);
                 }
                 exchangeAddY(&ps_context::Ap);
-                allreduce(1);
+                allreduce(2);
                 for (size_t q = 0; q < R.size(); ++q) {
                     ps_context* c = R[q];
                     Loc& l = loc[q];
-                    hipLaunchKernelGGL(k_dscal1, dim3(1), dim3(1), 0, c->stream, l.sc, c->redbuf.p);
-                    hipLaunchKernelGGL(k_cg_update_xr, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, c->pvec.p + l.lo, c->Ap.p + l.lo, l.dv, c->x.p + l.lo, c->r.p + l.lo, l.n, c->dotPartials.p);
-                    hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials.p, l.vb, l.vb, 3, c->redbuf.p);
+                    hipLaunchKernelGGL(k_dalpha, dim3(1), dim3(1), 0, c->stream, l.sc, c->redbuf.p);
+                    hipLaunchKernelGGL(k_cg_update_r, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, c->Ap.p + l.lo, l.dv, c->r.p + l.lo, l.n, c->dotPartials.p);
+                    hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials.p, l.vb, l.vb, 2, c->redbuf.p);
                 }
-                allreduce(3);
+                allreduce(2);
                 for (size_t q = 0; q < R.size(); ++q) {
                     ps_context* c = R[q];
                     Loc& l = loc[q];
-                    hipLaunchKernelGGL(k_dscal2, dim3(1), dim3(1), 0, c->stream, l.sc, c->redbuf.p, jac ? 1 : 0, it);
-                    hipLaunchKernelGGL(k_cg_update_p, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, c->r.p + l.lo, l.dv, c->pvec.p + l.lo, l.n);
+                    hipLaunchKernelGGL(k_dbeta, dim3(1), dim3(1), 0, c->stream, l.sc, c->redbuf.p, jac ? 1 : 0, it);
+                    hipLaunchKernelGGL(k_cg_update_xp, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, c->r.p + l.lo, l.dv, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p);
                 }
             }
+            for (size_t q = 0; q < R.size(); ++q)   // the stop test of the batch's last iteration
+                hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, R[q]->stream, (const CGScalars*)loc[q].sc, R[q]->dotPartials3.p, loc[q].vb, 0, 1, R[q]->redbuf.p);
+            allreduce(1);
+            for (size_t q = 0; q < R.size(); ++q) hipLaunchKernelGGL(k_dcheck, dim3(1), dim3(1), 0, R[q]->stream, loc[q].sc, R[q]->redbuf.p);
             HIP_CHECK(hipMemcpyAsync(&h, loc[0].sc, sizeof(h), hipMemcpyDeviceToHost, c0->stream));
             syncAll();
             if (h.done) finished = true;
