@@ -178,12 +178,12 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 // robin — rows that gather the same lines of x (k-plane neighbours, a few chunks apart) then share ONE L2, while
 // the chip as a whole still sweeps one compact window of memory.
 struct ChunkWalk {
-    int G, x, l, per;
-    __device__ ChunkWalk(int g) : G(g), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3) {}
+    int sh, x, l, per;   // G = 1 << sh chunks per run; sh < 0: plain walk
+    __device__ ChunkWalk(int g) : sh(g > 0 ? 31 - __builtin_clz((unsigned)g) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3) {}
     __device__ int at(int it) const {
-        if (G <= 0) return blockIdx.x + it * gridDim.x;
+        if (sh < 0) return blockIdx.x + it * gridDim.x;
         const int q = l + it * per;
-        return ((q / G) * 8 + x) * G + q % G;
+        return ((((q >> sh) << 3) + x) << sh) + (q & ((1 << sh) - 1));
     }
 };
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -877,13 +877,14 @@ struct Launch {
 #undef PS_LAUNCH_S
     }
     int pipeGrid;   // 0: one-shot kernels; >0: persistent software-pipelined kernels with this many blocks
-    int xcdAware;   // pipelined kernels: each XCD walks a contiguous eighth of the row chunks
+    int xcdAware;   // pipelined kernels: runs of this many chunks are dealt to the XCDs round robin (ChunkWalk); 0 = plain walk
     void spmvS(int mode, const double* x, double* out) const {
         if (rowsS == 0) return;
         const ps::DevCSR& M = c->S;
         if (pipeGrid > 0 && M.col16ok) {
             const int nChunks = gridFor(rowsS, BS);
-            const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
+            int xcdAware = this->xcdAware;
+            const dim3 gr(pipeBlocks(nChunks, xcdAware)), bl(BS);
 #define PS_LAUNCH_SP(MODE_, NV_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
                                                     M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, 0, nChunks, xcdAware)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP(0, 1); else PS_LAUNCH_SP(1, 1); }
@@ -924,7 +925,8 @@ struct Launch {
         const ps::DevCSR& M = c->St;
         if (pipeGrid > 0 && M.col16ok) {
             const int nChunks = gridFor(rowsSt, BS);
-            const dim3 gr(std::min(nChunks, pipeGrid)), bl(BS);
+            int xcdAware = this->xcdAware;
+            const dim3 gr(pipeBlocks(nChunks, xcdAware)), bl(BS);
 #define PS_LAUNCH_TP(MODE_, NV_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
                                                     M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, 0, nChunks, xcdAware)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP(0, 1); else PS_LAUNCH_TP(1, 1); }
@@ -934,9 +936,16 @@ struct Launch {
         }
         spmvSt_(mode, t, xin, add, out, partial);
     }
+    // grid of a persistent kernel; the XCD-grouped walk needs a multiple of 8 blocks (workgroup b runs on XCD b & 7)
+    int pipeBlocks(int nChunks, int& xcd) const {
+        int g = std::min(nChunks, pipeGrid);
+        if (xcd > 0) { if (g >= 8) g &= ~7; else xcd = 0; }
+        return g;
+    }
     int stBlocks() const {   // number of p.Ap partials the St kernel writes: one per block
         const int nChunks = gridFor(rowsSt, BS);
-        return (pipeGrid > 0 && c->St.col16ok) ? std::min(nChunks, pipeGrid) : nChunks;
+        int xcd = xcdAware;
+        return (pipeGrid > 0 && c->St.col16ok) ? pipeBlocks(nChunks, xcd) : nChunks;
     }
 };
 Launch mk(ps_context* c, const int* done) {
@@ -950,8 +959,8 @@ Launch mk(ps_context* c, const int* done) {
     }
     L.pipeGrid = pg;
     static int xa = -1;
-    if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 0; }
-    L.xcdAware = (xa > 0 && (pg % 8) == 0) ? xa : 0;
+    if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 16; }   // chunks per XCD run (rounded down to a power of two); 0: plain walk
+    L.xcdAware = xa > 0 ? xa : 0;
     return L;
 }
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
