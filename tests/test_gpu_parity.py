@@ -337,3 +337,37 @@ def test_exported_system_import_and_solve(gpu, tmp_path, precond):
 def test_exported_system_import_errors(gpu, tmp_path):
     with pytest.raises(RuntimeError, match="cannot open"):
         gpu.solve_exported_system(str(tmp_path) + "/nothing.", abi.default_params(), 0.1, 4)
+
+
+@pytest.mark.parametrize("env", [{"PS_COL32": "1"}, {"PS_FORCE_FP64_VALUES": "1"}, {"PS_PIPE_GRID": "0"}, {"PS_XCD": "0"}])
+def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
+    """The SpMV has three storage formats (compressed 3 B/nnz stream -> int8-coded CSR -> fp64 CSR) chosen at setup, and
+    A/B switches read once per process.  Run the alternatives in a child process: same iteration count, same velocities
+    to rounding (the formats reproduce the same fp64 products; only summation orders of the dot products differ)."""
+    import os
+    import subprocess
+    import sys
+    sc, p = scenes.blob(20, 18, 22, seed=9, tile=8)
+    p.tolerance = 1e-8
+    p.maxSolverIterations = 20000
+    assert gpu.step(sc, p) == abi.SUCCESS
+    out = str(tmp_path / "alt.npz")
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import polystokes_amd\nfrom polystokes_amd import scenes\n"
+        "sc, p = scenes.blob(20, 18, 22, seed=9, tile=8)\np.tolerance = 1e-8\np.maxSolverIterations = 20000\n"
+        "s = polystokes_amd.Solver(0)\nrc = s.step(sc, p)\n"
+        f"np.savez({out!r}, rc=rc, it=s.stats.solveData[1], vx=s.vel[0], vy=s.vel[1], vz=s.vel[2], c16=s.array('columns16'), coded=s.array('valuesCoded'))\n"
+    )
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), timeout=300)
+    alt = np.load(out)
+    assert int(alt["rc"]) == abi.SUCCESS
+    if "PS_COL32" in env:
+        assert int(alt["c16"][0]) == 0
+    if "PS_FORCE_FP64_VALUES" in env:
+        assert int(alt["coded"][0]) == 0 and int(alt["c16"][0]) == 0
+    assert abs(float(alt["it"]) - gpu.stats.solveData[1]) <= 1
+    for a, k in enumerate(("vx", "vy", "vz")):
+        scale = max(np.abs(gpu.vel[a]).max(), 1e-30)
+        assert np.abs(alt[k] - gpu.vel[a]).max() <= 1e-6 * scale
