@@ -201,5 +201,5 @@ int ps_dist_step_single(ps_context* c, ps_stats* stats);   // ps_solve.hip: dist
 
 namespace ps {
 constexpr int FB_CHUNK = 4096;   // face-box positions per work item (per-region dense reductions)
-constexpr int RC_ROWS = 512;     // reduced rows per chunk in the per-iteration tile kernels
+constexpr int RC_ROWS = 1280;    // reduced rows per chunk in the per-iteration tile kernels
 }  // namespace ps

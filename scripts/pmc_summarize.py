@@ -1,6 +1,6 @@
 """Summarise the FETCH_SIZE / WRITE_SIZE passes of scripts/profile_round.sh into per-kernel HBM traffic per launch.
 FETCH_SIZE is doubled (gfx950 tallies 128-B read requests as 64 B: MI355X_MICROARCH.md, HBM section; re-calibrated here
-on k_cg_update_p, which reads exactly three vectors of 8 n bytes); WRITE_SIZE is exact.  Counter unit: KiB."""
+on k_cg_update_r, which reads exactly three vectors of 8 n bytes and writes one); WRITE_SIZE is exact.  Counter unit: KiB."""
 import collections
 import csv
 import glob
@@ -8,7 +8,7 @@ import json
 import sys
 
 out_dir = sys.argv[1]
-KEYS = {"k_spmv_St_pipe<0": "k_spmv_St", "k_spmv_S_pipe<0": "k_spmv_S", "k_cg_update_xr": "k_cg_update_xr", "k_cg_update_p": "k_cg_update_p",
+KEYS = {"k_spmv_St_pipe<0": "k_spmv_St", "k_spmv_S_pipe<0": "k_spmv_S", "k_cg_update_r(": "k_cg_update_r", "k_cg_update_xp(": "k_cg_update_xp",
         "k_tile_gather": "k_tile_gather", "k_tile_expand": "k_tile_expand"}
 
 
@@ -27,7 +27,7 @@ def collect(sub, counter):
 
 f, w = collect("pmc_fetch", "FETCH_SIZE"), collect("pmc_write", "WRITE_SIZE")
 res = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --maxit 20, 256^3 cavity). Counter unit KiB. "
-               "FETCH_SIZE is doubled (gfx950: 128-B requests tallied as 64 B; k_cg_update_p reads exactly 3 vectors of 8 n bytes: "
+               "FETCH_SIZE is doubled (gfx950: 128-B requests tallied as 64 B; k_cg_update_r reads exactly 3 vectors of 8 n bytes: "
                "see its entry). WRITE_SIZE is exact. traffic = 2*FETCH + WRITE, per launch."}
 for k in KEYS.values():
     if k in f and k in w:
