@@ -17,10 +17,36 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 
 
+def _cpu_share():
+    """Threads this process may keep busy: the scheduler affinity, capped by the cgroup CPU quota and by 16 (a 1-GPU
+    box's share of its host; a worker pool larger than the share only thrashes)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw):
-    """CPU restatement (oracle, kind "port") timed on this host on a bounded sample: the same scene at
-    64^3.  Scaled to the metric's unit (ms/step at the benchmark size) by DOF count and the GPU run's
-    iteration count; the raw sample numbers are kept alongside."""
+    """CPU restatement (oracle, kind "port") timed on this host's cores on a bounded sample: the same scene at 64^3.
+    value = setup (single thread, the restatement is literal) + CG iterations with every row loop of the operator and
+    of the vector updates split over OpenMP threads (oracle/ps_oracle_mt.cpp), scaled to the metric's unit (ms/step at
+    the benchmark size) by cell count (setup) and by DOFs x the GPU run's iteration count (solve).  The single-thread
+    timings of the reference-shaped and of the fused operator are kept alongside."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before libgomp starts: spinning workers starve a shared host
     from oracle import ps_oracle
     from polystokes_amd import scenes
     ns = 64
@@ -30,19 +56,21 @@ def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw):
     o.run(sc, p, solve=False)
     setup_ms = (time.time() - t0) * 1e3
     n_s = o.nP + o.nT
-    iters = 8
-    ms_it = o.time_cg(iters, fair=False)
-    ms_it_fair = o.time_cg(iters, fair=True)
+    cores = _cpu_share()
+    ms_it = o.time_cg(6, fair=False)
+    ms_it_fair = o.time_cg(6, fair=True)
+    ms_it_mt, used = o.time_cg_mt(20, cores)
     scale_cells = n_gpu_cells / float(ns ** 3)
-    est = setup_ms * scale_cells + ms_it * (gpu_n / float(n_s)) * max(gpu_iters, 1)
+    est = setup_ms * scale_cells + ms_it_mt * (gpu_n / float(n_s)) * max(gpu_iters, 1)
+    est_1t = setup_ms * scale_cells + ms_it * (gpu_n / float(n_s)) * max(gpu_iters, 1)
     return {
-        "value": est, "unit": "ms/step", "cores": 1, "kind": "port",
-        "sample": ("oracle (single-thread restatement of ApplyPressureStressMatrix + pcg_external_matrix_A) on the same "
-                   "cavity scene at 64^3: setup %.0f ms, %.1f ms per reference-shaped CG iteration (%.1f ms fused) at n=%d; "
-                   "scaled to 256^3 by cell count (setup) and by DOFs x the GPU run's iteration count (solve)"
-                   % (setup_ms, ms_it, ms_it_fair, n_s)),
-        "sample_setup_ms": setup_ms, "sample_ms_per_cg_iter": ms_it, "sample_ms_per_cg_iter_fused": ms_it_fair,
-        "sample_dofs": n_s,
+        "value": est, "unit": "ms/step", "cores": used, "kind": "port",
+        "sample": ("oracle (C++ restatement of ApplyPressureStressMatrix + pcg_external_matrix_A) on the same cavity scene at 64^3, n=%d: "
+                   "setup %.0f ms (1 thread); per CG iteration %.2f ms with %d OpenMP threads (fused operator), %.1f ms single-thread "
+                   "reference-shaped, %.1f ms single-thread fused; scaled to 256^3 by cell count (setup) and by DOFs x the GPU run's "
+                   "iteration count (solve)" % (n_s, setup_ms, ms_it_mt, used, ms_it, ms_it_fair)),
+        "sample_setup_ms": setup_ms, "sample_ms_per_cg_iter_mt": ms_it_mt, "sample_ms_per_cg_iter": ms_it,
+        "sample_ms_per_cg_iter_fused": ms_it_fair, "sample_dofs": n_s, "value_single_thread_reference_shaped": est_1t,
     }
 
 

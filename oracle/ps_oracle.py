@@ -16,7 +16,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("ps_oracle_grid.cpp", "ps_oracle_blocks.cpp", "ps_oracle_solve.cpp",
+    srcs = [os.path.join(_HERE, f) for f in ("ps_oracle_grid.cpp", "ps_oracle_blocks.cpp", "ps_oracle_solve.cpp", "ps_oracle_mt.cpp",
                                               "ps_oracle.hpp", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "polystokes.h"))
     stale = (not os.path.exists(_LIB_PATH)) or any(
@@ -44,6 +44,8 @@ def lib():
         L.po_build_jacobi.argtypes = [C.c_void_p]
         L.po_time_cg_iterations.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.po_time_cg_iterations.restype = C.c_double
+        L.po_time_cg_iterations_mt.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+        L.po_time_cg_iterations_mt.restype = C.c_double
         L.po_last_error.argtypes = [C.c_void_p]
         L.po_last_error.restype = C.c_char_p
         L.po_basis.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -132,6 +134,12 @@ class Oracle:
 
     def time_cg(self, iters, fair=False):
         return self.L.po_time_cg_iterations(self.h, iters, 1 if fair else 0)
+
+    def time_cg_mt(self, iters, threads=0):
+        """(ms per CG iteration, threads used) of the OpenMP 'fair CPU' baseline; threads=0: OpenMP default."""
+        used = C.c_int32(0)
+        ms = self.L.po_time_cg_iterations_mt(self.h, iters, threads, C.byref(used))
+        return ms, int(used.value)
 
 
 def basis(off, axis):
