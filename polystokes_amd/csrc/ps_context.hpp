@@ -40,6 +40,7 @@ struct CGScalars {
     int pend;        // the stop test of iteration `pendIter` waits for ||x||^2 of the x it updated (deferred-x step)
     double tol2;
     int pendIter, pad;
+    double rsold2[2];   // r.z of the previous iteration, double-buffered by iteration parity (fused-scalar step kernels)
 };
 
 struct ArrayInfo {

@@ -48,6 +48,20 @@ __device__ inline double blockReduceSum(double v) {
     return s;
 }
 
+// same sum (same order), valid in every thread
+__device__ inline double blockSumAll(double v) {
+    __shared__ double wsA[BS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = waveReduceSum(v);
+    if (lane == 0) wsA[w] = v;
+    __syncthreads();
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) s += wsA[i];
+    __syncthreads();
+    return s;
+}
+
 // Streaming phase of the CSR-stream SpMV: the block's contiguous nnz range [p0,p1) (<= BS*MAXNNZ entries)
 // is read with a fixed-trip, fully unrolled loop so that all MAXNNZ (col,val) loads of a thread — and then
 // all MAXNNZ gathers — are in flight together (memory-level parallelism instead of a dependent chain).
@@ -548,6 +562,11 @@ __global__ void __launch_bounds__(BS) k_cg_init(const double* __restrict__ b, co
     const double s = blockReduceSum(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
+__device__ inline double sumLocal(const double* __restrict__ partial, int count) {   // this thread's share (fixed stride order)
+    double acc = 0.;
+    for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
+    return acc;
+}
 __device__ inline double sumPartials(const double* __restrict__ partial, int count) {
     double acc = 0.;
     for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
@@ -556,7 +575,7 @@ __device__ inline double sumPartials(const double* __restrict__ partial, int cou
 __global__ void __launch_bounds__(BS) k_cg_scal0(CGScalars* sc, const double* __restrict__ partial, int count, double tol, int maxit) {
     const double s = sumPartials(partial, count);
     if (threadIdx.x == 0) {
-        sc->rsold = s; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
+        sc->rsold = s; sc->rsold2[0] = s; sc->rsold2[1] = 0.; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
         sc->done = (s == 0.) ? 1 : 0;      // deviation: b == 0 -> return at once (reference divides 0/0, pcg.h:314)
         if (s == 0.) sc->iter = 0;
         sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
@@ -650,44 +669,46 @@ __global__ void __launch_bounds__(BS) k_cg_update_p(const CGScalars* __restrict_
     }
 }
 
-// ---- PCG step with the x update deferred into the p update (10 vector passes per iteration instead of 11) ----------
-// pcg.h:311-335 updates x and r together, tests min(rr, rr/xx) < tol^2, then forms beta and the new p.  Here r is updated
-// first (k_cg_update_r: reads Ap, r, dinv), beta follows, and ONE kernel then does x += alpha p, p = z + beta p
-// (k_cg_update_xp: p is read once for both) and sums ||x||^2 of the updated x.  The stop test of that iteration — same
-// rr, same xx, same iteration index — is evaluated by the next scalar kernel (k_cg_alpha of the following iteration, or
-// k_cg_check before the host polls); if it fires, every later kernel is a no-op, and x already holds the iterate the
-// reference would return.  The extra work is one unused p update, and one unused operator apply when the test fires at
-// the start of an iteration.
-__device__ inline void pendingStopTest(CGScalars* sc, double xx) {
+// ---- PCG step: x update deferred into the p update, scalar reductions folded into the vector kernels ---------------
+// pcg.h:311-335 updates x and r together, tests min(rr, rr/xx) < tol^2, then forms beta and the new p: 11 vector passes
+// and (here) two one-block scalar kernels.  This step is 10 passes and 2 launches:
+//   k_cg_update_r :  [stop test of the previous iteration]  alpha = rsold / p.Ap ;  r -= alpha Ap ;  partials r.r, r.z
+//   k_cg_update_xp:  beta = r.z / rsold ;  x += alpha p ;  p = z + beta p (p read once for both) ;  partials x.x
+// Every block sums the (<= 4096 + 1024) partials of the preceding kernel itself — same order in every block, so all
+// blocks hold bit-identical scalars — and block 0 records them for the host and the next kernel; rsold is double-buffered
+// by iteration parity so no block reads a scalar another block of the same launch writes.
+// The stop test of iteration k — same rr, xx of the updated x, same iteration index as the reference — is evaluated at
+// the start of iteration k+1 (or by k_cg_check before the host polls); when it fires every later kernel is a no-op and
+// x already holds the iterate the reference returns.  Cost: one unused p update and one unused operator apply.
+// With `red` (distributed solve) the sums come all-reduced from the ranks: red = {p.Ap, x.x} resp. {r.r, r.z}.
+__device__ inline bool stopTest(CGScalars* sc, double xx, int iterIndex, bool writer) {
     const double rr = sc->rr;
-    sc->xx = xx;
     double rre = rr;                                   // pcg.h:319-325
     if (rr / xx < rre) rre = rr / xx;
-    sc->rre = rre;
-    sc->pend = 0;
-    if (rre < sc->tol2) { sc->done = 1; sc->iter = sc->pendIter; }
+    const bool fire = rre < sc->tol2;
+    if (writer) { sc->xx = xx; sc->rre = rre; if (fire) { sc->done = 1; sc->iter = iterIndex; } }
+    return fire;
 }
-__global__ void __launch_bounds__(BS) k_cg_alpha(CGScalars* sc, const double* __restrict__ pApPartial, int count, const double* __restrict__ xxPartial,
-                                                 int vb) {
+__global__ void __launch_bounds__(BS) k_cg_check(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ xxPartial, int vb, int lastIter) {
     if (sc->done) return;
-    const int pend = sc->pend;                         // block-uniform
-    const double xx = pend ? sumPartials(xxPartial, vb) : 0.;
-    const double s = sumPartials(pApPartial, count);
-    if (threadIdx.x == 0) {
-        if (pend) pendingStopTest(sc, xx);
-        if (!sc->done) { sc->pAp = s; sc->alpha = sc->rsold / s; }   // pcg.h:314
+    const double xx = red ? red[0] : blockSumAll(sumLocal(xxPartial, vb));
+    stopTest(sc, xx, lastIter, threadIdx.x == 0);
+}
+// [stop test of iteration it-1] ; alpha ; r -= alpha Ap ; partials of r.r and r.z
+__global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ pApPartial, int pApCount,
+                                                    const double* __restrict__ xxPartial, int xxCount, int it, const double* __restrict__ Ap,
+                                                    const double* __restrict__ dinv, double* __restrict__ r, int64_t n, double* __restrict__ partial) {
+    if (sc->done) return;
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    double pAp, xx = 0.;
+    if (red) { pAp = red[0]; xx = red[1]; }
+    else {
+        if (it > 0) xx = blockSumAll(sumLocal(xxPartial, xxCount));
+        pAp = blockSumAll(sumLocal(pApPartial, pApCount));
     }
-}
-__global__ void __launch_bounds__(BS) k_cg_check(CGScalars* sc, const double* __restrict__ xxPartial, int vb) {
-    if (sc->done || !sc->pend) return;
-    const double xx = sumPartials(xxPartial, vb);
-    if (threadIdx.x == 0) pendingStopTest(sc, xx);
-}
-// r -= alpha Ap ; partials of r.r and r.z
-__global__ void __launch_bounds__(BS) k_cg_update_r(const CGScalars* __restrict__ sc, const double* __restrict__ Ap, const double* __restrict__ dinv,
-                                                    double* __restrict__ r, int64_t n, double* __restrict__ partial) {
-    if (sc->done) return;
-    const double alpha = sc->alpha;
+    if (it > 0 && stopTest(sc, xx, it - 1, writer)) return;           // same verdict in every block
+    const double alpha = sc->rsold2[it & 1] / pAp;                      // pcg.h:314
+    if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
     double arr = 0., arz = 0.;
     const bool vec = ((((uintptr_t)Ap | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
     const int64_t n2 = vec ? n / 2 : 0;
@@ -710,22 +731,19 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(const CGScalars* __restrict_
     const double s0 = blockReduceSum(arr), s2 = dinv ? blockReduceSum(arz) : 0.;
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s2; }
 }
-__device__ inline void cgBeta(CGScalars* sc, double rr, double rz, int iterIndex) {
-    sc->rr = rr; sc->rz = rz;
-    sc->beta = rz / sc->rsold; sc->rsold = rz;         // pcg.h:331-335
-    sc->pend = 1; sc->pendIter = iterIndex;
-}
-__global__ void __launch_bounds__(BS) k_cg_beta(CGScalars* sc, const double* __restrict__ partial, int count, int jacobi, int iterIndex) {
+// beta ; x += alpha p ; p = z + beta p (z = D^-1 r) ; partials of x.x
+__global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
+                                                     int it, const double* __restrict__ r, const double* __restrict__ dinv, double* __restrict__ x,
+                                                     double* __restrict__ p, int64_t n, double* __restrict__ partial) {
     if (sc->done) return;
-    const double rr = sumPartials(partial, count);
-    const double rz = jacobi ? sumPartials(partial + count, count) : rr;
-    if (threadIdx.x == 0) cgBeta(sc, rr, rz, iterIndex);
-}
-// x += alpha p ; p = z + beta p (z = D^-1 r) ; partials of x.x
-__global__ void __launch_bounds__(BS) k_cg_update_xp(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
-                                                     double* __restrict__ x, double* __restrict__ p, int64_t n, double* __restrict__ partial) {
-    if (sc->done) return;
-    const double alpha = sc->alpha, beta = sc->beta;
+    double rr, rz;
+    if (red) { rr = red[0]; rz = jacobi ? red[1] : red[0]; }
+    else {
+        rr = blockSumAll(sumLocal(rPartial, rCount));
+        rz = jacobi ? blockSumAll(sumLocal(rPartial + rCount, rCount)) : rr;
+    }
+    const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
     double axx = 0.;
     const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x | (uintptr_t)dinv) & 15) == 0);
     const int64_t n2 = vec ? n / 2 : 0;
@@ -1041,12 +1059,12 @@ int ps_context::solve() {
                 hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, stream, sc, dotPartials.p, stBlocks, dotPartials2.p);
                 pApPart = dotPartials2.p; pApCount = RED_BLOCKS;
             }
-            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BS), 0, stream, sc, pApPart, pApCount, dotPartials3.p, vb);
-            hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, stream, sc, Ap.p, dv, r.p, n, dotPartials.p);
-            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, dv ? 1 : 0, it);
-            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, stream, sc, r.p, dv, x.p, pvec.p, n, dotPartials3.p);
+            hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, pApPart, pApCount, dotPartials3.p, vb, it, Ap.p, dv,
+                               r.p, n, dotPartials.p);
+            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, dotPartials.p, vb, dv ? 1 : 0, it, r.p, dv, x.p,
+                               pvec.p, n, dotPartials3.p);
         }
-        hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BS), 0, stream, sc, dotPartials3.p, vb);
+        hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BS), 0, stream, sc, (const double*)nullptr, dotPartials3.p, vb, it - 1);
         HIP_CHECK(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         if (h.done) finished = true;
@@ -1145,7 +1163,17 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         static ps::DevBuf<CGScalars> scratch;
         scratch.alloc(1);
         CGScalars h{};
+        h.tol2 = -1.;                                  // the stop test never fires
+        if (base == "cg_update_xp") h.rsold2[0] = 1.;   // beta = 0 / 1 ; (cg_update_r: alpha = 0 / p.Ap with p.Ap = 1024 below)
         HIP_CHECK(hipMemcpyAsync(scratch.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        static ps::DevBuf<double> ones;                // input partials of the fused scalar prologues
+        if (ones.n < (size_t)2 * VGRID) {
+            ones.alloc((size_t)2 * VGRID);
+            std::vector<double> hv((size_t)2 * VGRID, 1.);
+            HIP_CHECK(hipMemcpy(ones.p, hv.data(), hv.size() * 8, hipMemcpyHostToDevice));
+        }
+        static ps::DevBuf<double> zeros;
+        if (zeros.n < (size_t)2 * VGRID) { zeros.alloc((size_t)2 * VGRID); HIP_CHECK(hipMemset(zeros.p, 0, (size_t)2 * VGRID * 8)); }
         const int64_t n = c->nSystem;
         const char* e = getenv("PS_VGRID");
         const int vb = e ? atoi(e) : dotBlocks(n);
@@ -1157,9 +1185,11 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         else if (base == "cg_update_p")
             hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, dv, c->tmp4.p, n);
         else if (base == "cg_update_r")
-            hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, c->stream, scratch.p, y, dv, c->tmp5.p, n, c->dotPartials.p);
+            hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)nullptr, ones.p, VGRID, ones.p, 0, 0, y, dv,
+                               c->tmp5.p, n, c->dotPartials.p);
         else
-            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, dv, c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);
+            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)nullptr, zeros.p, VGRID, dv ? 1 : 0, 0, x, dv,
+                               c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);
     }
     else { c->S.packed = keepS; c->St.packed = keepT; throw Error("unknown kernel name: " + k); }
     c->S.packed = keepS; c->St.packed = keepT;
@@ -1205,24 +1235,11 @@ __global__ void __launch_bounds__(BS) k_sumq(const CGScalars* __restrict__ sc, c
 }
 __global__ void k_dscal0(CGScalars* sc, const double* __restrict__ red, double tol, int maxit) {
     const double s = red[0];
-    sc->rsold = s; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
+    sc->rsold = s; sc->rsold2[0] = s; sc->rsold2[1] = 0.; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
     sc->done = (s == 0.) ? 1 : 0;
     if (s == 0.) sc->iter = 0;
     sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
     sc->pend = 0; sc->pendIter = 0;
-}
-__global__ void k_dalpha(CGScalars* sc, const double* __restrict__ red) {   // red = {p.Ap, ||x||^2} summed over the ranks
-    if (sc->done) return;
-    if (sc->pend) pendingStopTest(sc, red[1]);
-    if (!sc->done) { sc->pAp = red[0]; sc->alpha = sc->rsold / red[0]; }
-}
-__global__ void k_dbeta(CGScalars* sc, const double* __restrict__ red, int jacobi, int iterIndex) {   // red = {r.r, r.z}
-    if (sc->done) return;
-    cgBeta(sc, red[0], jacobi ? red[1] : red[0], iterIndex);
-}
-__global__ void k_dcheck(CGScalars* sc, const double* __restrict__ red) {    // red = {||x||^2}
-    if (sc->done || !sc->pend) return;
-    pendingStopTest(sc, red[0]);
 }
 __global__ void k_invert_diag(double* __restrict__ d, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1451,7 +1468,7 @@ struct Dist {
                         hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, c->stream, l.sc, c->dotPartials.p, l.stBlocks, c->dotPartials2.p);
                         hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials2.p, RED_BLOCKS, 0, 1, c->redbuf.p);
                     }
-                    // ||x||^2 of the x updated last iteration rides along (pending stop test, see k_cg_alpha)
+                    // ||x||^2 of the x updated last iteration rides along (stop test of the previous iteration, see k_cg_update_r)
                     hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials3.p, l.vb, 0, 1, c->redbuf.p + 1);
                 }
                 exchangeAddY(&ps_context::Ap);
@@ -1459,22 +1476,23 @@ struct Dist {
                 for (size_t q = 0; q < R.size(); ++q) {
                     ps_context* c = R[q];
                     Loc& l = loc[q];
-                    hipLaunchKernelGGL(k_dalpha, dim3(1), dim3(1), 0, c->stream, l.sc, c->redbuf.p);
-                    hipLaunchKernelGGL(k_cg_update_r, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, c->Ap.p + l.lo, l.dv, c->r.p + l.lo, l.n, c->dotPartials.p);
+                    hipLaunchKernelGGL(k_cg_update_r, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, (const double*)nullptr, 0,
+                                       (const double*)nullptr, 0, it, c->Ap.p + l.lo, l.dv, c->r.p + l.lo, l.n, c->dotPartials.p);
                     hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials.p, l.vb, l.vb, 2, c->redbuf.p);
                 }
                 allreduce(2);
                 for (size_t q = 0; q < R.size(); ++q) {
                     ps_context* c = R[q];
                     Loc& l = loc[q];
-                    hipLaunchKernelGGL(k_dbeta, dim3(1), dim3(1), 0, c->stream, l.sc, c->redbuf.p, jac ? 1 : 0, it);
-                    hipLaunchKernelGGL(k_cg_update_xp, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, c->r.p + l.lo, l.dv, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p);
+                    hipLaunchKernelGGL(k_cg_update_xp, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, (const double*)nullptr, 0,
+                                       jac ? 1 : 0, it, c->r.p + l.lo, l.dv, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p);
                 }
             }
             for (size_t q = 0; q < R.size(); ++q)   // the stop test of the batch's last iteration
                 hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, R[q]->stream, (const CGScalars*)loc[q].sc, R[q]->dotPartials3.p, loc[q].vb, 0, 1, R[q]->redbuf.p);
             allreduce(1);
-            for (size_t q = 0; q < R.size(); ++q) hipLaunchKernelGGL(k_dcheck, dim3(1), dim3(1), 0, R[q]->stream, loc[q].sc, R[q]->redbuf.p);
+            for (size_t q = 0; q < R.size(); ++q)
+                hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BS), 0, R[q]->stream, loc[q].sc, (const double*)R[q]->redbuf.p, (const double*)nullptr, 0, it - 1);
             HIP_CHECK(hipMemcpyAsync(&h, loc[0].sc, sizeof(h), hipMemcpyDeviceToHost, c0->stream));
             syncAll();
             if (h.done) finished = true;
