@@ -1211,17 +1211,20 @@ struct PsNcclUid { char internal[128]; };   // layout of ncclUniqueId
 
 namespace {
 
-__global__ void k_pack(const int32_t* __restrict__ list, int64_t n, const double* __restrict__ v, double* __restrict__ buf) {
+// both cut planes of a rank in one launch: entries [0, nA) use list A / buffer A, entries [nA, nA + nB) list B / buffer B.
+// (A DOF lies next to at most one cut — slabs are at least one 16-layer block thick — so the two lists are disjoint.)
+__global__ void k_pack2(const int32_t* __restrict__ listA, int64_t nA, double* __restrict__ bufA, const int32_t* __restrict__ listB, int64_t nB,
+                        double* __restrict__ bufB, const double* __restrict__ v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) buf[i] = v[list[i]];
+    if (i < nA) bufA[i] = v[listA[i]];
+    else if (i < nA + nB) bufB[i - nA] = v[listB[i - nA]];
 }
-__global__ void k_unpack_assign(const int32_t* __restrict__ list, int64_t n, const double* __restrict__ buf, double* __restrict__ v) {
+template <bool ADD>
+__global__ void k_unpack2(const int32_t* __restrict__ listA, int64_t nA, const double* __restrict__ bufA, const int32_t* __restrict__ listB, int64_t nB,
+                          const double* __restrict__ bufB, double* __restrict__ v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[list[i]] = buf[i];
-}
-__global__ void k_unpack_add(const int32_t* __restrict__ list, int64_t n, const double* __restrict__ buf, double* __restrict__ v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[list[i]] += buf[i];
+    if (i < nA) { if (ADD) v[listA[i]] += bufA[i]; else v[listA[i]] = bufA[i]; }
+    else if (i < nA + nB) { if (ADD) v[listB[i - nA]] += bufB[i - nA]; else v[listB[i - nA]] = bufB[i - nA]; }
 }
 // out[q] = sum of partial[q*stride .. q*stride+count)   (q < nq), one block
 __global__ void __launch_bounds__(BS) k_sumq(const CGScalars* __restrict__ sc, const double* __restrict__ partial, int count, int stride, int nq,
@@ -1308,10 +1311,6 @@ struct Dist {
     std::vector<ps_context*> R;   // the ranks living in this process (1 with RCCL, `world` for an in-process group)
     bool useRccl = false;
 
-    static void launch1(ps_context* c, void (*k)(const int32_t*, int64_t, const double*, double*), const int32_t* list, int64_t n,
-                        const double* v, double* buf) {
-        if (n > 0) hipLaunchKernelGGL(k, dim3(gridFor(n, BS)), dim3(BS), 0, c->stream, list, n, v, buf);
-    }
     // sizes: kind 0 = x exchange (send own layers, receive halo), kind 1 = y exchange (send halo contributions, receive for own)
     void transport(int kind) {
         if (useRccl) {
@@ -1341,26 +1340,26 @@ struct Dist {
         }
     }
     void exchangeX(DevBuf<double> ps_context::*vec) {
-        for (ps_context* c : R) {
-            launch1(c, k_pack, c->listLowOwn.p, c->nLowOwn, (c->*vec).p, c->sendLo.p);
-            launch1(c, k_pack, c->listUpOwn.p, c->nUpOwn, (c->*vec).p, c->sendUp.p);
-        }
+        for (ps_context* c : R)
+            if (c->nLowOwn + c->nUpOwn > 0)
+                hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn, c->sendLo.p,
+                                   c->listUpOwn.p, c->nUpOwn, c->sendUp.p, (c->*vec).p);
         transport(0);
-        for (ps_context* c : R) {
-            if (c->nLowHalo) hipLaunchKernelGGL(k_unpack_assign, dim3(gridFor(c->nLowHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->recvLo.p, (c->*vec).p);
-            if (c->nUpHalo) hipLaunchKernelGGL(k_unpack_assign, dim3(gridFor(c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listUpHalo.p, c->nUpHalo, c->recvUp.p, (c->*vec).p);
-        }
+        for (ps_context* c : R)
+            if (c->nLowHalo + c->nUpHalo > 0)
+                hipLaunchKernelGGL(k_unpack2<false>, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo,
+                                   c->recvLo.p, c->listUpHalo.p, c->nUpHalo, c->recvUp.p, (c->*vec).p);
     }
     void exchangeAddY(DevBuf<double> ps_context::*vec) {
-        for (ps_context* c : R) {
-            launch1(c, k_pack, c->listLowHalo.p, c->nLowHalo, (c->*vec).p, c->sendLo.p);
-            launch1(c, k_pack, c->listUpHalo.p, c->nUpHalo, (c->*vec).p, c->sendUp.p);
-        }
+        for (ps_context* c : R)
+            if (c->nLowHalo + c->nUpHalo > 0)
+                hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->sendLo.p,
+                                   c->listUpHalo.p, c->nUpHalo, c->sendUp.p, (c->*vec).p);
         transport(1);
-        for (ps_context* c : R) {   // fixed order: contribution from below, then from above
-            if (c->nLowOwn) hipLaunchKernelGGL(k_unpack_add, dim3(gridFor(c->nLowOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn, c->recvLo.p, (c->*vec).p);
-            if (c->nUpOwn) hipLaunchKernelGGL(k_unpack_add, dim3(gridFor(c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listUpOwn.p, c->nUpOwn, c->recvUp.p, (c->*vec).p);
-        }
+        for (ps_context* c : R)   // contributions from below and from above land on disjoint DOFs
+            if (c->nLowOwn + c->nUpOwn > 0)
+                hipLaunchKernelGGL(k_unpack2<true>, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn,
+                                   c->recvLo.p, c->listUpOwn.p, c->nUpOwn, c->recvUp.p, (c->*vec).p);
     }
     void allreduce(int count) {
         if (useRccl) {
