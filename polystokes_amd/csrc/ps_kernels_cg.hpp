@@ -1,0 +1,336 @@
+// PCG vector / scalar kernels, BiCGStab helpers, Jacobi diagonal, velocity recovery and write-back.
+// Part of the single translation unit ps_solve.hip (included there, inside its anonymous namespace where noted).
+#pragma once
+
+// ---- CG vector kernels ---------------------------------------------------------------------------
+__global__ void k_scale_rows(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+// r = b; x = 0; z = pre(r); p = z; partial rsold = r.z
+__global__ void __launch_bounds__(BS) k_cg_init(const double* __restrict__ b, const double* __restrict__ dinv, double* __restrict__ x,
+                                                double* __restrict__ r, double* __restrict__ p, int64_t n, double* __restrict__ partial) {
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double rv = b[i];
+        const double z = dinv ? dinv[i] * rv : rv;
+        x[i] = 0.; r[i] = rv; p[i] = z;
+        acc += rv * z;
+    }
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__device__ inline double sumLocal(const double* __restrict__ partial, int count) {   // this thread's share (fixed stride order)
+    double acc = 0.;
+    for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
+    return acc;
+}
+__device__ inline double sumPartials(const double* __restrict__ partial, int count) {
+    double acc = 0.;
+    for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
+    return blockReduceSum(acc);
+}
+__global__ void __launch_bounds__(BS) k_cg_scal0(CGScalars* sc, const double* __restrict__ partial, int count, double tol, int maxit) {
+    const double s = sumPartials(partial, count);
+    if (threadIdx.x == 0) {
+        sc->rsold = s; sc->rsold2[0] = s; sc->rsold2[1] = 0.; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
+        sc->done = (s == 0.) ? 1 : 0;      // deviation: b == 0 -> return at once (reference divides 0/0, pcg.h:314)
+        if (s == 0.) sc->iter = 0;
+        sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
+        sc->pend = 0; sc->pendIter = 0;
+    }
+}
+// stage A of the p.Ap reduction: RED_BLOCKS blocks each sum a contiguous slice of the SpMV block partials
+constexpr int RED_BLOCKS = 256;
+__global__ void __launch_bounds__(BS) k_reduce_partials(const CGScalars* __restrict__ sc, const double* __restrict__ partial, int count,
+                                                        double* __restrict__ out) {
+    if (sc->done) return;
+    const int per = (count + RED_BLOCKS - 1) / RED_BLOCKS;
+    const int lo = blockIdx.x * per, hi = min(lo + per, count);
+    double acc = 0.;
+    for (int i = lo + threadIdx.x; i < hi; i += BS) acc += partial[i];
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(BS) k_cg_scal1(CGScalars* sc, const double* __restrict__ partial, int count) {
+    if (sc->done) return;
+    const double s = sumPartials(partial, count);
+    if (threadIdx.x == 0) { sc->pAp = s; sc->alpha = sc->rsold / s; }   // pcg.h:314
+}
+// x += alpha p ; r -= alpha Ap ; partials of r.r, x.x, r.z   (pcg.h:315-319,331).  16-byte (double2) accesses.
+__global__ void __launch_bounds__(BS) k_cg_update_xr(const CGScalars* __restrict__ sc, const double* __restrict__ p, const double* __restrict__ Ap,
+                                                     const double* __restrict__ dinv, double* __restrict__ x, double* __restrict__ r, int64_t n,
+                                                     double* __restrict__ partial) {
+    if (sc->done) return;
+    const double alpha = sc->alpha;
+    double arr = 0., axx = 0., arz = 0.;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)Ap | (uintptr_t)x | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* p2 = (const double2*)p; const double2* A2 = (const double2*)Ap; const double2* d2 = (const double2*)dinv;
+    double2* x2 = (double2*)x; double2* r2 = (double2*)r;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        const double2 pv = p2[i], av = A2[i];
+        double2 xv = x2[i], rv = r2[i];
+        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
+        rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
+        x2[i] = xv; r2[i] = rv;
+        arr += rv.x * rv.x; arr += rv.y * rv.y;
+        axx += xv.x * xv.x; axx += xv.y * xv.y;
+        if (dinv) { const double2 dv = d2[i]; arz += rv.x * (dv.x * rv.x); arz += rv.y * (dv.y * rv.y); }
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double xv = x[i] + alpha * p[i];
+        const double rv = r[i] - alpha * Ap[i];
+        x[i] = xv; r[i] = rv;
+        arr += rv * rv; axx += xv * xv;
+        if (dinv) arz += rv * (dinv[i] * rv);
+    }
+    const double s0 = blockReduceSum(arr), s1 = blockReduceSum(axx), s2 = dinv ? blockReduceSum(arz) : 0.;
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s0;
+        partial[gridDim.x + blockIdx.x] = s1;
+        partial[2 * gridDim.x + blockIdx.x] = s2;
+    }
+}
+__global__ void __launch_bounds__(BS) k_cg_scal2(CGScalars* sc, const double* __restrict__ partial, int count, int jacobi, int iterIndex) {
+    if (sc->done) return;
+    const double rr = sumPartials(partial, count);
+    const double xx = sumPartials(partial + count, count);
+    const double rz = jacobi ? sumPartials(partial + 2 * count, count) : rr;
+    if (threadIdx.x == 0) {
+        sc->rr = rr; sc->xx = xx; sc->rz = rz;
+        double rre = rr;                              // pcg.h:319-325
+        if (rr / xx < rre) rre = rr / xx;
+        sc->rre = rre;
+        if (rre < sc->tol2) { sc->done = 1; sc->iter = iterIndex; }
+        else { sc->beta = rz / sc->rsold; sc->rsold = rz; }   // pcg.h:331-335
+    }
+}
+__global__ void __launch_bounds__(BS) k_cg_update_p(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                    double* __restrict__ p, int64_t n) {
+    if (sc->done) return;
+    const double beta = sc->beta;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* r2 = (const double2*)r; const double2* d2 = (const double2*)dinv;
+    double2* p2 = (double2*)p;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        double2 z = r2[i];
+        if (dinv) { const double2 dv = d2[i]; z.x = dv.x * z.x; z.y = dv.y * z.y; }
+        double2 pv = p2[i];
+        pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
+        p2[i] = pv;
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double z = dinv ? dinv[i] * r[i] : r[i];
+        p[i] = z + beta * p[i];
+    }
+}
+
+// ---- PCG step: x update deferred into the p update, scalar reductions folded into the vector kernels ---------------
+// pcg.h:311-335 updates x and r together, tests min(rr, rr/xx) < tol^2, then forms beta and the new p: 11 vector passes
+// and (here) two one-block scalar kernels.  This step is 10 passes and 2 launches:
+//   k_cg_update_r :  [stop test of the previous iteration]  alpha = rsold / p.Ap ;  r -= alpha Ap ;  partials r.r, r.z
+//   k_cg_update_xp:  beta = r.z / rsold ;  x += alpha p ;  p = z + beta p (p read once for both) ;  partials x.x
+// Every block sums the (<= 4096 + 1024) partials of the preceding kernel itself — same order in every block, so all
+// blocks hold bit-identical scalars — and block 0 records them for the host and the next kernel; rsold is double-buffered
+// by iteration parity so no block reads a scalar another block of the same launch writes.
+// The stop test of iteration k — same rr, xx of the updated x, same iteration index as the reference — is evaluated at
+// the start of iteration k+1 (or by k_cg_check before the host polls); when it fires every later kernel is a no-op and
+// x already holds the iterate the reference returns.  Cost: one unused p update and one unused operator apply.
+// With `red` (distributed solve) the sums come all-reduced from the ranks: red = {p.Ap, x.x} resp. {r.r, r.z}.
+__device__ inline bool stopTest(CGScalars* sc, double xx, int iterIndex, bool writer) {
+    const double rr = sc->rr;
+    double rre = rr;                                   // pcg.h:319-325
+    if (rr / xx < rre) rre = rr / xx;
+    const bool fire = rre < sc->tol2;
+    if (writer) { sc->xx = xx; sc->rre = rre; if (fire) { sc->done = 1; sc->iter = iterIndex; } }
+    return fire;
+}
+__global__ void __launch_bounds__(BS) k_cg_check(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ xxPartial, int vb, int lastIter) {
+    if (sc->done) return;
+    const double xx = red ? red[0] : blockSumAll(sumLocal(xxPartial, vb));
+    stopTest(sc, xx, lastIter, threadIdx.x == 0);
+}
+// [stop test of iteration it-1] ; alpha ; r -= alpha Ap ; partials of r.r and r.z
+__global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ pApPartial, int pApCount,
+                                                    const double* __restrict__ xxPartial, int xxCount, int it, const double* __restrict__ Ap,
+                                                    const double* __restrict__ dinv, double* __restrict__ r, int64_t n, double* __restrict__ partial) {
+    if (sc->done) return;
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    double pAp, xx = 0.;
+    if (red) { pAp = red[0]; xx = red[1]; }
+    else {
+        if (it > 0) xx = blockSumAll(sumLocal(xxPartial, xxCount));
+        pAp = blockSumAll(sumLocal(pApPartial, pApCount));
+    }
+    if (it > 0 && stopTest(sc, xx, it - 1, writer)) return;           // same verdict in every block
+    const double alpha = sc->rsold2[it & 1] / pAp;                      // pcg.h:314
+    if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
+    double arr = 0., arz = 0.;
+    const bool vec = ((((uintptr_t)Ap | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* A2 = (const double2*)Ap; const double2* d2 = (const double2*)dinv;
+    double2* r2 = (double2*)r;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        const double2 av = A2[i];
+        double2 rv = r2[i];
+        rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
+        r2[i] = rv;
+        arr += rv.x * rv.x; arr += rv.y * rv.y;
+        if (dinv) { const double2 dv = d2[i]; arz += rv.x * (dv.x * rv.x); arz += rv.y * (dv.y * rv.y); }
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double rv = r[i] - alpha * Ap[i];
+        r[i] = rv;
+        arr += rv * rv;
+        if (dinv) arz += rv * (dinv[i] * rv);
+    }
+    const double s0 = blockReduceSum(arr), s2 = dinv ? blockReduceSum(arz) : 0.;
+    if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s2; }
+}
+// beta ; x += alpha p ; p = z + beta p (z = D^-1 r) ; partials of x.x
+__global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
+                                                     int it, const double* __restrict__ r, const double* __restrict__ dinv, double* __restrict__ x,
+                                                     double* __restrict__ p, int64_t n, double* __restrict__ partial) {
+    if (sc->done) return;
+    double rr, rz;
+    if (red) { rr = red[0]; rz = jacobi ? red[1] : red[0]; }
+    else {
+        rr = blockSumAll(sumLocal(rPartial, rCount));
+        rz = jacobi ? blockSumAll(sumLocal(rPartial + rCount, rCount)) : rr;
+    }
+    const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
+    double axx = 0.;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x | (uintptr_t)dinv) & 15) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* r2 = (const double2*)r; const double2* d2 = (const double2*)dinv;
+    double2* p2 = (double2*)p; double2* x2 = (double2*)x;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        double2 z = r2[i];
+        if (dinv) { const double2 dv = d2[i]; z.x = dv.x * z.x; z.y = dv.y * z.y; }
+        double2 pv = p2[i], xv = x2[i];
+        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
+        pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
+        x2[i] = xv; p2[i] = pv;
+        axx += xv.x * xv.x; axx += xv.y * xv.y;
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double z = dinv ? dinv[i] * r[i] : r[i];
+        const double pv = p[i];
+        const double xv = x[i] + alpha * pv;
+        x[i] = xv; p[i] = z + beta * pv;
+        axx += xv * xv;
+    }
+    const double s1 = blockReduceSum(axx);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s1;
+}
+
+// ---- generic vector helpers (BiCGStab fallback, rare) -----------------------------------------------
+__global__ void __launch_bounds__(BS) k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ partial) {
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) acc += a[i] * b[i];
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(BS) k_sum1(const double* __restrict__ partial, int count, double* __restrict__ out) {
+    const double s = sumPartials(partial, count);
+    if (threadIdx.x == 0) *out = s;
+}
+// out = ca*a + cb*b + cc*c  (null pointers skipped)
+__global__ void k_lin(double* __restrict__ out, double ca, const double* __restrict__ a, double cb, const double* __restrict__ b, double cc,
+                      const double* __restrict__ c, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = ca * a[i];
+        if (b) v += cb * b[i];
+        if (c) v += cc * c[i];
+        out[i] = v;
+    }
+}
+
+// ---- Jacobi diagonal (extension; reference stub Preconditioners.cpp:37-41) ------------------------
+// diag_j = -dt sum_f McInv_f S_fj^2 - sum_r q^T BInv_r q - 1/2 uInv_j,  q = sum_{f in r} C_f S_fj
+__global__ void k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int n, int nP,
+                              int nA, double dt, const double* __restrict__ McInv, const double* __restrict__ uInv,
+                              const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, const double* __restrict__ COM,
+                              double dx, const double* __restrict__ Binv, double* __restrict__ dinv, int invert) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double diag = 0.;
+    double q[PS_RD];
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;
+        const double* B = Binv + (int64_t)cur * PS_RD * PS_RD;
+        double s = 0.;
+        for (int m = 0; m < PS_RD; ++m) {
+            double t = 0.;
+            for (int k = 0; k < PS_RD; ++k) t += B[m * PS_RD + k] * q[k];
+            s += q[m] * t;
+        }
+        diag -= s;
+    };
+    for (int p = ptr[j]; p < ptr[j + 1]; ++p) {
+        const int f = col[p];
+        const double v = val[p];
+        if (f < nA) { diag += -dt * McInv[f] * v * v; continue; }
+        const int rr = f - nA;
+        const int r = rrowRegion[rr];
+        if (r != cur) {
+            flush();
+            cur = r;
+            for (int m = 0; m < PS_RD; ++m) q[m] = 0.;
+        }
+        double o[3];
+        int axis;
+        rowOffset(rrowFace[rr], COM, r, dx, o, &axis);
+        double c[PS_RD];
+        basisRow(o[0], o[1], o[2], axis, c);
+        for (int m = 0; m < PS_RD; ++m) q[m] += c[m] * v;
+    }
+    flush();
+    diag += -0.5 * uInv[j];
+    dinv[j] = invert ? (diag != 0. ? 1. / diag : 1.) : diag;   // raw diagonal when halo contributions are still to be added
+}
+
+// ---- recovery and write-back ---------------------------------------------------------------------
+// u_a = dt McInv (invDt rhs_a - (G p + Dt tau))      Solver.cpp:507
+__global__ void k_recover_active(const double* __restrict__ s, const double* __restrict__ McInv, const double* __restrict__ rhsA, double dt,
+                                 double invDt, int64_t nA, double* __restrict__ ua) {
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < nA; f += (int64_t)gridDim.x * blockDim.x)
+        ua[f] = dt * McInv[f] * (invDt * rhsA[f] - s[f]);
+}
+// applySolutionToVelocity, Solver.cpp:937-1028
+__global__ void k_writeback(Grid g, int axis, const int32_t* __restrict__ lab, const int32_t* __restrict__ act, const int32_t* __restrict__ reg,
+                            const int32_t* __restrict__ faceRow, const double* __restrict__ ua, const double* __restrict__ creg, const double* __restrict__ COM,
+                            double dx, const float* __restrict__ cvel, const float* __restrict__ velIn, float* __restrict__ velOut, int apply) {
+    const int3 d = g.dims(1 + axis);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)d.x * d.y * d.z) return;
+    const int l = lab[c];
+    float out = velIn[c];
+    if (apply && !(l == PS_UNSOLVED || l == PS_UNASSIGNED)) {
+        const int r = reg[c];
+        const int a = act[c];
+        double v = 0.;
+        if (r >= 0) {
+            const int3 q = unlin3(d, c);
+            double p[3] = {(double)q.x, (double)q.y, (double)q.z};
+            p[axis] -= 0.5;
+            const double ox = p[0] * dx - COM[(int64_t)r * 3 + 0], oy = p[1] * dx - COM[(int64_t)r * 3 + 1], oz = p[2] * dx - COM[(int64_t)r * 3 + 2];
+            double C[PS_RD];
+            basisRow(ox, oy, oz, axis, C);
+            double s = 0.;
+            for (int n = 0; n < PS_RD; ++n) s += creg[(int64_t)r * PS_RD + n] * C[n];
+            v = s;
+        } else if (a >= 0) {
+            const int row = faceRow[c];
+            v = row >= 0 ? ua[row] : (double)velIn[c];   // active face of another rank (halo): left untouched
+        } else if (l == PS_SOLID) {
+            v = (double)cvel[c];
+        }
+        out = (float)v;
+    }
+    velOut[c] = out;
+}
+

@@ -1,0 +1,389 @@
+// SpMV kernels: block helpers, the CSR-stream one-shot kernels and the persistent kernels on the compressed stream.
+// Part of the single translation unit ps_solve.hip (included there, inside its anonymous namespace where noted).
+#pragma once
+
+
+constexpr int BS = 256;
+constexpr int VGRID = 1024;   // capped grid for streaming vector kernels (grid-stride); 4 blocks per CU measured best
+
+__device__ inline double waveReduceSum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// deterministic block sum (wave shuffles, then the 4 wave sums in order); result valid in thread 0
+__device__ inline double blockReduceSum(double v) {
+    __shared__ double ws[BS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = waveReduceSum(v);
+    if (lane == 0) ws[w] = v;
+    __syncthreads();
+    double s = 0.;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < BS / 64; ++i) s += ws[i];
+    }
+    __syncthreads();
+    return s;
+}
+
+// same sum (same order), valid in every thread
+__device__ inline double blockSumAll(double v) {
+    __shared__ double wsA[BS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = waveReduceSum(v);
+    if (lane == 0) wsA[w] = v;
+    __syncthreads();
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) s += wsA[i];
+    __syncthreads();
+    return s;
+}
+
+// Streaming phase of the CSR-stream SpMV: the block's contiguous nnz range [p0,p1) (<= BS*MAXNNZ entries)
+// is read with a fixed-trip, fully unrolled loop so that all MAXNNZ (col,val) loads of a thread — and then
+// all MAXNNZ gathers — are in flight together (memory-level parallelism instead of a dependent chain).
+template <int SLOTS, bool PACKED>
+__device__ inline void streamProducts(const int32_t* __restrict__ col, const double* __restrict__ val, const int8_t* __restrict__ code,
+                                      double scale, const double* __restrict__ x, int p0, int p1, double* __restrict__ prod) {
+    int c[SLOTS];
+    double v[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int p = p0 + threadIdx.x + u * BS;
+        const bool ok = p < p1;
+        c[u] = ok ? __builtin_nontemporal_load(col + p) : -1;
+        if (PACKED) v[u] = ok ? (double)__builtin_nontemporal_load(code + p) * scale : 0.;   // exact: see DevCSR::code
+        else v[u] = ok ? __builtin_nontemporal_load(val + p) : 0.;
+    }
+    double xv[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.;
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u)
+        if (c[u] >= 0) prod[threadIdx.x + u * BS] = v[u] * xv[u];
+}
+
+// ---- CSR-stream SpMV ------------------------------------------------------------------------------
+// One-shot variant: a block owns BS consecutive rows.  (More rows per thread was tried: 2 and 4 rows per thread are
+// 5-100 % slower — registers and LDS cost more occupancy than the extra loads in flight buy.)
+// MODE 0: out[row] = (row < nA ? dt*McInv[row] : 1) * (S x)[row]     (operator, forward half)
+// MODE 1: out[row] = (S x)[row]                                       (velocity recovery)
+template <int MODE, int MAXNNZ, bool PACKED>
+__global__ void __launch_bounds__(BS) k_spmv_S(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                               const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
+                                               double dt, const double* __restrict__ McInv, double* __restrict__ out,
+                                               const int* __restrict__ done) {
+    if (done && *done) return;
+    constexpr int RPT = 1;
+    __shared__ double prod[BS * MAXNNZ * RPT];
+    const int r0 = blockIdx.x * (BS * RPT);
+    const int r1 = min(r0 + BS * RPT, rows);
+    const int p0 = ptr[r0], p1 = ptr[r1];
+    // per-row loads that do not depend on the stream: issue them first
+    int pa[RPT], pb[RPT];
+    double sc[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int row = r0 + threadIdx.x + q * BS;
+        const bool ok = row < rows;
+        pa[q] = ok ? ptr[row] : 0;
+        pb[q] = ok ? ptr[row + 1] : 0;
+        sc[q] = (MODE == 0 && ok && row < nA) ? dt * McInv[row] : 1.;
+    }
+    streamProducts<MAXNNZ * RPT, PACKED>(col, val, code, scale, x, p0, p1, prod);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int row = r0 + threadIdx.x + q * BS;
+        if (row < rows) {
+            double s = 0.;
+            for (int e = pa[q] - p0; e < pb[q] - p0; ++e) s += prod[e];
+            out[row] = s * sc[q];
+        }
+    }
+}
+// MODE 0: out[j] = -(St t)[j] - 0.5*uInv[j]*xin[j];  partial[block] = sum xin[j]*out[j]
+// MODE 1: out[j] = -(St t)[j] + add[j]                                   (right-hand side b)
+template <int MODE, int MAXNNZ, bool PACKED>
+__global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
+                                                const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
+                                                double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done) {
+    if (done && *done) return;
+    constexpr int RPT = 1;
+    __shared__ double prod[BS * MAXNNZ * RPT];
+    const int r0 = blockIdx.x * (BS * RPT);
+    const int r1 = min(r0 + BS * RPT, rows);
+    const int p0 = ptr[r0], p1 = ptr[r1];
+    int pa[RPT], pb[RPT];
+    double e0[RPT], e1[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int row = r0 + threadIdx.x + q * BS;
+        const bool ok = row < rows;
+        pa[q] = ok ? ptr[row] : 0;
+        pb[q] = ok ? ptr[row + 1] : 0;
+        if (MODE == 0) { e0[q] = ok ? xin[row] : 0.; e1[q] = ok ? uInv[row] : 0.; }   // uInv is full length (0 on pressure rows)
+        else { e0[q] = ok ? add[row] : 0.; e1[q] = 0.; }
+    }
+    streamProducts<MAXNNZ * RPT, PACKED>(col, val, code, scale, t, p0, p1, prod);
+    __syncthreads();
+    double d = 0.;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int row = r0 + threadIdx.x + q * BS;
+        if (row < rows) {
+            double s = 0.;
+            for (int e = pa[q] - p0; e < pb[q] - p0; ++e) s += prod[e];
+            double y;
+            if (MODE == 0) {
+                y = -s;
+                y -= 0.5 * e1[q] * e0[q];
+                d += e0[q] * y;
+            } else {
+                y = -s + e0[q];
+            }
+            out[row] = y;
+        }
+    }
+    if (MODE == 0) {
+        const double bs = blockReduceSum(d);
+        if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+    }
+}
+
+
+// ---- persistent, software-pipelined kernels on the compressed stream -----------------------------------
+// PMC (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 85 %) shows the one-shot kernels above are latency bound: every block walks
+// three dependent memory round trips (row-pointer bounds -> (col,val) stream -> gather) at the occupancy cap of
+// 8 waves/SIMD.  Here a block loops over row chunks (grid = #CUs x 16) and, while the gathers / LDS reduction of
+// chunk i are in flight, the stream of chunk i+1 is already loading into a second register set and the bounds of
+// chunk i+2 are being fetched.  They read the compressed form of the matrix built by ps_context::buildCol16:
+//   * per 256-row chunk a 4-entry-aligned run of (16-bit windowed column, int8 value code): 3 B per entry, fetched as
+//     one 8-byte + one 4-byte load per lane for 4 consecutive entries,
+//   * 16 window bases and an (begin, end) pair per chunk, one row-length byte per row (prefix-summed in the block)
+// and reproduce the fp64 CSR product bit for bit (same values, same summation order within a row).
+//
+// chunk walk of a persistent block.  Plain: chunk = block + it * grid.  Grouped (G = xcdAware > 0): workgroups b, b+8, ...
+// run on XCD b & 7 (verified with s_getreg HW_REG_XCC_ID), so runs of G consecutive chunks are dealt to the XCDs round
+// robin — rows that gather the same lines of x (k-plane neighbours, a few chunks apart) then share ONE L2, while
+// the chip as a whole still sweeps one compact window of memory.
+struct ChunkWalk {
+    int sh, x, l, per;   // G = 1 << sh chunks per run; sh < 0: plain walk
+    __device__ ChunkWalk(int g) : sh(g > 0 ? 31 - __builtin_clz((unsigned)g) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3) {}
+    __device__ int at(int it) const {
+        if (sh < 0) return blockIdx.x + it * gridDim.x;
+        const int q = l + it * per;
+        return ((((q >> sh) << 3) + x) << sh) + (q & ((1 << sh) - 1));
+    }
+};
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// Every access of the loop body goes through a buffer descriptor (buffer_load/store ... offen): 32-bit byte offsets
+// instead of 64-bit address arithmetic, and hardware bounds checking (a load past `bytes` returns 0, a store is dropped),
+// so the body has NO branches: lanes past the end of a chunk / of the rows load and multiply harmless values into LDS
+// slots no row reads.  (Arrays must be < 4 GiB: checked by ps_context::buildCol16.)
+__device__ inline __amdgpu_buffer_rsrc_t bufRsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ inline double bufLoadF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, 0));
+}
+__device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, 0);
+}
+// one lane's share of a chunk's stream: NV groups of 4 consecutive entries (non-temporal: read once)
+template <int NV> struct Stream4 { u32x2 c[NV]; unsigned v[NV]; };
+template <int NV>
+__device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, int p0, int p1, Stream4<NV>& s) {
+#pragma unroll
+    for (int w = 0; w < NV; ++w) {
+        const unsigned first = (unsigned)p0 + 4u * (threadIdx.x + w * BS);     // p0 is a multiple of 4
+        // groups past the end of the chunk: offset 0xffffffff is out of range -> zeros without a memory access
+        // (zeros decode to window 0 / offset 0 / value 0, like the padding inside the last group)
+        const bool in = (int)first < p1;
+        s.c[w] = __builtin_amdgcn_raw_buffer_load_b64(rCol, in ? (int)(first * 2u) : -1, 0, 2);
+        s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, 2);
+    }
+}
+__device__ inline unsigned streamCol(u32x2 c, int j, int myBase) {   // window base (lane `window` of every 16-lane group) + 12-bit offset
+    const unsigned w = j < 2 ? c.x : c.y;
+    const unsigned raw = (w >> (16 * (j & 1))) & 0xffffu;
+    return (unsigned)__shfl(myBase, (int)(raw >> 12), 16) + (raw & 4095u);
+}
+__device__ inline double streamVal(unsigned v, int j, double scale) {   // exact: see DevCSR::code
+    return (double)((int)(v << (24 - 8 * j)) >> 24) * scale;
+}
+// inclusive prefix sum over the 64 lanes with DPP moves (VALU only, no LDS round trips): Hillis-Steele inside each row of
+// 16 lanes (row_shr 1,2,4,8; lanes without a source keep 0), then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
+__device__ inline int waveInclusiveScan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// sum of the row's products prod[ea .. ea+len) in entry order; all (<= ML) LDS reads are issued up front
+template <int ML, int PL>
+__device__ inline double rowSum(const double* prod, int ea, int len) {
+    double v[ML];
+#pragma unroll
+    for (int k = 0; k < ML; ++k) { const int e = min(ea + k, 4 * PL - 1); v[k] = prod[(e & 3) * PL + (e >> 2)]; }
+    double s = 0.;
+#pragma unroll
+    for (int k = 0; k < ML; ++k) s = k < len ? s + v[k] : s;
+    return s;
+}
+// Both kernels: gathers of the current chunk, prefetch of the next, products to LDS (entry e of the chunk at
+// prod[(e & 3) * PL + (e >> 2)]: conflict-free writes), row offsets from the length bytes (wave scans + 4 wave totals).
+template <int MODE, int NV>
+__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
+                                                    const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
+                                                    const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
+                                                    int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
+                                                    const int* __restrict__ done, int chunkBegin, int nChunks, int xcdAware) {
+    if (done && *done) return;
+    constexpr int PL = BS * NV;
+    __shared__ double prod[4 * PL];
+    __shared__ __align__(16) int wtot[BS / 64];
+    static_assert(BS == 256, "four waves per block");
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
+                                 rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
+                                 rOut = bufRsrc(out, (size_t)rows * 8);
+    const ChunkWalk W(xcdAware);
+    int it = 0;
+    int chunk = chunkBegin + W.at(0);   // this launch covers chunks [chunkBegin, nChunks)
+    if (chunk >= nChunks) return;
+    int2 pr = chunkRange[chunk];
+    Stream4<NV> cur, nxt;
+    loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
+    int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
+    int nchunk = chunkBegin + W.at(1);
+    int2 npr = {0, 0};
+    if (nchunk < nChunks) npr = chunkRange[nchunk];
+    while (true) {
+        const unsigned row = (unsigned)chunk * BS + threadIdx.x;
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
+        double sc = 1.;
+        if (MODE == 0) { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
+        double xv[4 * NV];
+#pragma unroll
+        for (int w = 0; w < NV; ++w) {
+            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufLoadF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
+        }
+        const bool hasNext = nchunk < nChunks;
+        if (hasNext) {
+            loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
+            nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
+        }
+        const int nn = chunkBegin + W.at(it + 2);
+        int2 nnpr = {0, 0};
+        if (nn < nChunks) nnpr = chunkRange[nn];
+#pragma unroll
+        for (int w = 0; w < NV; ++w) {
+            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = streamVal(cur.v[w], j, scale) * xv[4 * w + j];
+        }
+        const int incl = waveInclusiveScan(len);
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        {
+            const int4 wt = *reinterpret_cast<const int4*>(wtot);
+            const int wv = threadIdx.x >> 6;
+            const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
+            const double s = rowSum<8, PL>(prod, ea, len);
+            bufStoreF64(rOut, row * 8u, s * sc);                             // dropped past the last row
+        }
+        __syncthreads();
+        if (!hasNext) break;
+        chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
+        nchunk = nn; npr = nnpr;
+        ++it;
+    }
+}
+template <int MODE, int NV>
+__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
+                                                     const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
+                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
+                                                     const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
+                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done,
+                                                     int chunkBegin, int nChunks, int xcdAware) {
+    if (done && *done) return;
+    constexpr int PL = BS * NV;
+    __shared__ double prod[4 * PL];
+    __shared__ __align__(16) int wtot[BS / 64];
+    static_assert(BS == 256, "four waves per block");
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
+                                 rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
+                                 rE0 = bufRsrc(MODE == 0 ? xin : add, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
+                                 rOut = bufRsrc(out, (size_t)rows * 8);
+    const ChunkWalk W(xcdAware);
+    int it = 0;
+    int chunk = chunkBegin + W.at(0);
+    if (chunk >= nChunks) { if (MODE == 0 && threadIdx.x == 0) partial[blockIdx.x] = 0.; return; }
+    double dacc = 0.;
+    int2 pr = chunkRange[chunk];
+    Stream4<NV> cur, nxt;
+    loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
+    int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
+    int nchunk = chunkBegin + W.at(1);
+    int2 npr = {0, 0};
+    if (nchunk < nChunks) npr = chunkRange[nchunk];
+    while (true) {
+        const unsigned row = (unsigned)chunk * BS + threadIdx.x;
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
+        const double e0 = bufLoadF64(rE0, row * 8u);                                       // x (MODE 0) / the vector added (MODE 1)
+        double e1 = 0.;
+        if (MODE == 0) e1 = bufLoadF64(rE1, row * 8u);
+        double xv[4 * NV];
+#pragma unroll
+        for (int w = 0; w < NV; ++w) {
+            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufLoadF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
+        }
+        const bool hasNext = nchunk < nChunks;
+        if (hasNext) {
+            loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
+            nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
+        }
+        const int nn = chunkBegin + W.at(it + 2);
+        int2 nnpr = {0, 0};
+        if (nn < nChunks) nnpr = chunkRange[nn];
+#pragma unroll
+        for (int w = 0; w < NV; ++w) {
+            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = streamVal(cur.v[w], j, scale) * xv[4 * w + j];
+        }
+        const int incl = waveInclusiveScan(len);
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        {
+            const int4 wt = *reinterpret_cast<const int4*>(wtot);
+            const int wv = threadIdx.x >> 6;
+            const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
+            const double s = rowSum<6, PL>(prod, ea, len);
+            double y;
+            if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
+            else y = -s + e0;
+            bufStoreF64(rOut, row * 8u, y);
+        }
+        __syncthreads();    // protects the LDS reuse
+        if (!hasNext) break;
+        chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
+        nchunk = nn; npr = nnpr;
+        ++it;
+    }
+    if (MODE == 0) {
+        const double bs = blockReduceSum(dacc);
+        if (threadIdx.x == 0) partial[blockIdx.x] = bs;   // gridDim.x partials (Launch::stBlocks)
+    }
+}
+

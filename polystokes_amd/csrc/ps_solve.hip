@@ -5,15 +5,19 @@
 // evaluated as  s = S x;  t_f = dt McInv_f s_f (active rows),  t_f = C_f . (BInv_r sum_{g in r} C_g s_g)
 // (reduced rows, J evaluated on the fly);  y = -S^T t - 1/2 uInv x_tau.
 //
-// Kernels (all HBM-bound; fp64):
-//   k_spmv_S / k_spmv_St : CSR-stream SpMV — a 256-thread block owns 256 consecutive rows; it streams the
-//       block's contiguous (val,col) range coalesced, multiplies by the gathered x, parks the products in
-//       LDS and lets each thread reduce its own short row (<= 8 nnz) from LDS.  Epilogues fuse the
-//       diagonal scalings, the -1/2 uInv x term and the p.Ap dot partial.
-//   k_tile_gather / k_tile_solve / k_tile_expand : per-tile J^T, 26x26 BInv, J.
-//   k_cg_update_xr / k_cg_update_p : fused axpy + wavefront-shuffle dot partials.
-//   k_cg_scal1 / k_cg_scal2 : one-block reductions of the partials + the stop rule of
-//       pcg_external_matrix_A (lib/include/pcg.h:268-340); scalars stay on the device.
+// One translation unit, split over included parts:
+//   ps_kernels_spmv.hpp  : k_spmv_S / k_spmv_St (CSR-stream one-shot kernels, fp64 or int8-coded values) and
+//                          k_spmv_S_pipe / k_spmv_St_pipe (persistent, software-pipelined, compressed 3 B/nnz stream) —
+//                          a 256-thread block owns 256 consecutive rows, products go through LDS, each thread sums its
+//                          own short row; epilogues fuse the diagonal scalings, the -1/2 uInv x term and the p.Ap partials.
+//   ps_kernels_tiles.hpp : k_tile_gather / k_tile_solve / k_tile_expand — per-tile J^T, 26x26 BInv, J.
+//   ps_kernels_cg.hpp    : k_cg_update_r / k_cg_update_xp (the PCG step of pcg_external_matrix_A, lib/include/pcg.h:268-340,
+//                          with the scalar reductions and the stop rule folded in; scalars stay on the device), the legacy
+//                          k_cg_update_xr / _p / scal* used by the exported-system path, BiCGStab helpers, Jacobi diagonal,
+//                          velocity recovery / write-back.
+//   this file            : the launch dispatch (Launch), ps_context::applyOperator / assemble / solve / recover.
+//   ps_dist.hpp          : the z-slab distributed solve (RCCL or in-process ranks) and its C ABI.
+//   ps_import.hpp        : MatrixMarket import + general CSR PCG (ps_solve_exported_system).
 #include <chrono>
 #include <cmath>
 #include <ctime>
@@ -23,860 +27,9 @@
 using namespace ps;
 
 namespace {
-
-constexpr int BS = 256;
-constexpr int VGRID = 1024;   // capped grid for streaming vector kernels (grid-stride); 4 blocks per CU measured best
-
-__device__ inline double waveReduceSum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-// deterministic block sum (wave shuffles, then the 4 wave sums in order); result valid in thread 0
-__device__ inline double blockReduceSum(double v) {
-    __shared__ double ws[BS / 64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    v = waveReduceSum(v);
-    if (lane == 0) ws[w] = v;
-    __syncthreads();
-    double s = 0.;
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < BS / 64; ++i) s += ws[i];
-    }
-    __syncthreads();
-    return s;
-}
-
-// same sum (same order), valid in every thread
-__device__ inline double blockSumAll(double v) {
-    __shared__ double wsA[BS / 64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    v = waveReduceSum(v);
-    if (lane == 0) wsA[w] = v;
-    __syncthreads();
-    double s = 0.;
-#pragma unroll
-    for (int i = 0; i < BS / 64; ++i) s += wsA[i];
-    __syncthreads();
-    return s;
-}
-
-// Streaming phase of the CSR-stream SpMV: the block's contiguous nnz range [p0,p1) (<= BS*MAXNNZ entries)
-// is read with a fixed-trip, fully unrolled loop so that all MAXNNZ (col,val) loads of a thread — and then
-// all MAXNNZ gathers — are in flight together (memory-level parallelism instead of a dependent chain).
-template <int SLOTS, bool PACKED>
-__device__ inline void streamProducts(const int32_t* __restrict__ col, const double* __restrict__ val, const int8_t* __restrict__ code,
-                                      double scale, const double* __restrict__ x, int p0, int p1, double* __restrict__ prod) {
-    int c[SLOTS];
-    double v[SLOTS];
-#pragma unroll
-    for (int u = 0; u < SLOTS; ++u) {
-        const int p = p0 + threadIdx.x + u * BS;
-        const bool ok = p < p1;
-        c[u] = ok ? __builtin_nontemporal_load(col + p) : -1;
-        if (PACKED) v[u] = ok ? (double)__builtin_nontemporal_load(code + p) * scale : 0.;   // exact: see DevCSR::code
-        else v[u] = ok ? __builtin_nontemporal_load(val + p) : 0.;
-    }
-    double xv[SLOTS];
-#pragma unroll
-    for (int u = 0; u < SLOTS; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.;
-#pragma unroll
-    for (int u = 0; u < SLOTS; ++u)
-        if (c[u] >= 0) prod[threadIdx.x + u * BS] = v[u] * xv[u];
-}
-
-// ---- CSR-stream SpMV ------------------------------------------------------------------------------
-// One-shot variant: a block owns BS consecutive rows.  (More rows per thread was tried: 2 and 4 rows per thread are
-// 5-100 % slower — registers and LDS cost more occupancy than the extra loads in flight buy.)
-// MODE 0: out[row] = (row < nA ? dt*McInv[row] : 1) * (S x)[row]     (operator, forward half)
-// MODE 1: out[row] = (S x)[row]                                       (velocity recovery)
-template <int MODE, int MAXNNZ, bool PACKED>
-__global__ void __launch_bounds__(BS) k_spmv_S(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                               const int8_t* __restrict__ code, double scale, const double* __restrict__ x, int rows, int nA,
-                                               double dt, const double* __restrict__ McInv, double* __restrict__ out,
-                                               const int* __restrict__ done) {
-    if (done && *done) return;
-    constexpr int RPT = 1;
-    __shared__ double prod[BS * MAXNNZ * RPT];
-    const int r0 = blockIdx.x * (BS * RPT);
-    const int r1 = min(r0 + BS * RPT, rows);
-    const int p0 = ptr[r0], p1 = ptr[r1];
-    // per-row loads that do not depend on the stream: issue them first
-    int pa[RPT], pb[RPT];
-    double sc[RPT];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int row = r0 + threadIdx.x + q * BS;
-        const bool ok = row < rows;
-        pa[q] = ok ? ptr[row] : 0;
-        pb[q] = ok ? ptr[row + 1] : 0;
-        sc[q] = (MODE == 0 && ok && row < nA) ? dt * McInv[row] : 1.;
-    }
-    streamProducts<MAXNNZ * RPT, PACKED>(col, val, code, scale, x, p0, p1, prod);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int row = r0 + threadIdx.x + q * BS;
-        if (row < rows) {
-            double s = 0.;
-            for (int e = pa[q] - p0; e < pb[q] - p0; ++e) s += prod[e];
-            out[row] = s * sc[q];
-        }
-    }
-}
-// MODE 0: out[j] = -(St t)[j] - 0.5*uInv[j]*xin[j];  partial[block] = sum xin[j]*out[j]
-// MODE 1: out[j] = -(St t)[j] + add[j]                                   (right-hand side b)
-template <int MODE, int MAXNNZ, bool PACKED>
-__global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                const int8_t* __restrict__ code, double scale, const double* __restrict__ t, int rows, int nP,
-                                                const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
-                                                double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done) {
-    if (done && *done) return;
-    constexpr int RPT = 1;
-    __shared__ double prod[BS * MAXNNZ * RPT];
-    const int r0 = blockIdx.x * (BS * RPT);
-    const int r1 = min(r0 + BS * RPT, rows);
-    const int p0 = ptr[r0], p1 = ptr[r1];
-    int pa[RPT], pb[RPT];
-    double e0[RPT], e1[RPT];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int row = r0 + threadIdx.x + q * BS;
-        const bool ok = row < rows;
-        pa[q] = ok ? ptr[row] : 0;
-        pb[q] = ok ? ptr[row + 1] : 0;
-        if (MODE == 0) { e0[q] = ok ? xin[row] : 0.; e1[q] = ok ? uInv[row] : 0.; }   // uInv is full length (0 on pressure rows)
-        else { e0[q] = ok ? add[row] : 0.; e1[q] = 0.; }
-    }
-    streamProducts<MAXNNZ * RPT, PACKED>(col, val, code, scale, t, p0, p1, prod);
-    __syncthreads();
-    double d = 0.;
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int row = r0 + threadIdx.x + q * BS;
-        if (row < rows) {
-            double s = 0.;
-            for (int e = pa[q] - p0; e < pb[q] - p0; ++e) s += prod[e];
-            double y;
-            if (MODE == 0) {
-                y = -s;
-                y -= 0.5 * e1[q] * e0[q];
-                d += e0[q] * y;
-            } else {
-                y = -s + e0[q];
-            }
-            out[row] = y;
-        }
-    }
-    if (MODE == 0) {
-        const double bs = blockReduceSum(d);
-        if (threadIdx.x == 0) partial[blockIdx.x] = bs;
-    }
-}
-
-
-// ---- persistent, software-pipelined kernels on the compressed stream -----------------------------------
-// PMC (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 85 %) shows the one-shot kernels above are latency bound: every block walks
-// three dependent memory round trips (row-pointer bounds -> (col,val) stream -> gather) at the occupancy cap of
-// 8 waves/SIMD.  Here a block loops over row chunks (grid = #CUs x 16) and, while the gathers / LDS reduction of
-// chunk i are in flight, the stream of chunk i+1 is already loading into a second register set and the bounds of
-// chunk i+2 are being fetched.  They read the compressed form of the matrix built by ps_context::buildCol16:
-//   * per 256-row chunk a 4-entry-aligned run of (16-bit windowed column, int8 value code): 3 B per entry, fetched as
-//     one 8-byte + one 4-byte load per lane for 4 consecutive entries,
-//   * 16 window bases and an (begin, end) pair per chunk, one row-length byte per row (prefix-summed in the block)
-// and reproduce the fp64 CSR product bit for bit (same values, same summation order within a row).
-//
-// chunk walk of a persistent block.  Plain: chunk = block + it * grid.  Grouped (G = xcdAware > 0): workgroups b, b+8, ...
-// run on XCD b & 7 (verified with s_getreg HW_REG_XCC_ID), so runs of G consecutive chunks are dealt to the XCDs round
-// robin — rows that gather the same lines of x (k-plane neighbours, a few chunks apart) then share ONE L2, while
-// the chip as a whole still sweeps one compact window of memory.
-struct ChunkWalk {
-    int sh, x, l, per;   // G = 1 << sh chunks per run; sh < 0: plain walk
-    __device__ ChunkWalk(int g) : sh(g > 0 ? 31 - __builtin_clz((unsigned)g) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3) {}
-    __device__ int at(int it) const {
-        if (sh < 0) return blockIdx.x + it * gridDim.x;
-        const int q = l + it * per;
-        return ((((q >> sh) << 3) + x) << sh) + (q & ((1 << sh) - 1));
-    }
-};
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// Every access of the loop body goes through a buffer descriptor (buffer_load/store ... offen): 32-bit byte offsets
-// instead of 64-bit address arithmetic, and hardware bounds checking (a load past `bytes` returns 0, a store is dropped),
-// so the body has NO branches: lanes past the end of a chunk / of the rows load and multiply harmless values into LDS
-// slots no row reads.  (Arrays must be < 4 GiB: checked by ps_context::buildCol16.)
-__device__ inline __amdgpu_buffer_rsrc_t bufRsrc(const void* p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
-}
-__device__ inline double bufLoadF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, 0));
-}
-__device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, 0);
-}
-// one lane's share of a chunk's stream: NV groups of 4 consecutive entries (non-temporal: read once)
-template <int NV> struct Stream4 { u32x2 c[NV]; unsigned v[NV]; };
-template <int NV>
-__device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, int p0, int p1, Stream4<NV>& s) {
-#pragma unroll
-    for (int w = 0; w < NV; ++w) {
-        const unsigned first = (unsigned)p0 + 4u * (threadIdx.x + w * BS);     // p0 is a multiple of 4
-        // groups past the end of the chunk: offset 0xffffffff is out of range -> zeros without a memory access
-        // (zeros decode to window 0 / offset 0 / value 0, like the padding inside the last group)
-        const bool in = (int)first < p1;
-        s.c[w] = __builtin_amdgcn_raw_buffer_load_b64(rCol, in ? (int)(first * 2u) : -1, 0, 2);
-        s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, 2);
-    }
-}
-__device__ inline unsigned streamCol(u32x2 c, int j, int myBase) {   // window base (lane `window` of every 16-lane group) + 12-bit offset
-    const unsigned w = j < 2 ? c.x : c.y;
-    const unsigned raw = (w >> (16 * (j & 1))) & 0xffffu;
-    return (unsigned)__shfl(myBase, (int)(raw >> 12), 16) + (raw & 4095u);
-}
-__device__ inline double streamVal(unsigned v, int j, double scale) {   // exact: see DevCSR::code
-    return (double)((int)(v << (24 - 8 * j)) >> 24) * scale;
-}
-// inclusive prefix sum over the 64 lanes with DPP moves (VALU only, no LDS round trips): Hillis-Steele inside each row of
-// 16 lanes (row_shr 1,2,4,8; lanes without a source keep 0), then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
-__device__ inline int waveInclusiveScan(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-// sum of the row's products prod[ea .. ea+len) in entry order; all (<= ML) LDS reads are issued up front
-template <int ML, int PL>
-__device__ inline double rowSum(const double* prod, int ea, int len) {
-    double v[ML];
-#pragma unroll
-    for (int k = 0; k < ML; ++k) { const int e = min(ea + k, 4 * PL - 1); v[k] = prod[(e & 3) * PL + (e >> 2)]; }
-    double s = 0.;
-#pragma unroll
-    for (int k = 0; k < ML; ++k) s = k < len ? s + v[k] : s;
-    return s;
-}
-// Both kernels: gathers of the current chunk, prefetch of the next, products to LDS (entry e of the chunk at
-// prod[(e & 3) * PL + (e >> 2)]: conflict-free writes), row offsets from the length bytes (wave scans + 4 wave totals).
-template <int MODE, int NV>
-__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
-                                                    const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
-                                                    const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
-                                                    int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
-                                                    const int* __restrict__ done, int chunkBegin, int nChunks, int xcdAware) {
-    if (done && *done) return;
-    constexpr int PL = BS * NV;
-    __shared__ double prod[4 * PL];
-    __shared__ __align__(16) int wtot[BS / 64];
-    static_assert(BS == 256, "four waves per block");
-    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
-                                 rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
-                                 rOut = bufRsrc(out, (size_t)rows * 8);
-    const ChunkWalk W(xcdAware);
-    int it = 0;
-    int chunk = chunkBegin + W.at(0);   // this launch covers chunks [chunkBegin, nChunks)
-    if (chunk >= nChunks) return;
-    int2 pr = chunkRange[chunk];
-    Stream4<NV> cur, nxt;
-    loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
-    int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
-    int nchunk = chunkBegin + W.at(1);
-    int2 npr = {0, 0};
-    if (nchunk < nChunks) npr = chunkRange[nchunk];
-    while (true) {
-        const unsigned row = (unsigned)chunk * BS + threadIdx.x;
-        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
-        double sc = 1.;
-        if (MODE == 0) { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
-        double xv[4 * NV];
-#pragma unroll
-        for (int w = 0; w < NV; ++w) {
-            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufLoadF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
-        }
-        const bool hasNext = nchunk < nChunks;
-        if (hasNext) {
-            loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
-            nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
-        }
-        const int nn = chunkBegin + W.at(it + 2);
-        int2 nnpr = {0, 0};
-        if (nn < nChunks) nnpr = chunkRange[nn];
-#pragma unroll
-        for (int w = 0; w < NV; ++w) {
-            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = streamVal(cur.v[w], j, scale) * xv[4 * w + j];
-        }
-        const int incl = waveInclusiveScan(len);
-        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        {
-            const int4 wt = *reinterpret_cast<const int4*>(wtot);
-            const int wv = threadIdx.x >> 6;
-            const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
-            const double s = rowSum<8, PL>(prod, ea, len);
-            bufStoreF64(rOut, row * 8u, s * sc);                             // dropped past the last row
-        }
-        __syncthreads();
-        if (!hasNext) break;
-        chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
-        nchunk = nn; npr = nnpr;
-        ++it;
-    }
-}
-template <int MODE, int NV>
-__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
-                                                     const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
-                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
-                                                     const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
-                                                     double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done,
-                                                     int chunkBegin, int nChunks, int xcdAware) {
-    if (done && *done) return;
-    constexpr int PL = BS * NV;
-    __shared__ double prod[4 * PL];
-    __shared__ __align__(16) int wtot[BS / 64];
-    static_assert(BS == 256, "four waves per block");
-    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
-                                 rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
-                                 rE0 = bufRsrc(MODE == 0 ? xin : add, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
-                                 rOut = bufRsrc(out, (size_t)rows * 8);
-    const ChunkWalk W(xcdAware);
-    int it = 0;
-    int chunk = chunkBegin + W.at(0);
-    if (chunk >= nChunks) { if (MODE == 0 && threadIdx.x == 0) partial[blockIdx.x] = 0.; return; }
-    double dacc = 0.;
-    int2 pr = chunkRange[chunk];
-    Stream4<NV> cur, nxt;
-    loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
-    int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
-    int nchunk = chunkBegin + W.at(1);
-    int2 npr = {0, 0};
-    if (nchunk < nChunks) npr = chunkRange[nchunk];
-    while (true) {
-        const unsigned row = (unsigned)chunk * BS + threadIdx.x;
-        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
-        const double e0 = bufLoadF64(rE0, row * 8u);                                       // x (MODE 0) / the vector added (MODE 1)
-        double e1 = 0.;
-        if (MODE == 0) e1 = bufLoadF64(rE1, row * 8u);
-        double xv[4 * NV];
-#pragma unroll
-        for (int w = 0; w < NV; ++w) {
-            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufLoadF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
-        }
-        const bool hasNext = nchunk < nChunks;
-        if (hasNext) {
-            loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
-            nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
-        }
-        const int nn = chunkBegin + W.at(it + 2);
-        int2 nnpr = {0, 0};
-        if (nn < nChunks) nnpr = chunkRange[nn];
-#pragma unroll
-        for (int w = 0; w < NV; ++w) {
-            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = streamVal(cur.v[w], j, scale) * xv[4 * w + j];
-        }
-        const int incl = waveInclusiveScan(len);
-        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        {
-            const int4 wt = *reinterpret_cast<const int4*>(wtot);
-            const int wv = threadIdx.x >> 6;
-            const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
-            const double s = rowSum<6, PL>(prod, ea, len);
-            double y;
-            if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
-            else y = -s + e0;
-            bufStoreF64(rOut, row * 8u, y);
-        }
-        __syncthreads();    // protects the LDS reuse
-        if (!hasNext) break;
-        chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
-        nchunk = nn; npr = nnpr;
-        ++it;
-    }
-    if (MODE == 0) {
-        const double bs = blockReduceSum(dacc);
-        if (threadIdx.x == 0) partial[blockIdx.x] = bs;   // gridDim.x partials (Launch::stBlocks)
-    }
-}
-
-// ---- per-tile reduced apply -------------------------------------------------------------------------
-__device__ inline void rowOffset(uint32_t packed, const double* __restrict__ COM, int region, double dx, double* o, int* axis) {
-    int i, j, k, a;
-    unpackFace(packed, i, j, k, a);
-    double p[3] = {(double)i, (double)j, (double)k};
-    p[a] -= 0.5;
-    o[0] = p[0] * dx - COM[(int64_t)region * 3 + 0];
-    o[1] = p[1] * dx - COM[(int64_t)region * 3 + 1];
-    o[2] = p[2] * dx - COM[(int64_t)region * 3 + 2];
-    *axis = a;
-}
-// partial w (26) of one chunk of <= RC_ROWS reduced rows of ONE face axis:  w += C_f * s_f.  One wavefront per chunk:
-// all RC_ROWS/64 (face, s) pairs of a lane are requested up front (independent loads in flight together), then only
-// the 10 / 10 / 14 non-zero entries of that axis' basis row (buildConversionCoefficients, Solver.cpp:2112-2145) are
-// accumulated in registers and wave-shuffle reduced; no LDS, no barrier.
-template <int AXIS>
-__device__ inline void tileGatherAxis(int b0, int e, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx,
-                                      double cx, double cy, double cz, double* __restrict__ wout) {
-    constexpr int PER = RC_ROWS / 64;
-    constexpr int NW = AXIS == 2 ? 14 : 10;
-    uint32_t fq[PER];
-    double sq[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int rr = b0 + threadIdx.x + q * 64;
-        const bool ok = rr < e;
-        fq[q] = ok ? __builtin_nontemporal_load(rrowFace + rr) : 0u;
-        sq[q] = ok ? __builtin_nontemporal_load(sred + rr) : 0.;     // 0 for the lanes past the end: contributes nothing
-    }
-    double w[NW];
-#pragma unroll
-    for (int n = 0; n < NW; ++n) w[n] = 0.;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        int i, j, k, axis;
-        unpackFace(fq[q], i, j, k, axis);
-        const double s = sq[q];
-        const double ox = ((double)i - (AXIS == 0 ? 0.5 : 0.)) * dx - cx;
-        const double oy = ((double)j - (AXIS == 1 ? 0.5 : 0.)) * dx - cy;
-        const double oz = ((double)k - (AXIS == 2 ? 0.5 : 0.)) * dx - cz;
-        if (AXIS != 2) {    // x-row: entries 0,3..11 ; y-row: entries 1,12..20
-            w[0] += s; w[1] += ox * s; w[2] += oy * s; w[3] += oz * s;
-            w[4] += ox * ox * s; w[5] += ox * oy * s; w[6] += ox * oz * s; w[7] += oy * oy * s; w[8] += oy * oz * s; w[9] += oz * oz * s;
-        } else {            // z-row: entries 2,3,6,7,8,13,16,18,19,21..25
-            w[0] += s; w[1] += (-oz) * s; w[2] += (-2. * ox * oz) * s; w[3] += (-1. * oy * oz) * s; w[4] += (-0.5 * oz * oz) * s;
-            w[5] += (-oz) * s; w[6] += (-1. * ox * oz) * s; w[7] += (-2. * oy * oz) * s; w[8] += (-0.5 * oz * oz) * s;
-            w[9] += ox * s; w[10] += oy * s; w[11] += ox * ox * s; w[12] += ox * oy * s; w[13] += oy * oy * s;
-        }
-    }
-    constexpr int slotX[10] = {0, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-    constexpr int slotY[10] = {1, 12, 13, 14, 15, 16, 17, 18, 19, 20};
-    constexpr int slotZ[14] = {2, 3, 6, 7, 8, 13, 16, 18, 19, 21, 22, 23, 24, 25};
-    // lane n < 26 ends up holding entry n of the chunk's partial w (0 for the entries this axis never touches): one store
-    double mine = 0.;
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-        const double v = __shfl(waveReduceSum(w[n]), 0);
-        if ((int)threadIdx.x == (AXIS == 0 ? slotX[n] : (AXIS == 1 ? slotY[n] : slotZ[n]))) mine = v;
-    }
-    if (threadIdx.x < PS_RD) wout[threadIdx.x] = mine;
-}
-__global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ chunkRegion, const int32_t* __restrict__ chunkStart,
-                                                    const int32_t* __restrict__ chunkEnd, const int32_t* __restrict__ chunkAxis,
-                                                    const uint32_t* __restrict__ rrowFace, const double* __restrict__ COM, double dx,
-                                                    const double* __restrict__ sred, double* __restrict__ wpart, const int* __restrict__ done) {
-    if (done && *done) return;
-    const int ch = blockIdx.x;
-    const int r = chunkRegion[ch];
-    const double cx = COM[(int64_t)r * 3 + 0], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
-    const int e = chunkEnd[ch], b0 = chunkStart[ch], axis = chunkAxis[ch];
-    double* wout = wpart + (int64_t)ch * PS_RD;
-    if (axis == 0) tileGatherAxis<0>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
-    else if (axis == 1) tileGatherAxis<1>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
-    else tileGatherAxis<2>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
-}
-// MODE 0: v = BInv w ;  MODE 1: v = BInv (invDt*rhsR - w)  (velocity recovery, Solver.cpp:509)
-// MODE 2: v = invDt * BInv rhsR  (right-hand side, AssembleSystem.cpp:448-452; no gather)
-template <int MODE>
-__global__ void __launch_bounds__(64) k_tile_solve(const int32_t* __restrict__ regionChunkPtr, const double* __restrict__ wpart,
-                                                   const double* __restrict__ Binv, const double* __restrict__ rhsR, double invDt,
-                                                   double* __restrict__ vreg, const int* __restrict__ done) {
-    if (done && *done) return;
-    __shared__ double w[PS_RD];
-    const int r = blockIdx.x, lane = threadIdx.x;
-    if (lane < PS_RD) {
-        double s = 0.;
-        if (MODE != 2)
-            for (int ch = regionChunkPtr[r]; ch < regionChunkPtr[r + 1]; ++ch) s += wpart[(int64_t)ch * PS_RD + lane];
-        if (MODE == 1) s = invDt * rhsR[(int64_t)r * PS_RD + lane] - s;
-        if (MODE == 2) s = rhsR[(int64_t)r * PS_RD + lane];
-        w[lane] = s;
-    }
-    __syncthreads();
-    if (lane < PS_RD) {
-        const double* B = Binv + (int64_t)r * PS_RD * PS_RD + lane * PS_RD;
-        double s = 0.;
-#pragma unroll
-        for (int n = 0; n < PS_RD; ++n) s += B[n] * w[n];
-        if (MODE == 2) s *= invDt;
-        vreg[(int64_t)r * PS_RD + lane] = s;
-    }
-}
-// t_f = C_f . v_region(f).  One block per chunk of <= RC_ROWS rows of ONE region: the 26 coefficients are block-uniform
-// (scalar loads), each thread expands RC_ROWS/256 rows.
-__global__ void __launch_bounds__(BS) k_tile_expand(const int32_t* __restrict__ chunkRegion, const int32_t* __restrict__ chunkStart,
-                                                    const int32_t* __restrict__ chunkEnd, const uint32_t* __restrict__ rrowFace,
-                                                    const double* __restrict__ COM, double dx, const double* __restrict__ vreg,
-                                                    double* __restrict__ tred, const int* __restrict__ done) {
-    if (done && *done) return;
-    const int ch = blockIdx.x;
-    const int r = chunkRegion[ch];
-    const int b0 = chunkStart[ch], e = chunkEnd[ch];
-    const double cx = COM[(int64_t)r * 3 + 0], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
-    double v[PS_RD];
-#pragma unroll
-    for (int n = 0; n < PS_RD; ++n) v[n] = vreg[(int64_t)r * PS_RD + n];
-    constexpr int PER = RC_ROWS / BS;
-    uint32_t fq[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int rr = b0 + threadIdx.x + q * BS;
-        fq[q] = rr < e ? rrowFace[rr] : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int rr = b0 + threadIdx.x + q * BS;
-        if (rr < e) {
-            int i, j, k, axis;
-            unpackFace(fq[q], i, j, k, axis);
-            const double ox = ((double)i - (axis == 0 ? 0.5 : 0.)) * dx - cx;
-            const double oy = ((double)j - (axis == 1 ? 0.5 : 0.)) * dx - cy;
-            const double oz = ((double)k - (axis == 2 ? 0.5 : 0.)) * dx - cz;
-            tred[rr] = basisDot(ox, oy, oz, axis, v);
-        }
-    }
-}
-
-// ---- CG vector kernels ---------------------------------------------------------------------------
-__global__ void k_scale_rows(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
-}
-// r = b; x = 0; z = pre(r); p = z; partial rsold = r.z
-__global__ void __launch_bounds__(BS) k_cg_init(const double* __restrict__ b, const double* __restrict__ dinv, double* __restrict__ x,
-                                                double* __restrict__ r, double* __restrict__ p, int64_t n, double* __restrict__ partial) {
-    double acc = 0.;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
-        const double rv = b[i];
-        const double z = dinv ? dinv[i] * rv : rv;
-        x[i] = 0.; r[i] = rv; p[i] = z;
-        acc += rv * z;
-    }
-    const double s = blockReduceSum(acc);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-__device__ inline double sumLocal(const double* __restrict__ partial, int count) {   // this thread's share (fixed stride order)
-    double acc = 0.;
-    for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
-    return acc;
-}
-__device__ inline double sumPartials(const double* __restrict__ partial, int count) {
-    double acc = 0.;
-    for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
-    return blockReduceSum(acc);
-}
-__global__ void __launch_bounds__(BS) k_cg_scal0(CGScalars* sc, const double* __restrict__ partial, int count, double tol, int maxit) {
-    const double s = sumPartials(partial, count);
-    if (threadIdx.x == 0) {
-        sc->rsold = s; sc->rsold2[0] = s; sc->rsold2[1] = 0.; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
-        sc->done = (s == 0.) ? 1 : 0;      // deviation: b == 0 -> return at once (reference divides 0/0, pcg.h:314)
-        if (s == 0.) sc->iter = 0;
-        sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
-        sc->pend = 0; sc->pendIter = 0;
-    }
-}
-// stage A of the p.Ap reduction: RED_BLOCKS blocks each sum a contiguous slice of the SpMV block partials
-constexpr int RED_BLOCKS = 256;
-__global__ void __launch_bounds__(BS) k_reduce_partials(const CGScalars* __restrict__ sc, const double* __restrict__ partial, int count,
-                                                        double* __restrict__ out) {
-    if (sc->done) return;
-    const int per = (count + RED_BLOCKS - 1) / RED_BLOCKS;
-    const int lo = blockIdx.x * per, hi = min(lo + per, count);
-    double acc = 0.;
-    for (int i = lo + threadIdx.x; i < hi; i += BS) acc += partial[i];
-    const double s = blockReduceSum(acc);
-    if (threadIdx.x == 0) out[blockIdx.x] = s;
-}
-__global__ void __launch_bounds__(BS) k_cg_scal1(CGScalars* sc, const double* __restrict__ partial, int count) {
-    if (sc->done) return;
-    const double s = sumPartials(partial, count);
-    if (threadIdx.x == 0) { sc->pAp = s; sc->alpha = sc->rsold / s; }   // pcg.h:314
-}
-// x += alpha p ; r -= alpha Ap ; partials of r.r, x.x, r.z   (pcg.h:315-319,331).  16-byte (double2) accesses.
-__global__ void __launch_bounds__(BS) k_cg_update_xr(const CGScalars* __restrict__ sc, const double* __restrict__ p, const double* __restrict__ Ap,
-                                                     const double* __restrict__ dinv, double* __restrict__ x, double* __restrict__ r, int64_t n,
-                                                     double* __restrict__ partial) {
-    if (sc->done) return;
-    const double alpha = sc->alpha;
-    double arr = 0., axx = 0., arz = 0.;
-    const bool vec = ((((uintptr_t)p | (uintptr_t)Ap | (uintptr_t)x | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
-    const int64_t n2 = vec ? n / 2 : 0;
-    const double2* p2 = (const double2*)p; const double2* A2 = (const double2*)Ap; const double2* d2 = (const double2*)dinv;
-    double2* x2 = (double2*)x; double2* r2 = (double2*)r;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        const double2 pv = p2[i], av = A2[i];
-        double2 xv = x2[i], rv = r2[i];
-        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
-        rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
-        x2[i] = xv; r2[i] = rv;
-        arr += rv.x * rv.x; arr += rv.y * rv.y;
-        axx += xv.x * xv.x; axx += xv.y * xv.y;
-        if (dinv) { const double2 dv = d2[i]; arz += rv.x * (dv.x * rv.x); arz += rv.y * (dv.y * rv.y); }
-    }
-    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
-        const double xv = x[i] + alpha * p[i];
-        const double rv = r[i] - alpha * Ap[i];
-        x[i] = xv; r[i] = rv;
-        arr += rv * rv; axx += xv * xv;
-        if (dinv) arz += rv * (dinv[i] * rv);
-    }
-    const double s0 = blockReduceSum(arr), s1 = blockReduceSum(axx), s2 = dinv ? blockReduceSum(arz) : 0.;
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = s0;
-        partial[gridDim.x + blockIdx.x] = s1;
-        partial[2 * gridDim.x + blockIdx.x] = s2;
-    }
-}
-__global__ void __launch_bounds__(BS) k_cg_scal2(CGScalars* sc, const double* __restrict__ partial, int count, int jacobi, int iterIndex) {
-    if (sc->done) return;
-    const double rr = sumPartials(partial, count);
-    const double xx = sumPartials(partial + count, count);
-    const double rz = jacobi ? sumPartials(partial + 2 * count, count) : rr;
-    if (threadIdx.x == 0) {
-        sc->rr = rr; sc->xx = xx; sc->rz = rz;
-        double rre = rr;                              // pcg.h:319-325
-        if (rr / xx < rre) rre = rr / xx;
-        sc->rre = rre;
-        if (rre < sc->tol2) { sc->done = 1; sc->iter = iterIndex; }
-        else { sc->beta = rz / sc->rsold; sc->rsold = rz; }   // pcg.h:331-335
-    }
-}
-__global__ void __launch_bounds__(BS) k_cg_update_p(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
-                                                    double* __restrict__ p, int64_t n) {
-    if (sc->done) return;
-    const double beta = sc->beta;
-    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
-    const int64_t n2 = vec ? n / 2 : 0;
-    const double2* r2 = (const double2*)r; const double2* d2 = (const double2*)dinv;
-    double2* p2 = (double2*)p;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        double2 z = r2[i];
-        if (dinv) { const double2 dv = d2[i]; z.x = dv.x * z.x; z.y = dv.y * z.y; }
-        double2 pv = p2[i];
-        pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
-        p2[i] = pv;
-    }
-    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
-        const double z = dinv ? dinv[i] * r[i] : r[i];
-        p[i] = z + beta * p[i];
-    }
-}
-
-// ---- PCG step: x update deferred into the p update, scalar reductions folded into the vector kernels ---------------
-// pcg.h:311-335 updates x and r together, tests min(rr, rr/xx) < tol^2, then forms beta and the new p: 11 vector passes
-// and (here) two one-block scalar kernels.  This step is 10 passes and 2 launches:
-//   k_cg_update_r :  [stop test of the previous iteration]  alpha = rsold / p.Ap ;  r -= alpha Ap ;  partials r.r, r.z
-//   k_cg_update_xp:  beta = r.z / rsold ;  x += alpha p ;  p = z + beta p (p read once for both) ;  partials x.x
-// Every block sums the (<= 4096 + 1024) partials of the preceding kernel itself — same order in every block, so all
-// blocks hold bit-identical scalars — and block 0 records them for the host and the next kernel; rsold is double-buffered
-// by iteration parity so no block reads a scalar another block of the same launch writes.
-// The stop test of iteration k — same rr, xx of the updated x, same iteration index as the reference — is evaluated at
-// the start of iteration k+1 (or by k_cg_check before the host polls); when it fires every later kernel is a no-op and
-// x already holds the iterate the reference returns.  Cost: one unused p update and one unused operator apply.
-// With `red` (distributed solve) the sums come all-reduced from the ranks: red = {p.Ap, x.x} resp. {r.r, r.z}.
-__device__ inline bool stopTest(CGScalars* sc, double xx, int iterIndex, bool writer) {
-    const double rr = sc->rr;
-    double rre = rr;                                   // pcg.h:319-325
-    if (rr / xx < rre) rre = rr / xx;
-    const bool fire = rre < sc->tol2;
-    if (writer) { sc->xx = xx; sc->rre = rre; if (fire) { sc->done = 1; sc->iter = iterIndex; } }
-    return fire;
-}
-__global__ void __launch_bounds__(BS) k_cg_check(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ xxPartial, int vb, int lastIter) {
-    if (sc->done) return;
-    const double xx = red ? red[0] : blockSumAll(sumLocal(xxPartial, vb));
-    stopTest(sc, xx, lastIter, threadIdx.x == 0);
-}
-// [stop test of iteration it-1] ; alpha ; r -= alpha Ap ; partials of r.r and r.z
-__global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ pApPartial, int pApCount,
-                                                    const double* __restrict__ xxPartial, int xxCount, int it, const double* __restrict__ Ap,
-                                                    const double* __restrict__ dinv, double* __restrict__ r, int64_t n, double* __restrict__ partial) {
-    if (sc->done) return;
-    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
-    double pAp, xx = 0.;
-    if (red) { pAp = red[0]; xx = red[1]; }
-    else {
-        if (it > 0) xx = blockSumAll(sumLocal(xxPartial, xxCount));
-        pAp = blockSumAll(sumLocal(pApPartial, pApCount));
-    }
-    if (it > 0 && stopTest(sc, xx, it - 1, writer)) return;           // same verdict in every block
-    const double alpha = sc->rsold2[it & 1] / pAp;                      // pcg.h:314
-    if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
-    double arr = 0., arz = 0.;
-    const bool vec = ((((uintptr_t)Ap | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
-    const int64_t n2 = vec ? n / 2 : 0;
-    const double2* A2 = (const double2*)Ap; const double2* d2 = (const double2*)dinv;
-    double2* r2 = (double2*)r;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        const double2 av = A2[i];
-        double2 rv = r2[i];
-        rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
-        r2[i] = rv;
-        arr += rv.x * rv.x; arr += rv.y * rv.y;
-        if (dinv) { const double2 dv = d2[i]; arz += rv.x * (dv.x * rv.x); arz += rv.y * (dv.y * rv.y); }
-    }
-    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
-        const double rv = r[i] - alpha * Ap[i];
-        r[i] = rv;
-        arr += rv * rv;
-        if (dinv) arz += rv * (dinv[i] * rv);
-    }
-    const double s0 = blockReduceSum(arr), s2 = dinv ? blockReduceSum(arz) : 0.;
-    if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s2; }
-}
-// beta ; x += alpha p ; p = z + beta p (z = D^-1 r) ; partials of x.x
-__global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
-                                                     int it, const double* __restrict__ r, const double* __restrict__ dinv, double* __restrict__ x,
-                                                     double* __restrict__ p, int64_t n, double* __restrict__ partial) {
-    if (sc->done) return;
-    double rr, rz;
-    if (red) { rr = red[0]; rz = jacobi ? red[1] : red[0]; }
-    else {
-        rr = blockSumAll(sumLocal(rPartial, rCount));
-        rz = jacobi ? blockSumAll(sumLocal(rPartial + rCount, rCount)) : rr;
-    }
-    const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
-    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
-    double axx = 0.;
-    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x | (uintptr_t)dinv) & 15) == 0);
-    const int64_t n2 = vec ? n / 2 : 0;
-    const double2* r2 = (const double2*)r; const double2* d2 = (const double2*)dinv;
-    double2* p2 = (double2*)p; double2* x2 = (double2*)x;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        double2 z = r2[i];
-        if (dinv) { const double2 dv = d2[i]; z.x = dv.x * z.x; z.y = dv.y * z.y; }
-        double2 pv = p2[i], xv = x2[i];
-        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
-        pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
-        x2[i] = xv; p2[i] = pv;
-        axx += xv.x * xv.x; axx += xv.y * xv.y;
-    }
-    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
-        const double z = dinv ? dinv[i] * r[i] : r[i];
-        const double pv = p[i];
-        const double xv = x[i] + alpha * pv;
-        x[i] = xv; p[i] = z + beta * pv;
-        axx += xv * xv;
-    }
-    const double s1 = blockReduceSum(axx);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s1;
-}
-
-// ---- generic vector helpers (BiCGStab fallback, rare) -----------------------------------------------
-__global__ void __launch_bounds__(BS) k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ partial) {
-    double acc = 0.;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) acc += a[i] * b[i];
-    const double s = blockReduceSum(acc);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-__global__ void __launch_bounds__(BS) k_sum1(const double* __restrict__ partial, int count, double* __restrict__ out) {
-    const double s = sumPartials(partial, count);
-    if (threadIdx.x == 0) *out = s;
-}
-// out = ca*a + cb*b + cc*c  (null pointers skipped)
-__global__ void k_lin(double* __restrict__ out, double ca, const double* __restrict__ a, double cb, const double* __restrict__ b, double cc,
-                      const double* __restrict__ c, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double v = ca * a[i];
-        if (b) v += cb * b[i];
-        if (c) v += cc * c[i];
-        out[i] = v;
-    }
-}
-
-// ---- Jacobi diagonal (extension; reference stub Preconditioners.cpp:37-41) ------------------------
-// diag_j = -dt sum_f McInv_f S_fj^2 - sum_r q^T BInv_r q - 1/2 uInv_j,  q = sum_{f in r} C_f S_fj
-__global__ void k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int n, int nP,
-                              int nA, double dt, const double* __restrict__ McInv, const double* __restrict__ uInv,
-                              const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, const double* __restrict__ COM,
-                              double dx, const double* __restrict__ Binv, double* __restrict__ dinv, int invert) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    double diag = 0.;
-    double q[PS_RD];
-    int cur = -1;
-    auto flush = [&]() {
-        if (cur < 0) return;
-        const double* B = Binv + (int64_t)cur * PS_RD * PS_RD;
-        double s = 0.;
-        for (int m = 0; m < PS_RD; ++m) {
-            double t = 0.;
-            for (int k = 0; k < PS_RD; ++k) t += B[m * PS_RD + k] * q[k];
-            s += q[m] * t;
-        }
-        diag -= s;
-    };
-    for (int p = ptr[j]; p < ptr[j + 1]; ++p) {
-        const int f = col[p];
-        const double v = val[p];
-        if (f < nA) { diag += -dt * McInv[f] * v * v; continue; }
-        const int rr = f - nA;
-        const int r = rrowRegion[rr];
-        if (r != cur) {
-            flush();
-            cur = r;
-            for (int m = 0; m < PS_RD; ++m) q[m] = 0.;
-        }
-        double o[3];
-        int axis;
-        rowOffset(rrowFace[rr], COM, r, dx, o, &axis);
-        double c[PS_RD];
-        basisRow(o[0], o[1], o[2], axis, c);
-        for (int m = 0; m < PS_RD; ++m) q[m] += c[m] * v;
-    }
-    flush();
-    diag += -0.5 * uInv[j];
-    dinv[j] = invert ? (diag != 0. ? 1. / diag : 1.) : diag;   // raw diagonal when halo contributions are still to be added
-}
-
-// ---- recovery and write-back ---------------------------------------------------------------------
-// u_a = dt McInv (invDt rhs_a - (G p + Dt tau))      Solver.cpp:507
-__global__ void k_recover_active(const double* __restrict__ s, const double* __restrict__ McInv, const double* __restrict__ rhsA, double dt,
-                                 double invDt, int64_t nA, double* __restrict__ ua) {
-    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < nA; f += (int64_t)gridDim.x * blockDim.x)
-        ua[f] = dt * McInv[f] * (invDt * rhsA[f] - s[f]);
-}
-// applySolutionToVelocity, Solver.cpp:937-1028
-__global__ void k_writeback(Grid g, int axis, const int32_t* __restrict__ lab, const int32_t* __restrict__ act, const int32_t* __restrict__ reg,
-                            const int32_t* __restrict__ faceRow, const double* __restrict__ ua, const double* __restrict__ creg, const double* __restrict__ COM,
-                            double dx, const float* __restrict__ cvel, const float* __restrict__ velIn, float* __restrict__ velOut, int apply) {
-    const int3 d = g.dims(1 + axis);
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (int64_t)d.x * d.y * d.z) return;
-    const int l = lab[c];
-    float out = velIn[c];
-    if (apply && !(l == PS_UNSOLVED || l == PS_UNASSIGNED)) {
-        const int r = reg[c];
-        const int a = act[c];
-        double v = 0.;
-        if (r >= 0) {
-            const int3 q = unlin3(d, c);
-            double p[3] = {(double)q.x, (double)q.y, (double)q.z};
-            p[axis] -= 0.5;
-            const double ox = p[0] * dx - COM[(int64_t)r * 3 + 0], oy = p[1] * dx - COM[(int64_t)r * 3 + 1], oz = p[2] * dx - COM[(int64_t)r * 3 + 2];
-            double C[PS_RD];
-            basisRow(ox, oy, oz, axis, C);
-            double s = 0.;
-            for (int n = 0; n < PS_RD; ++n) s += creg[(int64_t)r * PS_RD + n] * C[n];
-            v = s;
-        } else if (a >= 0) {
-            const int row = faceRow[c];
-            v = row >= 0 ? ua[row] : (double)velIn[c];   // active face of another rank (halo): left untouched
-        } else if (l == PS_SOLID) {
-            v = (double)cvel[c];
-        }
-        out = (float)v;
-    }
-    velOut[c] = out;
-}
-
+#include "ps_kernels_spmv.hpp"
+#include "ps_kernels_tiles.hpp"
+#include "ps_kernels_cg.hpp"
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -1195,746 +348,5 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
     c->S.packed = keepS; c->St.packed = keepT;
 }
 
-// =====================================================================================================
-// Multi-GPU: distributed PCG over z-slabs.  Not in the reference (single process).
-// The same kernels as above run on every rank over its local rows / owned DOF range; what is added is
-//   * pack / unpack of the one-layer exchange lists,
-//   * a transport (RCCL send/recv + all-reduce on the solver stream, or device copies between ranks that
-//     live in one process), and
-//   * two-phase scalar kernels so that the all-reduce sits between "local sum" and "use".
-// =====================================================================================================
-#include <dlfcn.h>
-#include <cstring>
-#include <cstdio>
-
-struct PsNcclUid { char internal[128]; };   // layout of ncclUniqueId
-
-namespace {
-
-// both cut planes of a rank in one launch: entries [0, nA) use list A / buffer A, entries [nA, nA + nB) list B / buffer B.
-// (A DOF lies next to at most one cut — slabs are at least one 16-layer block thick — so the two lists are disjoint.)
-__global__ void k_pack2(const int32_t* __restrict__ listA, int64_t nA, double* __restrict__ bufA, const int32_t* __restrict__ listB, int64_t nB,
-                        double* __restrict__ bufB, const double* __restrict__ v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nA) bufA[i] = v[listA[i]];
-    else if (i < nA + nB) bufB[i - nA] = v[listB[i - nA]];
-}
-template <bool ADD>
-__global__ void k_unpack2(const int32_t* __restrict__ listA, int64_t nA, const double* __restrict__ bufA, const int32_t* __restrict__ listB, int64_t nB,
-                          const double* __restrict__ bufB, double* __restrict__ v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nA) { if (ADD) v[listA[i]] += bufA[i]; else v[listA[i]] = bufA[i]; }
-    else if (i < nA + nB) { if (ADD) v[listB[i - nA]] += bufB[i - nA]; else v[listB[i - nA]] = bufB[i - nA]; }
-}
-// out[q] = sum of partial[q*stride .. q*stride+count)   (q < nq), one block
-__global__ void __launch_bounds__(BS) k_sumq(const CGScalars* __restrict__ sc, const double* __restrict__ partial, int count, int stride, int nq,
-                                             double* __restrict__ out) {
-    if (sc && sc->done) return;
-    for (int q = 0; q < nq; ++q) {
-        const double s = sumPartials(partial + (int64_t)q * stride, count);
-        if (threadIdx.x == 0) out[q] = s;
-        __syncthreads();
-    }
-}
-__global__ void k_dscal0(CGScalars* sc, const double* __restrict__ red, double tol, int maxit) {
-    const double s = red[0];
-    sc->rsold = s; sc->rsold2[0] = s; sc->rsold2[1] = 0.; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
-    sc->done = (s == 0.) ? 1 : 0;
-    if (s == 0.) sc->iter = 0;
-    sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
-    sc->pend = 0; sc->pendIter = 0;
-}
-__global__ void k_invert_diag(double* __restrict__ d, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double v = d[i];
-        d[i] = v != 0. ? 1. / v : 1.;
-    }
-}
-struct SumPtrs { double* p[16]; int n; };
-__global__ void k_sum_across(SumPtrs P, int count) {
-    const int i = threadIdx.x;
-    if (i >= count) return;
-    double s = 0.;
-    for (int q = 0; q < P.n; ++q) s += P.p[q][i];
-    for (int q = 0; q < P.n; ++q) P.p[q][i] = s;
-}
-// faces this rank is responsible for in the output fields
-__global__ void k_owned_faces(Grid g, int axis, Own own, const int32_t* __restrict__ faceRow, const int32_t* __restrict__ reg,
-                              const int32_t* __restrict__ regionOwned, float* __restrict__ out) {
-    const int3 d = g.dims(1 + axis);
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (int64_t)d.x * d.y * d.z) return;
-    const int k = (int)(c / ((int64_t)d.x * d.y));
-    bool mine;
-    const int r = reg[c];
-    if (faceRow[c] >= 0) mine = true;
-    else if (r >= 0 && regionOwned) mine = regionOwned[r] != 0;
-    else mine = own.sample(1 + axis, k);
-    out[c] = mine ? 1.f : 0.f;
-}
-
-// ---- RCCL through dlopen (no link-time dependency; torch.distributed only bootstraps the unique id) ----
-struct Rccl {
-    void* h = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, /*ncclUniqueId by value*/ PsNcclUid, int) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-};
-Rccl& rccl() {
-    static Rccl R;
-    if (!R.h) {
-        R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!R.h) R.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!R.h) throw Error(std::string("cannot load librccl: ") + dlerror());
-        auto sym = [&](const char* n) { void* p = dlsym(R.h, n); if (!p) throw Error(std::string("librccl lacks ") + n); return p; };
-        R.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
-        R.CommInitRank = (int (*)(void**, int, PsNcclUid, int))sym("ncclCommInitRank");
-        R.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
-        R.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
-        R.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
-        R.GroupStart = (int (*)())sym("ncclGroupStart");
-        R.GroupEnd = (int (*)())sym("ncclGroupEnd");
-        R.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
-    }
-    return R;
-}
-constexpr int NCCL_DOUBLE = 8;   // ncclFloat64
-constexpr int NCCL_SUM = 0;
-void ncclCheck(int rc, const char* what) { if (rc != 0) throw Error(std::string("RCCL failure in ") + what + " (code " + std::to_string(rc) + ")"); }
-
-struct Dist {
-    std::vector<ps_context*> R;   // the ranks living in this process (1 with RCCL, `world` for an in-process group)
-    bool useRccl = false;
-
-    // sizes: kind 0 = x exchange (send own layers, receive halo), kind 1 = y exchange (send halo contributions, receive for own)
-    void transport(int kind) {
-        if (useRccl) {
-            ps_context* c = R[0];
-            Rccl& L = rccl();
-            const int64_t sLo = kind == 0 ? c->nLowOwn : c->nLowHalo, sUp = kind == 0 ? c->nUpOwn : c->nUpHalo;
-            const int64_t rLo = kind == 0 ? c->nLowHalo : c->nLowOwn, rUp = kind == 0 ? c->nUpHalo : c->nUpOwn;
-            ncclCheck(L.GroupStart(), "ncclGroupStart");
-            if (c->slab.hasLower) {
-                if (sLo) ncclCheck(L.Send(c->sendLo.p, (size_t)sLo, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, c->stream), "ncclSend");
-                if (rLo) ncclCheck(L.Recv(c->recvLo.p, (size_t)rLo, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, c->stream), "ncclRecv");
-            }
-            if (c->slab.hasUpper) {
-                if (sUp) ncclCheck(L.Send(c->sendUp.p, (size_t)sUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "ncclSend");
-                if (rUp) ncclCheck(L.Recv(c->recvUp.p, (size_t)rUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "ncclRecv");
-            }
-            ncclCheck(L.GroupEnd(), "ncclGroupEnd");
-            return;
-        }
-        for (size_t q = 0; q < R.size(); ++q) {   // in-process ranks share one stream: plain device copies
-            ps_context* c = R[q];
-            const int64_t sLo = kind == 0 ? c->nLowOwn : c->nLowHalo, sUp = kind == 0 ? c->nUpOwn : c->nUpHalo;
-            if (c->slab.hasLower && sLo)
-                HIP_CHECK(hipMemcpyAsync(R[q - 1]->recvUp.p, c->sendLo.p, (size_t)sLo * 8, hipMemcpyDeviceToDevice, c->stream));
-            if (c->slab.hasUpper && sUp)
-                HIP_CHECK(hipMemcpyAsync(R[q + 1]->recvLo.p, c->sendUp.p, (size_t)sUp * 8, hipMemcpyDeviceToDevice, c->stream));
-        }
-    }
-    void exchangeX(DevBuf<double> ps_context::*vec) {
-        for (ps_context* c : R)
-            if (c->nLowOwn + c->nUpOwn > 0)
-                hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn, c->sendLo.p,
-                                   c->listUpOwn.p, c->nUpOwn, c->sendUp.p, (c->*vec).p);
-        transport(0);
-        for (ps_context* c : R)
-            if (c->nLowHalo + c->nUpHalo > 0)
-                hipLaunchKernelGGL(k_unpack2<false>, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo,
-                                   c->recvLo.p, c->listUpHalo.p, c->nUpHalo, c->recvUp.p, (c->*vec).p);
-    }
-    void exchangeAddY(DevBuf<double> ps_context::*vec) {
-        for (ps_context* c : R)
-            if (c->nLowHalo + c->nUpHalo > 0)
-                hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->sendLo.p,
-                                   c->listUpHalo.p, c->nUpHalo, c->sendUp.p, (c->*vec).p);
-        transport(1);
-        for (ps_context* c : R)   // contributions from below and from above land on disjoint DOFs
-            if (c->nLowOwn + c->nUpOwn > 0)
-                hipLaunchKernelGGL(k_unpack2<true>, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn,
-                                   c->recvLo.p, c->listUpOwn.p, c->nUpOwn, c->recvUp.p, (c->*vec).p);
-    }
-    void allreduce(int count) {
-        if (useRccl) {
-            ps_context* c = R[0];
-            ncclCheck(rccl().AllReduce(c->redbuf.p, c->redbuf.p, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->rcclComm, c->stream), "ncclAllReduce");
-            return;
-        }
-        if (R.size() == 1) return;
-        SumPtrs P;
-        P.n = (int)R.size();
-        for (size_t q = 0; q < R.size(); ++q) P.p[q] = R[q]->redbuf.p;
-        hipLaunchKernelGGL(k_sum_across, dim3(1), dim3(64), 0, R[0]->stream, P, count);
-    }
-    void syncAll() { for (ps_context* c : R) HIP_CHECK(hipStreamSynchronize(c->stream)); }
-
-    // neighbours must agree on the exchange list lengths (same labels on both sides of a cut)
-    void checkLists() {
-        if (!useRccl) {
-            for (size_t q = 0; q + 1 < R.size(); ++q)
-                if (R[q]->nUpHalo != R[q + 1]->nLowOwn || R[q]->nUpOwn != R[q + 1]->nLowHalo)
-                    throw Error("slab exchange lists disagree across the cut between ranks " + std::to_string(q) + " and " + std::to_string(q + 1));
-            return;
-        }
-        ps_context* c = R[0];
-        const double mine[4] = {(double)c->nLowOwn, (double)c->nLowHalo, (double)c->nUpOwn, (double)c->nUpHalo};
-        HIP_CHECK(hipMemcpyAsync(c->sendLo.p, mine, 16, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(c->sendUp.p, mine + 2, 16, hipMemcpyHostToDevice, c->stream));
-        Rccl& L = rccl();
-        ncclCheck(L.GroupStart(), "ncclGroupStart");
-        if (c->slab.hasLower) { ncclCheck(L.Send(c->sendLo.p, 2, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, c->stream), "send"); ncclCheck(L.Recv(c->recvLo.p, 2, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, c->stream), "recv"); }
-        if (c->slab.hasUpper) { ncclCheck(L.Send(c->sendUp.p, 2, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "send"); ncclCheck(L.Recv(c->recvUp.p, 2, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "recv"); }
-        ncclCheck(L.GroupEnd(), "ncclGroupEnd");
-        double lo[2] = {0, 0}, up[2] = {0, 0};
-        if (c->slab.hasLower) HIP_CHECK(hipMemcpyAsync(lo, c->recvLo.p, 16, hipMemcpyDeviceToHost, c->stream));
-        if (c->slab.hasUpper) HIP_CHECK(hipMemcpyAsync(up, c->recvUp.p, 16, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        // the lower rank sent me its (nUpOwn, nUpHalo); the upper rank its (nLowOwn, nLowHalo)
-        if (c->slab.hasLower && ((int64_t)lo[0] != c->nLowHalo || (int64_t)lo[1] != c->nLowOwn)) throw Error("slab exchange lists disagree with the lower neighbour");
-        if (c->slab.hasUpper && ((int64_t)up[0] != c->nUpHalo || (int64_t)up[1] != c->nUpOwn)) throw Error("slab exchange lists disagree with the upper neighbour");
-    }
-
-    // everything after the per-rank local setup: finish b and the Jacobi diagonal across the cuts
-    void finishSetup() {
-        for (ps_context* c : R) c->redbuf.alloc(8);
-        checkLists();
-        exchangeAddY(&ps_context::b);
-        const bool jac = R[0]->P.preconditioner == PS_PRE_DIAGONAL;
-        if (jac) {
-            exchangeAddY(&ps_context::dinv);
-            for (ps_context* c : R) {
-                const int64_t n = c->ownHi - c->ownLo;
-                if (n > 0) hipLaunchKernelGGL(k_invert_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, n);
-            }
-        }
-    }
-
-    int solve() {
-        ps_context* c0 = R[0];
-        const int maxit = c0->P.maxSolverIterations;
-        const double tol = c0->P.tolerance;
-        const bool jac = c0->P.preconditioner == PS_PRE_DIAGONAL;
-        if (c0->P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { c0->err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
-        struct Loc { int64_t n, lo; int vb, stBlocks; const double* dv; CGScalars* sc; Launch L; };
-        std::vector<Loc> loc(R.size());
-        for (size_t q = 0; q < R.size(); ++q) {
-            ps_context* c = R[q];
-            Loc& l = loc[q];
-            l.lo = c->ownLo; l.n = c->ownHi - c->ownLo;
-            l.vb = dotBlocks(std::max<int64_t>(l.n, 1));
-            l.dv = jac ? c->dinv.p + l.lo : nullptr;
-            l.sc = c->scal.p;
-            l.L = mk(c, &l.sc->done);
-            l.stBlocks = l.L.stBlocks();
-            c->usedBiCGStab = 0;
-        }
-        // r = b, x = 0, p = z on the owned range; rsold = sum over ranks of r.z
-        for (size_t q = 0; q < R.size(); ++q) {
-            ps_context* c = R[q];
-            Loc& l = loc[q];
-            HIP_CHECK(hipMemsetAsync(c->pvec.p, 0, (size_t)std::max<int64_t>(c->nSystem, 1) * 8, c->stream));
-            HIP_CHECK(hipMemsetAsync(c->dotPartials3.p, 0, VGRID * sizeof(double), c->stream));
-            hipLaunchKernelGGL(k_cg_init, dim3(l.vb), dim3(BS), 0, c->stream, c->b.p + l.lo, l.dv, c->x.p + l.lo, c->r.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials.p);
-            hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)nullptr, c->dotPartials.p, l.vb, 0, 1, c->redbuf.p);
-        }
-        allreduce(1);
-        for (size_t q = 0; q < R.size(); ++q)
-            hipLaunchKernelGGL(k_dscal0, dim3(1), dim3(1), 0, R[q]->stream, loc[q].sc, R[q]->redbuf.p, tol, maxit);
-        CGScalars h{};
-        const int batch = 25;
-        int it = 0;
-        bool finished = false;
-        while (it < maxit && !finished) {
-            const int upto = std::min(maxit, it + batch);
-            for (; it < upto; ++it) {
-                exchangeX(&ps_context::pvec);
-                for (size_t q = 0; q < R.size(); ++q) {
-                    ps_context* c = R[q];
-                    Loc& l = loc[q];
-                    l.L.spmvS(0, c->pvec.p, c->ts.p);
-                    l.L.tiles(0, c->ts.p);
-                    l.L.spmvSt(0, c->ts.p, c->pvec.p, nullptr, c->Ap.p, c->dotPartials.p);
-                    if (l.stBlocks <= 8192) {
-                        hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials.p, l.stBlocks, 0, 1, c->redbuf.p);
-                    } else {
-                        hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, c->stream, l.sc, c->dotPartials.p, l.stBlocks, c->dotPartials2.p);
-                        hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials2.p, RED_BLOCKS, 0, 1, c->redbuf.p);
-                    }
-                    // ||x||^2 of the x updated last iteration rides along (stop test of the previous iteration, see k_cg_update_r)
-                    hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials3.p, l.vb, 0, 1, c->redbuf.p + 1);
-                }
-                exchangeAddY(&ps_context::Ap);
-                allreduce(2);
-                for (size_t q = 0; q < R.size(); ++q) {
-                    ps_context* c = R[q];
-                    Loc& l = loc[q];
-                    hipLaunchKernelGGL(k_cg_update_r, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, (const double*)nullptr, 0,
-                                       (const double*)nullptr, 0, it, c->Ap.p + l.lo, l.dv, c->r.p + l.lo, l.n, c->dotPartials.p);
-                    hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials.p, l.vb, l.vb, 2, c->redbuf.p);
-                }
-                allreduce(2);
-                for (size_t q = 0; q < R.size(); ++q) {
-                    ps_context* c = R[q];
-                    Loc& l = loc[q];
-                    hipLaunchKernelGGL(k_cg_update_xp, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, (const double*)nullptr, 0,
-                                       jac ? 1 : 0, it, c->r.p + l.lo, l.dv, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p);
-                }
-            }
-            for (size_t q = 0; q < R.size(); ++q)   // the stop test of the batch's last iteration
-                hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, R[q]->stream, (const CGScalars*)loc[q].sc, R[q]->dotPartials3.p, loc[q].vb, 0, 1, R[q]->redbuf.p);
-            allreduce(1);
-            for (size_t q = 0; q < R.size(); ++q)
-                hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BS), 0, R[q]->stream, loc[q].sc, (const double*)R[q]->redbuf.p, (const double*)nullptr, 0, it - 1);
-            HIP_CHECK(hipMemcpyAsync(&h, loc[0].sc, sizeof(h), hipMemcpyDeviceToHost, c0->stream));
-            syncAll();
-            if (h.done) finished = true;
-        }
-        const int iters = h.done ? h.iter : maxit;
-        for (ps_context* c : R) { c->solveIterations = iters; c->solveError = std::sqrt(h.rre); }
-        // the BiCGStab fallback (pcg.h:134-200) is not distributed; a non-converged slab solve reports NOCONVERGE
-        return iters == maxit ? PS_NOCONVERGE : PS_SUCCESS;
-    }
-
-    void recoverAndWriteBack(bool apply) {
-        if (apply) exchangeX(&ps_context::x);
-        for (ps_context* c : R) {
-            c->buildValidFaces();
-            if (apply) { c->recoverVelocityFromPressureStress(); c->applySolutionToVelocity(); }
-            else for (int a = 0; a < 3; ++a)
-                HIP_CHECK(hipMemcpyAsync(c->velOut[a].p, c->vel[a].p, (size_t)c->g.count(1 + a) * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-            for (int a = 0; a < 3; ++a) {
-                c->ownedFace[a].alloc((size_t)c->g.count(1 + a));
-                hipLaunchKernelGGL(k_owned_faces, dim3(gridFor(c->g.count(1 + a), BS)), dim3(BS), 0, c->stream, c->g, a, c->own(), c->faceRow[a].p,
-                                   c->reducedIdx[1 + a].p, (c->slabEnabled && c->regionCount > 0) ? c->regionOwned.p : (const int32_t*)nullptr,
-                                   c->ownedFace[a].p);
-            }
-        }
-        syncAll();
-    }
-};
-
-int distStep(Dist& D, ps_stats* stats) {
-    const auto w0 = std::chrono::high_resolution_clock::now();
-    for (ps_context* c : D.R) c->setup(nullptr);
-    D.finishSetup();
-    D.syncAll();
-    const auto w1 = std::chrono::high_resolution_clock::now();
-    int result = PS_INCOMPLETE;
-    ps_context* c0 = D.R[0];
-    if (c0->P.doSolve) result = D.solve();
-    D.syncAll();
-    const auto w2 = std::chrono::high_resolution_clock::now();
-    const bool apply = c0->P.doSolve && result != PS_UNSUPPORTED_SOLVER && (result == PS_SUCCESS || c0->P.keepNonConvergedResults);
-    D.recoverAndWriteBack(apply);
-    for (ps_context* c : D.R) {
-        c->lastStats.solveData[0] = c->solveError;
-        c->lastStats.solveData[1] = c->solveIterations;
-        c->lastStats.solveData[3] = std::chrono::duration<double, std::milli>(w2 - w1).count();
-        c->lastStats.solveData[5] = std::chrono::duration<double, std::milli>(w1 - w0).count();
-        c->lastStats.stage_ms[PS_STAGE_SOLVE] = c->lastStats.solveData[3];
-        c->lastStats.result = result;
-        c->isSolved = true;
-        c->registerArrays();
-    }
-    if (stats) *stats = c0->lastStats;
-    return result;
-}
-
-}  // namespace
-
-struct ps_group {
-    std::vector<ps_context*> ranks;
-    hipStream_t stream = nullptr;
-};
-
-int ps_dist_step_single(ps_context* c, ps_stats* stats) {   // one process per GPU, RCCL
-    Dist D;
-    D.R.push_back(c);
-    D.useRccl = true;
-    return distStep(D, stats);
-}
-
-extern "C" {
-
-int32_t ps_set_slab(ps_context* c, const ps_slab* slab) {
-    if (!c || !slab) return PS_FAILED;
-    try {
-        if (!c->uploaded) throw Error("ps_upload_fields first");
-        const int L = 16;
-        if (slab->zLoOwned % L || slab->zHiOwned % L) {
-            if (!(slab->zHiOwned == c->g.nz && !slab->hasUpper && slab->zLoOwned % L == 0)) throw Error("slab cuts must be multiples of 16");
-        }
-        if (c->P.doReducedRegions && c->P.doTile && (slab->zLoOwned % c->P.tileSize || (slab->hasUpper && slab->zHiOwned % c->P.tileSize)))
-            throw Error("slab cuts must be multiples of the tile size");
-        if (c->P.doReducedRegions && !c->P.doTile && slab->world > 1) throw Error("the slab decomposition needs doTile (tile-local regions)");
-        if (slab->zLoOwned < 0 || slab->zHiOwned > c->g.nz || slab->zLoOwned >= slab->zHiOwned) throw Error("bad slab range");
-        if ((slab->hasLower && slab->zLoOwned < 16) || (slab->hasUpper && c->g.nz - slab->zHiOwned < 16)) throw Error("a halo of at least 16 layers is required next to a cut");
-        if (!slab->hasLower && slab->zLoOwned != 0) throw Error("without a lower neighbour the slab must start at layer 0");
-        if (!slab->hasUpper && slab->zHiOwned != c->g.nz) throw Error("without an upper neighbour the slab must end at the top layer");
-        c->slab = *slab;
-        c->slabEnabled = slab->world > 1;
-        c->isSetup = false;
-        return PS_SUCCESS;
-    } catch (const ps::Error& e) { c->err = e.msg; return PS_FAILED; }
-}
-
-int32_t ps_comm_unique_id(void* id128) {
-    try { ncclCheck(rccl().GetUniqueId(id128), "ncclGetUniqueId"); return PS_SUCCESS; } catch (const ps::Error& e) { std::fprintf(stderr, "%s\n", e.msg.c_str()); return PS_FAILED; }
-}
-int32_t ps_comm_init_rccl(ps_context* c, const void* id128, int32_t rank, int32_t world) {
-    if (!c || !id128) return PS_FAILED;
-    try {
-        HIP_CHECK(hipSetDevice(c->device));
-        PsNcclUid id;
-        std::memcpy(&id, id128, sizeof(id));
-        void* comm = nullptr;
-        ncclCheck(rccl().CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
-        c->rcclComm = comm;
-        return PS_SUCCESS;
-    } catch (const ps::Error& e) { c->err = e.msg; return PS_FAILED; }
-}
-
-// exercises the RCCL entry points used by the distributed solve (all-reduce, grouped send/recv to self) on this
-// rank's communicator; returns PS_SUCCESS when the values come back right.
-int32_t ps_comm_selftest(ps_context* c) {
-    if (!c) return PS_FAILED;
-    try {
-        if (!c->rcclComm) throw Error("no communicator");
-        HIP_CHECK(hipSetDevice(c->device));
-        c->redbuf.alloc(8); c->sendLo.alloc(8); c->recvLo.alloc(8);
-        const double v[4] = {1.5, -2.0, 3.25, 4.0};
-        HIP_CHECK(hipMemcpyAsync(c->redbuf.p, v, 32, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(c->sendLo.p, v, 32, hipMemcpyHostToDevice, c->stream));
-        Rccl& L = rccl();
-        ncclCheck(L.AllReduce(c->redbuf.p, c->redbuf.p, 3, NCCL_DOUBLE, NCCL_SUM, c->rcclComm, c->stream), "ncclAllReduce");
-        ncclCheck(L.GroupStart(), "ncclGroupStart");
-        ncclCheck(L.Send(c->sendLo.p, 4, NCCL_DOUBLE, c->slab.rank, c->rcclComm, c->stream), "ncclSend");
-        ncclCheck(L.Recv(c->recvLo.p, 4, NCCL_DOUBLE, c->slab.rank, c->rcclComm, c->stream), "ncclRecv");
-        ncclCheck(L.GroupEnd(), "ncclGroupEnd");
-        double a[4], b[4];
-        HIP_CHECK(hipMemcpyAsync(a, c->redbuf.p, 32, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipMemcpyAsync(b, c->recvLo.p, 32, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < 4; ++i) if (b[i] != v[i]) throw Error("send/recv self-test mismatch");
-        if (a[3] != v[3]) throw Error("all-reduce touched elements beyond count");
-        return PS_SUCCESS;   // a[0..2] = world * v (checked by the caller, who knows the world size)
-    } catch (const ps::Error& e) { c->err = e.msg; return PS_FAILED; }
-}
-
-ps_group* ps_group_create(int32_t device, int32_t world) {
-    if (world < 1 || world > 16) return nullptr;
-    ps_group* g = new ps_group();
-    for (int q = 0; q < world; ++q) {
-        ps_context* c = ps_context_create(device);
-        if (!c) { for (ps_context* d : g->ranks) ps_context_destroy(d); delete g; return nullptr; }
-        if (q == 0) g->stream = c->stream;
-        else { (void)hipStreamDestroy(c->stream); c->stream = g->stream; c->ownsStream = false; }   // one shared stream: launches are ordered
-        g->ranks.push_back(c);
-    }
-    return g;
-}
-void ps_group_destroy(ps_group* g) {
-    if (!g) return;
-    for (size_t q = g->ranks.size(); q-- > 0;) ps_context_destroy(g->ranks[q]);
-    delete g;
-}
-ps_context* ps_group_rank(ps_group* g, int32_t rank) { return (g && rank >= 0 && rank < (int)g->ranks.size()) ? g->ranks[(size_t)rank] : nullptr; }
-int32_t ps_group_step(ps_group* g, ps_stats* stats) {
-    if (!g || g->ranks.empty()) return PS_FAILED;
-    try {
-        Dist D;
-        D.R = g->ranks;
-        D.useRccl = false;
-        return distStep(D, stats);
-    } catch (const ps::Error& e) { g->ranks[0]->err = e.msg; return PS_FAILED; }
-}
-
-}  // extern "C"
-
-// =====================================================================================================
-// Exported-system path: solve a component set written by exportComponentMatrices()
-// (exec/HDK_PolyStokesSolver.cpp:543-566) — Mat_G, Mat_Dt, Mat_JG, Mat_JDt, Mat_McInv, Mat_uInv,
-// Mat_Inv_Mr_plus_2JDtuDJ, Vec_b — with the same PCG.  JG / JDt arrive materialised, so the operator is applied
-// literally as in ApplyPressureStressMatrix.h:102-179 with general CSR SpMVs (a sub-wave group per row).
-// =====================================================================================================
-#include <fstream>
-#include <sstream>
-
-namespace {
-
-struct HostCSR {
-    int64_t rows = 0, cols = 0;
-    std::vector<int32_t> ptr, col;
-    std::vector<double> val;
-};
-// MatrixMarket "coordinate real general" as Eigen's saveMarket writes it (MarketIO.h:310-340): 1-based triplets;
-// loadMarket semantics: setFromTriplets (duplicates summed, rows sorted by column).
-HostCSR readMarketSparse(const std::string& fn) {
-    std::ifstream in(fn.c_str());
-    if (!in) throw Error("cannot open " + fn);
-    std::string line;
-    do { if (!std::getline(in, line)) throw Error("empty file " + fn); } while (!line.empty() && line[0] == '%');
-    std::istringstream hs(line);
-    int64_t R, Cc, N;
-    if (!(hs >> R >> Cc >> N)) throw Error("bad size line in " + fn);
-    struct T { int32_t r, c; double v; };
-    std::vector<T> t((size_t)N);
-    for (int64_t k = 0; k < N; ++k) {
-        int64_t i, j; double v;
-        if (!(in >> i >> j >> v)) throw Error("truncated " + fn);
-        if (i < 1 || i > R || j < 1 || j > Cc) throw Error("index out of range in " + fn);
-        t[(size_t)k] = {(int32_t)(i - 1), (int32_t)(j - 1), v};
-    }
-    std::stable_sort(t.begin(), t.end(), [](const T& a, const T& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
-    HostCSR M;
-    M.rows = R; M.cols = Cc;
-    M.ptr.assign((size_t)R + 1, 0);
-    size_t p = 0;
-    for (int64_t r = 0; r < R; ++r) {
-        M.ptr[(size_t)r] = (int32_t)M.val.size();
-        while (p < t.size() && t[p].r == r) {
-            const int32_t c = t[p].c;
-            double s = 0;
-            while (p < t.size() && t[p].r == r && t[p].c == c) { s += t[p].v; ++p; }
-            M.col.push_back(c); M.val.push_back(s);
-        }
-    }
-    M.ptr[(size_t)R] = (int32_t)M.val.size();
-    return M;
-}
-std::vector<double> readMarketVector(const std::string& fn) {   // "array real general", column major (MarketIO.h:349-371)
-    std::ifstream in(fn.c_str());
-    if (!in) throw Error("cannot open " + fn);
-    std::string line;
-    do { if (!std::getline(in, line)) throw Error("empty file " + fn); } while (!line.empty() && line[0] == '%');
-    std::istringstream hs(line);
-    int64_t R, Cc = 1;
-    if (!(hs >> R)) throw Error("bad size line in " + fn);
-    hs >> Cc;
-    std::vector<double> v((size_t)(R * Cc));
-    for (auto& x : v) if (!(in >> x)) throw Error("truncated " + fn);
-    return v;
-}
-HostCSR hcat(const HostCSR& A, const HostCSR& B) {   // concatenate_h (lib/include/util.h:442-459)
-    if (A.rows != B.rows) throw Error("hcat: row mismatch");
-    HostCSR M;
-    M.rows = A.rows; M.cols = A.cols + B.cols;
-    M.ptr.assign((size_t)A.rows + 1, 0);
-    for (int64_t r = 0; r < A.rows; ++r) {
-        M.ptr[(size_t)r] = (int32_t)M.val.size();
-        for (int p = A.ptr[(size_t)r]; p < A.ptr[(size_t)r + 1]; ++p) { M.col.push_back(A.col[(size_t)p]); M.val.push_back(A.val[(size_t)p]); }
-        for (int p = B.ptr[(size_t)r]; p < B.ptr[(size_t)r + 1]; ++p) { M.col.push_back((int32_t)(B.col[(size_t)p] + A.cols)); M.val.push_back(B.val[(size_t)p]); }
-    }
-    M.ptr[(size_t)A.rows] = (int32_t)M.val.size();
-    return M;
-}
-HostCSR transpose(const HostCSR& A) {
-    HostCSR T;
-    T.rows = A.cols; T.cols = A.rows;
-    T.ptr.assign((size_t)A.cols + 1, 0);
-    for (int32_t c : A.col) T.ptr[(size_t)c + 1]++;
-    for (int64_t c = 0; c < A.cols; ++c) T.ptr[(size_t)c + 1] += T.ptr[(size_t)c];
-    T.col.resize(A.val.size()); T.val.resize(A.val.size());
-    std::vector<int32_t> pos(T.ptr.begin(), T.ptr.end() - 1);
-    for (int64_t r = 0; r < A.rows; ++r)
-        for (int p = A.ptr[(size_t)r]; p < A.ptr[(size_t)r + 1]; ++p) {
-            const int q = pos[(size_t)A.col[(size_t)p]]++;
-            T.col[(size_t)q] = (int32_t)r; T.val[(size_t)q] = A.val[(size_t)p];
-        }
-    return T;
-}
-std::vector<double> diagOf(const HostCSR& A) {
-    std::vector<double> d((size_t)A.rows, 0.);
-    for (int64_t r = 0; r < A.rows; ++r)
-        for (int p = A.ptr[(size_t)r]; p < A.ptr[(size_t)r + 1]; ++p) if (A.col[(size_t)p] == r) d[(size_t)r] = A.val[(size_t)p];
-    return d;
-}
-
-struct GenCSR {   // general CSR on the device
-    int64_t rows = 0, cols = 0, nnz = 0;
-    DevBuf<int32_t> ptr, col;
-    DevBuf<double> val;
-    int tpr = 1;   // threads per row (power of two <= 64)
-    void upload(const HostCSR& H, hipStream_t s) {
-        rows = H.rows; cols = H.cols; nnz = (int64_t)H.val.size();
-        ptr.alloc(H.ptr.size()); col.alloc(H.col.size()); val.alloc(H.val.size());
-        HIP_CHECK(hipMemcpyAsync(ptr.p, H.ptr.data(), H.ptr.size() * 4, hipMemcpyHostToDevice, s));
-        if (nnz) {
-            HIP_CHECK(hipMemcpyAsync(col.p, H.col.data(), H.col.size() * 4, hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipMemcpyAsync(val.p, H.val.data(), H.val.size() * 8, hipMemcpyHostToDevice, s));
-        }
-        const double avg = rows ? (double)nnz / (double)rows : 0.;
-        tpr = 1;
-        while (tpr < 64 && tpr < avg) tpr <<= 1;
-    }
-};
-// y[row] = beta*y[row] + alpha * scale[row] * (M x)[row]; TPR threads cooperate on a row (CSR-vector), shuffle reduce
-template <int TPR>
-__global__ void __launch_bounds__(BS) k_gen_spmv(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                 const double* __restrict__ x, int rows, double alpha, const double* __restrict__ scale,
-                                                 double beta, double* __restrict__ y) {
-    const int gid = blockIdx.x * BS + threadIdx.x;
-    const int row = gid / TPR, sub = gid % TPR;
-    double s = 0.;
-    if (row < rows)
-        for (int p = ptr[row] + sub; p < ptr[row + 1]; p += TPR) s += val[p] * x[col[p]];
-#pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_down(s, o, TPR);
-    if (row < rows && sub == 0) {
-        double v = alpha * s;
-        if (scale) v *= scale[row];
-        y[row] = (beta != 0. ? beta * y[row] : 0.) + v;
-    }
-}
-void genSpmv(const GenCSR& M, const double* x, double alpha, const double* scale, double beta, double* y, hipStream_t st) {
-    if (M.rows == 0) return;
-    const int64_t threads = M.rows * M.tpr;
-    const dim3 gr(gridFor(threads, BS)), bl(BS);
-#define PS_GEN(T_) hipLaunchKernelGGL(k_gen_spmv<T_>, gr, bl, 0, st, M.ptr.p, M.col.p, M.val.p, x, (int)M.rows, alpha, scale, beta, y)
-    switch (M.tpr) { case 1: PS_GEN(1); break; case 2: PS_GEN(2); break; case 4: PS_GEN(4); break; case 8: PS_GEN(8); break;
-                     case 16: PS_GEN(16); break; case 32: PS_GEN(32); break; default: PS_GEN(64); }
-#undef PS_GEN
-}
-// v[26 r + m] = sum_n BInv[r][m][n] w[26 r + n]
-__global__ void k_binv_apply(const double* __restrict__ Binv, const double* __restrict__ w, double* __restrict__ v, int64_t nR) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nR) return;
-    const int64_t r = i / PS_RD;
-    const int m = (int)(i % PS_RD);
-    const double* B = Binv + r * PS_RD * PS_RD + m * PS_RD;
-    double s = 0.;
-#pragma unroll
-    for (int n = 0; n < PS_RD; ++n) s += B[n] * w[r * PS_RD + n];
-    v[i] = s;
-}
-// y[nP + i] -= 0.5 uInv[i] x[nP + i]
-__global__ void k_uinv_term(const double* __restrict__ uInv, const double* __restrict__ x, double* __restrict__ y, int64_t nP, int64_t nT) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nT) y[nP + i] -= 0.5 * uInv[i] * x[nP + i];
-}
-// Jacobi diagonal of the imported operator (thread per column, over the transposed blocks)
-__global__ void k_gen_jacobi(const int32_t* __restrict__ ctp, const int32_t* __restrict__ ctc, const double* __restrict__ ctv,
-                             const int32_t* __restrict__ jtp, const int32_t* __restrict__ jtc, const double* __restrict__ jtv, int n, int nP,
-                             double dt, const double* __restrict__ McInv, const double* __restrict__ uInv, const double* __restrict__ Binv,
-                             double* __restrict__ dinv) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    double diag = 0.;
-    for (int p = ctp[j]; p < ctp[j + 1]; ++p) diag += -dt * McInv[ctc[p]] * ctv[p] * ctv[p];
-    double q[PS_RD];
-    int cur = -1;
-    auto flush = [&]() {
-        if (cur < 0) return;
-        const double* B = Binv + (int64_t)cur * PS_RD * PS_RD;
-        double s = 0.;
-        for (int m = 0; m < PS_RD; ++m) { double t = 0.; for (int k = 0; k < PS_RD; ++k) t += B[m * PS_RD + k] * q[k]; s += q[m] * t; }
-        diag -= s;
-    };
-    for (int p = jtp[j]; p < jtp[j + 1]; ++p) {
-        const int r = jtc[p] / PS_RD, m = jtc[p] % PS_RD;
-        if (r != cur) { flush(); cur = r; for (int k = 0; k < PS_RD; ++k) q[k] = 0.; }
-        q[m] += jtv[p];
-    }
-    flush();
-    if (j >= nP) diag += -0.5 * uInv[j - nP];
-    dinv[j] = diag != 0. ? 1. / diag : 1.;
-}
-
-}  // namespace
-
-extern "C" int32_t ps_solve_exported_system(ps_context* c, const char* prefix, const ps_params* params, double dt, double* x_out,
-                                            int64_t x_len, ps_stats* stats) {
-    if (!c || !prefix || !params) return PS_FAILED;
-    try {
-        HIP_CHECK(hipSetDevice(c->device));
-        const std::string pre(prefix);
-        HostCSR G = readMarketSparse(pre + "Mat_G.mtx"), Dt = readMarketSparse(pre + "Mat_Dt.mtx");
-        HostCSR JG = readMarketSparse(pre + "Mat_JG.mtx"), JDt = readMarketSparse(pre + "Mat_JDt.mtx");
-        HostCSR McInvM = readMarketSparse(pre + "Mat_McInv.mtx"), uInvM = readMarketSparse(pre + "Mat_uInv.mtx");
-        HostCSR BinvM = readMarketSparse(pre + "Mat_Inv_Mr_plus_2JDtuDJ.mtx");
-        std::vector<double> bh = readMarketVector(pre + "Vec_b.mtx");
-        const int64_t nA = G.rows, nP = G.cols, nT = Dt.cols, n = nP + nT, nR = JG.rows, R = nR / PS_RD;
-        if (Dt.rows != nA || JG.cols != nP || JDt.cols != nT || JDt.rows != nR || nR % PS_RD) throw Error("inconsistent block sizes");
-        if (McInvM.rows != nA || uInvM.rows != nT || BinvM.rows != nR || (int64_t)bh.size() != n) throw Error("inconsistent diagonal / rhs sizes");
-        if (x_out && x_len < n) throw Error("x_out too small");
-        // blocks (setupMatrixVectorProducts, ApplyPressureStressMatrix.h:24-68): cat_G_Dt, its transpose, cat_JG_JDt, its transpose
-        HostCSR C = hcat(G, Dt), J = hcat(JG, JDt);
-        HostCSR Ct = transpose(C), Jt = transpose(J);
-        std::vector<double> mc = diagOf(McInvM), ui = diagOf(uInvM), bi((size_t)R * PS_RD * PS_RD, 0.);
-        for (int64_t r = 0; r < nR; ++r)
-            for (int p = BinvM.ptr[(size_t)r]; p < BinvM.ptr[(size_t)r + 1]; ++p) {
-                const int64_t cc = BinvM.col[(size_t)p];
-                if (cc / PS_RD != r / PS_RD) throw Error("Mat_Inv_Mr_plus_2JDtuDJ is not block diagonal");
-                bi[(size_t)((r / PS_RD) * PS_RD * PS_RD + (r % PS_RD) * PS_RD + cc % PS_RD)] = BinvM.val[(size_t)p];
-            }
-        hipStream_t st = c->stream;
-        GenCSR dC, dCt, dJ, dJt;
-        dC.upload(C, st); dCt.upload(Ct, st); dJ.upload(J, st); dJt.upload(Jt, st);
-        DevBuf<double> dMc, dUi, dBi, db, dx, dr, dp, dAp, ds, dw, dv, ddinv, part;
-        DevBuf<CGScalars> dsc;
-        auto up = [&](DevBuf<double>& d, const std::vector<double>& h) { d.alloc(h.size()); if (!h.empty()) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, st)); };
-        up(dMc, mc); up(dUi, ui); up(dBi, bi); up(db, bh);
-        dx.alloc((size_t)n); dr.alloc((size_t)n); dp.alloc((size_t)n); dAp.alloc((size_t)n);
-        ds.alloc((size_t)nA + 1); dw.alloc((size_t)nR + 1); dv.alloc((size_t)nR + 1); dsc.alloc(1);
-        part.alloc(3 * VGRID + 16);
-        const bool jac = params->preconditioner == PS_PRE_DIAGONAL;
-        if (jac) {
-            ddinv.alloc((size_t)n);
-            hipLaunchKernelGGL(k_gen_jacobi, dim3(gridFor(n, 128)), dim3(128), 0, st, dCt.ptr.p, dCt.col.p, dCt.val.p, dJt.ptr.p, dJt.col.p, dJt.val.p,
-                               (int)n, (int)nP, dt, dMc.p, dUi.p, dBi.p, ddinv.p);
-        }
-        auto apply = [&](const double* x, double* y) {   // y = A x
-            genSpmv(dC, x, dt, dMc.p, 0., ds.p, st);                 // s = dt McInv [G Dt] x
-            genSpmv(dCt, ds.p, -1., nullptr, 0., y, st);             // y = -[G Dt]^T s
-            if (nR > 0) {
-                genSpmv(dJ, x, 1., nullptr, 0., dw.p, st);           // w = [JG JDt] x
-                hipLaunchKernelGGL(k_binv_apply, dim3(gridFor(nR, BS)), dim3(BS), 0, st, dBi.p, dw.p, dv.p, nR);
-                genSpmv(dJt, dv.p, -1., nullptr, 1., y, st);         // y -= [JG JDt]^T BInv w
-            }
-            if (nT > 0) hipLaunchKernelGGL(k_uinv_term, dim3(gridFor(nT, BS)), dim3(BS), 0, st, dUi.p, x, y, nP, nT);
-        };
-        const auto w0 = std::chrono::high_resolution_clock::now();
-        const int vb = dotBlocks(n);
-        const double* dvp = jac ? ddinv.p : nullptr;
-        const int maxit = params->maxSolverIterations;
-        hipLaunchKernelGGL(k_cg_init, dim3(vb), dim3(BS), 0, st, db.p, dvp, dx.p, dr.p, dp.p, n, part.p);
-        hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, st, dsc.p, part.p, vb, params->tolerance, maxit);
-        CGScalars h{};
-        int it = 0;
-        bool finished = false;
-        while (it < maxit && !finished) {
-            const int upto = std::min(maxit, it + 25);
-            for (; it < upto; ++it) {
-                apply(dp.p, dAp.p);
-                hipLaunchKernelGGL(k_dot, dim3(vb), dim3(BS), 0, st, dp.p, dAp.p, n, part.p);
-                hipLaunchKernelGGL(k_cg_scal1, dim3(1), dim3(BS), 0, st, dsc.p, part.p, vb);
-                hipLaunchKernelGGL(k_cg_update_xr, dim3(vb), dim3(BS), 0, st, dsc.p, dp.p, dAp.p, dvp, dx.p, dr.p, n, part.p);
-                hipLaunchKernelGGL(k_cg_scal2, dim3(1), dim3(BS), 0, st, dsc.p, part.p, vb, jac ? 1 : 0, it);
-                hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, st, dsc.p, dr.p, dvp, dp.p, n);
-            }
-            HIP_CHECK(hipMemcpyAsync(&h, dsc.p, sizeof(h), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (h.done) finished = true;
-        }
-        const int iters = h.done ? h.iter : maxit;
-        if (x_out) { HIP_CHECK(hipMemcpyAsync(x_out, dx.p, (size_t)n * 8, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st)); }
-        const auto w1 = std::chrono::high_resolution_clock::now();
-        const int result = iters == maxit ? PS_NOCONVERGE : PS_SUCCESS;   // the BiCGStab fallback is not wired into this path
-        if (stats) {
-            std::memset(stats, 0, sizeof(*stats));
-            stats->dimData[7] = (double)nA; stats->dimData[11] = (double)nR; stats->dimData[12] = (double)nP; stats->dimData[13] = (double)nT;
-            stats->dimData[21] = (double)n; stats->dimData[24] = (double)R; stats->dimData[26] = dt;
-            stats->solveData[0] = std::sqrt(h.rre); stats->solveData[1] = iters;
-            stats->solveData[3] = std::chrono::duration<double, std::milli>(w1 - w0).count();
-            stats->result = result;
-        }
-        return result;
-    } catch (const ps::Error& e) { c->err = e.msg; return PS_FAILED; }
-}
+#include "ps_dist.hpp"
+#include "ps_import.hpp"
