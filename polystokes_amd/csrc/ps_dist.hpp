@@ -303,9 +303,84 @@ struct Dist {
             syncAll();
             if (h.done) finished = true;
         }
-        const int iters = h.done ? h.iter : maxit;
-        for (ps_context* c : R) { c->solveIterations = iters; c->solveError = std::sqrt(h.rre); }
-        // the BiCGStab fallback (pcg.h:134-200) is not distributed; a non-converged slab solve reports NOCONVERGE
+        int iters = h.done ? h.iter : maxit;
+        double err = std::sqrt(h.rre);
+        if (iters == maxit) {
+            // bicgstab_external_matrix_A (pcg.h:134-200), restarted from zero (Solver.cpp:784-799): the host-driven loop
+            // of ps_context::solve() with distributed applies and dots.  Rare path.
+            for (ps_context* c : R) {
+                c->usedBiCGStab = 1;
+                const size_t nl = (size_t)std::max<int64_t>(c->nSystem, 1);
+                c->tmp1.alloc(nl); c->tmp2.alloc(nl); c->tmp3.alloc(nl); c->tmp4.alloc(nl); c->tmp5.alloc(nl);
+            }
+            using Vec = DevBuf<double> ps_context::*;
+            const Vec X = &ps_context::x, Rv = &ps_context::r, Pv = &ps_context::pvec, B = &ps_context::b, H = &ps_context::Ap,
+                      Rhat = &ps_context::tmp1, V = &ps_context::tmp2, S = &ps_context::tmp3, T = &ps_context::tmp4, E = &ps_context::tmp5;
+            auto apply = [&](Vec in, Vec out) {
+                exchangeX(in);
+                for (size_t q = 0; q < R.size(); ++q) {
+                    ps_context* c = R[q];
+                    Launch L = mk(c, nullptr);
+                    L.spmvS(0, (c->*in).p, c->ts.p);
+                    L.tiles(0, c->ts.p);
+                    L.spmvSt(0, c->ts.p, (c->*in).p, nullptr, (c->*out).p, c->dotPartials.p);
+                }
+                exchangeAddY(out);
+            };
+            auto dot = [&](Vec a, Vec bvec) {
+                for (size_t q = 0; q < R.size(); ++q) {
+                    ps_context* c = R[q];
+                    Loc& l = loc[q];
+                    hipLaunchKernelGGL(k_dot, dim3(l.vb), dim3(BS), 0, c->stream, (c->*a).p + l.lo, (c->*bvec).p + l.lo, l.n, c->dotPartials.p);
+                    hipLaunchKernelGGL(k_sum1, dim3(1), dim3(BS), 0, c->stream, c->dotPartials.p, l.vb, c->redbuf.p);
+                }
+                allreduce(1);
+                double out = 0.;
+                HIP_CHECK(hipMemcpyAsync(&out, c0->redbuf.p, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+                syncAll();
+                return out;
+            };
+            auto lin = [&](Vec out, double ca, Vec a, double cb, Vec bvec, double cc, Vec c3) {   // out = ca a + cb b + cc c on the owned range
+                for (size_t q = 0; q < R.size(); ++q) {
+                    ps_context* c = R[q];
+                    Loc& l = loc[q];
+                    if (l.n <= 0) continue;
+                    hipLaunchKernelGGL(k_lin, dim3(l.vb), dim3(BS), 0, c->stream, (c->*out).p + l.lo, ca, (const double*)(c->*a).p + l.lo, cb,
+                                       bvec ? (const double*)(c->*bvec).p + l.lo : (const double*)nullptr, cc,
+                                       c3 ? (const double*)(c->*c3).p + l.lo : (const double*)nullptr, l.n);
+                }
+            };
+            auto zero = [&](Vec v) { for (ps_context* c : R) HIP_CHECK(hipMemsetAsync((c->*v).p, 0, (size_t)std::max<int64_t>(c->nSystem, 1) * 8, c->stream)); };
+            zero(X);
+            lin(Rv, 1., B, 0., nullptr, 0., nullptr);            // r = b - A*0
+            lin(Rhat, 1., Rv, 0., nullptr, 0., nullptr);
+            zero(Pv); zero(V);
+            double rhoCurr = 1., rhoOld = 1., alpha = 1., beta = 0., omega = 1., rre = 0.;
+            iters = maxit;
+            for (int i = 0; i < maxit; ++i) {
+                rhoOld = rhoCurr;
+                rhoCurr = dot(Rhat, Rv);
+                beta = (rhoCurr / rhoOld) * (alpha / omega);
+                lin(Pv, 1., Rv, beta, Pv, -beta * omega, V);      // p = r + beta (p - omega v)
+                apply(Pv, V);
+                alpha = rhoCurr / dot(Rhat, V);
+                lin(H, 1., X, alpha, Pv, 0., nullptr);             // h = x + alpha p
+                lin(S, 1., Rv, -alpha, V, 0., nullptr);            // s = r - alpha v
+                apply(S, T);
+                omega = dot(T, S) / dot(T, T);
+                lin(X, 1., H, omega, S, 0., nullptr);              // x = h + omega s
+                const double xmag = std::sqrt(dot(X, X));
+                apply(X, E);
+                lin(E, 1., B, -1., E, 0., nullptr);                // err = b - A x
+                const double rsnew = dot(E, E);
+                rre = rsnew;
+                if (std::sqrt(rsnew) / xmag < rre) rre = std::sqrt(rsnew) / xmag;
+                if (rre < tol) { iters = i; break; }
+                lin(Rv, 1., S, -omega, T, 0., nullptr);            // r = s - omega t
+            }
+            err = rre;
+        }
+        for (ps_context* c : R) { c->solveIterations = iters; c->solveError = err; }
         return iters == maxit ? PS_NOCONVERGE : PS_SUCCESS;
     }
 
@@ -347,6 +422,7 @@ int distStep(Dist& D, ps_stats* stats) {
         c->lastStats.solveData[5] = std::chrono::duration<double, std::milli>(w1 - w0).count();
         c->lastStats.stage_ms[PS_STAGE_SOLVE] = c->lastStats.solveData[3];
         c->lastStats.result = result;
+        c->lastStats.usedBiCGStab = c->usedBiCGStab;
         c->isSolved = true;
         c->registerArrays();
     }

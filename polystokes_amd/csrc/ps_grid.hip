@@ -640,6 +640,7 @@ struct ILDesc {
     int nseg;
     Own own;
     int ownFilter;             // 1: only owned voxels are numbered (face rows); 0: every active voxel (DOFs)
+    int planeMajor;
     int64_t probe[2];          // virtual positions whose running prefix is reported in counters[10], [11]
 };
 __device__ inline bool ilFlag(const ILDesc& D, const Grid& g, const Set7<const int32_t>& lab, int grp, int64_t c) {
@@ -659,7 +660,11 @@ __device__ inline bool ilDecode(const ILDesc& D, const Grid& g, int64_t u, int* 
     const int64_t per = (int64_t)4096 * D.ngroups;
     const int b = (int)(u / per);
     const int rem = (int)(u - (int64_t)b * per);
-    const int v = rem / D.ngroups, gg = rem - v * D.ngroups;
+    int v, gg;
+    if (D.planeMajor) {   // per k-plane of the block: group 0's 256 voxels, then group 1's, ... (type-major inside a plane)
+        const int pl = rem / (256 * D.ngroups), r2 = rem - pl * 256 * D.ngroups;
+        gg = r2 >> 8; v = (pl << 8) | (r2 & 255);
+    } else { v = rem / D.ngroups; gg = rem - v * D.ngroups; }
     const int bx = b % D.LBx, by = (b / D.LBx) % D.LBy, bz = b / (D.LBx * D.LBy);
     const int i = 16 * bx + (v & 15), j = 16 * by + ((v >> 4) & 15), k = 16 * bz + (v >> 8);
     const int3 d = g.dims(D.sample[gg]);
@@ -935,6 +940,7 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     D.ngroups = ngroups;
     D.own = own();
     D.ownFilter = ownFilter ? 1 : 0;
+    { const char* e = getenv("PS_IL"); const int m = e ? atoi(e) : 0; D.planeMajor = ownedRange ? (m & 1) : ((m >> 1) & 1); }   // bit 0: DOFs, bit 1: face rows
     D.probe[0] = D.probe[1] = -1;
     for (int q = 0; q < 4; ++q) { D.sample[q] = q < ngroups ? samples[q] : 0; D.weight[q] = q < ngroups ? weights[q] : 0; }
     D.LBx = (g.nx + 1 + 15) / 16; D.LBy = (g.ny + 1 + 15) / 16; D.LBz = (g.nz + 1 + 15) / 16;

@@ -102,3 +102,26 @@ def test_bench_weak_scaling_pieces_match_the_global_cavity():
             assert np.abs(lv[a][own] - ref[own]).max() <= 20 * p.tolerance * scale
     grp.close()
     single.close()
+
+
+def test_group_bicgstab_fallback_matches_single_domain():
+    """A slab solve that exhausts maxSolverIterations falls back to the distributed BiCGStab (pcg.h:134-200) like the
+    single-domain solve: same verdict, same BiCGStab iteration index (+-1), same velocities to solver tolerance."""
+    import polystokes_amd
+    sc, p = _tall_cavity(24, 64)
+    p.maxSolverIterations = 12
+    p.tolerance = 5e-2
+    single = polystokes_amd.Solver(0)
+    rc1 = single.step(sc, p)
+    assert single.stats.usedBiCGStab == 1
+    grp = polystokes_amd.Group(2)
+    rc2 = grp.solve_scene(sc, p)
+    assert grp.stats.usedBiCGStab == 1
+    assert rc1 == rc2
+    assert abs(single.stats.solveData[1] - grp.stats.solveData[1]) <= 1
+    if rc1 == abi.SUCCESS:
+        for a in range(3):
+            scale = max(np.abs(single.vel[a]).max(), 1e-30)
+            assert np.abs(grp.vel[a] - single.vel[a]).max() <= 20 * p.tolerance * scale
+    grp.close()
+    single.close()
