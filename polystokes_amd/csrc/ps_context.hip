@@ -520,8 +520,8 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             else if (kb == "spmv_St") *algorithmic_bytes = bT;
             else if (kb == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);
             else if (kb == "tiles") *algorithmic_bytes = (double)c->nReducedRows * (8. + 4. + 8. + 4.);   // s in, t out, packed face x2
-            else if (kb == "cg_update_r") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 32. : 24.) * rowsT;
-            else if (kb == "cg_update_xp") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 48. : 40.) * rowsT;
+            else if (kb == "cg_update_r") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 28. : 24.) * rowsT;   // fp32 diagonal
+            else if (kb == "cg_update_xp") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 44. : 40.) * rowsT;
             else if (kb == "cg_update_xr") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 56. : 48.) * rowsT;
             else if (kb == "cg_update_p") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 32. : 24.) * rowsT;
             else *algorithmic_bytes = 0;

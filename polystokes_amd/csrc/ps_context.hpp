@@ -114,8 +114,12 @@ struct ps_context {
     // ---- blocks (Solver.h:337-369): S = [G Dt ; Ghat Dhat] by face row, St its transpose ----
     ps::DevCSR S, St;
     ps::DevBuf<double> McInv, rhsA, uInv, rhsPT, Mc, uDiag, oldVs;
+    ps::DevBuf<float> dinvF;   // the Jacobi diagonal as the PCG kernels read it (fp32 storage, see constructPreconditioner)
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
-    ps::DevBuf<double> dotPartials, dotPartials2, dotPartials3;
+    // dotPartials: p.Ap partials of the St kernel; dotPartials2: their first-stage sums (one-shot St kernel only);
+    // dotPartialsR: r.r / r.z partials of k_cg_update_r; dotPartials3: x.x partials of k_cg_update_xp.  Separate buffers:
+    // every block of a step kernel sums its predecessor's partials while other blocks already write this kernel's.
+    ps::DevBuf<double> dotPartials, dotPartials2, dotPartials3, dotPartialsR;
     ps::DevBuf<ps::CGScalars> scal;
 
     // ---- multi-GPU (slab decomposition; ps_dist.hip) ----

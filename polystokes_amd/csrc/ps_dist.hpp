@@ -218,7 +218,10 @@ struct Dist {
             exchangeAddY(&ps_context::dinv);
             for (ps_context* c : R) {
                 const int64_t n = c->ownHi - c->ownLo;
-                if (n > 0) hipLaunchKernelGGL(k_invert_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, n);
+                if (n > 0) {
+                    hipLaunchKernelGGL(k_invert_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, n);
+                    hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);
+                }
             }
         }
     }
@@ -229,14 +232,14 @@ struct Dist {
         const double tol = c0->P.tolerance;
         const bool jac = c0->P.preconditioner == PS_PRE_DIAGONAL;
         if (c0->P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { c0->err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
-        struct Loc { int64_t n, lo; int vb, stBlocks; const double* dv; CGScalars* sc; Launch L; };
+        struct Loc { int64_t n, lo; int vb, stBlocks; const float* dv; CGScalars* sc; Launch L; };
         std::vector<Loc> loc(R.size());
         for (size_t q = 0; q < R.size(); ++q) {
             ps_context* c = R[q];
             Loc& l = loc[q];
             l.lo = c->ownLo; l.n = c->ownHi - c->ownLo;
             l.vb = dotBlocks(std::max<int64_t>(l.n, 1));
-            l.dv = jac ? c->dinv.p + l.lo : nullptr;
+            l.dv = jac ? c->dinvF.p + l.lo : nullptr;
             l.sc = c->scal.p;
             l.L = mk(c, &l.sc->done);
             l.stBlocks = l.L.stBlocks();
@@ -248,7 +251,7 @@ struct Dist {
             Loc& l = loc[q];
             HIP_CHECK(hipMemsetAsync(c->pvec.p, 0, (size_t)std::max<int64_t>(c->nSystem, 1) * 8, c->stream));
             HIP_CHECK(hipMemsetAsync(c->dotPartials3.p, 0, VGRID * sizeof(double), c->stream));
-            hipLaunchKernelGGL(k_cg_init, dim3(l.vb), dim3(BS), 0, c->stream, c->b.p + l.lo, l.dv, c->x.p + l.lo, c->r.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials.p);
+            hipLaunchKernelGGL(k_cg_init_f, dim3(l.vb), dim3(BS), 0, c->stream, c->b.p + l.lo, l.dv, c->x.p + l.lo, c->r.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials.p);
             hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)nullptr, c->dotPartials.p, l.vb, 0, 1, c->redbuf.p);
         }
         allreduce(1);
@@ -283,8 +286,8 @@ struct Dist {
                     ps_context* c = R[q];
                     Loc& l = loc[q];
                     hipLaunchKernelGGL(k_cg_update_r, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, (const double*)nullptr, 0,
-                                       (const double*)nullptr, 0, it, c->Ap.p + l.lo, l.dv, c->r.p + l.lo, l.n, c->dotPartials.p);
-                    hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartials.p, l.vb, l.vb, 2, c->redbuf.p);
+                                       (const double*)nullptr, 0, it, c->Ap.p + l.lo, l.dv, c->r.p + l.lo, l.n, c->dotPartialsR.p);
+                    hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartialsR.p, l.vb, l.vb, 2, c->redbuf.p);
                 }
                 allreduce(2);
                 for (size_t q = 0; q < R.size(); ++q) {

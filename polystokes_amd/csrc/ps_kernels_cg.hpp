@@ -19,6 +19,22 @@ __global__ void __launch_bounds__(BS) k_cg_init(const double* __restrict__ b, co
     const double s = blockReduceSum(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
+// r = b; x = 0; z = pre(r); p = z; partial rsold = r.z — with the fp32-stored Jacobi diagonal of the main PCG path
+__global__ void __launch_bounds__(BS) k_cg_init_f(const double* __restrict__ b, const float* __restrict__ dinv, double* __restrict__ x,
+                                                  double* __restrict__ r, double* __restrict__ p, int64_t n, double* __restrict__ partial) {
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double rv = b[i];
+        const double z = dinv ? (double)dinv[i] * rv : rv;
+        x[i] = 0.; r[i] = rv; p[i] = z;
+        acc += rv * z;
+    }
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void k_to_float(const double* __restrict__ a, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)a[i];
+}
 __device__ inline double sumLocal(const double* __restrict__ partial, int count) {   // this thread's share (fixed stride order)
     double acc = 0.;
     for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
@@ -154,7 +170,7 @@ __global__ void __launch_bounds__(BS) k_cg_check(CGScalars* sc, const double* __
 // [stop test of iteration it-1] ; alpha ; r -= alpha Ap ; partials of r.r and r.z
 __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ pApPartial, int pApCount,
                                                     const double* __restrict__ xxPartial, int xxCount, int it, const double* __restrict__ Ap,
-                                                    const double* __restrict__ dinv, double* __restrict__ r, int64_t n, double* __restrict__ partial) {
+                                                    const float* __restrict__ dinv, double* __restrict__ r, int64_t n, double* __restrict__ partial) {
     if (sc->done) return;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
     double pAp, xx = 0.;
@@ -167,9 +183,9 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double*
     const double alpha = sc->rsold2[it & 1] / pAp;                      // pcg.h:314
     if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
     double arr = 0., arz = 0.;
-    const bool vec = ((((uintptr_t)Ap | (uintptr_t)r | (uintptr_t)dinv) & 15) == 0);
+    const bool vec = ((((uintptr_t)Ap | (uintptr_t)r) & 15) == 0) && (((uintptr_t)dinv & 7) == 0);
     const int64_t n2 = vec ? n / 2 : 0;
-    const double2* A2 = (const double2*)Ap; const double2* d2 = (const double2*)dinv;
+    const double2* A2 = (const double2*)Ap; const float2* d2 = (const float2*)dinv;
     double2* r2 = (double2*)r;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
         const double2 av = A2[i];
@@ -177,20 +193,20 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double*
         rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
         r2[i] = rv;
         arr += rv.x * rv.x; arr += rv.y * rv.y;
-        if (dinv) { const double2 dv = d2[i]; arz += rv.x * (dv.x * rv.x); arz += rv.y * (dv.y * rv.y); }
+        if (dinv) { const float2 dv = d2[i]; arz += rv.x * ((double)dv.x * rv.x); arz += rv.y * ((double)dv.y * rv.y); }
     }
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = r[i] - alpha * Ap[i];
         r[i] = rv;
         arr += rv * rv;
-        if (dinv) arz += rv * (dinv[i] * rv);
+        if (dinv) arz += rv * ((double)dinv[i] * rv);
     }
     const double s0 = blockReduceSum(arr), s2 = dinv ? blockReduceSum(arz) : 0.;
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s2; }
 }
 // beta ; x += alpha p ; p = z + beta p (z = D^-1 r) ; partials of x.x
 __global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
-                                                     int it, const double* __restrict__ r, const double* __restrict__ dinv, double* __restrict__ x,
+                                                     int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
                                                      double* __restrict__ p, int64_t n, double* __restrict__ partial) {
     if (sc->done) return;
     double rr, rz;
@@ -202,13 +218,13 @@ __global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double
     const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
     double axx = 0.;
-    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x | (uintptr_t)dinv) & 15) == 0);
+    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x) & 15) == 0) && (((uintptr_t)dinv & 7) == 0);
     const int64_t n2 = vec ? n / 2 : 0;
-    const double2* r2 = (const double2*)r; const double2* d2 = (const double2*)dinv;
+    const double2* r2 = (const double2*)r; const float2* d2 = (const float2*)dinv;
     double2* p2 = (double2*)p; double2* x2 = (double2*)x;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
         double2 z = r2[i];
-        if (dinv) { const double2 dv = d2[i]; z.x = dv.x * z.x; z.y = dv.y * z.y; }
+        if (dinv) { const float2 dv = d2[i]; z.x = (double)dv.x * z.x; z.y = (double)dv.y * z.y; }
         double2 pv = p2[i], xv = x2[i];
         xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
         pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
@@ -216,7 +232,7 @@ __global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double
         axx += xv.x * xv.x; axx += xv.y * xv.y;
     }
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
-        const double z = dinv ? dinv[i] * r[i] : r[i];
+        const double z = dinv ? (double)dinv[i] * r[i] : r[i];
         const double pv = p[i];
         const double xv = x[i] + alpha * pv;
         x[i] = xv; p[i] = z + beta * pv;

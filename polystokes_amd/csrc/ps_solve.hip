@@ -158,6 +158,7 @@ void ps_context::assembleSystemPressureStressFactored() {
     scal.alloc(1);
     dotPartials2.alloc(RED_BLOCKS);
     dotPartials3.alloc(VGRID);
+    dotPartialsR.alloc(2 * VGRID);
     // t0 = McInv rhs_a on active rows, C (invDt BInv rhs_r) on reduced rows;  b = -S^T t0 + [rhs_p; rhs_tau]
     if (nActiveVs > 0)
         hipLaunchKernelGGL(k_scale_rows, dim3(dotBlocks(nActiveVs)), dim3(BS), 0, stream, ts.p, McInv.p, rhsA.p, nActiveVs);
@@ -175,6 +176,12 @@ void ps_context::constructPreconditioner() {
     hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 128)), dim3(128), 0, stream, St.ptr.p, St.col.p, St.val.p, (int)nSystem,
                        (int)nPressures, (int)nActiveVs, dt, McInv.p, uInv.p, rrowFace.p, rrowRegion.p, COM.p, dx, Binv.p, dinv.p,
                        slabEnabled ? 0 : 1);
+    // The PCG kernels read the diagonal in fp32 (4 instead of 8 bytes per DOF in both vector kernels).  Any positive
+    // diagonal is a valid preconditioner; the Jacobi option itself is an extension (the reference's is a stub,
+    // Preconditioners.cpp:37-41).  The fp64 array stays for export / tests; with a slab the conversion follows the
+    // cross-rank completion of the diagonal (Dist::finishSetup).
+    dinvF.alloc((size_t)nSystem);
+    if (!slabEnabled) hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(nSystem)), dim3(BS), 0, stream, dinv.p, dinvF.p, nSystem);
 }
 
 // Solver.cpp:734-812 solveSPDwithMatrixVectorPCG -> pcg_external_matrix_A (pcg.h:268-340), BiCGStab fallback (pcg.h:134-200)
@@ -186,7 +193,7 @@ int ps_context::solve() {
     interrupted = false;
     if (P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
     if (n == 0) { solveIterations = 0; solveError = 0; return PS_SUCCESS; }
-    const double* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinv.p : nullptr;
+    const float* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinvF.p : nullptr;
     const int vb = dotBlocks(n);
     CGScalars* sc = scal.p;
     const int* done = &sc->done;
@@ -194,7 +201,7 @@ int ps_context::solve() {
     const int stBlocks = L.stBlocks();
 
     HIP_CHECK(hipMemsetAsync(dotPartials3.p, 0, VGRID * sizeof(double), stream));
-    hipLaunchKernelGGL(k_cg_init, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
+    hipLaunchKernelGGL(k_cg_init_f, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
     hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, tol, maxit);
     CGScalars h{};
     const int batch = 25;
@@ -213,8 +220,8 @@ int ps_context::solve() {
                 pApPart = dotPartials2.p; pApCount = RED_BLOCKS;
             }
             hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, pApPart, pApCount, dotPartials3.p, vb, it, Ap.p, dv,
-                               r.p, n, dotPartials.p);
-            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, dotPartials.p, vb, dv ? 1 : 0, it, r.p, dv, x.p,
+                               r.p, n, dotPartialsR.p);
+            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, dotPartialsR.p, vb, dv ? 1 : 0, it, r.p, dv, x.p,
                                pvec.p, n, dotPartials3.p);
         }
         hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BS), 0, stream, sc, (const double*)nullptr, dotPartials3.p, vb, it - 1);
@@ -331,6 +338,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         const char* e = getenv("PS_VGRID");
         const int vb = e ? atoi(e) : dotBlocks(n);
         const double* dv = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinv.p : nullptr;
+        const float* dvf = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinvF.p : nullptr;
         c->tmp4.alloc((size_t)n); c->tmp5.alloc((size_t)n);
         c->dotPartials.alloc((size_t)3 * std::max(vb, VGRID) + 16);
         if (base == "cg_update_xr")
@@ -338,10 +346,10 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         else if (base == "cg_update_p")
             hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, dv, c->tmp4.p, n);
         else if (base == "cg_update_r")
-            hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)nullptr, ones.p, VGRID, ones.p, 0, 0, y, dv,
+            hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)nullptr, ones.p, VGRID, ones.p, 0, 0, y, dvf,
                                c->tmp5.p, n, c->dotPartials.p);
         else
-            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)nullptr, zeros.p, VGRID, dv ? 1 : 0, 0, x, dv,
+            hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)nullptr, zeros.p, VGRID, dvf ? 1 : 0, 0, x, dvf,
                                c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);
     }
     else { c->S.packed = keepS; c->St.packed = keepT; throw Error("unknown kernel name: " + k); }
