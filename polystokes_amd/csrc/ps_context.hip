@@ -648,6 +648,28 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
         blockOut("Mat_Mr.mtx", c->Mr.p);
         blockOut("Mat_JDtuDJ.mtx", c->Kv.p);
         blockOut("Mat_Inv_Mr_plus_2JDtuDJ.mtx", c->Binv.p);
+        {   // Mr_plus_2JDtuDJ = Mr/dt + 2 K (assembleReducedCombinedBlock, AssembleBlocks.cpp:147-205), formed like k_binv does
+            auto mr = fetch(c, c->Mr.p, R * PS_RD * PS_RD), kv = fetch(c, c->Kv.p, R * PS_RD * PS_RD);
+            std::vector<double> bsum(mr.size());
+            for (size_t i = 0; i < mr.size(); ++i) bsum[i] = mr[i] * c->invDt + 2. * kv[i];
+            std::vector<int64_t> ptr((size_t)R * PS_RD + 1);
+            std::vector<int32_t> col((size_t)R * PS_RD * PS_RD);
+            for (int64_t r = 0; r <= R * PS_RD; ++r) ptr[(size_t)r] = r * PS_RD;
+            for (int64_t r = 0; r < R; ++r)
+                for (int m = 0; m < PS_RD; ++m)
+                    for (int n = 0; n < PS_RD; ++n) col[(size_t)((r * PS_RD + m) * PS_RD + n)] = (int32_t)(r * PS_RD + n);
+            writeMarketSparse(pre + "Mat_Mr_plus_2JDtuDJ.mtx", R * PS_RD, R * PS_RD, ptr, col, bsum);
+        }
+        {   // members the live path of the reference never fills but still writes: MrInv (assembleReducedMassBlockInverse is only
+            // called from the unreachable Eq-14 preconditioner, Preconditioners.cpp:48) is a default 0x0 matrix; A is resized to
+            // n x n and left empty (AssembleSystem.cpp:445); the guess is zero (:461-467).  uRed / uInvRed / JDtRed are not built here.
+            const std::vector<int64_t> p0(1, 0), pn((size_t)(nP + nT) + 1, 0);
+            writeMarketSparse(pre + "Mat_MrInv.mtx", 0, 0, p0, {}, {});
+            if (c->P.exportMatrices) {
+                writeMarketSparse(pre + "Mat_A.mtx", nP + nT, nP + nT, pn, {}, {});
+                writeMarketVector(pre + "Vec_guess.mtx", std::vector<double>((size_t)(nP + nT), 0.));
+            }
+        }
         writeMarketVector(pre + "Vec_activeRHS.mtx", refRows(c->rhsA.p));
         writeMarketVector(pre + "Vec_reducedRHS.mtx", fetch(c, c->rhsR.p, R * PS_RD));
         writeMarketVector(pre + "Vec_pressureRHS.mtx", refSys(c->rhsPT.p, 0, nP));

@@ -195,6 +195,7 @@ def test_export_component_matrices_roundtrip(gpu, oracle_mod, tmp_path):
     import scipy.io
     sc, p = scenes.blob(seed=7)
     p.exportComponentMatrices = 1
+    p.exportMatrices = 1
     o = oracle_mod.Oracle()
     o.run(sc, p)
     rc = gpu.step(sc, p)
@@ -202,6 +203,20 @@ def test_export_component_matrices_roundtrip(gpu, oracle_mod, tmp_path):
     pre = str(tmp_path) + "/frame0001."
     gpu.export_component_matrices(pre)
     gpu.export_stats(pre)
+    # the reduced blocks: B = Mr/dt + 2K and its inverse are both in the file set; MrInv / A are written empty, the guess zero
+    B = scipy.io.mmread(pre + "Mat_Mr_plus_2JDtuDJ.mtx").tocsr()
+    Bi = scipy.io.mmread(pre + "Mat_Inv_Mr_plus_2JDtuDJ.mtx").tocsr()
+    Mr = scipy.io.mmread(pre + "Mat_Mr.mtx").tocsr()
+    K = scipy.io.mmread(pre + "Mat_JDtuDJ.mtx").tocsr()
+    assert abs(B - (Mr / sc.dt + 2 * K)).max() <= 1e-12 * abs(B).max()
+    nR = B.shape[0]
+    assert nR == 26 * int(gpu.stats.dimData[24]) and nR > 0
+    assert abs((B @ Bi) - __import__("scipy.sparse").sparse.identity(nR)).max() <= 1e-6
+    assert scipy.io.mmread(pre + "Mat_MrInv.mtx").shape == (0, 0)
+    n = int(gpu.stats.dimData[21])
+    A = scipy.io.mmread(pre + "Mat_A.mtx")
+    assert A.shape == (n, n) and A.nnz == 0
+    assert not scipy.io.mmread(pre + "Vec_guess.mtx").any()
     for nm in ("G", "Dt", "JG", "JDt"):
         M = scipy.io.mmread(pre + "Mat_%s.mtx" % nm).tocsr()
         Mo = o.csr(nm)
