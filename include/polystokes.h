@@ -190,6 +190,9 @@ int32_t ps_read_array(ps_context* ctx, const char* name, void* dst, int64_t dst_
 /* MatrixMarket export with the reference's file names and text format
  * (Solver.cpp:533-606; extern/eigen/unsupported/Eigen/src/SparseExtra/MarketIO.h:310-380). */
 int32_t ps_export_component_matrices(ps_context* ctx, const char* prefix);
+/* exportMatrices + exportMatricesPostSolve (Solver.cpp:533-572): <prefix>Mat_A.mtx (n x n, empty: the live factored path
+ * never assembles A), Vec_b.mtx, Vec_guess.mtx (zero) and, after a solve, solutionVector.mtx. */
+int32_t ps_export_matrices(ps_context* ctx, const char* prefix);
 int32_t ps_export_stats(ps_context* ctx, const ps_stats* stats, const char* prefix);
 
 /* Solve a component set exported by exportComponentMatrices() (Solver.cpp:543-566: <prefix>Mat_G.mtx, Mat_Dt, Mat_JG,

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "ps_abi_version", "ps_context_create", "ps_context_destroy", "ps_last_error", "ps_params_default",
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
     "polystokes_step", "ps_apply_operator", "ps_query_array", "ps_read_array",
-    "ps_export_component_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt", "ps_solve_exported_system",
+    "ps_export_component_matrices", "ps_export_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt", "ps_solve_exported_system",
     "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest",
     "ps_group_create", "ps_group_destroy", "ps_group_rank", "ps_group_step",
 ]
@@ -70,6 +70,8 @@ def lib():
         L.ps_read_array.restype = C.c_int32
         L.ps_export_component_matrices.argtypes = [C.c_void_p, C.c_char_p]
         L.ps_export_component_matrices.restype = C.c_int32
+        L.ps_export_matrices.argtypes = [C.c_void_p, C.c_char_p]
+        L.ps_export_matrices.restype = C.c_int32
         L.ps_export_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_char_p]
         L.ps_export_stats.restype = C.c_int32
         L.ps_bench_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -231,6 +233,9 @@ class Solver:
 
     def export_component_matrices(self, prefix):
         self._check(self.L.ps_export_component_matrices(self.h, prefix.encode()))
+
+    def export_matrices(self, prefix):
+        self._check(self.L.ps_export_matrices(self.h, prefix.encode()))
 
     def solve_exported_system(self, prefix, params, dt, n):
         """PCG on a component set written by exportComponentMatrices (files <prefix>Mat_*.mtx, Vec_b.mtx)."""

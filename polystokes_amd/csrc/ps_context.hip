@@ -426,6 +426,7 @@ int32_t polystokes_step(ps_context* c, const ps_params* p, const ps_fields_in* i
             const int rc2 = ps_download_fields(c, out);
             if (rc2 != PS_SUCCESS) return rc2;
         }
+        if (p->exportMatrices && p->exportDataPrefix) ps_export_matrices(c, p->exportDataPrefix);
         if (p->exportComponentMatrices && p->exportDataPrefix) ps_export_component_matrices(c, p->exportDataPrefix);
         if (p->exportStats && p->exportDataPrefix) ps_export_stats(c, st, p->exportDataPrefix);
         return result;
@@ -660,15 +661,11 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
                     for (int n = 0; n < PS_RD; ++n) col[(size_t)((r * PS_RD + m) * PS_RD + n)] = (int32_t)(r * PS_RD + n);
             writeMarketSparse(pre + "Mat_Mr_plus_2JDtuDJ.mtx", R * PS_RD, R * PS_RD, ptr, col, bsum);
         }
-        {   // members the live path of the reference never fills but still writes: MrInv (assembleReducedMassBlockInverse is only
-            // called from the unreachable Eq-14 preconditioner, Preconditioners.cpp:48) is a default 0x0 matrix; A is resized to
-            // n x n and left empty (AssembleSystem.cpp:445); the guess is zero (:461-467).  uRed / uInvRed / JDtRed are not built here.
-            const std::vector<int64_t> p0(1, 0), pn((size_t)(nP + nT) + 1, 0);
+        {   // a member the live path of the reference never fills but still writes: MrInv (assembleReducedMassBlockInverse is only
+            // called from the unreachable Eq-14 preconditioner, Preconditioners.cpp:48) is a default 0x0 matrix.
+            // uRed / uInvRed / JDtRed (dead in the live path) are not built here.
+            const std::vector<int64_t> p0(1, 0);
             writeMarketSparse(pre + "Mat_MrInv.mtx", 0, 0, p0, {}, {});
-            if (c->P.exportMatrices) {
-                writeMarketSparse(pre + "Mat_A.mtx", nP + nT, nP + nT, pn, {}, {});
-                writeMarketVector(pre + "Vec_guess.mtx", std::vector<double>((size_t)(nP + nT), 0.));
-            }
         }
         writeMarketVector(pre + "Vec_activeRHS.mtx", refRows(c->rhsA.p));
         writeMarketVector(pre + "Vec_reducedRHS.mtx", fetch(c, c->rhsR.p, R * PS_RD));
@@ -676,6 +673,31 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
         writeMarketVector(pre + "Vec_stressRHS.mtx", refSys(c->rhsPT.p, nP, nT));
         writeMarketVector(pre + "Vec_b.mtx", refSys(c->b.p, 0, nP + nT));
         if (c->isSolved) writeMarketVector(pre + "solutionVector.mtx", refSys(c->x.p, 0, nP + nT));
+        return PS_SUCCESS;
+    })
+}
+
+// exportMatrices + exportMatricesPostSolve (Solver.cpp:533-572): Mat_A (resized to n x n and left empty by the live
+// factored path, AssembleSystem.cpp:445), Vec_b, Vec_guess (zero, :461-467) and, after a solve, solutionVector.
+int32_t ps_export_matrices(ps_context* c, const char* prefix) {
+    if (!c || !prefix) return PS_FAILED;
+    PS_TRY(c, {
+        if (!c->isSetup) throw Error("not set up");
+        HIP_CHECK(hipSetDevice(c->device));
+        const std::string pre(prefix);
+        const int64_t n = c->nPressures + c->nStresses;
+        auto permSys = fetch(c, c->permSys.p, n);
+        auto refSys = [&](const double* dptr) {
+            auto v = fetch(c, dptr, n);
+            std::vector<double> o((size_t)n);
+            for (int64_t i = 0; i < n; ++i) o[(size_t)i] = v[(size_t)permSys[(size_t)i]];
+            return o;
+        };
+        const std::vector<int64_t> pn((size_t)n + 1, 0);
+        if (!writeMarketSparse(pre + "Mat_A.mtx", n, n, pn, {}, {})) throw Error("cannot write Mat_A.mtx");
+        writeMarketVector(pre + "Vec_b.mtx", refSys(c->b.p));
+        writeMarketVector(pre + "Vec_guess.mtx", std::vector<double>((size_t)n, 0.));
+        if (c->isSolved) writeMarketVector(pre + "solutionVector.mtx", refSys(c->x.p));
         return PS_SUCCESS;
     })
 }

@@ -202,6 +202,7 @@ def test_export_component_matrices_roundtrip(gpu, oracle_mod, tmp_path):
     assert rc == o.result
     pre = str(tmp_path) + "/frame0001."
     gpu.export_component_matrices(pre)
+    gpu.export_matrices(pre)
     gpu.export_stats(pre)
     # the reduced blocks: B = Mr/dt + 2K and its inverse are both in the file set; MrInv / A are written empty, the guess zero
     B = scipy.io.mmread(pre + "Mat_Mr_plus_2JDtuDJ.mtx").tocsr()
