@@ -228,6 +228,7 @@ void ps_context::registerArrays() {
     }
     const int64_t R = regionCount;
     reg("reducedRegionCOM", COM.p, R * 3, 8);
+    reg("reducedRegionCenterOfMass", COM.p, R * 3, 8);   // the reference's output-geometry name (HDK_PolyStokes.h:62-102)
     reg("reducedRegionBestFitVectors", cfit.p, R * PS_RD, 8);
     reg("reducedMassMatrices", Mr.p, R * PS_RD * PS_RD, 8);
     reg("reducedViscosityMatrices", Kv.p, R * PS_RD * PS_RD, 8);
