@@ -110,6 +110,7 @@ int ps_context::setup(ps_stats* stats) {
     const std::clock_t c0 = std::clock();
     const auto w0 = std::chrono::high_resolution_clock::now();
     StageTimer T(stream);
+    bboxValid = false;
     // Solver ctor: labels / indices start UNASSIGNED (Solver.cpp:86-152)
     for (int s = 0; s < 7; ++s) {
         const int64_t n = g.count(s);

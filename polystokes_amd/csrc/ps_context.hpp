@@ -110,6 +110,7 @@ struct ps_context {
     ps::DevBuf<int32_t> regionRowPtr;        // R+1, offsets into reduced rows
     ps::DevBuf<int32_t> rchunkRegion, rchunkStart, rchunkEnd, rchunkAxis, regionChunkPtr;  // <=RC rows of ONE face axis per chunk
     int64_t nRChunks = 0;
+    bool bboxValid = false;      // bbox[] holds the boxes of the final regions (set by the small-region fix, cleared per setup)
 
     // ---- blocks (Solver.h:337-369): S = [G Dt ; Ghat Dhat] by face row, St its transpose ----
     ps::DevCSR S, St;

@@ -417,6 +417,13 @@ __global__ void k_bbox_init(int32_t* __restrict__ bb, int64_t R) {
     bb[r * 6 + 0] = bb[r * 6 + 1] = bb[r * 6 + 2] = INT_MAX;
     bb[r * 6 + 3] = bb[r * 6 + 4] = bb[r * 6 + 5] = INT_MIN;
 }
+// boxes of the surviving regions, renumbered (fixSmallReducedRegions): out[remap[r]] = in[r] where keep[r]
+__global__ void k_bbox_compact(const int32_t* __restrict__ in, const int32_t* __restrict__ keep, const int32_t* __restrict__ remap, int64_t R,
+                               int32_t* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R || !keep[r]) return;
+    for (int q = 0; q < 6; ++q) out[(int64_t)remap[r] * 6 + q] = in[r * 6 + q];
+}
 __global__ void k_bbox(Grid g, const int32_t* __restrict__ lab, const int32_t* __restrict__ reg, int32_t* bb) {
     const int3 d = g.dims(0);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -885,8 +892,13 @@ void ps_context::constructCenterReducedIndices() {
         const int64_t newR = exclusiveScanI32(remap.p, R);
         if (newR < R) {
             hipLaunchKernelGGL(k_small_apply, gr, bl, 0, stream, labels[0].p, reducedIdx[0].p, n, keep.p, remap.p);
+            DevBuf<int32_t> compact;
+            compact.alloc((size_t)std::max<int64_t>(newR, 1) * 6);
+            hipLaunchKernelGGL(k_bbox_compact, dim3(gridFor(R, BS)), bl, 0, stream, bbox.p, keep.p, remap.p, R, compact.p);
+            HIP_CHECK(hipMemcpyAsync(bbox.p, compact.p, (size_t)newR * 6 * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
             regionCount = newR;
         }
+        bboxValid = true;   // the boxes of the final regions are already on the device (computeRegionBoxes only downloads them)
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 }
@@ -896,9 +908,11 @@ void ps_context::computeRegionBoxes() {
     hbbox.assign((size_t)R * 6, 0);
     if (R == 0) return;
     const int64_t n = g.count(0);
-    bbox.alloc((size_t)R * 6);
-    hipLaunchKernelGGL(k_bbox_init, dim3(gridFor(R, BS)), dim3(BS), 0, stream, bbox.p, R);
-    hipLaunchKernelGGL(k_bbox, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, labels[0].p, reducedIdx[0].p, bbox.p);
+    if (!bboxValid) {
+        bbox.alloc((size_t)R * 6);
+        hipLaunchKernelGGL(k_bbox_init, dim3(gridFor(R, BS)), dim3(BS), 0, stream, bbox.p, R);
+        hipLaunchKernelGGL(k_bbox, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, labels[0].p, reducedIdx[0].p, bbox.p);
+    }
     HIP_CHECK(hipMemcpyAsync(hbbox.data(), bbox.p, (size_t)R * 6 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 }

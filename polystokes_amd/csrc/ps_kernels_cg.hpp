@@ -266,7 +266,7 @@ __global__ void k_lin(double* __restrict__ out, double ca, const double* __restr
 
 // ---- Jacobi diagonal (extension; reference stub Preconditioners.cpp:37-41) ------------------------
 // diag_j = -dt sum_f McInv_f S_fj^2 - sum_r q^T BInv_r q - 1/2 uInv_j,  q = sum_{f in r} C_f S_fj
-__global__ void k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int n, int nP,
+__global__ void __launch_bounds__(128) k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int n, int nP,
                               int nA, double dt, const double* __restrict__ McInv, const double* __restrict__ uInv,
                               const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, const double* __restrict__ COM,
                               double dx, const double* __restrict__ Binv, double* __restrict__ dinv, int invert) {
