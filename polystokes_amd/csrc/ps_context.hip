@@ -59,6 +59,14 @@ void ps_context::upload(const ps_params* p, const ps_fields_in* in) {
     if (!in->collision) throw Error("Collision field is missing.");
     if (!in->viscosity) throw Error("Viscosity field is missing.");
     if (p->matrixSetup != PS_PRESSURE_STRESS) throw Error("Unsupported matrix setup.");
+    // numeric sanity the node's UI ranges guarantee (HDK_PolyStokes.C:88-208); a raw ABI caller gets an error instead of a
+    // division by zero in `cell % tileSize` or a non-finite operator
+    if (!(in->dx > 0.f) || !(in->dt > 0.f) || !std::isfinite(in->dx) || !std::isfinite(in->dt)) throw Error("dx and dt must be positive and finite");
+    if (!(in->density > 0.f) || !std::isfinite(in->density)) throw Error("density must be positive and finite");
+    if (p->doReducedRegions && p->doTile && p->tileSize < 1) throw Error("tileSize must be at least 1");
+    if (p->tilePadding < 0 || p->activeLiquidBoundaryLayerSize < 0 || p->activeSolidBoundaryLayerSize < 0) throw Error("layer sizes and tilePadding must not be negative");
+    if (!(p->tolerance >= 0.) || p->maxSolverIterations < 0) throw Error("tolerance and maxSolverIterations must not be negative");
+    if (p->preconditioner != PS_PRE_IDENTITY && p->preconditioner != PS_PRE_DIAGONAL) throw Error("Unsupported preconditioner.");
     P = *p;
     g.nx = in->nx; g.ny = in->ny; g.nz = in->nz; g.order = p->indexOrder;
     dx = in->dx; invDx = 1. / dx; dt = in->dt; invDt = 1. / dt; rho = (double)in->density;

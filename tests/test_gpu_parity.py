@@ -405,3 +405,21 @@ def test_repeated_solves_are_bit_identical(gpu, precond):
     vel1, _ = gpu.download()
     for a in range(3):
         assert np.array_equal(vel0[a], vel1[a])
+
+
+def test_bad_parameters_are_refused(gpu):
+    """A raw ABI caller gets an error (ps_last_error) instead of a division by zero or a non-finite system."""
+    sc, p = scenes.cavity(16)
+    for field, value, msg in (("tileSize", 0, "tileSize"), ("tilePadding", -1, "negative"), ("tolerance", -1.0, "negative"),
+                              ("maxSolverIterations", -5, "negative"), ("preconditioner", 3, "preconditioner")):
+        q = abi.default_params()
+        setattr(q, field, value)
+        with pytest.raises(RuntimeError, match=msg):
+            gpu.upload(sc, q)
+    bad = abi.Scene(16, 16, 16, 0.0, sc.dt, 1.0, [0.0, 0.0, 0.0], np.float32(-1.0), np.float32(1.0), 1.0)
+    with pytest.raises(RuntimeError, match="dx and dt"):
+        gpu.upload(bad, p)
+    bad = abi.Scene(16, 16, 16, sc.dx, sc.dt, 0.0, [0.0, 0.0, 0.0], np.float32(-1.0), np.float32(1.0), 1.0)
+    with pytest.raises(RuntimeError, match="density"):
+        gpu.upload(bad, p)
+    assert gpu.step(sc, p) == abi.SUCCESS   # the context stays usable
