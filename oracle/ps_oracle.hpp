@@ -104,6 +104,7 @@ struct Oracle {
     std::vector<double> COM;        // R*3
     std::vector<double> cfit;       // R*26
     std::vector<double> Mr, K, Binv; // R*26*26 row-major
+    std::vector<double> fitN, fitRhs; // the per-tile least-squares normal systems (diagnostics)
     std::vector<double> reducedRHS; // R*26
 
     // blocks

@@ -238,6 +238,7 @@ void Oracle::computeLeastSquaresFits() {
             }
     cfit.assign((size_t)R * RD, 0.);
     for (int64_t r = 0; r < R; ++r) fullPivLuSolve(&N[(size_t)r * RD * RD], &rhs[(size_t)r * RD], &cfit[(size_t)r * RD]);
+    fitN = N; fitRhs = rhs;   // kept for diagnostics (conditioning of the per-tile normal systems)
 }
 
 // Solver.cpp:419-441, 1405-1482

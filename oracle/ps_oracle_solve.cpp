@@ -425,6 +425,7 @@ void Oracle::registerArrays() {
     auto regv = [&](const std::string& n, const std::vector<double>& v) { reg(n, v.data(), (int64_t)v.size(), 8); };
     regv("reducedRegionCOM", COM);
     regv("reducedRegionBestFitVectors", cfit);
+    regv("reducedRegionBestFitSystems", fitN); regv("reducedRegionBestFitRHS", fitRhs);
     regv("reducedMassMatrices", Mr);
     regv("reducedViscosityMatrices", K);
     regv("Inv_Mr_plus_2JDtuDJ", Binv);
