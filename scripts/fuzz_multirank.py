@@ -1,0 +1,47 @@
+"""Randomised check of the slab decomposition: in-process ranks (Group) against the single-domain solve on random scenes."""
+import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import polystokes_amd
+from polystokes_amd import scenes, _abi as abi, partition
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = 0
+single = polystokes_amd.Solver(0)
+for case in range(n_cases):
+    rng = np.random.RandomState(seed0 + case)
+    world = int(rng.choice([2, 2, 3, 4]))
+    tile = int(rng.choice([8, 16, 16]))
+    nz = 16 * int(rng.randint(2 * world, 3 * world + 2))
+    nx, ny = (int(v) for v in rng.randint(16, 40, 2))
+    sc, p = scenes.blob(nx, ny, nz, seed=seed0 + case, tile=tile, pad=int(rng.choice([1, 2])), variable_viscosity=bool(rng.randint(2)))
+    p.preconditioner = int(rng.choice([abi.PRE_IDENTITY, abi.PRE_DIAGONAL]))
+    p.activeLiquidBoundaryLayerSize = int(rng.choice([1, 2, 3])); p.activeSolidBoundaryLayerSize = int(rng.choice([0, 1, 2]))
+    p.tolerance = 1e-6
+    p.maxSolverIterations = 20000
+    rc1 = single.step(sc, p)
+    grp = polystokes_amd.Group(world)
+    msgs = []
+    try:
+        rc2 = grp.solve_scene(sc, p)
+    except Exception as e:
+        msgs.append("exception %s" % str(e)[:80]); rc2 = None
+    if rc2 is not None:
+        if rc1 != rc2: msgs.append("rc %d vs %d" % (rc1, rc2))
+        it1, it2 = single.stats.solveData[1], grp.stats.solveData[1]
+        if abs(it1 - it2) > max(3, 0.03 * it1): msgs.append("iters %d vs %d" % (it1, it2))
+        lab = single.array("centerLabels").reshape(sc.nz, sc.ny, sc.nx)
+        for r, sl in enumerate(grp.slabs):
+            ll = grp.ranks[r].array("centerLabels").reshape(sl.nz_local, sc.ny, sc.nx)
+            if not np.array_equal(ll[sl.zLoOwned:sl.zHiOwned], lab[sl.z0:sl.z1]): msgs.append("labels rank %d" % r)
+        for a in range(3):
+            if not np.array_equal(grp.valid[a], single.valid[a]): msgs.append("valid%s" % "XYZ"[a])
+            scale = max(np.abs(single.vel[a]).max(), 1e-30)
+            dv = np.abs(grp.vel[a] - single.vel[a]).max() / scale
+            if dv > 1e-3: msgs.append("vel%s %.1e" % ("XYZ"[a], dv))
+    bad += bool(msgs)
+    print("BAD" if msgs else "OK ", case, "world", world, (nx, ny, nz), "tile", tile, p.tilePadding, "pre", p.preconditioner,
+          "dofs", int(single.stats.dimData[21]), "regions", int(single.stats.dimData[24]), "iters", int(single.stats.solveData[1]),
+          int(grp.stats.solveData[1]) if rc2 is not None else -1, msgs, flush=True)
+    grp.close()
+print("cases", n_cases, "bad", bad)
+sys.exit(1 if bad else 0)
