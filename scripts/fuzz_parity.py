@@ -15,7 +15,21 @@ for case in range(n_cases):
     nx, ny, nz = (int(v) for v in rng.randint(14, int(os.environ.get("FUZZ_MAX", "38")), 3))
     tile = int(rng.choice([5, 6, 7, 8, 9, 10, 12, 16]))
     pad = int(rng.choice([1, 2, 2, 3]))
-    sc, p = scenes.blob(nx, ny, nz, seed=seed0 + case, tile=tile, pad=min(pad, tile - 1), variable_viscosity=bool(rng.randint(2)))
+    fam = os.environ.get("FUZZ_FAMILY", "blob")
+    if fam == "mixed": fam = str(rng.choice(["blob", "cavity", "spheres", "coil", "droplet", "beam"]))
+    n1 = int(rng.randint(16, min(int(os.environ.get("FUZZ_MAX", "38")), 56)))
+    if fam == "blob":
+        sc, p = scenes.blob(nx, ny, nz, seed=seed0 + case, tile=tile, pad=min(pad, tile - 1), variable_viscosity=bool(rng.randint(2)))
+    elif fam == "cavity":
+        sc, p = scenes.cavity(n1, tile=tile, pad=min(pad, tile - 1)); nx = ny = nz = n1
+    elif fam == "spheres":
+        sc, p = scenes.spheres(n1, tile=tile, pad=min(pad, tile - 1), nspheres=int(rng.randint(1, 9)), seed=seed0 + case); nx = ny = nz = n1
+    elif fam == "coil":
+        sc, p = scenes.coil(n1); p.tileSize = tile; p.tilePadding = min(pad, tile - 1); nx = ny = nz = n1
+    elif fam == "droplet":
+        sc, p = scenes.droplet(n1); p.tileSize = tile; p.tilePadding = min(pad, tile - 1); nx = ny = nz = n1
+    else:
+        sc, p = scenes.beam(n1); nx = ny = nz = n1
     p.activeLiquidBoundaryLayerSize = int(rng.choice([1, 2, 2, 3]))
     p.activeSolidBoundaryLayerSize = int(rng.choice([0, 1, 2, 2, 3]))
     p.doTile = int(rng.rand() < 0.85)
@@ -80,7 +94,7 @@ for case in range(n_cases):
     if result_note: (notes if sing else msgs).append(result_note)
     tag = "OK " if not msgs else "BAD"
     bad += bool(msgs)
-    print(tag, case, (nx, ny, nz), "tile", tile, p.tilePadding, "L/S", p.activeLiquidBoundaryLayerSize, p.activeSolidBoundaryLayerSize, "doTile", p.doTile,
+    print(tag, case, fam, (nx, ny, nz), "tile", tile, p.tilePadding, "L/S", p.activeLiquidBoundaryLayerSize, p.activeSolidBoundaryLayerSize, "doTile", p.doTile,
           "red", p.doReducedRegions, "order", p.indexOrder, "pre", p.preconditioner, "| dofs", int(g.stats.dimData[21]), "regions", int(g.stats.dimData[24]),
           "iters", int(it_g), int(it_o), msgs, notes, flush=True)
 print("cases", n_cases, "bad", bad, "time %.0fs" % (time.time() - t0))
