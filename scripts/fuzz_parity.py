@@ -12,12 +12,12 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.RandomState(seed0 + case)
-    nx, ny, nz = (int(v) for v in rng.randint(14, int(os.environ.get("FUZZ_MAX", "38")), 3))
+    nx, ny, nz = (int(v) for v in rng.randint(int(os.environ.get("FUZZ_MIN", "14")), int(os.environ.get("FUZZ_MAX", "38")), 3))
     tile = int(rng.choice([5, 6, 7, 8, 9, 10, 12, 16]))
     pad = int(rng.choice([1, 2, 2, 3]))
     fam = os.environ.get("FUZZ_FAMILY", "blob")
     if fam == "mixed": fam = str(rng.choice(["blob", "cavity", "spheres", "coil", "droplet", "beam"]))
-    n1 = int(rng.randint(16, min(int(os.environ.get("FUZZ_MAX", "38")), 56)))
+    n1 = int(rng.randint(min(16, int(os.environ.get("FUZZ_MAX", "38")) - 1), min(int(os.environ.get("FUZZ_MAX", "38")), 56)))
     if fam == "blob":
         sc, p = scenes.blob(nx, ny, nz, seed=seed0 + case, tile=tile, pad=min(pad, tile - 1), variable_viscosity=bool(rng.randint(2)))
     elif fam == "cavity":
