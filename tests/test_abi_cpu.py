@@ -39,13 +39,17 @@ def test_struct_layout_matches_header():
 
 
 def test_no_gpu_fails_loudly():
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("GPU present")
+    """Without a HIP device the product refuses to construct a solver (there is no CPU fallback).  The device is probed through
+    the library itself, not through torch: importing torch after the library has dlopen'ed ROCm's librccl would bring a second
+    RCCL into the process (two copies abort at interpreter exit)."""
     import polystokes_amd
-    with pytest.raises(polystokes_amd.PolyStokesError) as e:
-        polystokes_amd.Solver(0)
-    assert "no HIP device" in str(e.value) or "no CPU fallback" in str(e.value)
+    try:
+        s = polystokes_amd.Solver(0)
+    except polystokes_amd.PolyStokesError as e:
+        assert "no HIP device" in str(e) or "no CPU fallback" in str(e)
+        return
+    s.close()
+    pytest.skip("GPU present")
 
 
 def test_traversal_order_roundtrip_matches_oracle(oracle_mod):
