@@ -7,7 +7,8 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = 0
 single = polystokes_amd.Solver(0)
-for case in range(n_cases):
+only = os.environ.get("FUZZ_ONLY")
+for case in ([int(only)] if only else range(n_cases)):
     rng = np.random.RandomState(seed0 + case)
     world = int(rng.choice([2, 2, 3, 4]))
     tile = int(rng.choice([8, 16, 16]))
@@ -16,8 +17,8 @@ for case in range(n_cases):
     sc, p = scenes.blob(nx, ny, nz, seed=seed0 + case, tile=tile, pad=int(rng.choice([1, 2])), variable_viscosity=bool(rng.randint(2)))
     p.preconditioner = int(rng.choice([abi.PRE_IDENTITY, abi.PRE_DIAGONAL]))
     p.activeLiquidBoundaryLayerSize = int(rng.choice([1, 2, 3])); p.activeSolidBoundaryLayerSize = int(rng.choice([0, 1, 2]))
-    p.tolerance = 1e-6
-    p.maxSolverIterations = 20000
+    p.tolerance = float(os.environ.get("FUZZ_TOL", "1e-6"))
+    p.maxSolverIterations = int(os.environ.get("FUZZ_MAXIT", "20000"))
     rc1 = single.step(sc, p)
     grp = polystokes_amd.Group(world)
     msgs = []
