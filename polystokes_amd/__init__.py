@@ -15,7 +15,7 @@ from . import _abi
 from ._abi import (FieldsIn, FieldsOut, Params, Scene, Stats, default_params)  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpolystokes_hip.so")
+LIB_PATH = os.environ.get("PS_LIB") or os.path.join(_HERE, "libpolystokes_hip.so")   # PS_LIB: A/B builds (scripts/build_variant.sh)
 _lib = None
 
 EXPORTED_SYMBOLS = [

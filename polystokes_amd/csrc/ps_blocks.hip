@@ -506,6 +506,107 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot) {
                                            (long long)M.rows, (long long)M.nnz, maxLen, M.nv, (int)M.col16ok);
 }
 
+// Chunk -> XCD schedule of the persistent SpMV kernels (ChunkWalk): built on the host from the block starts of the internal
+// numbering.  A 256-row chunk belongs to the super-block of its first row; the skin-row chunks of S go with the super-block
+// holding the min corner of their region's box.  Super-blocks (non-empty ones, in sequence order) are dealt to the 8 XCDs
+// round robin, so the chip as a whole still sweeps a compact window of memory.
+// OFF by default (PS_SCHED=1 enables it): measured at 256^3 it removes only 5-12 % of the L2 fills and no time
+// (profiles/r02_spmv_locality.md) — on this chip two workgroups share a fill only when they run on the same or the adjacent CU
+// (the PS_SCHED_DUP probe below: chunks walked twice by workgroups <= 16 apart cost +25 % fills, >= 32 apart +100 %), and
+// a line survives in the 4 MiB L2 for about one chunk time.  Kept for the probes and for scenes with other geometry.
+void ps_context::buildChunkSchedule(ps::DevCSR& M, bool faceRows) {
+    M.schedOk = false;
+    const char* e = getenv("PS_SCHED");
+    const int mode = e ? atoi(e) : 0;
+    if (!M.col16ok || mode == 0 || ilBlocks == 0) return;
+    const int nChunks = gridFor(M.rows, BS);
+    if (nChunks < 64) return;
+    const std::vector<int32_t>& bs = faceRows ? blockStartRow : blockStartSys;
+    const int sbv = ilSuper[0] * ilSuper[1] * ilSuper[2];
+    const int nSB = ilBlocks / sbv;
+    const int64_t nActive = faceRows ? nActiveVs : M.rows;
+    std::vector<int32_t> sbOf((size_t)nChunks);
+    {   // active part: walk the block starts
+        size_t b = 0;
+        for (int ch = 0; ch < nChunks; ++ch) {
+            const int64_t r0 = (int64_t)ch * BS;
+            if (r0 >= nActive) break;
+            while (b + 1 < bs.size() - 1 && bs[b + 1] <= r0) ++b;
+            sbOf[(size_t)ch] = (int32_t)(b / (size_t)sbv);
+        }
+    }
+    if (faceRows && nReducedRows > 0) {
+        const int LBx = (g.nx + 1 + ilOrigin[0] + 15) / 16, LBy = (g.ny + 1 + ilOrigin[1] + 15) / 16;
+        const int NSx = (LBx + ilSuper[0] - 1) / ilSuper[0], NSy = (LBy + ilSuper[1] - 1) / ilSuper[1];
+        size_t r = 0;
+        for (int ch = (int)((nActive + BS - 1) / BS); ch < nChunks; ++ch) {
+            const int64_t rr = (int64_t)ch * BS - nActive;
+            while (r + 1 < regionRowPtrHost.size() - 1 && regionRowPtrHost[r + 1] <= rr) ++r;
+            const int bx = (hbbox[r * 6 + 0] + ilOrigin[0]) / 16, by = (hbbox[r * 6 + 1] + ilOrigin[1]) / 16, bz = (hbbox[r * 6 + 2] + ilOrigin[2]) / 16;
+            const int sb = ((bz / ilSuper[2]) * NSy + by / ilSuper[1]) * NSx + bx / ilSuper[0];
+            sbOf[(size_t)ch] = std::min(sb, nSB - 1);
+        }
+    }
+    // counting sort of the chunks by super-block (stable: active chunks first, then the skin chunks, ascending)
+    std::vector<int32_t> cnt((size_t)nSB + 1, 0);
+    {   // PS_SCHED_ONLY=1|2 (traffic attribution runs): only the active / only the skin chunks of S are walked
+        const char* eo = getenv("PS_SCHED_ONLY");
+        const int only = (eo && faceRows) ? atoi(eo) : 0;
+        const int firstSkin = (int)((nActive + BS - 1) / BS);
+        if (only) for (int ch = 0; ch < nChunks; ++ch) if ((only == 1) != (ch < firstSkin)) sbOf[(size_t)ch] = -1;
+    }
+    for (int ch = 0; ch < nChunks; ++ch) if (sbOf[(size_t)ch] >= 0) cnt[(size_t)sbOf[(size_t)ch] + 1]++;
+    std::vector<int32_t> xcdOf((size_t)nSB, 0);
+    int next = 0;
+    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sb = 0; sb < nSB; ++sb)
+        if (cnt[(size_t)sb + 1] > 0) {
+            int x = next & 7;
+            if (mode == 2) { x = 0; for (int q = 1; q < 8; ++q) if (load[q] < load[x]) x = q; }   // least loaded (A/B)
+            xcdOf[(size_t)sb] = x; load[x] += cnt[(size_t)sb + 1]; ++next;
+        }
+    int64_t mx = 0;
+    for (int q = 0; q < 8; ++q) mx = std::max(mx, load[q]);
+    if (mx * 8 > (int64_t)nChunks * 5 / 4 + 8 * 64) return;   // a lopsided deal (few, uneven super-blocks): keep the computed walk
+    for (int sb = 0; sb < nSB; ++sb) cnt[(size_t)sb + 1] += cnt[(size_t)sb];
+    std::vector<int32_t> bySb((size_t)nChunks);
+    {
+        std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+        for (int ch = 0; ch < nChunks; ++ch) if (sbOf[(size_t)ch] >= 0) bySb[(size_t)pos[(size_t)sbOf[(size_t)ch]]++] = ch;
+    }
+    std::vector<int32_t> list((size_t)nChunks);
+    int o = 0;
+    for (int x = 0; x < 8; ++x) {
+        M.schedOff[x] = o;
+        for (int sb = 0; sb < nSB; ++sb)
+            if (xcdOf[(size_t)sb] == x)
+                for (int32_t q = cnt[(size_t)sb]; q < cnt[(size_t)sb + 1]; ++q) list[(size_t)o++] = bySb[(size_t)q];
+    }
+    M.schedOff[8] = o;
+    if (const char* ed = getenv("PS_SCHED_DUP")) {   // L2 retention probe: every group of d list entries is walked twice in a row (S only)
+        const int d = atoi(ed);
+        if (d > 0 && faceRows) {
+            std::vector<int32_t> l2;
+            int off2[9];
+            for (int x = 0; x < 8; ++x) {
+                off2[x] = (int)l2.size();
+                for (int g0 = M.schedOff[x]; g0 < M.schedOff[x + 1]; g0 += d)
+                    for (int rep = 0; rep < 2; ++rep)
+                        for (int q = g0; q < std::min(M.schedOff[x + 1], g0 + d); ++q) l2.push_back(list[(size_t)q]);
+            }
+            off2[8] = (int)l2.size();
+            list.swap(l2);
+            for (int x = 0; x < 9; ++x) M.schedOff[x] = off2[x];
+        }
+    }
+    M.sched.alloc(list.size());
+    HIP_CHECK(hipMemcpyAsync(M.sched.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    M.schedOk = true;
+    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] chunk schedule (%s): %d chunks, %d super-blocks, fullest XCD %lld\n",
+                                           faceRows ? "S" : "St", nChunks, nSB, (long long)mx);
+}
+
 // ConstructMatrixBlocks.cpp:9-292
 void ps_context::constructMatrixBlocks() {
     nActiveVs = nFace[0] + nFace[1] + nFace[2];
@@ -539,6 +640,7 @@ void ps_context::constructMatrixBlocks() {
         HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<int32_t> rptr((size_t)regionCount + 1), cR, cS, cE, cA, cptr((size_t)regionCount + 1);
         for (int64_t r = 0; r <= regionCount; ++r) rptr[(size_t)r] = itemOff[(size_t)itemPtr[(size_t)r]];
+        regionRowPtrHost = rptr;
         for (int64_t r = 0; r < regionCount; ++r) {
             cptr[(size_t)r] = (int32_t)cR.size();
             // rows are ordered (region, axis, position): cut every axis run into equal pieces of <= RC_ROWS rows
@@ -576,6 +678,7 @@ void ps_context::constructMatrixBlocks() {
         HIP_CHECK(hipStreamSynchronize(stream));
     } else {
         nRChunks = 0;
+        regionRowPtrHost.assign(1, 0);
     }
     nRows = nActiveVs + nReducedRows;
     if (nRows >= 0x7fffffff) throw Error("too many face rows");
@@ -642,6 +745,8 @@ void ps_context::constructMatrixBlocks() {
         HIP_CHECK(hipStreamSynchronize(stream));
         buildCol16(S, 22);
         buildCol16(St, 23);
+        buildChunkSchedule(S, true);
+        buildChunkSchedule(St, false);
         const int32_t c16 = (S.col16ok ? 1 : 0) | (St.col16ok ? 2 : 0);
         HIP_CHECK(hipMemcpyAsync(counters.p + 24, &c16, sizeof(c16), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

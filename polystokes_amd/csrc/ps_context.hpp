@@ -27,6 +27,11 @@ struct DevCSR {
     DevBuf<int2> chunkRange;
     DevBuf<uint8_t> len8;
     bool col16ok = false;
+    // Scheduled walk of the persistent kernels: the chunks of one super-block of the numbering lattice (and, for S, the skin
+    // rows of its tiles) go to ONE XCD, back to back, so the x / t lines they share are filled into one L2 once.
+    DevBuf<int32_t> sched;       // 8 lists, concatenated
+    int schedOff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool schedOk = false;
     int nv = 2;
     int64_t streamLen = 0;       // entries of col16 / code4 (multiple of 4)
 };
@@ -80,7 +85,11 @@ struct ps_context {
     // permSys[ref system index] = internal index; permRow[ref active-face index] = internal row.
     ps::DevBuf<int32_t> sysIdx[7];
     ps::DevBuf<int32_t> permSys, permRow;
-    ps::DevBuf<int64_t> ilSegStart;          // interleaved-scan segment table (host built)
+    // lattice of the internal numbering (ps_grid.hip:ILDesc): origin offset of the 16^3 blocks and the super-block shape
+    // (blocks of one super-block are consecutive: its DOFs / rows are one XCD's working set in the scheduled SpMV walk)
+    int ilOrigin[3] = {0, 0, 0}, ilSuper[3] = {1, 1, 1};
+    int ilBlocks = 0;                        // lattice blocks in sequence order (incl. the padding blocks of partial super-blocks)
+    std::vector<int32_t> blockStartSys, blockStartRow;   // first DOF / first active row of every lattice block (+ total): host copies
     ps::DevBuf<int32_t> cellScratch[3];      // layer marks / CC labels / fix flags
     ps::DevBuf<int32_t> scanBlock;           // block sums for scans
     ps::DevBuf<int32_t> counters;            // small device counters (flags, totals)
@@ -177,6 +186,8 @@ struct ps_context {
     void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
     void constructMatrixBlocks();                         // ps_blocks.hip
     void buildCol16(ps::DevCSR& M, int counterSlot);      // ps_blocks.hip
+    void buildChunkSchedule(ps::DevCSR& M, bool faceRows);
+    std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();
     int solve();

@@ -642,6 +642,9 @@ struct ILDesc {
     int sample[4];
     int weight[4];
     int LBx, LBy, LBz;
+    int SBx, SBy, SBz;         // super-block of SBx x SBy x SBz lattice blocks: consecutive in the sequence (L2 working set of one XCD)
+    int NSx, NSy;              // super-blocks per axis (x, y)
+    int ox, oy, oz;            // lattice origin offset: block (bx,by,bz) covers voxels [16 b - o, 16 b - o + 16)
     int64_t total;
     const int64_t* segStart;   // LB^3 * ngroups + 1
     int nseg;
@@ -672,10 +675,13 @@ __device__ inline bool ilDecode(const ILDesc& D, const Grid& g, int64_t u, int* 
         const int pl = rem / (256 * D.ngroups), r2 = rem - pl * 256 * D.ngroups;
         gg = r2 >> 8; v = (pl << 8) | (r2 & 255);
     } else { v = rem / D.ngroups; gg = rem - v * D.ngroups; }
-    const int bx = b % D.LBx, by = (b / D.LBx) % D.LBy, bz = b / (D.LBx * D.LBy);
-    const int i = 16 * bx + (v & 15), j = 16 * by + ((v >> 4) & 15), k = 16 * bz + (v >> 8);
+    const int sbv = D.SBx * D.SBy * D.SBz;
+    const int sb = b / sbv, wi = b - sb * sbv;
+    const int bx = (sb % D.NSx) * D.SBx + wi % D.SBx, by = ((sb / D.NSx) % D.NSy) * D.SBy + (wi / D.SBx) % D.SBy,
+              bz = (sb / (D.NSx * D.NSy)) * D.SBz + wi / (D.SBx * D.SBy);
+    const int i = 16 * bx + (v & 15) - D.ox, j = 16 * by + ((v >> 4) & 15) - D.oy, k = 16 * bz + (v >> 8) - D.oz;
     const int3 d = g.dims(D.sample[gg]);
-    if (i >= d.x || j >= d.y || k >= d.z) return false;
+    if (i < 0 || j < 0 || k < 0 || i >= d.x || j >= d.y || k >= d.z) return false;
     *grp = gg;
     *lin = lin3(d, i, j, k);
     return true;
@@ -692,7 +698,7 @@ __global__ void k_il_count(ILDesc D, Grid g, Set7<const int32_t> lab, int32_t* _
     if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
 }
 __global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int32_t* __restrict__ blockOffs, Set7<int32_t> outs,
-                            int32_t* __restrict__ probeOut) {
+                            int32_t* __restrict__ probeOut, int32_t* __restrict__ blockStart) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int w[SCAN_ITEMS], gr[SCAN_ITEMS];
     int64_t cc[SCAN_ITEMS];
@@ -707,6 +713,7 @@ __global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         if (base + i == D.probe[0]) probeOut[0] = off;
         if (base + i == D.probe[1]) probeOut[1] = off;
+        if (base + i < D.total && (base + i) % ((int64_t)4096 * D.ngroups) == 0) blockStart[(base + i) / ((int64_t)4096 * D.ngroups)] = off;
         if (w[i]) { outs.p[D.sample[gr[i]]][cc[i]] = off; off += w[i]; }
     }
 }
@@ -957,17 +964,22 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     { const char* e = getenv("PS_IL"); const int m = e ? atoi(e) : 0; D.planeMajor = ownedRange ? (m & 1) : ((m >> 1) & 1); }   // bit 0: DOFs, bit 1: face rows
     D.probe[0] = D.probe[1] = -1;
     for (int q = 0; q < 4; ++q) { D.sample[q] = q < ngroups ? samples[q] : 0; D.weight[q] = q < ngroups ? weights[q] : 0; }
-    D.LBx = (g.nx + 1 + 15) / 16; D.LBy = (g.ny + 1 + 15) / 16; D.LBz = (g.nz + 1 + 15) / 16;
+    D.ox = ilOrigin[0]; D.oy = ilOrigin[1]; D.oz = ilOrigin[2];
+    D.LBx = (g.nx + 1 + D.ox + 15) / 16; D.LBy = (g.ny + 1 + D.oy + 15) / 16; D.LBz = (g.nz + 1 + D.oz + 15) / 16;
+    D.SBx = ilSuper[0]; D.SBy = ilSuper[1]; D.SBz = ilSuper[2];
+    D.NSx = (D.LBx + D.SBx - 1) / D.SBx; D.NSy = (D.LBy + D.SBy - 1) / D.SBy;
+    const int NSz = (D.LBz + D.SBz - 1) / D.SBz;
     const int64_t per = (int64_t)4096 * ngroups;
-    const int64_t run = (int64_t)D.LBx * D.LBy * D.LBz * per;
+    const int64_t run = (int64_t)D.NSx * D.NSy * NSz * D.SBx * D.SBy * D.SBz * per;
     D.total = run;
     D.nseg = 0;
     D.segStart = nullptr;
     if (ownedRange) {   // owned DOFs = whole lattice blocks bz in [zLo/16, hasUpper ? zHi/16 : LBz): a contiguous index range
         const int b0 = slabEnabled ? slab.zLoOwned / 16 : 0;
         const int b1 = (slabEnabled && slab.hasUpper) ? slab.zHiOwned / 16 : D.LBz;
-        D.probe[0] = (int64_t)b0 * D.LBx * D.LBy * per;
-        D.probe[1] = (int64_t)b1 * D.LBx * D.LBy * per;
+        // (with a slab the lattice has SBz = 1 and oz = 0: z-layers of blocks stay whole and in order)
+        D.probe[0] = (int64_t)b0 * D.NSx * D.NSy * D.SBx * D.SBy * per;
+        D.probe[1] = (int64_t)b1 * D.NSx * D.NSy * D.SBx * D.SBy * per;
     }
     const int nbk = gridFor(run, SCAN_TILE);
     scanBlock.alloc((size_t)nbk);
@@ -976,8 +988,19 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     for (int q = 0; q < ngroups; ++q) o.p[samples[q]] = outs[q];
     hipLaunchKernelGGL(k_il_count, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nbk, counters.p + 8);
-    hipLaunchKernelGGL(k_il_assign, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p, o, counters.p + 10);
+    const int nBlocks = (int)(run / per);
+    DevBuf<int32_t> bstart;
+    bstart.alloc((size_t)nBlocks + 1);
+    hipLaunchKernelGGL(k_il_assign, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p, o, counters.p + 10, bstart.p);
     const int64_t total = readCounter(8);
+    {
+        std::vector<int32_t>& hs = ownedRange ? blockStartSys : blockStartRow;
+        hs.assign((size_t)nBlocks + 1, 0);
+        HIP_CHECK(hipMemcpyAsync(hs.data(), bstart.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        hs[(size_t)nBlocks] = (int32_t)total;
+        ilBlocks = nBlocks;
+    }
     if (ownedRange) {
         ownedRange[0] = D.probe[0] >= run ? total : readCounter(10);
         ownedRange[1] = D.probe[1] >= run ? total : readCounter(11);
@@ -988,6 +1011,19 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
 // Internal numbering of system DOFs and active face rows (see ps_context.hpp).  With PS_ORDER_LINEAR the
 // same interleaving is used: it is an internal layout, the reference numbering stays in activeIdx[].
 void ps_context::buildInternalNumbering() {
+    {   // lattice shape.  PS_IL_ORIGIN=o | ox,oy,oz and PS_IL_SUPER=s | sx,sy,sz override (A/B runs)
+        int o[3] = {0, 0, 0}, sb[3] = {1, 1, 1};
+        auto parse3 = [](const char* e, int* v) {
+            if (!e) return;
+            int a, b, c;
+            const int k = std::sscanf(e, "%d,%d,%d", &a, &b, &c);
+            if (k == 1) { v[0] = v[1] = v[2] = a; } else if (k == 3) { v[0] = a; v[1] = b; v[2] = c; }
+        };
+        parse3(getenv("PS_IL_ORIGIN"), o);
+        parse3(getenv("PS_IL_SUPER"), sb);
+        if (slabEnabled) { o[2] = 0; sb[2] = 1; }   // owned DOFs must stay one contiguous range of whole z-layers of blocks
+        for (int a = 0; a < 3; ++a) { ilOrigin[a] = std::min(15, std::max(0, o[a])); ilSuper[a] = std::min(8, std::max(1, sb[a])); }
+    }
     const int64_t nC = nCenter, nPq = nCenter;
     const int64_t nSys = 4 * nCenter + nEdge[0] + nEdge[1] + nEdge[2];
     const int64_t nAct = nFace[0] + nFace[1] + nFace[2];

@@ -170,10 +170,16 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 // run on XCD b & 7 (verified with s_getreg HW_REG_XCC_ID), so runs of G consecutive chunks are dealt to the XCDs round
 // robin — rows that gather the same lines of x (k-plane neighbours, a few chunks apart) then share ONE L2, while
 // the chip as a whole still sweeps one compact window of memory.
+struct ChunkSched { const int32_t* list; int off[9]; };   // per-XCD chunk lists (ps_context::buildChunkSchedule); list == null: computed walk
 struct ChunkWalk {
     int sh, x, l, per;   // G = 1 << sh chunks per run; sh < 0: plain walk
-    __device__ ChunkWalk(int g) : sh(g > 0 ? 31 - __builtin_clz((unsigned)g) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3) {}
+    const int32_t* list; // scheduled walk: this XCD's chunks list[lo .. lo + n), dealt to its workgroups round robin
+    int lo, n;
+    __device__ ChunkWalk(int g, const ChunkSched& s)
+        : sh(g > 0 ? 31 - __builtin_clz((unsigned)g) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3), list(s.list),
+          lo(s.list ? s.off[blockIdx.x & 7] : 0), n(s.list ? s.off[(blockIdx.x & 7) + 1] - s.off[blockIdx.x & 7] : 0) {}
     __device__ int at(int it) const {
+        if (list) { const int q = l + it * per; return q < n ? list[lo + q] : 0x7fffffff; }
         if (sh < 0) return blockIdx.x + it * gridDim.x;
         const int q = l + it * per;
         return ((((q >> sh) << 3) + x) << sh) + (q & ((1 << sh) - 1));
@@ -193,6 +199,25 @@ __device__ inline double bufLoadF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) 
 __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, 0);
 }
+// Cache policies of the three access classes (compile-time, scripts/build_variant.sh builds A/B copies).  Measured at 256^3
+// (profiles/r02_cache_policy.txt): result stores nt (aux 2: written once, read by the NEXT kernel; St -7 %, S -3 % against
+// default-policy stores; sc1 / sc0 sc1 stores +4 %); stream loads nt (sc1 / sc0 sc1 / default within 1 %); gathers default
+// policy — nt gathers bypass the CU's L1 and run 2x slower: what cross-row reuse there is comes from L1.
+#ifndef PS_STORE_AUX
+#define PS_STORE_AUX 2
+#endif
+#ifndef PS_STREAM_AUX
+#define PS_STREAM_AUX 2
+#endif
+#ifndef PS_GATHER_AUX
+#define PS_GATHER_AUX 0
+#endif
+__device__ inline void bufStoreF64nt(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, PS_STORE_AUX);
+}
+__device__ inline double bufGatherF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, PS_GATHER_AUX));
+}
 // one lane's share of a chunk's stream: NV groups of 4 consecutive entries (non-temporal: read once)
 template <int NV> struct Stream4 { u32x2 c[NV]; unsigned v[NV]; };
 template <int NV>
@@ -203,8 +228,8 @@ __device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_
         // groups past the end of the chunk: offset 0xffffffff is out of range -> zeros without a memory access
         // (zeros decode to window 0 / offset 0 / value 0, like the padding inside the last group)
         const bool in = (int)first < p1;
-        s.c[w] = __builtin_amdgcn_raw_buffer_load_b64(rCol, in ? (int)(first * 2u) : -1, 0, 2);
-        s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, 2);
+        s.c[w] = __builtin_amdgcn_raw_buffer_load_b64(rCol, in ? (int)(first * 2u) : -1, 0, PS_STREAM_AUX);
+        s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, PS_STREAM_AUX);
     }
 }
 __device__ inline unsigned streamCol(u32x2 c, int j, int myBase) {   // window base (lane `window` of every 16-lane group) + 12-bit offset
@@ -244,7 +269,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
                                                     const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
                                                     int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
-                                                    const int* __restrict__ done, int chunkBegin, int nChunks, int xcdAware) {
+                                                    const int* __restrict__ done, ChunkSched sched, int nChunks, int xcdAware) {
     if (done && *done) return;
     constexpr int PL = BS * NV;
     __shared__ double prod[4 * PL];
@@ -253,15 +278,15 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
                                  rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8);
-    const ChunkWalk W(xcdAware);
+    const ChunkWalk W(xcdAware, sched);
     int it = 0;
-    int chunk = chunkBegin + W.at(0);   // this launch covers chunks [chunkBegin, nChunks)
+    int chunk = W.at(0);
     if (chunk >= nChunks) return;
     int2 pr = chunkRange[chunk];
     Stream4<NV> cur, nxt;
     loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
-    int nchunk = chunkBegin + W.at(1);
+    int nchunk = W.at(1);
     int2 npr = {0, 0};
     if (nchunk < nChunks) npr = chunkRange[nchunk];
     while (true) {
@@ -274,14 +299,14 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
         for (int w = 0; w < NV; ++w) {
             if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufLoadF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
+            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
         }
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
             loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
-        const int nn = chunkBegin + W.at(it + 2);
+        const int nn = W.at(it + 2);
         int2 nnpr = {0, 0};
         if (nn < nChunks) nnpr = chunkRange[nn];
 #pragma unroll
@@ -298,7 +323,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
             const int wv = threadIdx.x >> 6;
             const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
             const double s = rowSum<8, PL>(prod, ea, len);
-            bufStoreF64(rOut, row * 8u, s * sc);                             // dropped past the last row
+            bufStoreF64nt(rOut, row * 8u, s * sc);                             // dropped past the last row
         }
         __syncthreads();
         if (!hasNext) break;
@@ -313,7 +338,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                                      const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
                                                      double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done,
-                                                     int chunkBegin, int nChunks, int xcdAware) {
+                                                     ChunkSched sched, int nChunks, int xcdAware) {
     if (done && *done) return;
     constexpr int PL = BS * NV;
     __shared__ double prod[4 * PL];
@@ -323,16 +348,16 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                  rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(MODE == 0 ? xin : add, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8);
-    const ChunkWalk W(xcdAware);
+    const ChunkWalk W(xcdAware, sched);
     int it = 0;
-    int chunk = chunkBegin + W.at(0);
+    int chunk = W.at(0);
     if (chunk >= nChunks) { if (MODE == 0 && threadIdx.x == 0) partial[blockIdx.x] = 0.; return; }
     double dacc = 0.;
     int2 pr = chunkRange[chunk];
     Stream4<NV> cur, nxt;
     loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
-    int nchunk = chunkBegin + W.at(1);
+    int nchunk = W.at(1);
     int2 npr = {0, 0};
     if (nchunk < nChunks) npr = chunkRange[nchunk];
     while (true) {
@@ -346,14 +371,14 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         for (int w = 0; w < NV; ++w) {
             if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufLoadF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
+            for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
         }
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
             loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
-        const int nn = chunkBegin + W.at(it + 2);
+        const int nn = W.at(it + 2);
         int2 nnpr = {0, 0};
         if (nn < nChunks) nnpr = chunkRange[nn];
 #pragma unroll
@@ -373,7 +398,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             double y;
             if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
             else y = -s + e0;
-            bufStoreF64(rOut, row * 8u, y);
+            bufStoreF64nt(rOut, row * 8u, y);
         }
         __syncthreads();    // protects the LDS reuse
         if (!hasNext) break;

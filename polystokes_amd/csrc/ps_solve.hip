@@ -47,6 +47,12 @@ struct Launch {
         else { if (M.packed) PS_LAUNCH_S(1, true); else PS_LAUNCH_S(1, false); }
 #undef PS_LAUNCH_S
     }
+    static ChunkSched sched(const ps::DevCSR& M, unsigned grid) {
+        ChunkSched s;
+        s.list = (M.schedOk && grid >= 8 && grid % 8 == 0) ? M.sched.p : nullptr;
+        for (int q = 0; q < 9; ++q) s.off[q] = M.schedOff[q];
+        return s;
+    }
     int pipeGrid;   // 0: one-shot kernels; >0: persistent software-pipelined kernels with this many blocks
     int xcdAware;   // pipelined kernels: runs of this many chunks are dealt to the XCDs round robin (ChunkWalk); 0 = plain walk
     void spmvS(int mode, const double* x, double* out) const {
@@ -57,7 +63,7 @@ struct Launch {
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware)), bl(BS);
 #define PS_LAUNCH_SP(MODE_, NV_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, 0, nChunks, xcdAware)
+                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, sched(M, gr.x), nChunks, xcdAware)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP(0, 1); else PS_LAUNCH_SP(1, 1); }
             else { if (mode == 0) PS_LAUNCH_SP(0, 2); else PS_LAUNCH_SP(1, 2); }
 #undef PS_LAUNCH_SP
@@ -99,7 +105,7 @@ struct Launch {
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware)), bl(BS);
 #define PS_LAUNCH_TP(MODE_, NV_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, 0, nChunks, xcdAware)
+                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP(0, 1); else PS_LAUNCH_TP(1, 1); }
             else { if (mode == 0) PS_LAUNCH_TP(0, 2); else PS_LAUNCH_TP(1, 2); }
 #undef PS_LAUNCH_TP
