@@ -40,16 +40,31 @@ def _cpu_share():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw):
-    """CPU restatement (oracle, kind "port") timed on this host's cores on a bounded sample: the same scene at 64^3.
-    value = setup (single thread, the restatement is literal) + CG iterations with every row loop of the operator and
-    of the vector updates split over OpenMP threads (oracle/ps_oracle_mt.cpp), scaled to the metric's unit (ms/step at
-    the benchmark size) by cell count (setup) and by DOFs x the GPU run's iteration count (solve).  The single-thread
-    timings of the reference-shaped and of the fused operator are kept alongside."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw, sample_res=128):
+    """CPU restatement (oracle, kind "port") timed on this host's cores on a bounded sample: the same scene at 128^3
+    (5.9 M DOFs; the operator's matrices alone are > 2 GB, far beyond the last-level cache).  Three timings of the CG
+    iteration (pcg.h:311-335 around ApplyPressureStressMatrix.h:102-179), >= 10 iterations each:
+      A  "reference-shaped": the reference's own pass structure — the three bodies of applyMatrixVectorProducts under
+         `omp parallel sections` (so 3 threads at most, McInv*G and McInv*Dt re-formed on every call), Eigen-style
+         single-thread vector updates (BASELINE.md section 2, baseline A);
+      B  "fair": one pass per block, every row loop split over all OpenMP threads of this process' CPU share;
+      and A on one thread.
+    value = setup (single thread: the restatement is literal) scaled by cell count + B's iteration time scaled by the DOF
+    ratio x the GPU run's iteration count: ms/step at the benchmark size, with the best CPU variant."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before libgomp starts: spinning workers starve a shared host
     from oracle import ps_oracle
     from polystokes_amd import scenes
-    ns = 64
+    ns = sample_res
     sc, p = scenes.cavity(ns, **params_kw)
     o = ps_oracle.Oracle()
     t0 = time.time()
@@ -57,21 +72,52 @@ def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw):
     setup_ms = (time.time() - t0) * 1e3
     n_s = o.nP + o.nT
     cores = _cpu_share()
-    ms_it = o.time_cg(6, fair=False)
-    ms_it_fair = o.time_cg(6, fair=True)
-    ms_it_mt, used = o.time_cg_mt(20, cores)
+    iters = 10
+    ms_it_a, used_a = o.time_cg_sections(iters)
+    ms_it_1t = o.time_cg(iters, fair=False)
+    ms_it_b, used_b = o.time_cg_mt(iters, cores)
     scale_cells = n_gpu_cells / float(ns ** 3)
-    est = setup_ms * scale_cells + ms_it_mt * (gpu_n / float(n_s)) * max(gpu_iters, 1)
-    est_1t = setup_ms * scale_cells + ms_it * (gpu_n / float(n_s)) * max(gpu_iters, 1)
+    dof_ratio = gpu_n / float(n_s)
+    est = lambda ms_it: setup_ms * scale_cells + ms_it * dof_ratio * max(gpu_iters, 1)
     return {
-        "value": est, "unit": "ms/step", "cores": used, "kind": "port",
-        "sample": ("oracle (C++ restatement of ApplyPressureStressMatrix + pcg_external_matrix_A) on the same cavity scene at 64^3, n=%d: "
-                   "setup %.0f ms (1 thread); per CG iteration %.2f ms with %d OpenMP threads (fused operator), %.1f ms single-thread "
-                   "reference-shaped, %.1f ms single-thread fused; scaled to 256^3 by cell count (setup) and by DOFs x the GPU run's "
-                   "iteration count (solve)" % (n_s, setup_ms, ms_it_mt, used, ms_it, ms_it_fair)),
-        "sample_setup_ms": setup_ms, "sample_ms_per_cg_iter_mt": ms_it_mt, "sample_ms_per_cg_iter": ms_it,
-        "sample_ms_per_cg_iter_fused": ms_it_fair, "sample_dofs": n_s, "value_single_thread_reference_shaped": est_1t,
+        "value": est(min(ms_it_b, ms_it_a)), "unit": "ms/step", "cores": used_b if ms_it_b <= ms_it_a else used_a, "kind": "port",
+        "cpu_model": _cpu_model(), "nproc": os.cpu_count(), "cpu_share": cores,
+        "sample": ("oracle (C++ restatement of ApplyPressureStressMatrix + pcg_external_matrix_A) on the same cavity scene at %d^3 "
+                   "(n = %d DOFs, DRAM-resident): setup %.0f ms (1 thread); per CG iteration over %d iterations: baseline A "
+                   "(reference-shaped, 3 omp sections, per-call McInv*G) %.1f ms on %d threads and %.1f ms on 1 thread; baseline B "
+                   "(fair CSR passes, OpenMP rows) %.1f ms on %d threads; scaled to the benchmark size by cell count (setup) and by "
+                   "the DOF ratio %.2f x the GPU run's %d iterations (solve)" % (ns, n_s, setup_ms, iters, ms_it_a, used_a, ms_it_1t, ms_it_b, used_b, dof_ratio, gpu_iters)),
+        "sample_res": ns, "sample_dofs": n_s, "sample_setup_ms": setup_ms, "sample_iterations_timed": iters,
+        "baseline_A_reference_shaped": {"ms_per_cg_iter": ms_it_a, "threads": used_a, "ms_per_cg_iter_1_thread": ms_it_1t, "value_ms_per_step": est(ms_it_a)},
+        "baseline_B_fair_openmp": {"ms_per_cg_iter": ms_it_b, "threads": used_b, "value_ms_per_step": est(ms_it_b)},
     }
+
+
+def _latest_traffic():
+    """Newest committed PMC summary (profiles/rNN_pmc_traffic.json, written by scripts/profile_round.sh).  The counters
+    cannot be collected inside this process: traffic is a pointer to that measurement, and says which."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d.get("k_spmv_St", {}).get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def _spawn(args):
+    """`bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run BEFORE this process touches the
+    GPU (no exec of a process that has initialised HIP), wait, return their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -79,50 +125,78 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--res", dest="n", type=int, default=256, help="grid resolution per axis (default 256)")
+    ap.add_argument("--res", dest="n", type=int, default=0, help="grid resolution per axis (default 256; 512 with --scaling strong)")
+    ap.add_argument("--scene", choices=["cavity", "coil", "spheres"], default=None, help="default: cavity (config 3); coil with --scaling strong (config 4)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = the n x n x (n N) cavity, one n-layer slab per GPU (default); strong = one n^3 scene cut into N slabs "
+                         "(BASELINE config 4: --scaling strong --scene coil --res 512; config 5: --scene spheres --res 256)")
     ap.add_argument("--precond", choices=["jacobi", "identity"], default="jacobi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-res", type=int, default=128)
     ap.add_argument("--maxit", type=int, default=0, help="cap on solver iterations (profiling runs only; 0 = node default 5000)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
     import polystokes_amd
     from polystokes_amd import _abi as abi
     from polystokes_amd import scenes
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
+        # torch.distributed is the launcher's rendezvous only: gloo (CPU) carries the RCCL unique id, the barrier and the
+        # max-over-ranks of the wall time.  The data path is the library's own RCCL communicator (dlopen'ed librccl, the copy
+        # torch has already mapped); torch's NCCL backend is never initialised, so one RCCL instance owns the device.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
 
-    n = args.n
-    kw = dict(tile=16, pad=2, precond=abi.PRE_DIAGONAL if args.precond == "jacobi" else abi.PRE_IDENTITY)
+    strong = args.scaling == "strong"
+    scene_name = args.scene or ("coil" if strong else "cavity")
+    n = args.n or (512 if strong else 256)
+    pre = abi.PRE_DIAGONAL if args.precond == "jacobi" else abi.PRE_IDENTITY
+    kw = dict(tile=16, pad=2, precond=pre)
     solver = polystokes_amd.Solver(local_rank)
+    slab = None
     if world == 1:
-        sc, p = scenes.cavity(n, **kw)
-        slab = None
+        if scene_name == "cavity":
+            sc, p = scenes.cavity(n, **kw)
+        else:
+            sc, p = getattr(scenes, scene_name)(n, tile=16, pad=2)
+            p.preconditioner = pre
+        grid = [n, n, n]
+    elif strong:
+        # strong scaling: ONE n^3 scene cut into `world` z-slabs at multiples of 16 (tile-aligned); every rank generates
+        # only its own layers (+ one halo block per interior side)
+        sc, p, slab = scenes.scene_slab(scene_name, n, world, rank, **kw)
+        grid = [n, n, n]
     else:
+        if scene_name != "cavity":
+            raise SystemExit("weak scaling is defined for the cavity scene; use --scaling strong for %s" % scene_name)
         # weak scaling: the n x n x (n*world) cavity cut into z-slabs of n layers, one per GPU, coupled through the
         # one-layer halo exchange + scalar all-reduces over RCCL
         sc, p, slab = scenes.cavity_slab(n, world, rank, **kw)
+        grid = [n, n, n * world]
     if args.maxit > 0:
         p.maxSolverIterations = args.maxit   # the BiCGStab fallback then runs too: use for kernel profiling only
     solver.upload(sc, p)           # host -> HBM, outside the timed region
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             uid.copy_(torch.tensor(list(polystokes_amd.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         solver.set_slab(slab)
-        solver.comm_init(bytes(uid.cpu().tolist()), rank, world)
+        solver.comm_init(bytes(uid.tolist()), rank, world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -140,7 +214,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
@@ -149,8 +223,8 @@ def main():
     iters = int(st.solveData[1])
     solve_ms = float(st.stage_ms[8])
     nsys = solver.nP + solver.nT
-    if dist is not None:   # whole-job DOF count (owned DOFs only would need the owned range; local systems include the halo)
-        t = torch.tensor([float(nsys)], dtype=torch.float64, device="cuda")
+    if dist is not None:   # local systems include the halo DOFs: an upper bound of the whole-job DOF count
+        t = torch.tensor([float(nsys)], dtype=torch.float64)
         dist.all_reduce(t)
         nsys_total = int(t.item())
     else:
@@ -158,62 +232,74 @@ def main():
 
     # roofline of the dominant kernels, measured live with HIP events on the solver stream
     coded = bool(solver.array("valuesCoded")[0])
+    c16 = int(solver.array("columns16")[0]) == 3
     kern = {}
-    names = ["spmv_St", "spmv_S", "apply", "tiles", "cg_update_r", "cg_update_xp"] + (["spmv_St_fp64", "spmv_S_fp64"] if coded else [])
+    names = ["spmv_St", "spmv_S", "apply", "tiles", "cg_update_r", "cg_update_xp"]
+    if coded and c16:
+        names += ["spmv_St_fp64", "spmv_S_fp64"]     # the pipelined kernels on fp64 values (10 B/nnz): the non-dyadic-weights fallback
+    names += ["spmv_St_csr", "spmv_S_csr"]            # the one-shot kernels on the plain CSR (12 B/nnz): the last-resort fallback
+    # the five kernels of a CG iteration are timed IN SEQUENCE ("seq:": the loop's predecessor kernel runs, untimed, before
+    # every timed launch: what rocprof sees in a real solve); "replayed_ms" is the same kernel launched back to back
+    in_loop = ("spmv_St", "spmv_S", "tiles", "cg_update_r", "cg_update_xp")
     for name in names:
-        ms, by = solver.bench_kernel(name, 20)
+        ms, by = solver.bench_kernel(("seq:" + name) if name in in_loop else name, 20)
         kern[name] = {"ms": ms, "algorithmic_bytes": by, "GBps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                       "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0}
+        if name in in_loop:
+            kern[name]["replayed_ms"] = solver.bench_kernel(name, 20)[0]
     dom = "spmv_St"
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tp) and n == 256 and world == 1:
-        try:
-            traffic = json.load(open(tp)).get("k_spmv_St", {}).get("traffic_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = _latest_traffic() if (n == 256 and world == 1 and scene_name == "cavity") else (None, None)
     # achieved = the bytes the production kernel has to move per launch (its stored matrix format + the vectors, each once)
     # / its launch duration: the HBM utilisation of the kernel as it runs.  The production kernel streams a lossless 3 B/nnz
     # encoding of the matrix, so this is FEWER bytes than SURVEY section 8(d)'s CSR figure (12 B/nnz + row pointers +
     # vectors); that figure over the same launch duration is reported beside it ("csr_equivalent": it can exceed the
-    # HBM peak, which only says the kernel beats a CSR SpMV running at the roofline), and so is the kernel variant that
-    # really streams the fp64 CSR values ("spmv_St_fp64").
+    # HBM peak, which only says the kernel beats a CSR SpMV running at the roofline).  Every fraction in "other_kernels" is
+    # that kernel's OWN stored bytes over its OWN measured duration (the fallbacks are timed as themselves).
     ms = kern[dom]["ms"]
-    csr = kern[dom + "_fp64"]["algorithmic_bytes"] if coded else kern[dom]["algorithmic_bytes"]
+    csr = kern[dom + "_csr"]["algorithmic_bytes"]
     csr_gbps = csr / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    c16 = int(solver.array("columns16")[0]) == 3
     roofline = {
-        "bound": "hbm", "kernel": "k_spmv_St_pipe<0,%s>" % ("compressed stream" if (coded and c16) else ("int8-coded values" if coded else "fp64 values")),
-        "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
+        "bound": "hbm", "kernel": "k_spmv_St_pipe<0,2,%s>" % ("false" if coded else "true") if c16 else "k_spmv_St<0,6,%s>" % ("true" if coded else "false"),
+        "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
+        "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_ms": ms,
         "algorithmic_bytes_definition": ("stored format: 3*nnz (16-bit windowed column + int8 value code) + 1*rows (row length) + 72 B per 256-row chunk "
                                          "+ 8*rows (y) + 8*cols (x once) + 16*rows (fused -1/2 uInv x epilogue)") if (coded and c16) else
-                                        "CSR: (12 | 5)*nnz + 4*(rows+1) + 8*rows (y) + 8*cols (x once) + 16*rows (fused epilogue)",
+                                        "CSR: (12 | 10 | 5)*nnz + 4*(rows+1) + 8*rows (y) + 8*cols (x once) + 16*rows (fused epilogue)",
         "value_format": ("16-bit windowed col + int8 value code (3 B/nnz, lossless)" if c16 else "int32 col + int8 value code (5 B/nnz, lossless)") if coded
-                        else "int32 col + fp64 value (12 B/nnz)",
-        "csr_equivalent": {"bytes_per_launch": csr, "GBps": csr_gbps, "frac": csr_gbps / HBM_PEAK_GBS,
-                           "definition": "SURVEY 8(d): 12*nnz + 4*(rows+1) + 8*rows + 8*cols + 16*rows, over the production kernel's launch duration"},
+                        else ("16-bit windowed col + fp64 value (10 B/nnz)" if c16 else "int32 col + fp64 value (12 B/nnz)"),
+        "csr_equivalent": {"bytes_per_launch": csr, "GBps": csr_gbps, "frac_of_peak_if_it_moved_them": csr_gbps / HBM_PEAK_GBS,
+                           "definition": "SURVEY 8(d): 12*nnz + 4*(rows+1) + 8*rows + 8*cols + 16*rows, over the production kernel's launch duration (not bytes it moves)"},
         "other_kernels": {k: v for k, v in kern.items() if k != dom},
     }
 
+    par = "1 GPU" if world == 1 else ("%d z-slabs of one %d^3 scene (strong), RCCL halo exchange + all-reduce" % (world, n) if strong
+                                       else "%d z-slabs, one %d-layer slab per GPU (weak), RCCL halo exchange + all-reduce" % (world, n))
+    workload = {"cavity": "synthetic lid-driven cavity", "coil": "synthetic coiling column (honey_coil stand-in)", "spheres": "pool with 8 moving solid spheres (armadillos stand-in)"}[scene_name]
     out = {
         "metric": "Stokes-solve wall ms/step (assembly+PCG) on 256^3 grid; CG iters/sec",
         "value": ms_per_step, "unit": "ms/step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "synthetic lid-driven cavity %d^3, reduced tiles (tile=16, pad=2), %s-PCG, tol 1e-3" % (n, args.precond),
-                   "grid": [n, n, n * world], "parallelism": "1 GPU" if world == 1 else "%d z-slabs, RCCL halo exchange + all-reduce" % world},
+        "config": {"workload": "%s %dx%dx%d, reduced tiles (tile=16, pad=2), %s-PCG, tol 1e-3" % (workload, grid[0], grid[1], grid[2], args.precond),
+                   "grid": grid, "parallelism": par},
         "cg_iterations": iters, "cg_iters_per_s": iters / (solve_ms * 1e-3) if solve_ms > 0 else 0.0,
         "system_dofs": nsys_total, "dof_iterations_per_s": nsys_total * iters / (solve_ms * 1e-3) if solve_ms > 0 else 0.0, "active_faces": solver.nA, "regions": solver.nRegions, "result": int(st.result),
         "stage_ms": {abi.STAGE_NAMES[i]: float(st.stage_ms[i]) for i in range(len(abi.STAGE_NAMES))},
         "roofline": roofline,
     }
+    if world == 1:
+        # the boundary as the Houdini shim uses it: host fp32 fields in, velocity / valid fields out (polystokes_step)
+        t0 = time.perf_counter()
+        solver.step(sc, p)
+        out["pcie_inclusive_ms"] = (time.perf_counter() - t0) * 1e3
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n ** 3, nsys, iters, dict(tile=16, pad=2, precond=kw["precond"]))
+        out["cpu_baseline"] = cpu_baseline(n ** 3, nsys, iters, dict(tile=16, pad=2, precond=kw["precond"]), args.cpu_sample_res)
     if rank == 0:
         print(json.dumps(out))
     solver.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

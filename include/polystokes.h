@@ -220,11 +220,19 @@ typedef struct ps_slab {
 int32_t ps_set_slab(ps_context* ctx, const ps_slab* slab);            /* after ps_upload_fields, before setup */
 
 /* One process per GPU: RCCL communicator on the solver stream.  Rank 0 calls ps_comm_unique_id and hands the
- * 128 bytes to the other ranks (bench.py broadcasts them with torch.distributed); every rank then calls
- * ps_comm_init_rccl.  ps_step_device / ps_setup_device / ps_solve_device then run the distributed solve. */
+ * 128 bytes to the other ranks (bench.py broadcasts them over gloo); every rank then calls ps_comm_init_rccl.
+ * ps_step_device then runs the distributed step; ps_setup_device / ps_solve_device / polystokes_step refuse a
+ * context with a slab (a rank's local system is only a fragment).  The communicator is destroyed with the context.
+ * An interrupt callback (ps_set_interrupt) on ANY rank stops all ranks at the same CG batch (PS_INCOMPLETE); a rank
+ * whose setup fails makes every rank return PS_FAILED instead of leaving its neighbours waiting. */
 int32_t ps_comm_unique_id(void* id128);
 int32_t ps_comm_init_rccl(ps_context* ctx, const void* id128, int32_t rank, int32_t world);
 int32_t ps_comm_selftest(ps_context* ctx);   /* all-reduce + grouped send/recv on the communicator */
+/* Host-staged transport instead of RCCL (pack -> D2H -> TCP -> H2D -> unpack; scalar all-reduce through rank 0):
+ * one process per rank, several ranks may share one GPU (RCCL refuses duplicate devices) — the route by which the
+ * real multi-process path runs on a single-GPU box, and the fallback where librccl is missing.  Rank r listens on
+ * base_port + r of `host` (dotted IPv4).  Collective over the `world` ranks. */
+int32_t ps_comm_init_tcp(ps_context* ctx, int32_t rank, int32_t world, const char* host, int32_t base_port);
 
 /* Several ranks inside ONE process on one GPU (device-to-device copies instead of RCCL): used to test the
  * distributed algorithm on a single-GPU box.  Same kernels, same exchange lists, same reduction order. */

@@ -114,7 +114,7 @@ struct Oracle {
     CSR Gt, D;  // explicit transposes (ApplyPressureStressMatrix.h:42-45)
     CSR A;      // explicit operator (AssembleSystem.cpp:351-430), optional
     std::vector<double> diagA; // Jacobi extension
-    std::vector<double> b, solution, recovered;
+    std::vector<double> b, solution, recovered, guess;
     Field<float> velOut[3], valid[3];
 
     ps_stats stats;
@@ -153,6 +153,12 @@ struct Oracle {
 
     // operator
     void applyOperator(const double* x, double* y) const;        // reference-shaped (ApplyPressureStressMatrix.h:102-179)
+    void constructGuessVectors();                                 // Solver.cpp:512-531
+    void applySection1(const double* x, std::vector<double>& A11_1, std::vector<double>& A21_1) const;
+    void applySection2(const double* x, std::vector<double>& tp, std::vector<double>& tt) const;
+    void applySection3(const double* x, std::vector<double>& A12_1, std::vector<double>& A22_1) const;
+    void applyCombine(const double* x, const std::vector<double>& A11_1, const std::vector<double>& A21_1, const std::vector<double>& tp,
+                      const std::vector<double>& tt, const std::vector<double>& A12_1, const std::vector<double>& A22_1, double* y) const;
     void applyOperatorFair(const double* x, double* y) const;    // same math, fused passes ("fair CPU")
     int pcg(std::vector<double>& x, const std::vector<double>& rhs, double tol, int maxit, double& rre) const;
     int bicgstab(std::vector<double>& x, const std::vector<double>& rhs, double tol, int maxit, double& rre) const;

@@ -46,6 +46,8 @@ def lib():
         L.po_time_cg_iterations.restype = C.c_double
         L.po_time_cg_iterations_mt.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         L.po_time_cg_iterations_mt.restype = C.c_double
+        L.po_time_cg_iterations_sections.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.po_time_cg_iterations_sections.restype = C.c_double
         L.po_last_error.argtypes = [C.c_void_p]
         L.po_last_error.restype = C.c_char_p
         L.po_basis.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -134,6 +136,12 @@ class Oracle:
 
     def time_cg(self, iters, fair=False):
         return self.L.po_time_cg_iterations(self.h, iters, 1 if fair else 0)
+
+    def time_cg_sections(self, iters):
+        """(ms per CG iteration, threads used) of the reference-shaped apply under its three `omp sections` (baseline A)"""
+        used = C.c_int32(0)
+        ms = self.L.po_time_cg_iterations_sections(self.h, iters, C.byref(used))
+        return ms, int(used.value)
 
     def time_cg_mt(self, iters, threads=0):
         """(ms per CG iteration, threads used) of the OpenMP 'fair CPU' baseline; threads=0: OpenMP default."""

@@ -91,3 +91,49 @@ extern "C" double po_time_cg_iterations_mt(void* h, int32_t iters, int32_t threa
     const auto w1 = std::chrono::high_resolution_clock::now();
     return std::chrono::duration<double, std::milli>(w1 - w0).count() / (double)iters;
 }
+
+// BASELINE.md section 2 "baseline A": the reference's own pass structure — applyMatrixVectorProducts with its three bodies
+// under `#pragma omp parallel sections` (ApplyPressureStressMatrix.h:122-164, so at most 3 threads work inside an apply,
+// and McInv*G / McInv*Dt are re-formed on every call) and the vector part of pcg_external_matrix_A as Eigen runs it
+// (expression per line, single thread, pcg.h:311-335).  Returns ms per CG iteration.
+extern "C" double po_time_cg_iterations_sections(void* h, int32_t iters, int32_t* threads_used) {
+    using namespace psoracle;
+    Oracle* o = (Oracle*)h;
+    const int64_t n = o->nPressures + o->nStresses;
+    omp_set_num_threads(3);
+    int used = 1;
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+    }
+    if (threads_used) *threads_used = used;
+    std::vector<double> x((size_t)n, 0.), r = o->b, p = o->b, Ap((size_t)n);
+    auto dot = [&](const std::vector<double>& a, const std::vector<double>& b) { double s = 0; for (int64_t i = 0; i < n; ++i) s += a[(size_t)i] * b[(size_t)i]; return s; };
+    double rsold = dot(r, r);
+    const auto w0 = std::chrono::high_resolution_clock::now();
+    for (int it = 0; it < iters; ++it) {
+        std::vector<double> A11_1, A21_1, tp, tt, A12_1, A22_1;
+#pragma omp parallel sections
+        {
+#pragma omp section
+            o->applySection1(p.data(), A11_1, A21_1);
+#pragma omp section
+            o->applySection2(p.data(), tp, tt);
+#pragma omp section
+            o->applySection3(p.data(), A12_1, A22_1);
+        }
+        o->applyCombine(p.data(), A11_1, A21_1, tp, tt, A12_1, A22_1, Ap.data());
+        const double alpha = rsold / dot(p, Ap);
+        for (int64_t i = 0; i < n; ++i) x[(size_t)i] = x[(size_t)i] + alpha * p[(size_t)i];
+        for (int64_t i = 0; i < n; ++i) r[(size_t)i] = r[(size_t)i] - alpha * Ap[(size_t)i];
+        const double rsnew = dot(r, r);
+        const double xmag = dot(x, x);
+        (void)xmag;
+        const double beta = rsnew / rsold;
+        for (int64_t i = 0; i < n; ++i) p[(size_t)i] = r[(size_t)i] + beta * p[(size_t)i];
+        rsold = rsnew;
+    }
+    const auto w1 = std::chrono::high_resolution_clock::now();
+    return std::chrono::duration<double, std::milli>(w1 - w0).count() / (double)iters;
+}

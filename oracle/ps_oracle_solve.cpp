@@ -22,12 +22,13 @@ static double dot(const std::vector<double>& a, const std::vector<double>& b) {
 // ApplyPressureStressMatrix::applyMatrixVectorProducts, lib/include/ApplyPressureStressMatrix.h:102-179,
 // with manualMatrixTransposeVectorDistribute2 (lib/include/util.h:203-230).  Same pass structure,
 // including the per-call McInv*G / McInv*Dt products (:126,:156) and by-value temporaries.
-void Oracle::applyOperator(const double* x, double* y) const {
-    const int64_t nP = nPressures, nT = nStresses, nA = nActiveVs, nR = nReducedVs;
+// The three `omp section` bodies of applyMatrixVectorProducts (:122-164), one function each so that the single-thread
+// parity path below and the timing harness (ps_oracle_mt.cpp: the same three bodies under `#pragma omp parallel sections`,
+// BASELINE.md section 2 "baseline A") run the same code.
+void Oracle::applySection1(const double* x, std::vector<double>& A11_1, std::vector<double>& A21_1) const {   // :124-134
+    const int64_t nP = nPressures, nT = nStresses, nA = nActiveVs;
     const double* x_ps = x;
-    const double* x_ts = x + nP;
-    // section 1 (:124-134)
-    std::vector<double> McInv_G_val(G.val.size());
+    std::vector<double> McInv_G_val(G.val.size());   // SparseMatrix McInv_G = McInv_Matrix * G_Matrix, formed on EVERY call (:126)
     for (int64_t f = 0; f < nA; ++f)
         for (int64_t p = G.ptr[(size_t)f]; p < G.ptr[(size_t)f + 1]; ++p) McInv_G_val[(size_t)p] = McInv[(size_t)f] * G.val[(size_t)p];
     std::vector<double> McInv_G_xps((size_t)nA);
@@ -36,12 +37,16 @@ void Oracle::applyOperator(const double* x, double* y) const {
         for (int64_t p = G.ptr[(size_t)f]; p < G.ptr[(size_t)f + 1]; ++p) s += McInv_G_val[(size_t)p] * x_ps[G.col[(size_t)p]];
         McInv_G_xps[(size_t)f] = s;
     }
-    std::vector<double> A11_1((size_t)nP), A21_1((size_t)nT);
+    A11_1.assign((size_t)nP, 0.); A21_1.assign((size_t)nT, 0.);
     Gt.mul(McInv_G_xps.data(), A11_1.data());
     for (auto& v : A11_1) v = -dt * v;
     D.mul(McInv_G_xps.data(), A21_1.data());
     for (auto& v : A21_1) v = -dt * v;
-    // section 2 (:136-152)
+}
+void Oracle::applySection2(const double* x, std::vector<double>& tp, std::vector<double>& tt) const {   // :136-152
+    const int64_t nP = nPressures, nR = nReducedVs;
+    const double* x_ps = x;
+    const double* x_ts = x + nP;
     std::vector<double> BInv_JDt_xts((size_t)nR), BInv_JG_xps((size_t)nR), tmp((size_t)nR);
     auto binvMul = [&](const std::vector<double>& in, std::vector<double>& out) {
         for (int64_t r = 0; r < regionCount; ++r)
@@ -68,11 +73,13 @@ void Oracle::applyOperator(const double* x, double* y) const {
             }
         for (auto& v : out) v = -v;
     };
-    std::vector<double> tp, tt;
     distribute2(JG, tp);    // A11_2 = head, A12_2 = tail
     distribute2(JDt, tt);   // A21_2 = head, A22_2 = tail
-    // section 3 (:154-162)
-    std::vector<double> McInv_Dt_val(Dt.val.size());
+}
+void Oracle::applySection3(const double* x, std::vector<double>& A12_1, std::vector<double>& A22_1) const {   // :154-162
+    const int64_t nP = nPressures, nT = nStresses, nA = nActiveVs;
+    const double* x_ts = x + nP;
+    std::vector<double> McInv_Dt_val(Dt.val.size());   // SparseMatrix McInv_Dt = McInv_Matrix * Dt_Matrix, per call (:156)
     for (int64_t f = 0; f < nA; ++f)
         for (int64_t p = Dt.ptr[(size_t)f]; p < Dt.ptr[(size_t)f + 1]; ++p) McInv_Dt_val[(size_t)p] = McInv[(size_t)f] * Dt.val[(size_t)p];
     std::vector<double> McInv_Dt_xts((size_t)nA);
@@ -81,12 +88,16 @@ void Oracle::applyOperator(const double* x, double* y) const {
         for (int64_t p = Dt.ptr[(size_t)f]; p < Dt.ptr[(size_t)f + 1]; ++p) s += McInv_Dt_val[(size_t)p] * x_ts[Dt.col[(size_t)p]];
         McInv_Dt_xts[(size_t)f] = s;
     }
-    std::vector<double> A12_1((size_t)nP), A22_1((size_t)nT);
+    A12_1.assign((size_t)nP, 0.); A22_1.assign((size_t)nT, 0.);
     Gt.mul(McInv_Dt_xts.data(), A12_1.data());
     for (auto& v : A12_1) v = -dt * v;
     D.mul(McInv_Dt_xts.data(), A22_1.data());
     for (auto& v : A22_1) v = -dt * v;
-    // combine (:166-176)
+}
+void Oracle::applyCombine(const double* x, const std::vector<double>& A11_1, const std::vector<double>& A21_1, const std::vector<double>& tp,
+                          const std::vector<double>& tt, const std::vector<double>& A12_1, const std::vector<double>& A22_1, double* y) const {   // :166-176
+    const int64_t nP = nPressures, nT = nStresses;
+    const double* x_ts = x + nP;
     for (int64_t i = 0; i < nP; ++i) {
         const double A11 = A11_1[(size_t)i] + tp[(size_t)i];
         const double A12 = A12_1[(size_t)i] + tp[(size_t)(i + nP)];
@@ -98,6 +109,13 @@ void Oracle::applyOperator(const double* x, double* y) const {
         const double A22 = A22_1[(size_t)i] + tt[(size_t)(i + nT)] + A22_3;
         y[nP + i] = A21 + A22;
     }
+}
+void Oracle::applyOperator(const double* x, double* y) const {
+    std::vector<double> A11_1, A21_1, tp, tt, A12_1, A22_1;
+    applySection1(x, A11_1, A21_1);
+    applySection2(x, tp, tt);
+    applySection3(x, A12_1, A22_1);
+    applyCombine(x, A11_1, A21_1, tp, tt, A12_1, A22_1, y);
 }
 
 // "Fair CPU" variant of the same operator (BASELINE.md §2 baseline B): t = McInv [G Dt] x once,
@@ -231,6 +249,25 @@ int Oracle::eigenCG(std::vector<double>& x, const std::vector<double>& rhs, doub
     return i;
 }
 
+// initializeGuessVectors / constructGuessVectors (Solver.cpp:512-531) and the guessVector every assemble*() fills
+// (AssembleSystem.cpp:421-427, 461-467): [pressureGuess; stressGuess].  Only solveEigenCG uses it (solveWithGuess, :834);
+// the matrix-vector PCG starts from zero (:768) — but exportMatrices writes it as Vec_guess.mtx either way (:540).
+void Oracle::constructGuessVectors() {
+    const int64_t nP = nPressures, nT = nStresses;
+    guess.assign((size_t)(nP + nT), 0.);
+    if (!P.useWarmStart) return;
+    // pressureGuess = -G^T oldActiveVs - JG^T cfit ;  stressGuess = -2 uInv (-Dt^T oldActiveVs - JDt^T cfit)
+    std::vector<double> gp((size_t)nP, 0.), gt((size_t)nT, 0.);
+    G.mulT_add(oldActiveVs.data(), gp.data());
+    Dt.mulT_add(oldActiveVs.data(), gt.data());
+    if (regionCount > 0) {
+        JG.mulT_add(cfit.data(), gp.data());
+        JDt.mulT_add(cfit.data(), gt.data());
+    }
+    for (int64_t i = 0; i < nP; ++i) guess[(size_t)i] = -gp[(size_t)i];
+    for (int64_t i = 0; i < nT; ++i) guess[(size_t)(nP + i)] = -2. * uInv[(size_t)i] * (-gt[(size_t)i]);
+}
+
 // Solver.cpp:646-668, 734-812 (solveSPDwithMatrixVectorPCG) / :814-862 (solveEigenCG)
 int Oracle::solve() {
     const double tol = P.tolerance;
@@ -243,6 +280,7 @@ int Oracle::solve() {
     if (P.solverType == PS_EIGEN) {
         assembleSystemPressureStress();
         double e = 0;
+        solution = guess;   // solver.solveWithGuess(b, guessVector), :834
         solveIterations = eigenCG(solution, b, tol, maxit, e);
         solveError = e;
         result = e <= tol ? PS_SUCCESS : PS_NOCONVERGE;   // IterativeSolverBase: info = error <= tolerance
@@ -377,6 +415,8 @@ int Oracle::setup(const ps_params* p, const ps_fields_in* in) {
         COM.clear(); cfit.clear(); Mr.clear(); K.clear();
     }
     constructMatrixBlocks();
+    // HDK_PolyStokes.C:462-467: initializeGuessVectors(); if (getUseWarmStart()) constructGuessVectors();
+    constructGuessVectors();
     assembleSystemPressureStressFactored();
     if (P.preconditioner == PS_PRE_DIAGONAL) buildJacobiDiagonal();
     const auto w1 = std::chrono::high_resolution_clock::now();
@@ -433,6 +473,7 @@ void Oracle::registerArrays() {
     regv("Mc", Mc); regv("McInv", McInv); regv("uInv", uInv); regv("u", u);
     regv("activeRHSVector", activeRHS); regv("pressureRHSVector", pressureRHS); regv("stressRHSVector", stressRHS);
     regv("oldActiveVs", oldActiveVs);
+    regv("guessVector", guess);
     regv("b", b); regv("solutionVector", solution); regv("recoveredVelocity", recovered); regv("diagA", diagA);
     auto regcsr = [&](const std::string& n, const CSR& m) {
         reg(n + ".ptr", m.ptr.data(), (int64_t)m.ptr.size(), 8);

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
     "polystokes_step", "ps_apply_operator", "ps_query_array", "ps_read_array",
     "ps_export_component_matrices", "ps_export_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt", "ps_solve_exported_system",
-    "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest",
+    "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest", "ps_comm_init_tcp",
     "ps_group_create", "ps_group_destroy", "ps_group_rank", "ps_group_step",
 ]
 
@@ -86,6 +86,8 @@ def lib():
         L.ps_comm_unique_id.restype = C.c_int32
         L.ps_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.ps_comm_init_rccl.restype = C.c_int32
+        L.ps_comm_init_tcp.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]
+        L.ps_comm_init_tcp.restype = C.c_int32
         L.ps_comm_selftest.argtypes = [C.c_void_p]
         L.ps_comm_selftest.restype = C.c_int32
         L.ps_group_create.argtypes = [C.c_int32, C.c_int32]
@@ -159,6 +161,10 @@ class Solver:
     def comm_init(self, uid_bytes, rank, world):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)
         self._check(self.L.ps_comm_init_rccl(self.h, buf, rank, world))
+
+    def comm_init_tcp(self, rank, world, host="127.0.0.1", base_port=29600):
+        """host-staged transport (one process per rank, ranks may share a GPU); collective over the world"""
+        self._check(self.L.ps_comm_init_tcp(self.h, rank, world, host.encode(), base_port))
 
     def __del__(self):
         try:

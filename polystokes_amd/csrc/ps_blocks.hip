@@ -476,13 +476,28 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
     for (int u = 0; u < SL; ++u) left |= open[u];
     if (left) *fail = 1;
 }
+// the fp64 values of a matrix in the aligned chunk layout of its compressed stream (padding entries 0)
+__global__ void __launch_bounds__(BS) k_val4_build(const int32_t* __restrict__ ptr, const double* __restrict__ val, int rows,
+                                                   const int2* __restrict__ chunkRange, double* __restrict__ val4) {
+    const int chunk = blockIdx.x;
+    const int p0 = ptr[chunk * BS], n = chunkRange[chunk].y - chunkRange[chunk].x, q0 = chunkRange[chunk].x;
+    const int n4 = (n + 3) & ~3;
+    for (int i = threadIdx.x; i < n4; i += BS) val4[q0 + i] = i < n ? val[p0 + i] : 0.;
+}
 }  // namespace
-
-// Compressed SpMV stream (DevCSR::col16 ...); decided per matrix, like the value coding.  PS_COL32=1 keeps the CSR kernels.
+void ps_context::buildVal4(ps::DevCSR& M) {
+    if (!M.col16ok || M.val4.p) return;
+    M.val4.alloc((size_t)M.streamLen + 8);
+    hipLaunchKernelGGL(k_val4_build, dim3((unsigned)gridFor(M.rows, BS)), dim3(BS), 0, stream, M.ptr.p, M.val.p, (int)M.rows, M.chunkRange.p, M.val4.p);
+}
+// Compressed SpMV stream (DevCSR::col16 ...); decided per matrix.  With coded values it is 3 B per entry; when the values are
+// not code * scale (user-supplied weights, PS_FORCE_FP64_VALUES=1) the same windowed 16-bit columns go with the fp64 values
+// (10 B per entry, DevCSR::val4) and the same pipelined kernels run.  PS_COL32=1 keeps the one-shot CSR kernels.
 void ps_context::buildCol16(ps::DevCSR& M, int slot) {
     M.col16ok = false;
+    M.val4.free();
     const char* e = getenv("PS_COL32");
-    if (!M.packed || M.rows == 0 || M.nnz == 0 || (e && atoi(e) != 0)) return;
+    if (M.rows == 0 || M.nnz == 0 || (e && atoi(e) != 0)) return;
     const int nChunks = gridFor(M.rows, BS);
     DevBuf<int32_t> start4;
     start4.alloc((size_t)nChunks + 1);
@@ -502,6 +517,7 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot) {
     hipLaunchKernelGGL(k_col16_build, dim3((unsigned)nChunks), dim3(BS), 0, stream, M.ptr.p, M.col.p, M.code.p, (int)M.rows, start4.p, M.col16.p,
                        M.code4.p, M.winBase.p, M.chunkRange.p, M.len8.p, counters.p + slot);
     M.col16ok = readCounter(slot) == 0;
+    if (M.col16ok && !M.packed) buildVal4(M);
     if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] compressed stream: rows %lld nnz %lld, fullest chunk %d (nv %d), ok %d\n",
                                            (long long)M.rows, (long long)M.nnz, maxLen, M.nv, (int)M.col16ok);
 }

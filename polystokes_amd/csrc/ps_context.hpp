@@ -23,6 +23,7 @@ struct DevCSR {
     // len8 = entries per row.  nv = ceil(fullest chunk / 1024) = 4-entry groups per lane.
     DevBuf<uint16_t> col16;
     DevBuf<int8_t> code4;
+    DevBuf<double> val4;         // the fp64 values in the same aligned chunk layout (only when the values are not coded)
     DevBuf<int32_t> winBase;
     DevBuf<int2> chunkRange;
     DevBuf<uint8_t> len8;
@@ -143,6 +144,10 @@ struct ps_context {
     int64_t nLowHalo = 0, nLowOwn = 0, nUpHalo = 0, nUpOwn = 0;
     ps::DevBuf<double> sendLo, sendUp, recvLo, recvUp, redbuf;
     void* rcclComm = nullptr;                // ncclComm_t when one process per GPU
+    void* hostComm = nullptr;                // host-staged TCP transport (ps_comm_init_tcp): same algorithm without RCCL
+    uint64_t hashLowHalo = 0, hashLowOwn = 0, hashUpHalo = 0, hashUpOwn = 0;   // order-sensitive hashes of the lists' global (i, j, kind) keys
+    ps::DevBuf<ps::CGScalars> benchScal;     // scratch of ps_bench_kernel
+    ps::DevBuf<double> benchOnes, benchZeros;
     bool ownsStream = true;
     ps::DevBuf<float> ownedFace[3];          // 1 where this rank is responsible for the output face
     ps::Own own() const {
@@ -186,6 +191,7 @@ struct ps_context {
     void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
     void constructMatrixBlocks();                         // ps_blocks.hip
     void buildCol16(ps::DevCSR& M, int counterSlot);      // ps_blocks.hip
+    void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
     void buildChunkSchedule(ps::DevCSR& M, bool faceRows);
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
     void assembleSystemPressureStressFactored();          // ps_solve.hip
@@ -214,7 +220,8 @@ struct ps_context {
 
 // kernel micro-benchmark dispatch (ps_solve.hip), used by ps_bench_kernel
 void ps_bench_launch(ps_context* c, const std::string& kernel, const double* x, double* y);
-int ps_dist_step_single(ps_context* c, ps_stats* stats);   // ps_solve.hip: distributed step of one RCCL rank
+int ps_dist_step_single(ps_context* c, ps_stats* stats);   // ps_solve.hip: distributed step of one rank (RCCL or TCP transport)
+void ps_dist_release(ps_context* c);                       // ps_solve.hip: destroys the rank's communicator / sockets
 
 namespace ps {
 constexpr int FB_CHUNK = 4096;   // face-box positions per work item (per-region dense reductions)

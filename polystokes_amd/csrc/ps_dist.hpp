@@ -11,6 +11,12 @@
 //   * two-phase scalar kernels so that the all-reduce sits between "local sum" and "use".
 // =====================================================================================================
 #include <dlfcn.h>
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <poll.h>
+#include <sys/socket.h>
+#include <unistd.h>
 #include <cstring>
 #include <cstdio>
 
@@ -95,7 +101,10 @@ struct Rccl {
 Rccl& rccl() {
     static Rccl R;
     if (!R.h) {
-        R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        // a copy the process has already mapped (torch links its own) must be THE copy: two RCCLs on one device abort at exit
+        R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!R.h) R.h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!R.h) R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!R.h) R.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!R.h) throw Error(std::string("cannot load librccl: ") + dlerror());
         auto sym = [&](const char* n) { void* p = dlsym(R.h, n); if (!p) throw Error(std::string("librccl lacks ") + n); return p; };
@@ -110,13 +119,103 @@ Rccl& rccl() {
     }
     return R;
 }
+// ---- host-staged transport: TCP sockets between the ranks' processes (pack -> D2H -> socket -> H2D -> unpack) ----
+// The same distributed algorithm without RCCL: for boxes where RCCL cannot run (several ranks on one GPU: RCCL refuses
+// duplicate devices) and as the fallback when librccl is absent.  Rank r listens on port base + r; it connects to rank r-1
+// (halo exchange) and, for the scalar all-reduce, to rank 0 (star: rank 0 adds the contributions in rank order).
+struct HostComm {
+    int rank = 0, world = 1;
+    int fdListen = -1, fdLo = -1, fdUp = -1, fdRoot = -1;
+    std::vector<int> fdLeaf;            // rank 0: connection of every other rank (index = rank)
+    std::vector<double> hs0, hs1, hr0, hr1;
+    ~HostComm() {
+        for (int fd : {fdListen, fdLo, fdUp, fdRoot}) if (fd >= 0) ::close(fd);
+        for (int fd : fdLeaf) if (fd >= 0) ::close(fd);
+    }
+    static void sendAll(int fd, const void* p, size_t n) {
+        const char* b = (const char*)p;
+        while (n) { const ssize_t k = ::send(fd, b, n, MSG_NOSIGNAL); if (k <= 0) throw Error("TCP transport: send failed (peer gone?)"); b += k; n -= (size_t)k; }
+    }
+    static void recvAll(int fd, void* p, size_t n) {
+        char* b = (char*)p;
+        while (n) {
+            pollfd pf{fd, POLLIN, 0};
+            const int pr = ::poll(&pf, 1, 120000);   // a dead peer must not block this rank for ever
+            if (pr <= 0) throw Error("TCP transport: timed out waiting for a peer");
+            const ssize_t k = ::recv(fd, b, n, 0);
+            if (k <= 0) throw Error("TCP transport: receive failed (peer gone?)");
+            b += k; n -= (size_t)k;
+        }
+    }
+    static int connectTo(const char* host, int port, int rank, int kind) {
+        for (int attempt = 0; attempt < 1200; ++attempt) {   // the peer may not listen yet: retry for up to 60 s
+            const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+            if (fd < 0) throw Error("TCP transport: socket() failed");
+            sockaddr_in a{};
+            a.sin_family = AF_INET; a.sin_port = htons((uint16_t)port);
+            if (::inet_pton(AF_INET, host, &a.sin_addr) != 1) { ::close(fd); throw Error("TCP transport: bad host address (dotted IPv4 expected)"); }
+            if (::connect(fd, (sockaddr*)&a, sizeof(a)) == 0) {
+                const int one = 1;
+                ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+                const int32_t hello[2] = {rank, kind};
+                sendAll(fd, hello, sizeof(hello));
+                return fd;
+            }
+            ::close(fd);
+            ::usleep(50000);
+        }
+        throw Error("TCP transport: cannot connect to port " + std::to_string(port));
+    }
+    void init(int r, int w, const char* host, int basePort) {
+        rank = r; world = w;
+        fdLeaf.assign((size_t)w, -1);
+        fdListen = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (fdListen < 0) throw Error("TCP transport: socket() failed");
+        const int one = 1;
+        ::setsockopt(fdListen, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        sockaddr_in a{};
+        a.sin_family = AF_INET; a.sin_port = htons((uint16_t)(basePort + r)); a.sin_addr.s_addr = htonl(INADDR_ANY);
+        if (::bind(fdListen, (sockaddr*)&a, sizeof(a)) != 0 || ::listen(fdListen, w + 2) != 0)
+            throw Error("TCP transport: cannot listen on port " + std::to_string(basePort + r));
+        if (r > 0) { fdLo = connectTo(host, basePort + r - 1, r, 0); fdRoot = connectTo(host, basePort, r, 1); }
+        int expect = (r + 1 < w ? 1 : 0) + (r == 0 ? w - 1 : 0);
+        while (expect > 0) {
+            pollfd pf{fdListen, POLLIN, 0};
+            if (::poll(&pf, 1, 120000) <= 0) throw Error("TCP transport: timed out waiting for the other ranks to connect");
+            const int fd = ::accept(fdListen, nullptr, nullptr);
+            if (fd < 0) throw Error("TCP transport: accept() failed");
+            ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            int32_t hello[2];
+            recvAll(fd, hello, sizeof(hello));
+            if (hello[1] == 0 && hello[0] == r + 1 && fdUp < 0) fdUp = fd;
+            else if (hello[1] == 1 && r == 0 && hello[0] > 0 && hello[0] < w && fdLeaf[(size_t)hello[0]] < 0) fdLeaf[(size_t)hello[0]] = fd;
+            else { ::close(fd); throw Error("TCP transport: unexpected connection"); }
+            --expect;
+        }
+    }
+    // neighbour exchange, ordered so that the chain cannot deadlock: with the lower neighbour receive first, with the upper send first
+    void exchange(const double* sLo, size_t nsLo, double* rLo, size_t nrLo, const double* sUp, size_t nsUp, double* rUp, size_t nrUp) {
+        if (fdLo >= 0) { if (nrLo) recvAll(fdLo, rLo, nrLo * 8); if (nsLo) sendAll(fdLo, sLo, nsLo * 8); }
+        if (fdUp >= 0) { if (nsUp) sendAll(fdUp, sUp, nsUp * 8); if (nrUp) recvAll(fdUp, rUp, nrUp * 8); }
+    }
+    void allreduceSum(double* v, int count) {
+        if (world == 1) return;
+        if (rank > 0) { sendAll(fdRoot, v, (size_t)count * 8); recvAll(fdRoot, v, (size_t)count * 8); return; }
+        std::vector<double> t((size_t)count);
+        for (int q = 1; q < world; ++q) { recvAll(fdLeaf[(size_t)q], t.data(), (size_t)count * 8); for (int i = 0; i < count; ++i) v[i] += t[(size_t)i]; }
+        for (int q = 1; q < world; ++q) sendAll(fdLeaf[(size_t)q], v, (size_t)count * 8);
+    }
+};
+
 constexpr int NCCL_DOUBLE = 8;   // ncclFloat64
 constexpr int NCCL_SUM = 0;
 void ncclCheck(int rc, const char* what) { if (rc != 0) throw Error(std::string("RCCL failure in ") + what + " (code " + std::to_string(rc) + ")"); }
 
 struct Dist {
-    std::vector<ps_context*> R;   // the ranks living in this process (1 with RCCL, `world` for an in-process group)
-    bool useRccl = false;
+    std::vector<ps_context*> R;   // the ranks living in this process (1 with RCCL / TCP, `world` for an in-process group)
+    bool useRccl = false;         // one process per GPU, RCCL
+    bool useTcp = false;          // one process per rank, host-staged TCP (HostComm)
+    HostComm* hc() const { return (HostComm*)R[0]->hostComm; }
 
     // sizes: kind 0 = x exchange (send own layers, receive halo), kind 1 = y exchange (send halo contributions, receive for own)
     void transport(int kind) {
@@ -135,6 +234,21 @@ struct Dist {
                 if (rUp) ncclCheck(L.Recv(c->recvUp.p, (size_t)rUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "ncclRecv");
             }
             ncclCheck(L.GroupEnd(), "ncclGroupEnd");
+            return;
+        }
+        if (useTcp) {
+            ps_context* c = R[0];
+            HostComm& H = *hc();
+            const size_t sLo = (size_t)(c->slab.hasLower ? (kind == 0 ? c->nLowOwn : c->nLowHalo) : 0), sUp = (size_t)(c->slab.hasUpper ? (kind == 0 ? c->nUpOwn : c->nUpHalo) : 0);
+            const size_t rLo = (size_t)(c->slab.hasLower ? (kind == 0 ? c->nLowHalo : c->nLowOwn) : 0), rUp = (size_t)(c->slab.hasUpper ? (kind == 0 ? c->nUpHalo : c->nUpOwn) : 0);
+            H.hs0.resize(sLo + 1); H.hs1.resize(sUp + 1); H.hr0.resize(rLo + 1); H.hr1.resize(rUp + 1);
+            if (sLo) HIP_CHECK(hipMemcpyAsync(H.hs0.data(), c->sendLo.p, sLo * 8, hipMemcpyDeviceToHost, c->stream));
+            if (sUp) HIP_CHECK(hipMemcpyAsync(H.hs1.data(), c->sendUp.p, sUp * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            H.exchange(H.hs0.data(), sLo, H.hr0.data(), rLo, H.hs1.data(), sUp, H.hr1.data(), rUp);
+            if (rLo) HIP_CHECK(hipMemcpyAsync(c->recvLo.p, H.hr0.data(), rLo * 8, hipMemcpyHostToDevice, c->stream));
+            if (rUp) HIP_CHECK(hipMemcpyAsync(c->recvUp.p, H.hr1.data(), rUp * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));   // the host buffers are reused by the next exchange
             return;
         }
         for (size_t q = 0; q < R.size(); ++q) {   // in-process ranks share one stream: plain device copies
@@ -174,6 +288,16 @@ struct Dist {
             ncclCheck(rccl().AllReduce(c->redbuf.p, c->redbuf.p, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->rcclComm, c->stream), "ncclAllReduce");
             return;
         }
+        if (useTcp) {
+            ps_context* c = R[0];
+            double v[8];
+            HIP_CHECK(hipMemcpyAsync(v, c->redbuf.p, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            hc()->allreduceSum(v, count);
+            HIP_CHECK(hipMemcpyAsync(c->redbuf.p, v, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            return;
+        }
         if (R.size() == 1) return;
         SumPtrs P;
         P.n = (int)R.size();
@@ -182,30 +306,51 @@ struct Dist {
     }
     void syncAll() { for (ps_context* c : R) HIP_CHECK(hipStreamSynchronize(c->stream)); }
 
-    // neighbours must agree on the exchange list lengths (same labels on both sides of a cut)
+    // a flag summed over all ranks (setup failures, interrupts): every rank learns that some rank wants to stop
+    double sumFlag(double mine) {
+        for (ps_context* c : R) HIP_CHECK(hipMemcpyAsync(c->redbuf.p, &mine, 8, hipMemcpyHostToDevice, c->stream));
+        if (!useRccl && !useTcp) return mine * (double)R.size();   // in-process ranks: the caller already knows
+        allreduce(1);
+        double out = 0.;
+        HIP_CHECK(hipMemcpyAsync(&out, R[0]->redbuf.p, 8, hipMemcpyDeviceToHost, R[0]->stream));
+        HIP_CHECK(hipStreamSynchronize(R[0]->stream));
+        return out;
+    }
+    // neighbours must agree on the exchange lists: same lengths AND the same global (i, j, kind) keys in the same order
+    // (ps_context::buildHaloLists hashes them) — equal counts of different DOF sets would otherwise pair the wrong entries.
     void checkLists() {
-        if (!useRccl) {
-            for (size_t q = 0; q + 1 < R.size(); ++q)
-                if (R[q]->nUpHalo != R[q + 1]->nLowOwn || R[q]->nUpOwn != R[q + 1]->nLowHalo)
+        auto enc = [](int64_t n, uint64_t h, double* o) { o[0] = (double)n; o[1] = (double)(h & 0xffffffu); o[2] = (double)((h >> 24) & 0xffffffu); o[3] = (double)((h >> 48) & 0xffffu); };
+        auto same = [](const double* a, const double* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]; };
+        if (!useRccl && !useTcp) {
+            for (size_t q = 0; q + 1 < R.size(); ++q) {
+                const ps_context* lo = R[q]; const ps_context* up = R[q + 1];
+                if (lo->nUpHalo != up->nLowOwn || lo->nUpOwn != up->nLowHalo || lo->hashUpHalo != up->hashLowOwn || lo->hashUpOwn != up->hashLowHalo)
                     throw Error("slab exchange lists disagree across the cut between ranks " + std::to_string(q) + " and " + std::to_string(q + 1));
+            }
             return;
         }
         ps_context* c = R[0];
-        const double mine[4] = {(double)c->nLowOwn, (double)c->nLowHalo, (double)c->nUpOwn, (double)c->nUpHalo};
-        HIP_CHECK(hipMemcpyAsync(c->sendLo.p, mine, 16, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(c->sendUp.p, mine + 2, 16, hipMemcpyHostToDevice, c->stream));
-        Rccl& L = rccl();
-        ncclCheck(L.GroupStart(), "ncclGroupStart");
-        if (c->slab.hasLower) { ncclCheck(L.Send(c->sendLo.p, 2, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, c->stream), "send"); ncclCheck(L.Recv(c->recvLo.p, 2, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, c->stream), "recv"); }
-        if (c->slab.hasUpper) { ncclCheck(L.Send(c->sendUp.p, 2, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "send"); ncclCheck(L.Recv(c->recvUp.p, 2, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "recv"); }
-        ncclCheck(L.GroupEnd(), "ncclGroupEnd");
-        double lo[2] = {0, 0}, up[2] = {0, 0};
-        if (c->slab.hasLower) HIP_CHECK(hipMemcpyAsync(lo, c->recvLo.p, 16, hipMemcpyDeviceToHost, c->stream));
-        if (c->slab.hasUpper) HIP_CHECK(hipMemcpyAsync(up, c->recvUp.p, 16, hipMemcpyDeviceToHost, c->stream));
+        double mineLo[8], mineUp[8], wantLo[8], wantUp[8];
+        enc(c->nLowOwn, c->hashLowOwn, mineLo); enc(c->nLowHalo, c->hashLowHalo, mineLo + 4);   // what I send down
+        enc(c->nUpOwn, c->hashUpOwn, mineUp); enc(c->nUpHalo, c->hashUpHalo, mineUp + 4);       // what I send up
+        // the lower rank's (UpHalo, UpOwn) must equal my (LowOwn, LowHalo); the upper rank's (LowHalo, LowOwn) my (UpOwn, UpHalo)
+        std::memcpy(wantLo, mineLo, sizeof(wantLo)); std::memcpy(wantUp, mineUp, sizeof(wantUp));
+        HIP_CHECK(hipMemcpyAsync(c->sendLo.p, mineLo, 64, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(c->sendUp.p, mineUp, 64, hipMemcpyHostToDevice, c->stream));
+        const int64_t keep[4] = {c->nLowOwn, c->nLowHalo, c->nUpOwn, c->nUpHalo};
+        c->nLowOwn = c->nLowHalo = c->slab.hasLower ? 8 : 0; c->nUpOwn = c->nUpHalo = c->slab.hasUpper ? 8 : 0;   // ship 8 doubles each way through the x-exchange path
+        try { transport(0); } catch (...) { c->nLowOwn = keep[0]; c->nLowHalo = keep[1]; c->nUpOwn = keep[2]; c->nUpHalo = keep[3]; throw; }
+        c->nLowOwn = keep[0]; c->nLowHalo = keep[1]; c->nUpOwn = keep[2]; c->nUpHalo = keep[3];
+        double lo[8] = {0}, up[8] = {0};
+        if (c->slab.hasLower) HIP_CHECK(hipMemcpyAsync(lo, c->recvLo.p, 64, hipMemcpyDeviceToHost, c->stream));
+        if (c->slab.hasUpper) HIP_CHECK(hipMemcpyAsync(up, c->recvUp.p, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
-        // the lower rank sent me its (nUpOwn, nUpHalo); the upper rank its (nLowOwn, nLowHalo)
-        if (c->slab.hasLower && ((int64_t)lo[0] != c->nLowHalo || (int64_t)lo[1] != c->nLowOwn)) throw Error("slab exchange lists disagree with the lower neighbour");
-        if (c->slab.hasUpper && ((int64_t)up[0] != c->nUpHalo || (int64_t)up[1] != c->nUpOwn)) throw Error("slab exchange lists disagree with the upper neighbour");
+        // received from below: its (UpOwn, UpHalo); from above: its (LowOwn, LowHalo)
+        bool bad = false;
+        if (c->slab.hasLower && !(same(lo, wantLo + 4) && same(lo + 4, wantLo))) bad = true;
+        if (c->slab.hasUpper && !(same(up, wantUp + 4) && same(up + 4, wantUp))) bad = true;
+        if (sumFlag(bad ? 1. : 0.) > 0.) throw Error(bad ? "slab exchange lists disagree with a neighbour (labels differ across the cut: halo too thin for the layer sizes?)"
+                                                          : "another rank found its exchange lists in disagreement");
     }
 
     // everything after the per-rank local setup: finish b and the Jacobi diagonal across the cuts
@@ -260,7 +405,8 @@ struct Dist {
         CGScalars h{};
         const int batch = 25;
         int it = 0;
-        bool finished = false;
+        bool finished = false, interrupted = false;
+        for (ps_context* c : R) c->interrupted = false;
         while (it < maxit && !finished) {
             const int upto = std::min(maxit, it + batch);
             for (; it < upto; ++it) {
@@ -297,14 +443,27 @@ struct Dist {
                                        jac ? 1 : 0, it, c->r.p + l.lo, l.dv, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p);
                 }
             }
-            for (size_t q = 0; q < R.size(); ++q)   // the stop test of the batch's last iteration
+            // the stop test of the batch's last iteration; the ranks' interrupt requests ride along in the same all-reduce,
+            // so that every rank leaves the loop at the same batch (a rank stopping alone would strand its neighbours in a receive)
+            double wantStop = 0.;
+            for (ps_context* c : R) if (c->interruptCb && c->interruptCb(c->interruptUser)) wantStop = 1.;
+            for (size_t q = 0; q < R.size(); ++q) {
                 hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, R[q]->stream, (const CGScalars*)loc[q].sc, R[q]->dotPartials3.p, loc[q].vb, 0, 1, R[q]->redbuf.p);
-            allreduce(1);
+                HIP_CHECK(hipMemcpyAsync(R[q]->redbuf.p + 1, &wantStop, 8, hipMemcpyHostToDevice, R[q]->stream));
+            }
+            allreduce(2);
             for (size_t q = 0; q < R.size(); ++q)
                 hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BS), 0, R[q]->stream, loc[q].sc, (const double*)R[q]->redbuf.p, (const double*)nullptr, 0, it - 1);
+            double stopSum = 0.;
             HIP_CHECK(hipMemcpyAsync(&h, loc[0].sc, sizeof(h), hipMemcpyDeviceToHost, c0->stream));
+            HIP_CHECK(hipMemcpyAsync(&stopSum, c0->redbuf.p + 1, 8, hipMemcpyDeviceToHost, c0->stream));
             syncAll();
             if (h.done) finished = true;
+            else if (stopSum > 0. || (wantStop > 0. && !useRccl && !useTcp)) { interrupted = true; break; }
+        }
+        if (interrupted) {
+            for (ps_context* c : R) { c->solveIterations = it; c->solveError = std::sqrt(h.rre); c->interrupted = true; }
+            return PS_INCOMPLETE;
         }
         int iters = h.done ? h.iter : maxit;
         double err = std::sqrt(h.rre);
@@ -407,7 +566,16 @@ struct Dist {
 
 int distStep(Dist& D, ps_stats* stats) {
     const auto w0 = std::chrono::high_resolution_clock::now();
-    for (ps_context* c : D.R) c->setup(nullptr);
+    for (ps_context* c : D.R) c->redbuf.alloc(8);
+    // a rank whose local setup throws must tell the others before they enter the first exchange (they would wait for ever)
+    std::string failure;
+    for (ps_context* c : D.R) {
+        try { c->setup(nullptr); }
+        catch (const ps::Error& e) { failure = e.msg; }
+        catch (const std::exception& e) { failure = e.what(); }
+    }
+    if (D.sumFlag(failure.empty() ? 0. : 1.) > 0.)
+        throw Error(failure.empty() ? std::string("another rank failed during setup") : failure);
     D.finishSetup();
     D.syncAll();
     const auto w1 = std::chrono::high_resolution_clock::now();
@@ -416,7 +584,7 @@ int distStep(Dist& D, ps_stats* stats) {
     if (c0->P.doSolve) result = D.solve();
     D.syncAll();
     const auto w2 = std::chrono::high_resolution_clock::now();
-    const bool apply = c0->P.doSolve && result != PS_UNSUPPORTED_SOLVER && (result == PS_SUCCESS || c0->P.keepNonConvergedResults);
+    const bool apply = c0->P.doSolve && result != PS_UNSUPPORTED_SOLVER && result != PS_INCOMPLETE && (result == PS_SUCCESS || c0->P.keepNonConvergedResults);
     D.recoverAndWriteBack(apply);
     for (ps_context* c : D.R) {
         c->lastStats.solveData[0] = c->solveError;
@@ -440,12 +608,20 @@ struct ps_group {
     hipStream_t stream = nullptr;
 };
 
-int ps_dist_step_single(ps_context* c, ps_stats* stats) {   // one process per GPU, RCCL
+int ps_dist_step_single(ps_context* c, ps_stats* stats) {   // one process per rank: RCCL (one GPU each) or the TCP transport
     Dist D;
     D.R.push_back(c);
-    D.useRccl = true;
+    D.useRccl = c->rcclComm != nullptr;
+    D.useTcp = !D.useRccl && c->hostComm != nullptr;
     return distStep(D, stats);
 }
+void ps_dist_release(ps_context* c) {
+    if (c->rcclComm) { try { (void)rccl().CommDestroy(c->rcclComm); } catch (...) {} c->rcclComm = nullptr; }
+    if (c->hostComm) { delete (HostComm*)c->hostComm; c->hostComm = nullptr; }
+}
+#define PS_CATCH_ALL(ctx)                                                                    \
+    catch (const ps::Error& e) { if (ctx) (ctx)->err = e.msg; return PS_FAILED; }            \
+    catch (const std::exception& e) { if (ctx) (ctx)->err = e.what(); return PS_FAILED; }
 
 extern "C" {
 
@@ -462,17 +638,25 @@ int32_t ps_set_slab(ps_context* c, const ps_slab* slab) {
         if (c->P.doReducedRegions && !c->P.doTile && slab->world > 1) throw Error("the slab decomposition needs doTile (tile-local regions)");
         if (slab->zLoOwned < 0 || slab->zHiOwned > c->g.nz || slab->zLoOwned >= slab->zHiOwned) throw Error("bad slab range");
         if ((slab->hasLower && slab->zLoOwned < 16) || (slab->hasUpper && c->g.nz - slab->zHiOwned < 16)) throw Error("a halo of at least 16 layers is required next to a cut");
+        // every label inside the owned range must equal the global one: the classification reaches L + S cells, the tile
+        // relabelling tilePadding more, the trilinear samplers one cell each side — all of it has to lie inside the halo block
+        if (slab->world > 1 && c->P.doReducedRegions &&
+            c->P.activeLiquidBoundaryLayerSize + c->P.activeSolidBoundaryLayerSize + c->P.tilePadding + 2 > 16)
+            throw Error("activeLiquidBoundaryLayerSize + activeSolidBoundaryLayerSize + tilePadding + 2 exceeds the 16-layer halo of the slab decomposition");
         if (!slab->hasLower && slab->zLoOwned != 0) throw Error("without a lower neighbour the slab must start at layer 0");
         if (!slab->hasUpper && slab->zHiOwned != c->g.nz) throw Error("without an upper neighbour the slab must end at the top layer");
         c->slab = *slab;
         c->slabEnabled = slab->world > 1;
         c->isSetup = false;
         return PS_SUCCESS;
-    } catch (const ps::Error& e) { c->err = e.msg; return PS_FAILED; }
+    } PS_CATCH_ALL(c)
 }
 
 int32_t ps_comm_unique_id(void* id128) {
-    try { ncclCheck(rccl().GetUniqueId(id128), "ncclGetUniqueId"); return PS_SUCCESS; } catch (const ps::Error& e) { std::fprintf(stderr, "%s\n", e.msg.c_str()); return PS_FAILED; }
+    if (!id128) return PS_FAILED;
+    try { ncclCheck(rccl().GetUniqueId(id128), "ncclGetUniqueId"); return PS_SUCCESS; }
+    catch (const ps::Error& e) { std::fprintf(stderr, "%s\n", e.msg.c_str()); return PS_FAILED; }
+    catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return PS_FAILED; }
 }
 int32_t ps_comm_init_rccl(ps_context* c, const void* id128, int32_t rank, int32_t world) {
     if (!c || !id128) return PS_FAILED;
@@ -482,9 +666,23 @@ int32_t ps_comm_init_rccl(ps_context* c, const void* id128, int32_t rank, int32_
         std::memcpy(&id, id128, sizeof(id));
         void* comm = nullptr;
         ncclCheck(rccl().CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+        ps_dist_release(c);
         c->rcclComm = comm;
         return PS_SUCCESS;
-    } catch (const ps::Error& e) { c->err = e.msg; return PS_FAILED; }
+    } PS_CATCH_ALL(c)
+}
+// Host-staged transport between one process per rank (several ranks may share a GPU): rank r listens on base_port + r of
+// `host` (dotted IPv4, e.g. "127.0.0.1").  Collective: every rank of the world calls it.
+int32_t ps_comm_init_tcp(ps_context* c, int32_t rank, int32_t world, const char* host, int32_t base_port) {
+    if (!c || !host) return PS_FAILED;
+    try {
+        if (world < 1 || world > 64 || rank < 0 || rank >= world || base_port < 1024 || base_port + world > 65535) throw Error("ps_comm_init_tcp: bad rank / world / port");
+        ps_dist_release(c);
+        HostComm* H = new HostComm();
+        try { H->init(rank, world, host, base_port); } catch (...) { delete H; throw; }
+        c->hostComm = H;
+        return PS_SUCCESS;
+    } PS_CATCH_ALL(c)
 }
 
 // exercises the RCCL entry points used by the distributed solve (all-reduce, grouped send/recv to self) on this
@@ -511,7 +709,7 @@ int32_t ps_comm_selftest(ps_context* c) {
         for (int i = 0; i < 4; ++i) if (b[i] != v[i]) throw Error("send/recv self-test mismatch");
         if (a[3] != v[3]) throw Error("all-reduce touched elements beyond count");
         return PS_SUCCESS;   // a[0..2] = world * v (checked by the caller, who knows the world size)
-    } catch (const ps::Error& e) { c->err = e.msg; return PS_FAILED; }
+    } PS_CATCH_ALL(c)
 }
 
 ps_group* ps_group_create(int32_t device, int32_t world) {
@@ -539,7 +737,7 @@ int32_t ps_group_step(ps_group* g, ps_stats* stats) {
         D.R = g->ranks;
         D.useRccl = false;
         return distStep(D, stats);
-    } catch (const ps::Error& e) { g->ranks[0]->err = e.msg; return PS_FAILED; }
+    } PS_CATCH_ALL(g->ranks[0])
 }
 
 }  // extern "C"

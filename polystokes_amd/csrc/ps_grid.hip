@@ -1074,24 +1074,28 @@ void ps_context::buildHaloLists() {
         HIP_CHECK(hipMemcpyAsync(out.data(), sysIdx[s].p + (int64_t)d.x * d.y * k, out.size() * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     };
-    auto cellsOf = [&](int k, std::vector<int32_t>& list) {
+    // order-sensitive hash of the GLOBAL keys (position in the x-fastest slice, sample grid) of a list: local indices differ
+    // between the two ranks of a cut, the keys must not (Dist::checkLists)
+    auto mix = [](uint64_t& h, uint64_t key) { h = (h ^ key) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
+    auto cellsOf = [&](int k, std::vector<int32_t>& list, uint64_t& h) {
         std::vector<int32_t> sl;
         slice(0, k, sl);
-        for (int32_t b : sl) if (b >= 0) { list.push_back(b); list.push_back(b + 1); list.push_back(b + 2); list.push_back(b + 3); }
+        for (size_t q = 0; q < sl.size(); ++q) { const int32_t b = sl[q]; if (b >= 0) { list.push_back(b); list.push_back(b + 1); list.push_back(b + 2); list.push_back(b + 3); mix(h, (uint64_t)q * 8); } }
     };
-    auto edgesOf = [&](int s, int k, std::vector<int32_t>& list) {
+    auto edgesOf = [&](int s, int k, std::vector<int32_t>& list, uint64_t& h) {
         std::vector<int32_t> sl;
         slice(s, k, sl);
-        for (int32_t b : sl) if (b >= 0) list.push_back(b);
+        for (size_t q = 0; q < sl.size(); ++q) { const int32_t b = sl[q]; if (b >= 0) { list.push_back(b); mix(h, (uint64_t)q * 8 + (uint64_t)s); } }
     };
     std::vector<int32_t> lowHalo, lowOwn, upHalo, upOwn;
+    hashLowHalo = hashLowOwn = hashUpHalo = hashUpOwn = 0;
     if (slab.hasLower) {
-        cellsOf(zLo - 1, lowHalo);                                   // their top layer, touched by my z-faces on plane zLo
-        cellsOf(zLo, lowOwn); edgesOf(4, zLo, lowOwn); edgesOf(5, zLo, lowOwn);   // mine, touched by their rows
+        cellsOf(zLo - 1, lowHalo, hashLowHalo);                                   // their top layer, touched by my z-faces on plane zLo
+        cellsOf(zLo, lowOwn, hashLowOwn); edgesOf(4, zLo, lowOwn, hashLowOwn); edgesOf(5, zLo, lowOwn, hashLowOwn);   // mine, touched by their rows
     }
     if (slab.hasUpper) {
-        cellsOf(zHi, upHalo); edgesOf(4, zHi, upHalo); edgesOf(5, zHi, upHalo);   // theirs, touched by my rows
-        cellsOf(zHi - 1, upOwn);                                     // mine, touched by their z-faces on plane zHi
+        cellsOf(zHi, upHalo, hashUpHalo); edgesOf(4, zHi, upHalo, hashUpHalo); edgesOf(5, zHi, upHalo, hashUpHalo);   // theirs, touched by my rows
+        cellsOf(zHi - 1, upOwn, hashUpOwn);                                     // mine, touched by their z-faces on plane zHi
     }
     auto up = [&](const std::vector<int32_t>& h, DevBuf<int32_t>& d, int64_t& n) {
         n = (int64_t)h.size();
@@ -1099,7 +1103,7 @@ void ps_context::buildHaloLists() {
         if (n) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, stream));
     };
     up(lowHalo, listLowHalo, nLowHalo); up(lowOwn, listLowOwn, nLowOwn); up(upHalo, listUpHalo, nUpHalo); up(upOwn, listUpOwn, nUpOwn);
-    const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo, nLowOwn), std::max(nUpHalo, nUpOwn)) + 2;   // >= 2: Dist::checkLists ships two counters through these buffers
+    const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo, nLowOwn), std::max(nUpHalo, nUpOwn)) + 8;   // >= 8: Dist::checkLists ships counts + hashes through these buffers
     sendLo.alloc(mx); sendUp.alloc(mx); recvLo.alloc(mx); recvUp.alloc(mx);
     HIP_CHECK(hipStreamSynchronize(stream));
 }

@@ -28,6 +28,9 @@ HostCSR readMarketSparse(const std::string& fn) {
     std::istringstream hs(line);
     int64_t R, Cc, N;
     if (!(hs >> R >> Cc >> N)) throw Error("bad size line in " + fn);
+    // sizes come from a file: refuse what cannot be a matrix before allocating for it
+    if (R < 0 || Cc < 0 || N < 0 || R >= 0x7fffffffLL || Cc >= 0x7fffffffLL || N >= 0x7fffffffLL) throw Error("bad sizes in " + fn);
+    if (R == 0 || Cc == 0 ? N != 0 : N / R > Cc + 1 + (int64_t)1e6) throw Error("more entries than the matrix can hold in " + fn);
     struct T { int32_t r, c; double v; };
     std::vector<T> t((size_t)N);
     for (int64_t k = 0; k < N; ++k) {
@@ -62,6 +65,7 @@ std::vector<double> readMarketVector(const std::string& fn) {   // "array real g
     int64_t R, Cc = 1;
     if (!(hs >> R)) throw Error("bad size line in " + fn);
     hs >> Cc;
+    if (R < 0 || Cc < 0 || R >= 0x7fffffffLL || Cc > 1024 || R * Cc >= 0x7fffffffLL) throw Error("bad sizes in " + fn);
     std::vector<double> v((size_t)(R * Cc));
     for (auto& x : v) if (!(in >> x)) throw Error("truncated " + fn);
     return v;
@@ -281,5 +285,6 @@ extern "C" int32_t ps_solve_exported_system(ps_context* c, const char* prefix, c
         }
         return result;
     } catch (const ps::Error& e) { c->err = e.msg; return PS_FAILED; }
+    catch (const std::exception& e) { c->err = e.what(); return PS_FAILED; }
 }
 

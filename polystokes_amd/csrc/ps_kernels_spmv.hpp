@@ -219,9 +219,28 @@ __device__ inline double bufGatherF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, PS_GATHER_AUX));
 }
 // one lane's share of a chunk's stream: NV groups of 4 consecutive entries (non-temporal: read once)
-template <int NV> struct Stream4 { u32x2 c[NV]; unsigned v[NV]; };
+// F64 = false: int8 value codes (3 B per entry with the column);  F64 = true: the fp64 values themselves in the same 4-aligned
+// chunk layout (10 B per entry) — the form that runs when the stencil values are not code * scale (user-supplied weights)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NV, bool F64> struct Stream4;
+template <int NV> struct Stream4<NV, false> { u32x2 c[NV]; unsigned v[NV]; };
+template <int NV> struct Stream4<NV, true> { u32x2 c[NV]; };   // the fp64 values are fetched for the CURRENT chunk only (below):
+// double-buffering 16 more VGPR pairs per lane costs more occupancy than the prefetch buys
+template <int NV> struct Vals4 { u32x4 v[NV][2]; };
 template <int NV>
-__device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, int p0, int p1, Stream4<NV>& s) {
+__device__ inline void loadVals4(const double* val4, int p0, int p1, Vals4<NV>& s) {
+    const __amdgpu_buffer_rsrc_t rVal = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(val4 + p0), 0, (int)(((unsigned)(p1 - p0 + 3) & ~3u) * 8u), 0x00020000);
+#pragma unroll
+    for (int w = 0; w < NV; ++w) {
+        const unsigned rel = 4u * (threadIdx.x + w * BS) * 8u;                   // byte offset inside this chunk's values
+        const bool in = (int)(p0 + 4 * (threadIdx.x + w * BS)) < p1;
+        s.v[w][0] = __builtin_amdgcn_raw_buffer_load_b128(rVal, in ? (int)rel : -1, 0, PS_STREAM_AUX);
+        s.v[w][1] = __builtin_amdgcn_raw_buffer_load_b128(rVal, in ? (int)(rel + 16u) : -1, 0, PS_STREAM_AUX);
+    }
+}
+// (the fp64 value array can exceed the 4 GiB a buffer descriptor spans: its descriptor is rebuilt per chunk on the chunk's base)
+template <int NV, bool F64>
+__device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, const double* val4, int p0, int p1, Stream4<NV, F64>& s) {
 #pragma unroll
     for (int w = 0; w < NV; ++w) {
         const unsigned first = (unsigned)p0 + 4u * (threadIdx.x + w * BS);     // p0 is a multiple of 4
@@ -229,7 +248,7 @@ __device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_
         // (zeros decode to window 0 / offset 0 / value 0, like the padding inside the last group)
         const bool in = (int)first < p1;
         s.c[w] = __builtin_amdgcn_raw_buffer_load_b64(rCol, in ? (int)(first * 2u) : -1, 0, PS_STREAM_AUX);
-        s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, PS_STREAM_AUX);
+        if constexpr (!F64) s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, PS_STREAM_AUX);
     }
 }
 __device__ inline unsigned streamCol(u32x2 c, int j, int myBase) {   // window base (lane `window` of every 16-lane group) + 12-bit offset
@@ -239,6 +258,15 @@ __device__ inline unsigned streamCol(u32x2 c, int j, int myBase) {   // window b
 }
 __device__ inline double streamVal(unsigned v, int j, double scale) {   // exact: see DevCSR::code
     return (double)((int)(v << (24 - 8 * j)) >> 24) * scale;
+}
+__device__ inline double streamVal(const u32x4 (&v)[2], int j, double) {
+    const u32x4 q = v[j >> 1];
+    const u32x2 h = (j & 1) ? u32x2{q.z, q.w} : u32x2{q.x, q.y};
+    return __builtin_bit_cast(double, h);
+}
+template <bool F64, class S, class V>
+__device__ inline double prodVal(const S& cur, const V& cv, int w, int j, double scale) {
+    if constexpr (F64) return streamVal(cv.v[w], j, scale); else return streamVal(cur.v[w], j, scale);
 }
 // inclusive prefix sum over the 64 lanes with DPP moves (VALU only, no LDS round trips): Hillis-Steele inside each row of
 // 16 lanes (row_shr 1,2,4,8; lanes without a source keep 0), then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
@@ -264,8 +292,8 @@ __device__ inline double rowSum(const double* prod, int ea, int len) {
 }
 // Both kernels: gathers of the current chunk, prefetch of the next, products to LDS (entry e of the chunk at
 // prod[(e & 3) * PL + (e >> 2)]: conflict-free writes), row offsets from the length bytes (wave scans + 4 wave totals).
-template <int MODE, int NV>
-__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
+template <int MODE, int NV, bool F64>
+__global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, const double* __restrict__ val4, int streamLen,
                                                     const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
                                                     int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
@@ -275,7 +303,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
     static_assert(BS == 256, "four waves per block");
-    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, F64 ? 0 : (size_t)streamLen),
                                  rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8);
     const ChunkWalk W(xcdAware, sched);
@@ -283,8 +311,8 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     int chunk = W.at(0);
     if (chunk >= nChunks) return;
     int2 pr = chunkRange[chunk];
-    Stream4<NV> cur, nxt;
-    loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
+    Stream4<NV, F64> cur, nxt;
+    loadStream4<NV, F64>(rCol, rCode, val4, pr.x, pr.y, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = W.at(1);
     int2 npr = {0, 0};
@@ -301,9 +329,11 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
         }
+        Vals4<F64 ? NV : 0> cv;
+        if constexpr (F64) loadVals4<NV>(val4, pr.x, pr.y, cv);
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
+            loadStream4<NV, F64>(rCol, rCode, val4, npr.x, npr.y, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = W.at(it + 2);
@@ -313,7 +343,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
         for (int w = 0; w < NV; ++w) {
             if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = streamVal(cur.v[w], j, scale) * xv[4 * w + j];
+            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = prodVal<F64>(cur, cv, w, j, scale) * xv[4 * w + j];
         }
         const int incl = waveInclusiveScan(len);
         if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
@@ -332,8 +362,8 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
         ++it;
     }
 }
-template <int MODE, int NV>
-__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
+template <int MODE, int NV, bool F64>
+__global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, const double* __restrict__ val4, int streamLen,
                                                      const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
                                                      const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
@@ -344,7 +374,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
     static_assert(BS == 256, "four waves per block");
-    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, F64 ? 0 : (size_t)streamLen),
                                  rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(MODE == 0 ? xin : add, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8);
@@ -354,8 +384,8 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
     if (chunk >= nChunks) { if (MODE == 0 && threadIdx.x == 0) partial[blockIdx.x] = 0.; return; }
     double dacc = 0.;
     int2 pr = chunkRange[chunk];
-    Stream4<NV> cur, nxt;
-    loadStream4<NV>(rCol, rCode, pr.x, pr.y, cur);
+    Stream4<NV, F64> cur, nxt;
+    loadStream4<NV, F64>(rCol, rCode, val4, pr.x, pr.y, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = W.at(1);
     int2 npr = {0, 0};
@@ -373,9 +403,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
         }
+        Vals4<F64 ? NV : 0> cv;
+        if constexpr (F64) loadVals4<NV>(val4, pr.x, pr.y, cv);
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream4<NV>(rCol, rCode, npr.x, npr.y, nxt);
+            loadStream4<NV, F64>(rCol, rCode, val4, npr.x, npr.y, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = W.at(it + 2);
@@ -385,7 +417,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         for (int w = 0; w < NV; ++w) {
             if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = streamVal(cur.v[w], j, scale) * xv[4 * w + j];
+            for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = prodVal<F64>(cur, cv, w, j, scale) * xv[4 * w + j];
         }
         const int incl = waveInclusiveScan(len);
         if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;

@@ -42,7 +42,7 @@ __device__ inline void tileGatherAxis(int b0, int e, const uint32_t* __restrict_
         const double ox = ((double)i - (AXIS == 0 ? 0.5 : 0.)) * dx - cx;
         const double oy = ((double)j - (AXIS == 1 ? 0.5 : 0.)) * dx - cy;
         const double oz = ((double)k - (AXIS == 2 ? 0.5 : 0.)) * dx - cz;
-        if (AXIS != 2) {    // x-row: entries 0,3..11 ; y-row: entries 1,12..20
+        if constexpr (AXIS != 2) {    // x-row: entries 0,3..11 ; y-row: entries 1,12..20
             w[0] += s; w[1] += ox * s; w[2] += oy * s; w[3] += oz * s;
             w[4] += ox * ox * s; w[5] += ox * oy * s; w[6] += ox * oz * s; w[7] += oy * oy * s; w[8] += oy * oz * s; w[9] += oz * oz * s;
         } else {            // z-row: entries 2,3,6,7,8,13,16,18,19,21..25

@@ -19,6 +19,7 @@
 //   ps_dist.hpp          : the z-slab distributed solve (RCCL or in-process ranks) and its C ABI.
 //   ps_import.hpp        : MatrixMarket import + general CSR PCG (ps_solve_exported_system).
 #include <chrono>
+#include <cstring>
 #include <cmath>
 #include <ctime>
 
@@ -58,14 +59,16 @@ struct Launch {
     void spmvS(int mode, const double* x, double* out) const {
         if (rowsS == 0) return;
         const ps::DevCSR& M = c->S;
-        if (pipeGrid > 0 && M.col16ok) {
+        if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
             const int nChunks = gridFor(rowsS, BS);
             int xcdAware = this->xcdAware;
-            const dim3 gr(pipeBlocks(nChunks, xcdAware)), bl(BS);
-#define PS_LAUNCH_SP(MODE_, NV_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
+            const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
+#define PS_LAUNCH_SP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
                                                     M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, sched(M, gr.x), nChunks, xcdAware)
-            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP(0, 1); else PS_LAUNCH_SP(1, 1); }
-            else { if (mode == 0) PS_LAUNCH_SP(0, 2); else PS_LAUNCH_SP(1, 2); }
+#define PS_LAUNCH_SP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_SP(MODE_, NV_, false); else PS_LAUNCH_SP(MODE_, NV_, true); } while (0)
+            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP2(0, 1); else PS_LAUNCH_SP2(1, 1); }
+            else { if (mode == 0) PS_LAUNCH_SP2(0, 2); else PS_LAUNCH_SP2(1, 2); }
+#undef PS_LAUNCH_SP2
 #undef PS_LAUNCH_SP
             return;
         }
@@ -100,21 +103,26 @@ struct Launch {
     void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
         if (rowsSt == 0) return;
         const ps::DevCSR& M = c->St;
-        if (pipeGrid > 0 && M.col16ok) {
+        if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
             const int nChunks = gridFor(rowsSt, BS);
             int xcdAware = this->xcdAware;
-            const dim3 gr(pipeBlocks(nChunks, xcdAware)), bl(BS);
-#define PS_LAUNCH_TP(MODE_, NV_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
+            const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
+#define PS_LAUNCH_TP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
                                                     M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware)
-            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP(0, 1); else PS_LAUNCH_TP(1, 1); }
-            else { if (mode == 0) PS_LAUNCH_TP(0, 2); else PS_LAUNCH_TP(1, 2); }
+#define PS_LAUNCH_TP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_TP(MODE_, NV_, false); else PS_LAUNCH_TP(MODE_, NV_, true); } while (0)
+            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP2(0, 1); else PS_LAUNCH_TP2(1, 1); }
+            else { if (mode == 0) PS_LAUNCH_TP2(0, 2); else PS_LAUNCH_TP2(1, 2); }
+#undef PS_LAUNCH_TP2
 #undef PS_LAUNCH_TP
             return;
         }
         spmvSt_(mode, t, xin, add, out, partial);
     }
     // grid of a persistent kernel; the XCD-grouped walk needs a multiple of 8 blocks (workgroup b runs on XCD b & 7)
-    int pipeBlocks(int nChunks, int& xcd) const {
+    // The fp64-value stream (10 B per entry) runs one chunk per workgroup: measured at 256^3 St 0.54 ms against 0.64 ms
+    // persistent (the persistent walk pays when the stream is short and the loop is issue-bound, not when it is 3x heavier).
+    int pipeBlocks(int nChunks, int& xcd, bool packed) const {
+        if (!packed) { xcd = 0; return nChunks; }
         int g = std::min(nChunks, pipeGrid);
         if (xcd > 0) { if (g >= 8) g &= ~7; else xcd = 0; }
         return g;
@@ -122,7 +130,7 @@ struct Launch {
     int stBlocks() const {   // number of p.Ap partials the St kernel writes: one per block
         const int nChunks = gridFor(rowsSt, BS);
         int xcd = xcdAware;
-        return (pipeGrid > 0 && c->St.col16ok) ? pipeBlocks(nChunks, xcd) : nChunks;
+        return (pipeGrid > 0 && c->St.col16ok && (c->St.packed || c->St.val4.p)) ? pipeBlocks(nChunks, xcd, c->St.packed) : nChunks;
     }
 };
 Launch mk(ps_context* c, const int* done) {
@@ -315,30 +323,39 @@ void ps_context::applySolutionToVelocity() {
 // micro-benchmark dispatch for ps_bench_kernel (bench.py roofline object)
 void ps_bench_launch(ps_context* c, const std::string& k, const double* x, double* y) {
     Launch L = mk(c, nullptr);
-    // "<name>_fp64": the same kernel streaming the fp64 value array instead of the int8 codes (A/B of the two formats)
-    const bool fp64 = k.size() > 5 && k.compare(k.size() - 5, 5, "_fp64") == 0;
-    const std::string base = fp64 ? k.substr(0, k.size() - 5) : k;
-    const bool keepS = c->S.packed, keepT = c->St.packed;
-    if (fp64) { c->S.packed = false; c->St.packed = false; }
+    // "<name>_fp64": the pipelined kernels on the fp64-value form of the stream (16-bit windowed columns + fp64 values, 10 B per
+    // entry: what runs when the stencil values are not code * scale);  "<name>_csr": the one-shot kernels on the plain CSR
+    // (int32 columns + fp64 values, 12 B per entry: what runs when a chunk needs more than 16 column windows)
+    auto endsWith = [&](const char* suf) { const size_t m = std::strlen(suf); return k.size() > m && k.compare(k.size() - m, m, suf) == 0; };
+    const bool fp64 = endsWith("_fp64"), csr = endsWith("_csr");
+    const std::string base = fp64 ? k.substr(0, k.size() - 5) : (csr ? k.substr(0, k.size() - 4) : k);
+    const bool keepS = c->S.packed, keepT = c->St.packed, keepS16 = c->S.col16ok, keepT16 = c->St.col16ok;
+    struct Restore { ps_context* c; bool a, b, d, e; ~Restore() { c->S.packed = a; c->St.packed = b; c->S.col16ok = d; c->St.col16ok = e; } } restore{c, keepS, keepT, keepS16, keepT16};
+    if (fp64) {
+        if (!c->S.col16ok || !c->St.col16ok) throw Error("no compressed stream on this system");
+        c->buildVal4(c->S); c->buildVal4(c->St);
+        c->S.packed = false; c->St.packed = false;
+    }
+    if (csr) { c->S.packed = c->St.packed = false; c->S.col16ok = c->St.col16ok = false; }
     if (base == "spmv_S") L.spmvS(0, x, c->ts.p);
     else if (base == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
     else if (base == "apply") c->applyOperator(x, y, c->dotPartials.p);
     else if (base == "tiles") L.tiles(0, c->ts.p);
     else if (base == "cg_update_xr" || base == "cg_update_p" || base == "cg_update_r" || base == "cg_update_xp") {
         // streaming vector kernels on scratch vectors (alpha = beta = 0 keeps them finite over many launches)
-        static ps::DevBuf<CGScalars> scratch;
+        ps::DevBuf<CGScalars>& scratch = c->benchScal;
         scratch.alloc(1);
         CGScalars h{};
         h.tol2 = -1.;                                  // the stop test never fires
         if (base == "cg_update_xp") h.rsold2[0] = 1.;   // beta = 0 / 1 ; (cg_update_r: alpha = 0 / p.Ap with p.Ap = 1024 below)
         HIP_CHECK(hipMemcpyAsync(scratch.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-        static ps::DevBuf<double> ones;                // input partials of the fused scalar prologues
+        ps::DevBuf<double>& ones = c->benchOnes;       // input partials of the fused scalar prologues
         if (ones.n < (size_t)2 * VGRID) {
             ones.alloc((size_t)2 * VGRID);
             std::vector<double> hv((size_t)2 * VGRID, 1.);
             HIP_CHECK(hipMemcpy(ones.p, hv.data(), hv.size() * 8, hipMemcpyHostToDevice));
         }
-        static ps::DevBuf<double> zeros;
+        ps::DevBuf<double>& zeros = c->benchZeros;
         if (zeros.n < (size_t)2 * VGRID) { zeros.alloc((size_t)2 * VGRID); HIP_CHECK(hipMemset(zeros.p, 0, (size_t)2 * VGRID * 8)); }
         const int64_t n = c->nSystem;
         const char* e = getenv("PS_VGRID");
@@ -358,8 +375,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
             hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)nullptr, zeros.p, VGRID, dvf ? 1 : 0, 0, x, dvf,
                                c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);
     }
-    else { c->S.packed = keepS; c->St.packed = keepT; throw Error("unknown kernel name: " + k); }
-    c->S.packed = keepS; c->St.packed = keepT;
+    else throw Error("unknown kernel name: " + k);
 }
 
 #include "ps_dist.hpp"

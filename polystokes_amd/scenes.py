@@ -10,8 +10,9 @@ import numpy as np
 from ._abi import Scene, default_params
 
 
-def _centers(nx, ny, nz, dx):
-    z, y, x = np.meshgrid((np.arange(nz) + 0.5) * dx, (np.arange(ny) + 0.5) * dx, (np.arange(nx) + 0.5) * dx,
+def _centers(nx, ny, nz, dx, k0=0):
+    """cell-centre coordinates of layers k0 .. k0 + nz - 1 (a z-slab of a taller grid generates exactly the global values)"""
+    z, y, x = np.meshgrid((np.arange(k0, k0 + nz) + 0.5) * dx, (np.arange(ny) + 0.5) * dx, (np.arange(nx) + 0.5) * dx,
                           indexing="ij")
     return x, y, z
 
@@ -38,11 +39,13 @@ def beam(n=32):
     return sc, default_params(doReducedRegions=0)
 
 
-def coil(n=64, tile=16, pad=2):
-    """Config 2/4 stand-in: a liquid column falling into a pool over a solid floor."""
+def coil(n=64, tile=16, pad=2, zrange=None):
+    """Config 2/4 stand-in: a liquid column falling into a pool over a solid floor.
+    zrange = (k0, nz): only the layers k0 .. k0 + nz - 1 of the n^3 scene (a rank's slab + halo, see scene_slab)."""
     dx, dt = 1.0 / n, 1.0 / 24.0
     s = n / 128.0
-    x, y, z = _centers(n, n, n, dx)
+    k0, nzl = zrange if zrange is not None else (0, n)
+    x, y, z = _centers(n, n, nzl, dx, k0)
     cx = cz = 0.5
     r = 12 * s * dx
     col = np.maximum(np.sqrt((x - cx) ** 2 + (z - cz) ** 2) - r, -(y - 0.0))   # infinite-up cylinder
@@ -50,7 +53,7 @@ def coil(n=64, tile=16, pad=2):
     surface = np.minimum(col, pool)
     collision = y - 2 * dx                 # floor slab of 2 cells
     vel = [0.0, -1.0, 0.0]
-    sc = Scene(n, n, n, dx, dt, 1000.0, vel, surface, collision, 100.0, name=f"coil{n}")
+    sc = Scene(n, n, nzl, dx, dt, 1000.0, vel, surface, collision, 100.0, name=f"coil{n}")
     return sc, default_params(tileSize=tile, tilePadding=pad)
 
 
@@ -65,15 +68,18 @@ def cavity(n=64, tile=16, pad=2, precond=1):
     return sc, default_params(tileSize=tile, tilePadding=pad, preconditioner=precond)
 
 
-def spheres(n=64, tile=16, pad=2, nspheres=8, seed=12345):
-    """Config 5 stand-in: half-filled pool with moving solid spheres, mixed uniform/reduced regions."""
+def spheres(n=64, tile=16, pad=2, nspheres=8, seed=12345, zrange=None):
+    """Config 5 stand-in: half-filled pool with moving solid spheres, mixed uniform/reduced regions.
+    zrange = (k0, nz): only the layers k0 .. k0 + nz - 1 of the n^3 scene (a rank's slab + halo, see scene_slab)."""
     dx, dt = 1.0 / n, 1.0 / 48.0
     rng = np.random.RandomState(seed)
-    x, y, z = _centers(n, n, n, dx)
+    k0, nzl = zrange if zrange is not None else (0, n)
+    x, y, z = _centers(n, n, nzl, dx, k0)
     surface = y - 0.5
     collision = np.full_like(x, 10.0)
     fx = (np.arange(n + 1) * dx, (np.arange(n) + 0.5) * dx)
-    cv = [np.zeros((n, n, n + 1), np.float32), np.zeros((n, n + 1, n), np.float32), np.zeros((n + 1, n, n), np.float32)]
+    fz = (np.arange(k0, k0 + nzl + 1) * dx, (np.arange(k0, k0 + nzl) + 0.5) * dx)
+    cv = [np.zeros((nzl, n, n + 1), np.float32), np.zeros((nzl, n + 1, n), np.float32), np.zeros((nzl + 1, n, n), np.float32)]
     for _ in range(nspheres):
         c = rng.uniform(0.2, 0.8, 3)
         c[1] = rng.uniform(0.25, 0.55)
@@ -81,12 +87,12 @@ def spheres(n=64, tile=16, pad=2, nspheres=8, seed=12345):
         v = rng.uniform(-1.0, 1.0, 3)
         collision = np.minimum(collision, np.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) - rad)
         for a in range(3):
-            zz, yy, xx = np.meshgrid(fx[0] if a == 2 else fx[1], fx[0] if a == 1 else fx[1],
+            zz, yy, xx = np.meshgrid(fz[0] if a == 2 else fz[1], fx[0] if a == 1 else fx[1],
                                      fx[0] if a == 0 else fx[1], indexing="ij")
             inside = np.sqrt((xx - c[0]) ** 2 + (yy - c[1]) ** 2 + (zz - c[2]) ** 2) < rad + 1.5 * dx
             cv[a][inside] = v[a]
     vel = [0.0, np.float32(-9.8 * dt), 0.0]
-    sc = Scene(n, n, n, dx, dt, 1000.0, vel, surface, collision, 1.0e4, collisionvel=cv, name=f"spheres{n}")
+    sc = Scene(n, n, nzl, dx, dt, 1000.0, vel, surface, collision, 1.0e4, collisionvel=cv, name=f"spheres{n}")
     return sc, default_params(tileSize=tile, tilePadding=pad)
 
 
@@ -122,6 +128,21 @@ def droplet(n=24, tile=8, pad=2, radius=0.33):
     surface = np.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) - radius
     sc = Scene(n, n, n, dx, dt, 1000.0, [0.0, 0.0, 0.0], surface, np.float32(10.0), 50.0, name=f"droplet{n}")
     return sc, default_params(tileSize=tile, tilePadding=pad)
+
+
+def scene_slab(name, n, world, rank, tile=16, pad=2, precond=1):
+    """Rank-local piece (slab + halo) of the n^3 scene `name` ("coil" | "spheres" | "cavity") for STRONG scaling: the
+    global problem is fixed, every rank generates only its own layers — bit-identical to cutting the global arrays
+    (tests/test_scenes_slab.py).  Returns (local Scene, params, Slab)."""
+    from . import partition
+    sl = partition.make_slab(n, world, rank, tile)
+    if name == "cavity":
+        sc, p = cavity(n, tile, pad, precond)
+        return partition.local_scene(sc, sl), p, sl
+    fn = {"coil": coil, "spheres": spheres}[name]
+    sc, p = fn(n, tile, pad, zrange=(sl.g0, sl.nz_local))
+    p.preconditioner = precond
+    return sc, p, sl
 
 
 def cavity_slab(n, world, rank, tile=16, pad=2, precond=1):

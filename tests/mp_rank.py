@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""One rank of a real multi-process distributed step (one process per rank, ps_step_device on a slab context) with the
+host-staged TCP transport — several ranks may share one GPU.  Started by tests/test_gpu_multiprocess.py:
+    mp_rank.py <case> <world> <rank> <base_port> <out.npz> [device]
+Writes the rank's owned faces (local layout), masks, result code and iteration count."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    case, world, rank, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    device = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    import polystokes_amd
+    from polystokes_amd import partition
+    import mp_cases
+    sc, p = mp_cases.make(case)
+    sl = partition.make_slab(sc.nz, world, rank, p.tileSize)
+    s = polystokes_amd.Solver(device)
+    loc = partition.local_scene(sc, sl)
+    if case.endswith("_failrank") and rank == 1:
+        # this rank sees air in a patch of its own first layers: its labels on the cut differ from what rank 0 computes
+        # from its halo copy, so the exchange lists disagree (same tile structure, other DOF sets)
+        loc.surface[sl.zLoOwned:sl.zLoOwned + 3, 5:12, 5:12] = 1.0
+    s.upload(loc, p)
+    s.set_slab(sl)
+    s.comm_init_tcp(rank, world, "127.0.0.1", port)
+    if case.endswith("_interrupt") and rank == world - 1:
+        s.set_interrupt(lambda: True)     # ONE rank asks to stop: every rank must return PS_INCOMPLETE at the same batch
+    try:
+        rc = s.step_device()
+        err = ""
+    except polystokes_amd.PolyStokesError as e:
+        rc, err = -1, str(e)
+    res = dict(rc=rc, err=err, iters=int(s.stats.solveData[1]), used_bicgstab=int(s.stats.usedBiCGStab))
+    if rc in (0, 1):
+        lv, lval = s.download()
+        for a in range(3):
+            res["vel%d" % a], res["valid%d" % a] = lv[a], lval[a]
+            res["owned%d" % a] = s.array("owned" + "XYZ"[a])
+        res["labels"] = s.array("centerLabels")
+    np.savez(out, **res)
+    s.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""The REAL multi-process distributed path on one GPU: one process per rank, each with its own ps_context holding a
+slab, ps_step_device -> ps_dist_step_single, halos and scalars exchanged through the host-staged TCP transport
+(ps_comm_init_tcp; RCCL refuses several ranks on one device).  Same Dist code as the RCCL path except transport()/
+allreduce().  Compared with the single-domain solve of the whole scene."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from polystokes_amd import _abi as abi
+from polystokes_amd import partition
+
+import mp_cases
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port_base(n):
+    """a base port with n consecutive free ports (checked by binding them once)"""
+    for base in range(29600 + (os.getpid() % 500) * 8, 40000, 64):
+        socks = []
+        try:
+            for q in range(n):
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.bind(("127.0.0.1", base + q))
+                socks.append(s)
+            return base
+        except OSError:
+            continue
+        finally:
+            for s in socks:
+                s.close()
+    raise RuntimeError("no free port range")
+
+
+def _run_ranks(case, world, tmp_path):
+    base = _free_port_base(world)
+    outs = [str(tmp_path / f"{case}.r{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_rank.py"), case, str(world), str(r), str(base), outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, (r, logs[r][-2000:])
+    return [np.load(o) for o in outs]
+
+
+@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w2_bicgstab"])
+def test_multiprocess_tcp_matches_single_domain(case, tmp_path):
+    import polystokes_amd
+    world = mp_cases.WORLD[case]
+    res = _run_ranks(case, world, tmp_path)          # children first: the parent's own GPU context comes after
+    sc, p = mp_cases.make(case)
+    single = polystokes_amd.Solver(0)
+    rc1 = single.step(sc, p)
+    assert all(int(r["rc"]) == rc1 for r in res), [(int(r["rc"]), str(r["err"])) for r in res]
+    it1 = single.stats.solveData[1]
+    assert all(abs(int(r["iters"]) - it1) <= max(2, 0.02 * it1) for r in res), (it1, [int(r["iters"]) for r in res])
+    assert all(int(r["used_bicgstab"]) == single.stats.usedBiCGStab for r in res)
+    lab = single.array("centerLabels").reshape(sc.nz, sc.ny, sc.nx)
+    sh = abi.grid_shapes(sc.nx, sc.ny, sc.nz)
+    vel = [np.array(sc.vel[a], copy=True) for a in range(3)]
+    valid = [np.zeros(sh["face" + "XYZ"[a]], np.float32) for a in range(3)]
+    for r in range(world):
+        sl = partition.make_slab(sc.nz, world, r, p.tileSize)
+        ll = res[r]["labels"].reshape(sl.nz_local, sc.ny, sc.nx)
+        assert np.array_equal(ll[sl.zLoOwned:sl.zHiOwned], lab[sl.z0:sl.z1]), (case, r)
+        for a in range(3):
+            partition.merge_faces(vel[a], res[r]["vel%d" % a], res[r]["owned%d" % a], sl, a)
+            partition.merge_faces(valid[a], res[r]["valid%d" % a], res[r]["owned%d" % a], sl, a)
+    for a in range(3):
+        assert np.array_equal(valid[a], single.valid[a]), case
+        if rc1 == abi.SUCCESS:
+            scale = max(np.abs(single.vel[a]).max(), 1e-30)
+            assert np.abs(vel[a] - single.vel[a]).max() <= 20 * p.tolerance * scale, case
+    single.close()
+
+
+def test_multiprocess_interrupt_stops_every_rank(tmp_path):
+    """An interrupt callback on ONE rank: all ranks return PS_INCOMPLETE after the same batch, nobody hangs in a receive."""
+    res = _run_ranks("cavity_w2_interrupt", 2, tmp_path)
+    assert [int(r["rc"]) for r in res] == [abi.INCOMPLETE, abi.INCOMPLETE]
+    assert int(res[0]["iters"]) == int(res[1]["iters"]) == 25
+
+
+def test_multiprocess_list_mismatch_fails_every_rank(tmp_path):
+    """Ranks that disagree about the labels on a cut (here: rank 1 was handed other data than rank 0's halo copy) detect it
+    through the counts / key hashes of their exchange lists, and EVERY rank returns FAILED instead of pairing wrong entries
+    or waiting for ever."""
+    res = _run_ranks("cavity_w2_failrank", 2, tmp_path)
+    assert [int(r["rc"]) for r in res] == [-1, -1], [str(r["err"]) for r in res]
+    assert all("exchange lists" in str(r["err"]) for r in res), [str(r["err"]) for r in res]

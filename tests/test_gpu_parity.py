@@ -275,6 +275,41 @@ def test_input_weights_are_used_verbatim(gpu, oracle_mod):
     assert abs(gpu.stats.solveData[1] - o2.stats.solveData[1]) <= 2
 
 
+def test_non_dyadic_weights_take_the_fp64_stream(gpu, oracle_mod):
+    """Volume fractions that are not multiples of 1/8 (a sampler other than the 2x2x2 one, e.g. HDK's own handed in through
+    ps_fields_in.weights): the value coding fails its bit-for-bit check at setup and the pipelined kernels run on the
+    fp64-value stream (16-bit windowed columns + fp64 values) — by itself, no environment switch.  Checked against the
+    oracle given the same weights."""
+    sc, p = scenes.blob(seed=8)
+    o = oracle_mod.Oracle()
+    o.run(sc, p, solve=False)
+    rng = np.random.RandomState(3)
+    w = []
+    for s_ in abi.SAMPLE_NAMES:
+        a = o.array(s_ + "LiquidWeights").copy()
+        m = a > 0
+        a[m] = np.clip(a[m] * rng.uniform(0.55, 1.0, m.sum()), 0.03, 1.0).astype(np.float32)   # arbitrary fractions, same support
+        w.append(a)
+    w += [o.array(s_ + "FluidWeights") for s_ in abi.SAMPLE_NAMES]
+    sh = abi.grid_shapes(sc.nx, sc.ny, sc.nz)
+    sc2 = abi.Scene(sc.nx, sc.ny, sc.nz, sc.dx, sc.dt, sc.density, sc.vel, sc.surface, sc.collision, sc.viscosity,
+                    collisionvel=sc.collisionvel, weights=[w[i].reshape(sh[abi.SAMPLE_NAMES[i % 7]]) for i in range(14)])
+    p.tolerance = 1e-6
+    p.maxSolverIterations = 20000
+    o2 = oracle_mod.Oracle()
+    o2.run(sc2, p)
+    rc = gpu.step(sc2, p)
+    assert rc == o2.result == abi.SUCCESS
+    assert int(gpu.array("valuesCoded")[0]) == 0 and int(gpu.array("columns16")[0]) == 3
+    assert np.array_equal(gpu.array("faceXActiveIndices"), o2.array("faceXActiveIndices"))
+    x = np.random.RandomState(4).standard_normal(gpu.nP + gpu.nT)
+    yo, yg = o2.apply(x), gpu.apply(x)
+    assert np.abs(yo - yg).max() <= 1e-10 * np.abs(yo).max()
+    assert abs(gpu.stats.solveData[1] - o2.stats.solveData[1]) <= max(2, 0.02 * o2.stats.solveData[1])
+    xs, xo = gpu.array("solutionVector"), o2.array("solutionVector")
+    assert np.linalg.norm(xs - xo) <= 10 * p.tolerance * np.linalg.norm(xo)
+
+
 def test_exported_system_solved_independently(gpu, tmp_path):
     """North-star parity route: export the component matrices as .mtx (the reference's file set), rebuild the explicit
     operator A = -dt [G Dt]^T McInv [G Dt] - [JG JDt]^T BInv [JG JDt] - 1/2 diag(0,uInv) (AssembleSystem.cpp:381-389)
@@ -355,11 +390,15 @@ def test_exported_system_import_errors(gpu, tmp_path):
         gpu.solve_exported_system(str(tmp_path) + "/nothing.", abi.default_params(), 0.1, 4)
 
 
-@pytest.mark.parametrize("env", [{"PS_COL32": "1"}, {"PS_FORCE_FP64_VALUES": "1"}, {"PS_PIPE_GRID": "0"}, {"PS_XCD": "0"}])
+@pytest.mark.parametrize("env", [{"PS_COL32": "1"}, {"PS_FORCE_FP64_VALUES": "1"}, {"PS_FORCE_FP64_VALUES": "1", "PS_COL32": "1"},
+                                 {"PS_PIPE_GRID": "0"}, {"PS_XCD": "0"}, {"PS_SCHED": "1", "PS_IL_SUPER": "2"},
+                                 {"PS_IL_ORIGIN": "8", "PS_IL_SUPER": "2,2,1"}])
 def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
-    """The SpMV has three storage formats (compressed 3 B/nnz stream -> int8-coded CSR -> fp64 CSR) chosen at setup, and
-    A/B switches read once per process.  Run the alternatives in a child process: same iteration count, same velocities
-    to rounding (the formats reproduce the same fp64 products; only summation orders of the dot products differ)."""
+    """The SpMV has four storage formats chosen at setup — compressed stream with int8 value codes (3 B/nnz) or with fp64
+    values (10 B/nnz: values that are not code * scale), both on the pipelined kernels; int8-coded CSR and fp64 CSR on the
+    one-shot kernels — plus A/B switches read once per process (numbering lattice, chunk schedule, walk).  Run the
+    alternatives in a child process: same iteration count, same velocities to rounding (the formats reproduce the same
+    fp64 products; only summation orders of the dot products differ)."""
     import os
     import subprocess
     import sys
@@ -382,7 +421,7 @@ def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     if "PS_COL32" in env:
         assert int(alt["c16"][0]) == 0
     if "PS_FORCE_FP64_VALUES" in env:
-        assert int(alt["coded"][0]) == 0 and int(alt["c16"][0]) == 0
+        assert int(alt["coded"][0]) == 0 and int(alt["c16"][0]) == (0 if "PS_COL32" in env else 3)
     assert abs(float(alt["it"]) - gpu.stats.solveData[1]) <= 1
     for a, k in enumerate(("vx", "vy", "vz")):
         scale = max(np.abs(gpu.vel[a]).max(), 1e-30)
