@@ -701,7 +701,8 @@ void ps_context::constructMatrixBlocks() {
 
     const bool wantExport = P.exportComponentMatrices != 0;
     McInv.alloc((size_t)nActiveVs); rhsA.alloc((size_t)nActiveVs);
-    if (wantExport) { Mc.alloc((size_t)nActiveVs); oldVs.alloc((size_t)nActiveVs); uDiag.alloc((size_t)nSystem); }
+    oldVs.alloc((size_t)nActiveVs);   // the warm-start guess needs the old face velocities themselves (constructGuessVectors)
+    if (wantExport) { Mc.alloc((size_t)nActiveVs); uDiag.alloc((size_t)nSystem); }
     uInv.alloc((size_t)nSystem); rhsPT.alloc((size_t)nSystem);
 
     // S
@@ -725,7 +726,7 @@ void ps_context::constructMatrixBlocks() {
     for (int a = 0; a < 3; ++a) {
         const int64_t n = g.count(1 + a);
         hipLaunchKernelGGL(k_S_fill, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, S.ptr.p, S.col.p, S.val.p, S.code.p, McInv.p, rhsA.p,
-                           wantExport ? Mc.p : (double*)nullptr, wantExport ? oldVs.p : (double*)nullptr);
+                           wantExport ? Mc.p : (double*)nullptr, oldVs.p);
     }
     // St
     St.rows = nSystem; St.cols = nRows;

@@ -160,6 +160,7 @@ int ps_context::setup(ps_stats* stats) {
     constructMatrixBlocks();
     T.mark(6);
     assembleSystemPressureStressFactored();
+    constructGuessVectors();   // HDK_PolyStokes.C:462-467 (runs before assemble() there; it only needs the blocks)
     T.mark(7);
     constructPreconditioner();
     T.mark(8);
@@ -255,16 +256,17 @@ void ps_context::registerArrays() {
     // vectors are stored in the internal (block-interleaved) numbering; these views are in reference order
     regp("McInv", McInv.p, nActiveVs, permRow.p, 0);
     regp("activeRHSVector", rhsA.p, nActiveVs, permRow.p, 0);
+    regp("oldActiveVs", oldVs.p, nActiveVs, permRow.p, 0);
     regp("uInv", uInv.p, nStresses, permSys.p, nPressures);
     if (P.exportComponentMatrices) {
         regp("Mc", Mc.p, nActiveVs, permRow.p, 0);
-        regp("oldActiveVs", oldVs.p, nActiveVs, permRow.p, 0);
         regp("u", uDiag.p, nStresses, permSys.p, nPressures);
     }
     regp("pressureRHSVector", rhsPT.p, nPressures, permSys.p, 0);
     regp("stressRHSVector", rhsPT.p, nStresses, permSys.p, nPressures);
     regp("b", b.p, nSystem, permSys.p, 0);
     regp("solutionVector", x.p, nSystem, permSys.p, 0);
+    regp("guessVector", guess.p, nSystem, permSys.p, 0);
     if (P.preconditioner == PS_PRE_DIAGONAL) regp("dinv", dinv.p, nSystem, permSys.p, 0);
     if (isSolved) {
         regp("recoveredActiveVelocity", recovered.p, nActiveVs, permRow.p, 0);
@@ -332,6 +334,93 @@ static std::vector<T> fetch(ps_context* c, const T* dptr, int64_t n) {
         HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     return h;
+}
+
+// assembleSystemPressureStress (AssembleSystem.cpp:351-430) from the device-side blocks: export tooling for solverType EIGEN
+// (the solve itself applies the same operator in factored form).  Triplets -> sorted, duplicates summed (setFromTriplets).
+void ps_context::buildExplicitA(std::vector<int64_t>& aptr, std::vector<int32_t>& acol, std::vector<double>& aval) {
+    const int64_t n = nSystem, nA = nActiveVs, nP = nPressures;
+    auto sp = fetch(this, S.ptr.p, nRows + 1);
+    auto sc = fetch(this, S.col.p, S.nnz);
+    auto sv = fetch(this, S.val.p, S.nnz);
+    auto mc = fetch(this, McInv.p, nA);
+    auto ui = fetch(this, uInv.p, n);
+    auto perm = fetch(this, permSys.p, n);              // reference -> internal
+    std::vector<int32_t> inv((size_t)n);
+    for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
+    struct T { int32_t r, c; double v; };
+    std::vector<T> t;
+    double est = 0;
+    for (int64_t f = 0; f < nA; ++f) { const double l = (double)(sp[(size_t)f + 1] - sp[(size_t)f]); est += l * l; }
+    std::vector<std::vector<int32_t>> regCols((size_t)regionCount);
+    std::vector<int32_t> rreg;
+    std::vector<uint32_t> rface;
+    if (regionCount > 0) {
+        rreg = fetch(this, rrowRegion.p, nReducedRows);
+        rface = fetch(this, rrowFace.p, nReducedRows);
+        for (int64_t q = 0; q < nReducedRows; ++q)
+            for (int32_t p = sp[(size_t)(nA + q)]; p < sp[(size_t)(nA + q) + 1]; ++p) regCols[(size_t)rreg[(size_t)q]].push_back(sc[(size_t)p]);
+        for (auto& v : regCols) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); est += (double)v.size() * (double)v.size(); }
+    }
+    if (est > 4.0e8) throw Error("the explicit matrix A is too large to export (its reduced part is dense per tile): export the component matrices instead");
+    t.reserve((size_t)est + (size_t)n);
+    for (int64_t f = 0; f < nA; ++f) {                   // -dt [G Dt]^T McInv [G Dt]
+        const double d = -dt * mc[(size_t)f];
+        for (int32_t a = sp[(size_t)f]; a < sp[(size_t)f + 1]; ++a)
+            for (int32_t b2 = sp[(size_t)f]; b2 < sp[(size_t)f + 1]; ++b2)
+                t.push_back({inv[(size_t)sc[(size_t)a]], inv[(size_t)sc[(size_t)b2]], d * sv[(size_t)a] * sv[(size_t)b2]});
+    }
+    if (regionCount > 0) {                               // -[JG JDt]^T BInv [JG JDt], JS_r = sum_f C_f (x) S_f
+        auto com = fetch(this, COM.p, regionCount * 3);
+        auto bi = fetch(this, Binv.p, regionCount * PS_RD * PS_RD);
+        std::vector<int64_t> first((size_t)regionCount + 1, 0);
+        for (int64_t q = 0; q < nReducedRows; ++q) first[(size_t)rreg[(size_t)q] + 1]++;
+        for (int64_t r = 0; r < regionCount; ++r) first[(size_t)r + 1] += first[(size_t)r];   // rows are region-contiguous
+        for (int64_t r = 0; r < regionCount; ++r) {
+            const std::vector<int32_t>& cols = regCols[(size_t)r];
+            const size_t m = cols.size();
+            if (m == 0) continue;
+            std::vector<double> JS((size_t)PS_RD * m, 0.), W((size_t)PS_RD * m, 0.);
+            for (int64_t q = first[(size_t)r]; q < first[(size_t)r + 1]; ++q) {
+                int i, j, k, axis;
+                unpackFace(rface[(size_t)q], i, j, k, axis);
+                double pos[3] = {(double)i, (double)j, (double)k};
+                pos[axis] -= 0.5;
+                double cf[PS_RD];
+                basisRow(pos[0] * dx - com[(size_t)r * 3], pos[1] * dx - com[(size_t)r * 3 + 1], pos[2] * dx - com[(size_t)r * 3 + 2], axis, cf);
+                for (int32_t p = sp[(size_t)(nA + q)]; p < sp[(size_t)(nA + q) + 1]; ++p) {
+                    const size_t lc = (size_t)(std::lower_bound(cols.begin(), cols.end(), sc[(size_t)p]) - cols.begin());
+                    for (int e = 0; e < PS_RD; ++e) JS[(size_t)e * m + lc] += cf[e] * sv[(size_t)p];
+                }
+            }
+            for (int e = 0; e < PS_RD; ++e)
+                for (int g2 = 0; g2 < PS_RD; ++g2) {
+                    const double bv = bi[(size_t)r * PS_RD * PS_RD + (size_t)e * PS_RD + g2];
+                    if (bv == 0.) continue;
+                    for (size_t c2 = 0; c2 < m; ++c2) W[(size_t)e * m + c2] += bv * JS[(size_t)g2 * m + c2];
+                }
+            for (size_t a = 0; a < m; ++a)
+                for (size_t b2 = 0; b2 < m; ++b2) {
+                    double s2 = 0;
+                    for (int e = 0; e < PS_RD; ++e) s2 += JS[(size_t)e * m + a] * W[(size_t)e * m + b2];
+                    t.push_back({inv[(size_t)cols[a]], inv[(size_t)cols[b2]], -s2});
+                }
+        }
+    }
+    for (int64_t i = nP; i < n; ++i) t.push_back({(int32_t)i, (int32_t)i, -0.5 * ui[(size_t)perm[(size_t)i]]});   // -1/2 uInv on the stress block
+    std::stable_sort(t.begin(), t.end(), [](const T& a, const T& b2) { return a.r != b2.r ? a.r < b2.r : a.c < b2.c; });
+    aptr.assign((size_t)n + 1, 0); acol.clear(); aval.clear();
+    size_t p = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        aptr[(size_t)r] = (int64_t)aval.size();
+        while (p < t.size() && t[p].r == r) {
+            const int32_t cc = t[p].c;
+            double s2 = 0;
+            while (p < t.size() && t[p].r == r && t[p].c == cc) { s2 += t[p].v; ++p; }
+            acol.push_back(cc); aval.push_back(s2);
+        }
+    }
+    aptr[(size_t)n] = (int64_t)aval.size();
 }
 
 extern "C" {
@@ -727,8 +816,13 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
     })
 }
 
-// exportMatrices + exportMatricesPostSolve (Solver.cpp:533-572): Mat_A (resized to n x n and left empty by the live
-// factored path, AssembleSystem.cpp:445), Vec_b, Vec_guess (zero, :461-467) and, after a solve, solutionVector.
+// exportMatrices + exportMatricesPostSolve (Solver.cpp:533-572): Mat_A, Vec_b, Vec_guess (the warm-start vector of
+// constructGuessVectors, :461-467; zero with useWarmStart off) and, after a solve, solutionVector.
+// Mat_A: with solverType PCG_MATRIX_VECTOR_PRODUCTS the reference resizes A to n x n and leaves it empty
+// (assembleSystemPressureStressFactored, AssembleSystem.cpp:445) — so does this; with solverType EIGEN it assembles the
+// explicit operator (assembleSystemPressureStress, :351-430) and so does this, on the host from the device blocks:
+//   A = -dt S_a^T McInv S_a - (J^T S_r)^T BInv (J^T S_r) - 1/2 diag(0, uInv)
+// (setFromTriplets semantics: duplicates summed, explicit zeros kept out).  The reduced part is dense per tile; export tooling.
 int32_t ps_export_matrices(ps_context* c, const char* prefix) {
     if (!c || !prefix) return PS_FAILED;
     PS_TRY(c, {
@@ -743,10 +837,16 @@ int32_t ps_export_matrices(ps_context* c, const char* prefix) {
             for (int64_t i = 0; i < n; ++i) o[(size_t)i] = v[(size_t)permSys[(size_t)i]];
             return o;
         };
-        const std::vector<int64_t> pn((size_t)n + 1, 0);
-        if (!writeMarketSparse(pre + "Mat_A.mtx", n, n, pn, {}, {})) throw Error("cannot write Mat_A.mtx");
+        if (c->P.solverType != PS_EIGEN) {
+            const std::vector<int64_t> pn((size_t)n + 1, 0);
+            if (!writeMarketSparse(pre + "Mat_A.mtx", n, n, pn, {}, {})) throw Error("cannot write Mat_A.mtx");
+        } else {
+            std::vector<int64_t> ap; std::vector<int32_t> ac; std::vector<double> av;
+            c->buildExplicitA(ap, ac, av);
+            if (!writeMarketSparse(pre + "Mat_A.mtx", n, n, ap, ac, av)) throw Error("cannot write Mat_A.mtx");
+        }
         writeMarketVector(pre + "Vec_b.mtx", refSys(c->b.p));
-        writeMarketVector(pre + "Vec_guess.mtx", std::vector<double>((size_t)n, 0.));
+        writeMarketVector(pre + "Vec_guess.mtx", refSys(c->guess.p));
         if (c->isSolved) writeMarketVector(pre + "solutionVector.mtx", refSys(c->x.p));
         return PS_SUCCESS;
     })

@@ -127,6 +127,7 @@ struct ps_context {
     ps::DevBuf<double> McInv, rhsA, uInv, rhsPT, Mc, uDiag, oldVs;
     ps::DevBuf<float> dinvF;   // the Jacobi diagonal as the PCG kernels read it (fp32 storage, see constructPreconditioner)
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
+    ps::DevBuf<double> guess;   // [pressureGuess; stressGuess] of constructGuessVectors (Solver.cpp:512-531), internal numbering
     // dotPartials: p.Ap partials of the St kernel; dotPartials2: their first-stage sums (one-shot St kernel only);
     // dotPartialsR: r.r / r.z partials of k_cg_update_r; dotPartials3: x.x partials of k_cg_update_xp.  Separate buffers:
     // every block of a step kernel sums its predecessor's partials while other blocks already write this kernel's.
@@ -197,6 +198,10 @@ struct ps_context {
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();
     int solve();
+    int solveEigenCG();                                   // Solver.cpp:814-862 on the factored device operator
+    void constructGuessVectors();                         // Solver.cpp:512-531
+    // explicit A (AssembleSystem.cpp:351-430) in reference numbering, assembled on the host from the device blocks (export only)
+    void buildExplicitA(std::vector<int64_t>& ptr, std::vector<int32_t>& col, std::vector<double>& val);
     void recoverVelocityFromPressureStress();
     void applySolutionToVelocity();
     void applyOperator(const double* x, double* y, double* dotPartialsOut);   // device pointers

@@ -253,6 +253,19 @@ __global__ void __launch_bounds__(BS) k_sum1(const double* __restrict__ partial,
     const double s = sumPartials(partial, count);
     if (threadIdx.x == 0) *out = s;
 }
+// out = a .* b
+__global__ void k_mulv(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+// constructGuessVectors (Solver.cpp:528-529): g holds -(S^T t) in the internal numbering; pressure entries stay, stress entries
+// become -2 uInv g.  Indexed by REFERENCE index (pressures first) through permSys: every internal index is visited once.
+__global__ void k_guess_finish(double* __restrict__ g, const double* __restrict__ uInv, const int32_t* __restrict__ permSys, int64_t nP, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nP) continue;
+        const int32_t j = permSys[i];
+        g[j] = -2. * uInv[j] * g[j];
+    }
+}
 // out = ca*a + cb*b + cc*c  (null pointers skipped)
 __global__ void k_lin(double* __restrict__ out, double ca, const double* __restrict__ a, double cb, const double* __restrict__ b, double cc,
                       const double* __restrict__ c, int64_t n) {

@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cstring>
 #include <cmath>
+#include <limits>
 #include <ctime>
 
 #include "ps_context.hpp"
@@ -184,7 +185,7 @@ void ps_context::assembleSystemPressureStressFactored() {
 
 // Preconditioners.cpp:4-9 (identity) / Jacobi extension
 void ps_context::constructPreconditioner() {
-    if (P.preconditioner != PS_PRE_DIAGONAL) return;
+    if (P.preconditioner != PS_PRE_DIAGONAL && P.solverType != PS_EIGEN) return;   // Eigen's CG always runs its DiagonalPreconditioner
     dinv.alloc((size_t)nSystem);
     if (nSystem == 0) return;
     hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 128)), dim3(128), 0, stream, St.ptr.p, St.col.p, St.val.p, (int)nSystem,
@@ -205,6 +206,7 @@ int ps_context::solve() {
     const double tol = P.tolerance;
     usedBiCGStab = 0;
     interrupted = false;
+    if (P.solverType == PS_EIGEN) return solveEigenCG();
     if (P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
     if (n == 0) { solveIterations = 0; solveError = 0; return PS_SUCCESS; }
     const float* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinvF.p : nullptr;
@@ -297,6 +299,87 @@ int ps_context::solve() {
         solveError = rre;
     }
     return solveIterations == maxit ? PS_NOCONVERGE : PS_SUCCESS;
+}
+
+// initializeGuessVectors + constructGuessVectors (Solver.cpp:512-531) and the guessVector of the assemble functions
+// (AssembleSystem.cpp:461-467):  pressureGuess = -G^T oldVs - JG^T cfit,  stressGuess = -2 uInv (-Dt^T oldVs - JDt^T cfit).
+// With t = [oldVs ; C_f . cfit_region(f)] on the face rows this is one transposed product: g = -S^T t, stress part scaled.
+void ps_context::constructGuessVectors() {
+    const int64_t n = nSystem;
+    guess.alloc((size_t)std::max<int64_t>(n, 1));
+    HIP_CHECK(hipMemsetAsync(guess.p, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), stream));
+    if (!P.useWarmStart || n == 0 || slabEnabled) return;
+    if (nActiveVs > 0) HIP_CHECK(hipMemcpyAsync(ts.p, oldVs.p, (size_t)nActiveVs * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    if (regionCount > 0 && nRChunks > 0)
+        hipLaunchKernelGGL(k_tile_expand, dim3((unsigned)nRChunks), dim3(BS), 0, stream, rchunkRegion.p, rchunkStart.p, rchunkEnd.p, rrowFace.p,
+                           COM.p, dx, cfit.p, ts.p + nActiveVs, (const int*)nullptr);
+    Launch L = mk(this, nullptr);
+    L.spmvSt(1, ts.p, nullptr, x.p, guess.p, nullptr);   // x is zero here (assemble): guess = -S^T t
+    hipLaunchKernelGGL(k_guess_finish, dim3(dotBlocks(n)), dim3(BS), 0, stream, guess.p, uInv.p, permSys.p, nPressures, n);
+}
+
+// solveEigenCG (Solver.cpp:814-862): Eigen::ConjugateGradient<SparseMatrix, Lower|Upper> with its default diagonal
+// preconditioner, solveWithGuess(b, guessVector) — extern/eigen/Eigen/src/IterativeLinearSolvers/ConjugateGradient.h:30-93,
+// BasicPreconditioners.h:69-77 — run on the factored device operator instead of an assembled A (same A x; BASELINE config 1,
+// a plumbing path: host-driven loop, one scalar read-back per dot product).  Stop rule ||r||^2 < tol^2 ||b||^2, returned
+// count = completed iterations, error = ||r|| / ||b||, SUCCESS iff error <= tol (IterativeSolverBase::info()).
+int ps_context::solveEigenCG() {
+    const int64_t n = nSystem;
+    const int maxit = P.maxSolverIterations;
+    const double tol = P.tolerance;
+    usedBiCGStab = 0;
+    interrupted = false;
+    if (slabEnabled) { err = "solverType EIGEN is a single-domain path"; return PS_UNSUPPORTED_SOLVER; }
+    if (n == 0) { solveIterations = 0; solveError = 0; return PS_SUCCESS; }
+    const int vb = dotBlocks(n);
+    tmp1.alloc((size_t)n);
+    double* z = tmp1.p;
+    auto dotH = [&](const double* a, const double* bb) {
+        hipLaunchKernelGGL(k_dot, dim3(vb), dim3(BS), 0, stream, a, bb, n, dotPartials.p);
+        hipLaunchKernelGGL(k_sum1, dim3(1), dim3(BS), 0, stream, dotPartials.p, vb, dotPartials.p + 3 * VGRID);
+        double out;
+        HIP_CHECK(hipMemcpyAsync(&out, dotPartials.p + 3 * VGRID, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return out;
+    };
+    auto lin = [&](double* out, double ca, const double* a, double cb, const double* bb) {
+        hipLaunchKernelGGL(k_lin, dim3(vb), dim3(BS), 0, stream, out, ca, a, cb, bb, 0., (const double*)nullptr, n);
+    };
+    HIP_CHECK(hipMemcpyAsync(x.p, guess.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));   // solveWithGuess
+    applyOperator(x.p, Ap.p, dotPartials.p);
+    lin(r.p, 1., b.p, -1., Ap.p);                                   // residual = rhs - A x
+    const double rhsNorm2 = dotH(b.p, b.p);
+    if (rhsNorm2 == 0.) {
+        HIP_CHECK(hipMemsetAsync(x.p, 0, (size_t)n * sizeof(double), stream));
+        solveIterations = 0; solveError = 0.;
+        return PS_SUCCESS;
+    }
+    const double threshold = std::max(tol * tol * rhsNorm2, std::numeric_limits<double>::min());
+    double residualNorm2 = dotH(r.p, r.p);
+    int i = 0;
+    if (residualNorm2 >= threshold) {
+        hipLaunchKernelGGL(k_mulv, dim3(vb), dim3(BS), 0, stream, pvec.p, dinv.p, r.p, n);   // p = precond.solve(residual)
+        double absNew = dotH(r.p, pvec.p);
+        while (i < maxit) {
+            applyOperator(pvec.p, Ap.p, dotPartials.p);
+            const double alpha = absNew / dotH(pvec.p, Ap.p);
+            lin(x.p, 1., x.p, alpha, pvec.p);
+            lin(r.p, 1., r.p, -alpha, Ap.p);
+            residualNorm2 = dotH(r.p, r.p);
+            if (residualNorm2 < threshold) break;
+            hipLaunchKernelGGL(k_mulv, dim3(vb), dim3(BS), 0, stream, z, dinv.p, r.p, n);
+            const double absOld = absNew;
+            absNew = dotH(r.p, z);
+            const double beta = absNew / absOld;
+            lin(pvec.p, 1., z, beta, pvec.p);
+            ++i;
+            if ((i % 25) == 0 && interruptCb && interruptCb(interruptUser)) { interrupted = true; break; }
+        }
+    }
+    solveIterations = i;
+    solveError = std::sqrt(residualNorm2 / rhsNorm2);
+    if (interrupted) return PS_INCOMPLETE;
+    return solveError <= tol ? PS_SUCCESS : PS_NOCONVERGE;
 }
 
 // Solver.cpp:492-510

@@ -189,6 +189,80 @@ def test_noconverge_falls_back_to_bicgstab(gpu, oracle_mod):
     assert rc == o.result
 
 
+@pytest.mark.parametrize("scene,maxit,tol", [("blob6", 20, 1e-3), ("blob6", 40, 1e-4), ("spheres24", 12, 1e-3), ("spheres24", 30, 1e-4),
+                                             ("coil32", 30, 1e-3)])
+def test_bicgstab_fallback_converges_like_the_oracle(gpu, oracle_mod, scene, maxit, tol):
+    """A PCG that runs out of iterations falls back to bicgstab_external_matrix_A restarted from zero (Solver.cpp:784-799,
+    pcg.h:134-200) — and that BiCGStab CONVERGES here: same verdict, same 0-based iteration index, same error measure
+    (min(||e||^2, ||e|| / ||x||), pcg.h:190-196) and the same solution as the oracle's restatement."""
+    if scene == "blob6":
+        sc, p = scenes.blob(seed=6)
+    elif scene == "coil32":
+        sc, p = scenes.coil(32, tile=8)
+    else:
+        sc, p = scenes.spheres(24, tile=8)
+    p.maxSolverIterations = maxit
+    p.tolerance = tol
+    o = oracle_mod.Oracle()
+    o.run(sc, p)
+    rc = gpu.step(sc, p)
+    assert o.stats.usedBiCGStab == 1 and gpu.stats.usedBiCGStab == 1
+    assert rc == o.result == abi.SUCCESS, (rc, o.result, o.stats.solveData[1])
+    assert int(gpu.stats.solveData[1]) == int(o.stats.solveData[1]) < maxit
+    # BiCGStab amplifies rounding differences (the two implementations sum their dot products in other orders): after 7-38
+    # iterations the error measures agree to 1e-3 ... 6e-2 relative, the iteration index exactly
+    assert gpu.stats.solveData[0] < tol and o.stats.solveData[0] < tol
+    assert abs(gpu.stats.solveData[0] - o.stats.solveData[0]) <= 0.25 * abs(o.stats.solveData[0])
+    xo, xg = o.array("solutionVector"), gpu.array("solutionVector")
+    assert np.linalg.norm(xg - xo) <= 10 * tol * np.linalg.norm(xo)
+    for a in range(3):
+        vo = o.array("vel" + "XYZ"[a])
+        assert np.abs(gpu.vel[a].ravel() - vo).max() <= 20 * tol * max(np.abs(vo).max(), 1e-30)
+
+
+@pytest.mark.parametrize("case", ["beam32", "beam16_nowarm", "blob_reduced"])
+def test_solver_type_eigen_matches_oracle(gpu, oracle_mod, tmp_path, case):
+    """solverType = EIGEN (BASELINE config 1: uniform 32^3 beam): Eigen's ConjugateGradient semantics — diagonal preconditioner,
+    ||r||^2 < tol^2 ||b||^2, solveWithGuess from the warm-start vector (Solver.cpp:814-862, 512-531) — on the factored device
+    operator, against the oracle's Eigen-CG restatement on its explicitly assembled A; and the explicit A itself (Mat_A.mtx,
+    AssembleSystem.cpp:351-430) against the oracle's."""
+    import scipy.io
+    if case == "beam32":
+        sc, p = scenes.beam(32)
+    elif case == "beam16_nowarm":
+        sc, p = scenes.beam(16)
+        p.useWarmStart = 0
+    else:
+        sc, p = scenes.blob(16, 14, 18, seed=5, tile=6)
+    p.solverType = abi.EIGEN
+    p.tolerance = 1e-8
+    p.maxSolverIterations = 20000
+    o = oracle_mod.Oracle()
+    o.run(sc, p)
+    rc = gpu.step(sc, p)
+    assert rc == o.result == abi.SUCCESS
+    g, go = gpu.array("guessVector"), o.array("guessVector")
+    if case == "beam16_nowarm":
+        assert not go.any() and not g.any()
+    else:
+        assert np.abs(go).max() > 0 and np.abs(g - go).max() <= 1e-11 * np.abs(go).max()
+    it, ito = int(gpu.stats.solveData[1]), int(o.stats.solveData[1])
+    assert abs(it - ito) <= max(2, 0.02 * ito), (it, ito)
+    assert gpu.stats.solveData[0] <= p.tolerance
+    xo, xg = o.array("solutionVector"), gpu.array("solutionVector")
+    assert np.linalg.norm(xg - xo) <= 10 * p.tolerance * np.linalg.norm(xo)
+    for a in range(3):
+        vo = o.array("vel" + "XYZ"[a])
+        assert np.abs(gpu.vel[a].ravel() - vo).max() <= 1e-4 * max(np.abs(vo).max(), 1e-30)
+    pre = str(tmp_path) + "/e."
+    gpu.export_matrices(pre)
+    A = scipy.io.mmread(pre + "Mat_A.mtx").tocsr()
+    Ao = o.csr("A")
+    assert A.shape == Ao.shape and A.nnz > 0
+    assert abs(A - Ao).max() <= 1e-9 * abs(Ao).max()
+    assert abs(A - A.T).max() <= 1e-9 * abs(Ao).max()
+
+
 def test_export_component_matrices_roundtrip(gpu, oracle_mod, tmp_path):
     """exportComponentMatrices / exportStats (Solver.cpp:543-606): MatrixMarket files with the reference's names,
     read back with scipy and compared with the oracle's blocks (reference numbering)."""
@@ -217,7 +291,10 @@ def test_export_component_matrices_roundtrip(gpu, oracle_mod, tmp_path):
     n = int(gpu.stats.dimData[21])
     A = scipy.io.mmread(pre + "Mat_A.mtx")
     assert A.shape == (n, n) and A.nnz == 0
-    assert not scipy.io.mmread(pre + "Vec_guess.mtx").any()
+    # Vec_guess is the warm-start vector of constructGuessVectors (Solver.cpp:512-531, useWarmStart defaults to 1)
+    g = np.asarray(scipy.io.mmread(pre + "Vec_guess.mtx")).ravel()
+    go = o.array("guessVector")
+    assert np.abs(go).max() > 0 and np.abs(g - go).max() <= 1e-11 * np.abs(go).max()
     for nm in ("G", "Dt", "JG", "JDt"):
         M = scipy.io.mmread(pre + "Mat_%s.mtx" % nm).tocsr()
         Mo = o.csr(nm)
