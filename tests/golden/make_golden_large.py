@@ -1,0 +1,79 @@
+"""Larger golden fixtures in DIGEST form (tests/golden/large_*.npz), generated from the CPU oracle like make_golden.py:
+the scenes of BASELINE configs 2/4 (coil) and 5 (spheres) at 96^3, and the reference's only shipped parameter set
+(scenes/jelly_jam: tileSize 32, tilePadding 3, layer sizes 3/3) on a 64^3 cavity and on an irregular blob.
+Per case: SHA-256 of every integer / label / index / valid array (bit-exact state), dimData, iteration count, solve error,
+every 5th entry of the solution x in float32 (the comparison is at 10*tol), and float64 checksums of b, x and of the operator
+applied to a seeded vector w: norms and projections on w (||b||, b.w, ||x||, x.w, ||A w||, w.A w).  Output velocities are NOT part of it: on the coil
+they difference 1e5-sized terms (AMP) and are decided by rounding at tol 1e-3.
+
+    python tests/golden/make_golden_large.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from polystokes_amd import _abi as abi  # noqa: E402
+from polystokes_amd import scenes  # noqa: E402
+
+
+def _shipped(sp):
+    sc, p = sp
+    p.activeLiquidBoundaryLayerSize = p.activeSolidBoundaryLayerSize = 3
+    return sc, p
+
+
+CASES = {
+    "coil96": lambda: scenes.coil(96),
+    "spheres96": lambda: scenes.spheres(96),
+    "cavity64_t32p3_L3S3": lambda: _shipped(scenes.cavity(64, tile=32, pad=3)),
+    "blob_t32p3_L3S3": lambda: _shipped(scenes.blob(52, 44, 48, seed=3, tile=32, pad=3)),
+}
+INT_ARRAYS = [s + k for s in abi.SAMPLE_NAMES for k in ("Labels", "ActiveIndices", "ReducedIndices")] + ["validX", "validY", "validZ"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def probe_vector(n):
+    return np.random.RandomState(20261004).standard_normal(n)
+
+
+def digest(get, stats, apply):
+    """get(name) -> array, stats -> ps_stats-like, apply(w) -> A w: the same digest from the oracle or from the HIP path"""
+    out = {"dimData": np.array(stats.dimData), "iterations": np.int32(stats.solveData[1]), "solveError": np.float64(stats.solveData[0])}
+    for nm in INT_ARRAYS:
+        a = get(nm)
+        out["sha_" + nm] = np.array(sha(a.astype(np.int32) if nm.startswith("valid") else a))
+    for s in abi.SAMPLE_NAMES:
+        out["sha_" + s + "Weights8"] = np.array(sha(np.round(np.concatenate([get(s + "LiquidWeights"), get(s + "FluidWeights")]) * 8).astype(np.int8)))
+    b, x = get("b"), get("solutionVector")
+    w = probe_vector(b.size)
+    out["x32_stride5"] = x[::5].astype(np.float32)
+    out["b_norm"], out["b_dot_w"] = np.float64(np.linalg.norm(b)), np.float64(b @ w)
+    out["x_norm"], out["x_dot_w"] = np.float64(np.linalg.norm(x)), np.float64(x @ w)
+    y = apply(w)
+    out["Aw_norm"], out["wAw"] = np.float64(np.linalg.norm(y)), np.float64(w @ y)
+    return out
+
+
+def build(name):
+    from oracle import ps_oracle
+    sc, p = CASES[name]()
+    o = ps_oracle.Oracle()
+    rc = o.run(sc, p)
+    d = digest(o.array, o.stats, o.apply)
+    d["result"] = np.int32(rc)
+    return d
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in CASES:
+        np.savez_compressed(os.path.join(here, "large_" + name + ".npz"), **build(name))
+        print("wrote", name)

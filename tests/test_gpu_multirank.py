@@ -31,10 +31,16 @@ def _tall_coil(n, nz):
     return sc, p
 
 
-@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w4_tile8"])
+@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w4_tile8", "spheres_w2", "spheres_w4_jacobi"])
 def test_group_matches_single_domain(case):
     import polystokes_amd
-    if case == "cavity_w2":
+    if case.startswith("spheres"):
+        # BASELINE config 5 stand-in (moving solid spheres, mu = 1e4, mixed uniform / reduced regions) cut into 2 and 4 slabs
+        sc, p = scenes.spheres(64)
+        world = 2 if case == "spheres_w2" else 4
+        if world == 4:
+            p.preconditioner = abi.PRE_DIAGONAL
+    elif case == "cavity_w2":
         (sc, p), world = _tall_cavity(32, 64), 2
     elif case == "cavity_w3_jacobi":
         (sc, p), world = _tall_cavity(24, 96, precond=abi.PRE_DIAGONAL), 3
