@@ -73,3 +73,27 @@ def test_traversal_order_roundtrip_matches_oracle(oracle_mod):
     for _ in range(500):
         i, j, k = rng.randint(37), rng.randint(18), rng.randint(21)
         assert idx[k, j, i] == order(i, j, k)
+
+
+def test_shim_parameter_table_covers_the_params_struct():
+    """shim/HDK_PolyStokes_shim.C (the Houdini DSO source, built only where $HFS exists): every node parameter of ps_params has
+    a row in its template table with the header's default, and the DOP names of the reference are there."""
+    src = open(os.path.join(ROOT, "shim", "HDK_PolyStokes_shim.C")).read()
+    rows = dict()
+    for m in re.finditer(r"\{'([SFITO])',\s*(\"[^\"]+\"|[A-Z_]+),\s*\"[^\"]*\",\s*(nullptr|\"(?:[^\"\\]|\\.)*\"),\s*([-0-9.e]+)\}", src):
+        rows[m.group(2).strip('"')] = (m.group(1), float(m.group(4)))
+    hdr = open(os.path.join(ROOT, "include", "polystokes.h")).read()
+    body = hdr[hdr.index("typedef struct ps_params {"):hdr.index("} ps_params;")]
+    body = body[:body.index("extensions")]
+    members = re.findall(r"(?:double|int32_t)\s+(\w+);\s*/\*\s*([-0-9.e]+)?", body)
+    assert len(members) >= 20
+    alias = {"tolerance": "SIM_NAME_TOLERANCE"}
+    for name, default in members:
+        key = alias.get(name, name)
+        assert key in rows, name
+        if default and name not in ("matrixSetup", "solverType"):   # the menus keep the reference's off-by-one template ordinal
+            assert rows[key][1] == float(default), (name, rows[key], default)
+    for needle in ('"hdk_polystokes"', '"HDK Polynomial Stokes Solver"', "initializeSIM", "IMPLEMENT_DATAFACTORY(HDK_PolyStokes)",
+                   "polystokes_step(", "ps_set_interrupt("):
+        assert needle in src, needle
+    assert '"HDK PolyStokes Solver"' in open(os.path.join(ROOT, "shim", "HDK_PolyStokes_shim.h")).read()
