@@ -55,7 +55,11 @@ enum ps_matrix_scheme { PS_PRESSURE_STRESS = 0 };
 enum ps_solver_type { PS_PCG_MATRIX_VECTOR_PRODUCTS = 0, PS_EIGEN = 1 };
 /* lib/include/units.h:47-53; DIAGONAL is the empty stub at
  * exec/HDK_PolyStokesSolver_Preconditioners.cpp:37-41 that BASELINE.json asks for (Jacobi-PCG). */
-enum ps_preconditioner { PS_PRE_IDENTITY = 1, PS_PRE_DIAGONAL = 5 };
+/* PS_PRE_CHEBYSHEV (extension): z = q(D^-1 A) D^-1 r with q the degree-(k-1) Chebyshev polynomial
+ * of the interval [lmax/30, lmax], D = diag(A), k = ps_params.preconditionerDegree (default 4): k-1 operator applies per
+ * CG iteration, the same smoother-as-preconditioner idea as the reference's abandoned GS designs
+ * (lib/src/Preconditioner.cpp:30-158) on the live pressure-stress operator.  lmax = max(8.4, 1.25 x the estimate of 10 power iterations at setup). */
+enum ps_preconditioner { PS_PRE_IDENTITY = 1, PS_PRE_DIAGONAL = 5, PS_PRE_CHEBYSHEV = 6 };
 /* order in which serialAssignFieldIndices walks a field (Classifier.cpp:1738-1770):
  * 0 = UT_VoxelArray order (16^3 voxel tiles, tile-linear, x-fastest inside), 1 = plain x-fastest. */
 enum ps_index_order { PS_ORDER_VOXEL_TILES = 0, PS_ORDER_LINEAR = 1 };
@@ -93,7 +97,7 @@ typedef struct ps_params {
                                            solid) and is negated before the reference's
                                            computeSDFWeightsSampled(invert=false) call is applied
                                            (Solver.cpp:308-326); 0: use as given. default 1 */
-    int32_t reserved;
+    int32_t preconditionerDegree;       /* PS_PRE_CHEBYSHEV: terms k of the polynomial (k-1 applies); 0 = default 4 */
     const char* exportDataPrefix;       /* may be NULL */
 } ps_params;
 
@@ -179,6 +183,10 @@ int32_t polystokes_step(ps_context* ctx, const ps_params* p, const ps_fields_in*
 /* y = A x for host vectors of length nPressures+nStresses:
  * ApplyPressureStressMatrix::apply (lib/include/ApplyPressureStressMatrix.h:102-184). */
 int32_t ps_apply_operator(ps_context* ctx, const double* x, double* y);
+
+/* z = M^-1 r with the preconditioner of the set-up context (identity, Jacobi, Chebyshev), host vectors in reference numbering:
+ * the parity hook for the preconditioner (tests compare it with the oracle's). */
+int32_t ps_apply_preconditioner(ps_context* ctx, const double* r, double* z);
 
 /* Inspection of solver state by name — the data behind printAllData()'s 43 point clouds
  * (Solver.cpp:1030-1074) and exportComponentMatrices() (Solver.cpp:543-566).

@@ -154,6 +154,11 @@ struct Oracle {
     // operator
     void applyOperator(const double* x, double* y) const;        // reference-shaped (ApplyPressureStressMatrix.h:102-179)
     void constructGuessVectors();                                 // Solver.cpp:512-531
+    // Chebyshev-Jacobi polynomial preconditioner (extension PS_PRE_CHEBYSHEV, include/polystokes.h)
+    double chebLmax = 0;
+    void estimateLambdaMax();
+    void chebyshev(const std::vector<double>& r, std::vector<double>& z) const;
+    void precondition(const std::vector<double>& r, std::vector<double>& z) const;   // z = M^-1 r of the configured preconditioner
     void applySection1(const double* x, std::vector<double>& A11_1, std::vector<double>& A21_1) const;
     void applySection2(const double* x, std::vector<double>& tp, std::vector<double>& tt) const;
     void applySection3(const double* x, std::vector<double>& A12_1, std::vector<double>& A22_1) const;

@@ -44,6 +44,7 @@ def lib():
         L.po_build_jacobi.argtypes = [C.c_void_p]
         L.po_time_cg_iterations.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.po_time_cg_iterations.restype = C.c_double
+        L.po_precondition.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.po_time_cg_iterations_mt.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         L.po_time_cg_iterations_mt.restype = C.c_double
         L.po_time_cg_iterations_sections.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -127,6 +128,19 @@ class Oracle:
         y = np.empty_like(x)
         self.L.po_apply_operator(self.h, x.ctypes.data, y.ctypes.data, 1 if fair else 0)
         return y
+
+    def precondition(self, r):
+        """z = M^-1 r of the configured preconditioner (identity / Jacobi / Chebyshev)"""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.empty_like(r)
+        self.L.po_precondition(self.h, r.ctypes.data, z.ctypes.data)
+        return z
+
+    @property
+    def cheb_lmax(self):
+        self.L.po_cheb_lmax.restype = C.c_double
+        self.L.po_cheb_lmax.argtypes = [C.c_void_p]
+        return self.L.po_cheb_lmax(self.h)
 
     def build_explicit_A(self):
         self.L.po_build_explicit_A(self.h)

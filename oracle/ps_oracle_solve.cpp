@@ -142,16 +142,63 @@ void Oracle::applyOperatorFair(const double* x, double* y) const {
     for (int64_t i = 0; i < nT; ++i) y[nP + i] += -0.5 * uInv[(size_t)i] * x[nP + i];
 }
 
+// z = M^-1 r: identity (Preconditioner.cpp:271-274), the Jacobi extension, or the Chebyshev extension
+void Oracle::precondition(const std::vector<double>& in, std::vector<double>& out) const {
+    const size_t n = in.size();
+    if (P.preconditioner == PS_PRE_CHEBYSHEV) { chebyshev(in, out); return; }
+    if (P.preconditioner != PS_PRE_DIAGONAL) { out = in; return; }
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) out[i] = diagA[i] != 0. ? in[i] / diagA[i] : in[i];
+}
+// Largest eigenvalue of D^-1 A by 10 power iterations from the all-ones vector (Rayleigh quotient of the last iterate), with
+// the safety margin the polynomial needs: an UNDER-estimate would make it negative beyond the interval.  A = sum over faces of
+// rank-one terms with <= 8 entries, so lambda_max(D^-1 A) <= 8 for the stencil part (Cauchy-Schwarz); the tile part is not
+// covered by that bound, hence the measurement:  lmax = max(8.4, 1.25 * estimate).
+void Oracle::estimateLambdaMax() {
+    const size_t n = (size_t)(nPressures + nStresses);
+    std::vector<double> v(n, 1.), w(n), Av(n);
+    double lam = 0.;
+    for (int it = 0; it < 10 && n > 0; ++it) {
+        applyOperator(v.data(), Av.data());
+        for (size_t i = 0; i < n; ++i) w[i] = (diagA[i] != 0. ? 1. / diagA[i] : 1.) * Av[i];
+        const double vv = dot(v, v);
+        lam = dot(v, w) / vv;
+        const double nw = std::sqrt(dot(w, w));
+        if (nw == 0.) break;
+        for (size_t i = 0; i < n; ++i) v[i] = w[i] / nw;
+    }
+    chebLmax = std::max(8.4, 1.25 * lam);
+}
+// k terms of the Chebyshev iteration for D^-1 A z = D^-1 r from z = 0 on [lmax/30, lmax] (k-1 operator applies)
+void Oracle::chebyshev(const std::vector<double>& r, std::vector<double>& z) const {
+    const size_t n = r.size();
+    const int k = P.preconditionerDegree > 0 ? P.preconditionerDegree : 4;
+    const double lmax = chebLmax, lmin = lmax / 30.;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1. / sigma;
+    std::vector<double> d(n), Az(n);
+    z.resize(n);
+    auto dinv = [&](size_t i) { return diagA[i] != 0. ? 1. / diagA[i] : 1.; };
+    for (size_t i = 0; i < n; ++i) { d[i] = dinv(i) * r[i] / theta; z[i] = d[i]; }
+    for (int j = 1; j < k; ++j) {
+        const double rhoN = 1. / (2. * sigma - rho);
+        const double c1 = rhoN * rho, c2 = 2. * rhoN / delta;
+        applyOperator(z.data(), Az.data());
+        for (size_t i = 0; i < n; ++i) {
+            const double res = dinv(i) * (r[i] - Az[i]);
+            d[i] = c1 * d[i] + c2 * res;
+            z[i] = z[i] + d[i];
+        }
+        rho = rhoN;
+    }
+}
+
 // pcg_external_matrix_A, lib/include/pcg.h:268-340.  Preconditioner: identity (Preconditioner.cpp:18-28,
 // 271-274) or the Jacobi extension.  Deviation: b == 0 returns immediately (reference divides 0/0, pcg.h:314).
 int Oracle::pcg(std::vector<double>& x, const std::vector<double>& rhs, double tol, int maxit, double& rre) const {
     const size_t n = rhs.size();
     std::vector<double> r(n), z(n), p(n), Ap(n);
-    const bool jacobi = P.preconditioner == PS_PRE_DIAGONAL;
-    auto pre = [&](const std::vector<double>& in, std::vector<double>& out) {
-        if (!jacobi) { out = in; return; }
-        for (size_t i = 0; i < n; ++i) out[i] = diagA[i] != 0. ? in[i] / diagA[i] : in[i];
-    };
+    auto pre = [&](const std::vector<double>& in, std::vector<double>& out) { precondition(in, out); };
     applyOperator(x.data(), Ap.data());
     for (size_t i = 0; i < n; ++i) r[i] = rhs[i] - Ap[i];
     pre(r, z);
@@ -418,7 +465,8 @@ int Oracle::setup(const ps_params* p, const ps_fields_in* in) {
     // HDK_PolyStokes.C:462-467: initializeGuessVectors(); if (getUseWarmStart()) constructGuessVectors();
     constructGuessVectors();
     assembleSystemPressureStressFactored();
-    if (P.preconditioner == PS_PRE_DIAGONAL) buildJacobiDiagonal();
+    if (P.preconditioner == PS_PRE_DIAGONAL || P.preconditioner == PS_PRE_CHEBYSHEV) buildJacobiDiagonal();
+    if (P.preconditioner == PS_PRE_CHEBYSHEV) estimateLambdaMax();
     const auto w1 = std::chrono::high_resolution_clock::now();
     stats.solveData[4] = 1000.0 * (double)(std::clock() - c0) / CLOCKS_PER_SEC;
     stats.solveData[5] = std::chrono::duration<double, std::milli>(w1 - w0).count();
@@ -572,6 +620,14 @@ double po_time_cg_iterations(void* h, int32_t iters, int32_t fair) {
     const auto w1 = std::chrono::high_resolution_clock::now();
     return std::chrono::duration<double, std::milli>(w1 - w0).count() / (double)iters;
 }
+void po_precondition(void* h, const double* r, double* z) {
+    Oracle* o = (Oracle*)h;
+    const size_t n = (size_t)(o->nPressures + o->nStresses);
+    std::vector<double> in(r, r + n), out;
+    o->precondition(in, out);
+    std::copy(out.begin(), out.end(), z);
+}
+double po_cheb_lmax(void* h) { return ((Oracle*)h)->chebLmax; }
 void po_basis(const double* off, int32_t axis, double* out) { psoracle::buildConversionCoefficients(off, axis, out); }
 int32_t po_fullpivlu_solve(const double* N, const double* rhs, double* x) { return psoracle::fullPivLuSolve(N, rhs, x) ? 1 : 0; }
 int32_t po_partialpiv_inverse(const double* B, double* Binv) { return psoracle::partialPivInverse(B, Binv) ? 1 : 0; }

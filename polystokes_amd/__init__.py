@@ -21,7 +21,7 @@ _lib = None
 EXPORTED_SYMBOLS = [
     "ps_abi_version", "ps_context_create", "ps_context_destroy", "ps_last_error", "ps_params_default",
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
-    "polystokes_step", "ps_apply_operator", "ps_query_array", "ps_read_array",
+    "polystokes_step", "ps_apply_operator", "ps_apply_preconditioner", "ps_query_array", "ps_read_array",
     "ps_export_component_matrices", "ps_export_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt", "ps_solve_exported_system",
     "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest", "ps_comm_init_tcp",
     "ps_group_create", "ps_group_destroy", "ps_group_rank", "ps_group_step",
@@ -64,6 +64,8 @@ def lib():
         L.polystokes_step.restype = C.c_int32
         L.ps_apply_operator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ps_apply_operator.restype = C.c_int32
+        L.ps_apply_preconditioner.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ps_apply_preconditioner.restype = C.c_int32
         L.ps_query_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
         L.ps_query_array.restype = C.c_int64
         L.ps_read_array.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -231,6 +233,13 @@ class Solver:
         y = np.empty_like(x)
         self._check(self.L.ps_apply_operator(self.h, x.ctypes.data, y.ctypes.data))
         return y
+
+    def precondition(self, r):
+        """z = M^-1 r of the configured preconditioner (reference numbering)"""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.empty_like(r)
+        self._check(self.L.ps_apply_preconditioner(self.h, r.ctypes.data, z.ctypes.data))
+        return z
 
     def bench_kernel(self, name, iters=20):
         ms, by = C.c_double(0), C.c_double(0)

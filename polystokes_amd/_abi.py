@@ -14,7 +14,7 @@ UNSUPPORTED_SOLVER, INCOMPLETE, INVALID, FAILED, NOCONVERGE, SUCCESS, NOCHANGE =
 UNASSIGNED, UNSOLVED, GENERICFLUID, ACTIVEFLUID, SOLID, REDUCED, UNVISITED, VISITED, BOUNDARY = (
     -1, -2, -3, -4, -5, -6, -7, -8, -9)
 PCG_MATRIX_VECTOR_PRODUCTS, EIGEN = 0, 1
-PRE_IDENTITY, PRE_DIAGONAL = 1, 5
+PRE_IDENTITY, PRE_DIAGONAL, PRE_CHEBYSHEV = 1, 5, 6
 ORDER_VOXEL_TILES, ORDER_LINEAR = 0, 1
 
 STAGE_NAMES = ["weights", "classify", "regions", "indices", "tile_matrices", "blocks", "assemble",
@@ -36,7 +36,7 @@ class Params(C.Structure):
         ("activeSolidBoundaryLayerSize", C.c_int32), ("doReducedRegions", C.c_int32),
         ("doTile", C.c_int32), ("tileSize", C.c_int32), ("tilePadding", C.c_int32),
         ("preconditioner", C.c_int32), ("indexOrder", C.c_int32), ("negateCollision", C.c_int32),
-        ("reserved", C.c_int32),
+        ("preconditionerDegree", C.c_int32),
         ("exportDataPrefix", C.c_char_p),
     ]
 

@@ -66,7 +66,8 @@ void ps_context::upload(const ps_params* p, const ps_fields_in* in) {
     if (p->doReducedRegions && p->doTile && p->tileSize < 1) throw Error("tileSize must be at least 1");
     if (p->tilePadding < 0 || p->activeLiquidBoundaryLayerSize < 0 || p->activeSolidBoundaryLayerSize < 0) throw Error("layer sizes and tilePadding must not be negative");
     if (!(p->tolerance >= 0.) || p->maxSolverIterations < 0) throw Error("tolerance and maxSolverIterations must not be negative");
-    if (p->preconditioner != PS_PRE_IDENTITY && p->preconditioner != PS_PRE_DIAGONAL) throw Error("Unsupported preconditioner.");
+    if (p->preconditioner != PS_PRE_IDENTITY && p->preconditioner != PS_PRE_DIAGONAL && p->preconditioner != PS_PRE_CHEBYSHEV) throw Error("Unsupported preconditioner.");
+    if (p->preconditionerDegree < 0 || p->preconditionerDegree > 64) throw Error("preconditionerDegree must lie in 0..64");
     P = *p;
     g.nx = in->nx; g.ny = in->ny; g.nz = in->nz; g.order = p->indexOrder;
     dx = in->dx; invDx = 1. / dx; dt = in->dt; invDt = 1. / dt; rho = (double)in->density;
@@ -555,6 +556,24 @@ int32_t ps_apply_operator(ps_context* c, const double* x, double* y) {
         c->applyOperator(c->tmp1.p, c->tmp2.p, c->dotPartials.p);
         hipLaunchKernelGGL(k_gather_perm8, dim3(gridFor((int64_t)n, 256)), dim3(256), 0, c->stream, c->tmp3.p, c->tmp2.p, c->permSys.p, (int64_t)0, (int64_t)n);
         HIP_CHECK(hipMemcpyAsync(y, c->tmp3.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return PS_SUCCESS;
+    })
+}
+
+int32_t ps_apply_preconditioner(ps_context* c, const double* rin, double* zout) {
+    if (!c || !rin || !zout) return PS_FAILED;
+    PS_TRY(c, {
+        if (!c->isSetup) throw Error("not set up");
+        if (c->slabEnabled) throw Error("ps_apply_preconditioner is a single-domain call");
+        HIP_CHECK(hipSetDevice(c->device));
+        const size_t n = (size_t)c->nSystem;
+        c->tmp3.alloc(n); c->tmp4.alloc(n); c->tmp1.alloc(n); c->tmp2.alloc(n);
+        HIP_CHECK(hipMemcpyAsync(c->tmp3.p, rin, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scatter_perm8, dim3(gridFor((int64_t)n, 256)), dim3(256), 0, c->stream, c->tmp4.p, c->tmp3.p, c->permSys.p, (int64_t)n);   // tmp4 = r (internal order)
+        c->applyPreconditionerDevice(c->tmp4.p, c->tmp1.p, c->tmp2.p);                                                                                  // tmp1 = z
+        hipLaunchKernelGGL(k_gather_perm8, dim3(gridFor((int64_t)n, 256)), dim3(256), 0, c->stream, c->tmp3.p, c->tmp1.p, c->permSys.p, (int64_t)0, (int64_t)n);
+        HIP_CHECK(hipMemcpyAsync(zout, c->tmp3.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
         return PS_SUCCESS;
     })

@@ -127,6 +127,8 @@ struct ps_context {
     ps::DevBuf<double> McInv, rhsA, uInv, rhsPT, Mc, uDiag, oldVs;
     ps::DevBuf<float> dinvF;   // the Jacobi diagonal as the PCG kernels read it (fp32 storage, see constructPreconditioner)
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
+    ps::DevBuf<double> chebPartials, chebPartials2;   // r.z partials of the Chebyshev polynomial's last term
+    double chebLmax = 8.4;                            // upper end of the Chebyshev interval (estimateLambdaMax)
     ps::DevBuf<double> guess;   // [pressureGuess; stressGuess] of constructGuessVectors (Solver.cpp:512-531), internal numbering
     // dotPartials: p.Ap partials of the St kernel; dotPartials2: their first-stage sums (one-shot St kernel only);
     // dotPartialsR: r.r / r.z partials of k_cg_update_r; dotPartials3: x.x partials of k_cg_update_xp.  Separate buffers:
@@ -198,6 +200,9 @@ struct ps_context {
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();
     int solve();
+    void estimateLambdaMax();
+    void applyPreconditionerDevice(const double* r, double* z, double* scratch);   // z = M^-1 r (parity hook, ps_apply_preconditioner)
+    int chebyshevApply(const double* r, double* z, double* d, double* rzPartial, const ps::CGScalars* sc);
     int solveEigenCG();                                   // Solver.cpp:814-862 on the factored device operator
     void constructGuessVectors();                         // Solver.cpp:512-531
     // explicit A (AssembleSystem.cpp:351-430) in reference numbering, assembled on the host from the device blocks (export only)

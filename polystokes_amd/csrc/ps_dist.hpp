@@ -566,6 +566,8 @@ struct Dist {
 
 int distStep(Dist& D, ps_stats* stats) {
     const auto w0 = std::chrono::high_resolution_clock::now();
+    for (ps_context* c : D.R)
+        if (c->P.preconditioner == PS_PRE_CHEBYSHEV) throw Error("the Chebyshev preconditioner is a single-domain option (slab decomposition: identity or Jacobi)");
     for (ps_context* c : D.R) c->redbuf.alloc(8);
     // a rank whose local setup throws must tell the others before they enter the first exchange (they would wait for ever)
     std::string failure;

@@ -253,6 +253,64 @@ __global__ void __launch_bounds__(BS) k_sum1(const double* __restrict__ partial,
     const double s = sumPartials(partial, count);
     if (threadIdx.x == 0) *out = s;
 }
+// ---- Chebyshev-Jacobi polynomial preconditioner (PS_PRE_CHEBYSHEV) -------------------------------------------------
+// first term: d = z = dinv r / theta ; partial of r.z (used when the polynomial has this one term only)
+__global__ void __launch_bounds__(BS) k_cheb_first(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                   double invTheta, double* __restrict__ d, double* __restrict__ z, int64_t n, double* __restrict__ partial) {
+    if (sc && sc->done) return;
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double rv = r[i];
+        const double v = dinv[i] * rv * invTheta;
+        d[i] = v; z[i] = v;
+        acc += rv * v;
+    }
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// a later term, unfused form (the St kernel's MODE 2 epilogue does the same per row): Az given
+__global__ void __launch_bounds__(BS) k_cheb_step(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                  const double* __restrict__ Az, double c1, double c2, double* __restrict__ d, double* __restrict__ z,
+                                                  int64_t n, double* __restrict__ partial) {
+    if (sc && sc->done) return;
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double rv = r[i];
+        const double dn = c1 * d[i] + c2 * (dinv[i] * (rv - Az[i]));
+        const double zn = z[i] + dn;
+        d[i] = dn; z[i] = zn;
+        acc += rv * zn;
+    }
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// beta = r.z / rsold ; x += alpha p ; p = z + beta p with z a VECTOR (polynomial preconditioner) ; partials of x.x
+__global__ void __launch_bounds__(BS) k_cg_update_xp_z(CGScalars* sc, const double* __restrict__ rrPartial, int rrCount, const double* __restrict__ rzPartial,
+                                                       int rzCount, int it, const double* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
+                                                       int64_t n, double* __restrict__ partial) {
+    if (sc->done) return;
+    const double rr = blockSumAll(sumLocal(rrPartial, rrCount));
+    const double rz = blockSumAll(sumLocal(rzPartial, rzCount));
+    const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
+    double axx = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double pv = p[i];
+        const double xv = x[i] + alpha * pv;
+        x[i] = xv; p[i] = z[i] + beta * pv;
+        axx += xv * xv;
+    }
+    const double s1 = blockReduceSum(axx);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s1;
+}
+__global__ void k_fill_f64(double* __restrict__ a, double v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = v;
+}
+// out[0] = sum of partial[0..count)   (one block, fixed order)
+__global__ void __launch_bounds__(BS) k_sum_to(const double* __restrict__ partial, int count, double* __restrict__ out) {
+    const double s = sumPartials(partial, count);
+    if (threadIdx.x == 0) out[0] = s;
+}
 // out = a .* b
 __global__ void k_mulv(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];

@@ -170,6 +170,9 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 // run on XCD b & 7 (verified with s_getreg HW_REG_XCC_ID), so runs of G consecutive chunks are dealt to the XCDs round
 // robin — rows that gather the same lines of x (k-plane neighbours, a few chunks apart) then share ONE L2, while
 // the chip as a whole still sweeps one compact window of memory.
+// MODE 2 of the St kernel: one term of the Chebyshev preconditioner fused into the epilogue (ps_context::solve):
+//   Az = (A z)[row];  d[row] = c1 d[row] + c2 dinv[row] (r[row] - Az);  z[row] += d[row];  partial += r[row] z[row]
+struct ChebArgs { const double* r; const double* dinv; double* d; double c1, c2; };
 struct ChunkSched { const int32_t* list; int off[9]; };   // per-XCD chunk lists (ps_context::buildChunkSchedule); list == null: computed walk
 struct ChunkWalk {
     int sh, x, l, per;   // G = 1 << sh chunks per run; sh < 0: plain walk
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                                      const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
                                                      double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done,
-                                                     ChunkSched sched, int nChunks, int xcdAware) {
+                                                     ChunkSched sched, int nChunks, int xcdAware, ChebArgs cheb) {
     if (done && *done) return;
     constexpr int PL = BS * NV;
     __shared__ double prod[4 * PL];
@@ -376,12 +379,14 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
     static_assert(BS == 256, "four waves per block");
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, F64 ? 0 : (size_t)streamLen),
                                  rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
-                                 rE0 = bufRsrc(MODE == 0 ? xin : add, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
-                                 rOut = bufRsrc(out, (size_t)rows * 8);
+                                 rE0 = bufRsrc(MODE == 1 ? add : xin, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
+                                 rOut = bufRsrc(out, (size_t)rows * 8),
+                                 rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
+                                 rCd = bufRsrc(cheb.d, MODE == 2 ? (size_t)rows * 8 : 0);
     const ChunkWalk W(xcdAware, sched);
     int it = 0;
     int chunk = W.at(0);
-    if (chunk >= nChunks) { if (MODE == 0 && threadIdx.x == 0) partial[blockIdx.x] = 0.; return; }
+    if (chunk >= nChunks) { if (MODE != 1 && threadIdx.x == 0) partial[blockIdx.x] = 0.; return; }
     double dacc = 0.;
     int2 pr = chunkRange[chunk];
     Stream4<NV, F64> cur, nxt;
@@ -393,9 +398,10 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
     while (true) {
         const unsigned row = (unsigned)chunk * BS + threadIdx.x;
         const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
-        const double e0 = bufLoadF64(rE0, row * 8u);                                       // x (MODE 0) / the vector added (MODE 1)
-        double e1 = 0.;
-        if (MODE == 0) e1 = bufLoadF64(rE1, row * 8u);
+        const double e0 = bufLoadF64(rE0, row * 8u);                                       // x (MODE 0, 2) / the vector added (MODE 1)
+        double e1 = 0., cr = 0., ci = 0., cd = 0.;
+        if (MODE != 1) e1 = bufLoadF64(rE1, row * 8u);
+        if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }
         double xv[4 * NV];
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
@@ -429,7 +435,14 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             const double s = rowSum<6, PL>(prod, ea, len);
             double y;
             if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
-            else y = -s + e0;
+            else if (MODE == 1) y = -s + e0;
+            else {
+                double az = -s; az -= 0.5 * e1 * e0;
+                const double dn = cheb.c1 * cd + cheb.c2 * (ci * (cr - az));
+                bufStoreF64nt(rCd, row * 8u, dn);
+                y = e0 + dn;
+                dacc += cr * y;                                                  // r.z of the updated z
+            }
             bufStoreF64nt(rOut, row * 8u, y);
         }
         __syncthreads();    // protects the LDS reuse
@@ -438,7 +451,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         nchunk = nn; npr = nnpr;
         ++it;
     }
-    if (MODE == 0) {
+    if (MODE != 1) {
         const double bs = blockReduceSum(dacc);
         if (threadIdx.x == 0) partial[blockIdx.x] = bs;   // gridDim.x partials (Launch::stBlocks)
     }

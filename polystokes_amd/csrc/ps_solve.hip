@@ -101,22 +101,27 @@ struct Launch {
         else { if (M.packed) PS_LAUNCH_T(1, true); else PS_LAUNCH_T(1, false); }
 #undef PS_LAUNCH_T
     }
-    void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
+    bool stOnPipe() const { return pipeGrid > 0 && c->St.col16ok && (c->St.packed || c->St.val4.p); }
+    // mode 2 (Chebyshev term fused into the epilogue, ChebArgs) exists on the pipelined kernels only: callers check stOnPipe()
+    void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial, const ChebArgs* cheb = nullptr) const {
         if (rowsSt == 0) return;
         const ps::DevCSR& M = c->St;
+        ChebArgs ca{nullptr, nullptr, nullptr, 0., 0.};
+        if (cheb) ca = *cheb;
         if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
             const int nChunks = gridFor(rowsSt, BS);
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
 #define PS_LAUNCH_TP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware)
+                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware, ca)
 #define PS_LAUNCH_TP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_TP(MODE_, NV_, false); else PS_LAUNCH_TP(MODE_, NV_, true); } while (0)
-            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP2(0, 1); else PS_LAUNCH_TP2(1, 1); }
-            else { if (mode == 0) PS_LAUNCH_TP2(0, 2); else PS_LAUNCH_TP2(1, 2); }
+            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP2(0, 1); else if (mode == 1) PS_LAUNCH_TP2(1, 1); else PS_LAUNCH_TP2(2, 1); }
+            else { if (mode == 0) PS_LAUNCH_TP2(0, 2); else if (mode == 1) PS_LAUNCH_TP2(1, 2); else PS_LAUNCH_TP2(2, 2); }
 #undef PS_LAUNCH_TP2
 #undef PS_LAUNCH_TP
             return;
         }
+        if (mode == 2) throw Error("internal: fused Chebyshev term without the pipelined St kernel");
         spmvSt_(mode, t, xin, add, out, partial);
     }
     // grid of a persistent kernel; the XCD-grouped walk needs a multiple of 8 blocks (workgroup b runs on XCD b & 7)
@@ -131,7 +136,7 @@ struct Launch {
     int stBlocks() const {   // number of p.Ap partials the St kernel writes: one per block
         const int nChunks = gridFor(rowsSt, BS);
         int xcd = xcdAware;
-        return (pipeGrid > 0 && c->St.col16ok && (c->St.packed || c->St.val4.p)) ? pipeBlocks(nChunks, xcd, c->St.packed) : nChunks;
+        return stOnPipe() ? pipeBlocks(nChunks, xcd, c->St.packed) : nChunks;
     }
 };
 Launch mk(ps_context* c, const int* done) {
@@ -185,7 +190,7 @@ void ps_context::assembleSystemPressureStressFactored() {
 
 // Preconditioners.cpp:4-9 (identity) / Jacobi extension
 void ps_context::constructPreconditioner() {
-    if (P.preconditioner != PS_PRE_DIAGONAL && P.solverType != PS_EIGEN) return;   // Eigen's CG always runs its DiagonalPreconditioner
+    if (P.preconditioner != PS_PRE_DIAGONAL && P.preconditioner != PS_PRE_CHEBYSHEV && P.solverType != PS_EIGEN) return;   // Eigen's CG always runs its DiagonalPreconditioner
     dinv.alloc((size_t)nSystem);
     if (nSystem == 0) return;
     hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 128)), dim3(128), 0, stream, St.ptr.p, St.col.p, St.val.p, (int)nSystem,
@@ -197,6 +202,89 @@ void ps_context::constructPreconditioner() {
     // cross-rank completion of the diagonal (Dist::finishSetup).
     dinvF.alloc((size_t)nSystem);
     if (!slabEnabled) hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(nSystem)), dim3(BS), 0, stream, dinv.p, dinvF.p, nSystem);
+    if (P.preconditioner == PS_PRE_CHEBYSHEV) estimateLambdaMax();
+}
+
+// lambda_max(D^-1 A) for the Chebyshev polynomial: 10 power iterations from the all-ones vector, Rayleigh quotient of the
+// last iterate, then max(8.4, 1.25 * estimate) — same procedure as the oracle (ps_oracle_solve.cpp:estimateLambdaMax).
+// The stencil part of A is a sum of rank-one face terms with <= 8 entries, so its lambda_max(D^-1 A) <= 8 by Cauchy-Schwarz;
+// the measurement covers the tile part.  10 applies at setup (~1 % of a 256^3 step).
+void ps_context::estimateLambdaMax() {
+    const int64_t n = nSystem;
+    chebLmax = 8.4;
+    if (n == 0) return;
+    const int vb = dotBlocks(n);
+    tmp1.alloc((size_t)n); tmp2.alloc((size_t)n); tmp3.alloc((size_t)n);
+    double* v = tmp1.p; double* w = tmp2.p; double* Av = tmp3.p;
+    auto dotH = [&](const double* a, const double* bb) {
+        hipLaunchKernelGGL(k_dot, dim3(vb), dim3(BS), 0, stream, a, bb, n, dotPartials.p);
+        hipLaunchKernelGGL(k_sum1, dim3(1), dim3(BS), 0, stream, dotPartials.p, vb, dotPartials.p + 3 * VGRID);
+        double out;
+        HIP_CHECK(hipMemcpyAsync(&out, dotPartials.p + 3 * VGRID, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return out;
+    };
+    hipLaunchKernelGGL(k_fill_f64, dim3(vb), dim3(BS), 0, stream, v, 1., n);
+    double lam = 0.;
+    for (int it = 0; it < 10; ++it) {
+        applyOperator(v, Av, dotPartials.p);
+        hipLaunchKernelGGL(k_mulv, dim3(vb), dim3(BS), 0, stream, w, dinv.p, Av, n);
+        const double vv = dotH(v, v);
+        lam = dotH(v, w) / vv;
+        const double nw = std::sqrt(dotH(w, w));
+        if (nw == 0.) break;
+        hipLaunchKernelGGL(k_lin, dim3(vb), dim3(BS), 0, stream, v, 1. / nw, (const double*)w, 0., (const double*)nullptr, 0., (const double*)nullptr, n);
+    }
+    chebLmax = std::max(8.4, 1.25 * lam);
+}
+
+// z = q(D^-1 A) D^-1 r: k terms of the Chebyshev iteration on [lmax/30, lmax] (k-1 operator applies), see include/polystokes.h.
+// Terms 2..k run as S, tiles and the St kernel with the update fused into its epilogue (MODE 2): per term the St kernel reads
+// r, dinv, d besides its own operands and writes d and z in place — no separate vector pass.  rzPartial receives the partials
+// of r.z of the final z (count returned); `sc` (may be null) lets the kernels of a converged solve exit early.
+int ps_context::chebyshevApply(const double* rvec, double* z, double* d, double* rzPartial, const ps::CGScalars* sc) {
+    const int64_t n = nSystem;
+    const int k = P.preconditionerDegree > 0 ? P.preconditionerDegree : 4;
+    const double lmax = chebLmax, lmin = lmax / 30.;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1. / sigma;
+    const int vb = dotBlocks(n);
+    const int* done = sc ? &sc->done : nullptr;
+    Launch L = mk(this, done);
+    hipLaunchKernelGGL(k_cheb_first, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, 1. / theta, d, z, n, rzPartial);
+    int count = vb;
+    for (int j = 1; j < k; ++j) {
+        const double rhoN = 1. / (2. * sigma - rho);
+        const double c1 = rhoN * rho, c2 = 2. * rhoN / delta;
+        L.spmvS(0, z, ts.p);
+        L.tiles(0, ts.p);
+        if (L.stOnPipe()) {
+            const ChebArgs ca{rvec, dinv.p, d, c1, c2};
+            L.spmvSt(2, ts.p, z, nullptr, z, rzPartial, &ca);
+            count = L.stBlocks();
+        } else {
+            tmp5.alloc((size_t)n);
+            L.spmvSt(0, ts.p, z, nullptr, tmp5.p, dotPartials2.p);
+            hipLaunchKernelGGL(k_cheb_step, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, (const double*)tmp5.p, c1, c2, d, z, n, rzPartial);
+            count = vb;
+        }
+        rho = rhoN;
+    }
+    return count;
+}
+
+void ps_context::applyPreconditionerDevice(const double* rvec, double* z, double* scratch) {
+    const int64_t n = nSystem;
+    if (n == 0) return;
+    const int vb = dotBlocks(n);
+    if (P.preconditioner == PS_PRE_CHEBYSHEV) {
+        chebPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(n, BS)) + 16);
+        chebyshevApply(rvec, z, scratch, chebPartials.p, nullptr);
+    } else if (P.preconditioner == PS_PRE_DIAGONAL) {
+        hipLaunchKernelGGL(k_mulv, dim3(vb), dim3(BS), 0, stream, z, dinv.p, rvec, n);   // the fp64 diagonal (the PCG kernels read its fp32 copy)
+    } else {
+        HIP_CHECK(hipMemcpyAsync(z, rvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
 }
 
 // Solver.cpp:734-812 solveSPDwithMatrixVectorPCG -> pcg_external_matrix_A (pcg.h:268-340), BiCGStab fallback (pcg.h:134-200)
@@ -209,15 +297,39 @@ int ps_context::solve() {
     if (P.solverType == PS_EIGEN) return solveEigenCG();
     if (P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
     if (n == 0) { solveIterations = 0; solveError = 0; return PS_SUCCESS; }
+    const bool cheb = P.preconditioner == PS_PRE_CHEBYSHEV;
     const float* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinvF.p : nullptr;
     const int vb = dotBlocks(n);
     CGScalars* sc = scal.p;
     const int* done = &sc->done;
     Launch L = mk(this, done);
     const int stBlocks = L.stBlocks();
+    double* zvec = nullptr; double* dvec = nullptr; double* rzPart = nullptr;
+    if (cheb) {
+        tmp1.alloc((size_t)n); tmp2.alloc((size_t)n);
+        zvec = tmp1.p; dvec = tmp2.p;
+        chebPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(n, BS)) + 16);
+        chebPartials2.alloc(RED_BLOCKS);
+        rzPart = chebPartials.p;
+    }
+    // r.z partials of the polynomial's last term, reduced to <= RED_BLOCKS values when there is one per 256-row chunk
+    auto rzReduce = [&](int count, const double*& part, int& cnt) {
+        part = rzPart; cnt = count;
+        if (count > 8192) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, stream, sc, rzPart, count, chebPartials2.p);
+            part = chebPartials2.p; cnt = RED_BLOCKS;
+        }
+    };
 
     HIP_CHECK(hipMemsetAsync(dotPartials3.p, 0, VGRID * sizeof(double), stream));
     hipLaunchKernelGGL(k_cg_init_f, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
+    if (cheb) {   // z = M^-1 r, p = z, rsold = r.z
+        HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(CGScalars), stream));   // `done` must read 0 inside the polynomial's kernels
+        const int cnt0 = chebyshevApply(r.p, zvec, dvec, rzPart, nullptr);
+        HIP_CHECK(hipMemcpyAsync(pvec.p, zvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(BS), 0, stream, rzPart, cnt0, dotPartials.p);
+        hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, 1, tol, maxit);
+    } else
     hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, tol, maxit);
     CGScalars h{};
     const int batch = 25;
@@ -237,6 +349,12 @@ int ps_context::solve() {
             }
             hipLaunchKernelGGL(k_cg_update_r, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, pApPart, pApCount, dotPartials3.p, vb, it, Ap.p, dv,
                                r.p, n, dotPartialsR.p);
+            if (cheb) {
+                const double* part; int cnt;
+                rzReduce(chebyshevApply(r.p, zvec, dvec, rzPart, sc), part, cnt);
+                hipLaunchKernelGGL(k_cg_update_xp_z, dim3(vb), dim3(BS), 0, stream, sc, (const double*)dotPartialsR.p, vb, part, cnt, it, (const double*)zvec,
+                                   x.p, pvec.p, n, dotPartials3.p);
+            } else
             hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, dotPartialsR.p, vb, dv ? 1 : 0, it, r.p, dv, x.p,
                                pvec.p, n, dotPartials3.p);
         }
