@@ -522,6 +522,57 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot) {
                                            (long long)M.rows, (long long)M.nnz, maxLen, M.nv, (int)M.col16ok);
 }
 
+// ---- value-set coding of the diagonals (ps_context.hpp: uCode / mcCode) ----------------------------------------------
+namespace {
+constexpr unsigned long long DICT_EMPTY = 0xfff8dead0000beefull;   // a NaN payload no diagonal value takes
+__device__ inline int dictHash(unsigned long long k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 29; return (int)(k & 255ull); }
+// insert every value into a 256-slot open-addressing table (linear probing); slot index = the value's code
+__global__ void k_dict_build(const double* __restrict__ v, int64_t n, unsigned long long* __restrict__ table, int32_t* __restrict__ overflow) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+        if (key == DICT_EMPTY) { *overflow = 1; continue; }
+        int h = dictHash(key);
+        bool placed = false;
+        for (int probe = 0; probe < 256 && !placed; ++probe) {
+            unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == DICT_EMPTY) cur = atomicCAS(&table[h], DICT_EMPTY, key), cur = (cur == DICT_EMPTY) ? key : cur;
+            if (cur == key) placed = true; else h = (h + 1) & 255;
+        }
+        if (!placed) *overflow = 1;
+    }
+}
+__global__ void k_dict_code(const double* __restrict__ v, int64_t n, const unsigned long long* __restrict__ table, uint8_t* __restrict__ code) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+        int h = dictHash(key);
+        for (int probe = 0; probe < 256 && table[h] != key; ++probe) h = (h + 1) & 255;
+        code[i] = (uint8_t)h;
+    }
+}
+__global__ void k_dict_init(unsigned long long* table) { table[threadIdx.x] = DICT_EMPTY; }
+__global__ void k_dict_finish(unsigned long long* table) { if (table[threadIdx.x] == DICT_EMPTY) table[threadIdx.x] = 0ull; }   // unused slots decode to 0.0
+}  // namespace
+void ps_context::buildDiagonalCodes() {
+    uCoded = mcCoded = false;
+    const char* e = getenv("PS_NO_DIAG_CODES");
+    if (e && atoi(e) != 0) return;
+    auto build = [&](const DevBuf<double>& vals, int64_t n, DevBuf<uint8_t>& code, DevBuf<double>& dict) -> bool {
+        if (n <= 0) return false;
+        dict.alloc(256); code.alloc((size_t)n);
+        unsigned long long* table = (unsigned long long*)dict.p;
+        HIP_CHECK(hipMemsetAsync(counters.p + 26, 0, sizeof(int32_t), stream));
+        hipLaunchKernelGGL(k_dict_init, dim3(1), dim3(256), 0, stream, table);
+        hipLaunchKernelGGL(k_dict_build, dim3(1024), dim3(BS), 0, stream, vals.p, n, table, counters.p + 26);
+        if (readCounter(26) != 0) return false;
+        hipLaunchKernelGGL(k_dict_code, dim3(1024), dim3(BS), 0, stream, vals.p, n, (const unsigned long long*)table, code.p);
+        hipLaunchKernelGGL(k_dict_finish, dim3(1), dim3(256), 0, stream, table);
+        return true;
+    };
+    uCoded = build(uInv, nSystem, uCode, uDict);
+    mcCoded = build(McInv, nActiveVs, mcCode, mcDict);
+    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] diagonal value sets: uInv %s, McInv %s\n", uCoded ? "coded (<= 256 values)" : "fp64", mcCoded ? "coded" : "fp64");
+}
+
 // Chunk -> XCD schedule of the persistent SpMV kernels (ChunkWalk): built on the host from the block starts of the internal
 // numbering.  A 256-row chunk belongs to the super-block of its first row; the skin-row chunks of S go with the super-block
 // holding the min corner of their region's box.  Super-blocks (non-empty ones, in sequence order) are dealt to the 8 XCDs
@@ -764,6 +815,7 @@ void ps_context::constructMatrixBlocks() {
         buildCol16(St, 23);
         buildChunkSchedule(S, true);
         buildChunkSchedule(St, false);
+        buildDiagonalCodes();
         const int32_t c16 = (S.col16ok ? 1 : 0) | (St.col16ok ? 2 : 0);
         HIP_CHECK(hipMemcpyAsync(counters.p + 24, &c16, sizeof(c16), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

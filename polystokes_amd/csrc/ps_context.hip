@@ -274,6 +274,9 @@ void ps_context::registerArrays() {
         reg("recoveredReducedVelocity", recovered.p ? recovered.p + nActiveVs : nullptr, nReducedVs, 8);
     }
     reg("valuesCoded", counters.p + 21, 1, 4);
+    diagFlagsHost = (uCoded ? 1 : 0) | (mcCoded ? 2 : 0);
+    HIP_CHECK(hipMemcpyAsync(counters.p + 27, &diagFlagsHost, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    reg("diagonalsCoded", counters.p + 27, 1, 4);
     reg("columns16", counters.p + 24, 1, 4);
     reg("sysPerm", permSys.p, nSystem, 4);
     reg("rowPerm", permRow.p, nActiveVs, 4);
@@ -673,8 +676,10 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             const double perNnzS = perNnz(c->S), perNnzT = perNnz(c->St);
             const double winS = c16(c->S) ? 0.25 * (double)c->nRows : 0., winT = c16(c->St) ? 0.25 * (double)c->nSystem : 0.;   // 64 B of window bases per 256-row chunk
             const double ptrS = c16(c->S) ? 1. : 4., ptrT = c16(c->St) ? 1. : 4.;   // row length byte | row pointer
-            const double bS = winS + perNnzS * nnz + ptrS * (rowsS + 1) + 8. * rowsS + 8. * rowsT + 8. * (double)c->nActiveVs;
-            const double bT = winT + perNnzT * nnz + ptrT * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + 8. * rowsT;
+            // the fused diagonals: fp64 array, or a 1-byte value-set code per row on the pipelined kernels (ps_context.hpp: uCode / mcCode)
+            const double dMc = (c16(c->S) && c->mcCoded) ? 1. : 8., dU = (c16(c->St) && c->uCoded) ? 1. : 8.;
+            const double bS = winS + perNnzS * nnz + ptrS * (rowsS + 1) + 8. * rowsS + 8. * rowsT + dMc * (double)c->nActiveVs;
+            const double bT = winT + perNnzT * nnz + ptrT * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + dU * rowsT;
             if (kb == "spmv_S") *algorithmic_bytes = bS;
             else if (kb == "spmv_St") *algorithmic_bytes = bT;
             else if (kb == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);

@@ -125,6 +125,15 @@ struct ps_context {
     // ---- blocks (Solver.h:337-369): S = [G Dt ; Ghat Dhat] by face row, St its transpose ----
     ps::DevCSR S, St;
     ps::DevBuf<double> McInv, rhsA, uInv, rhsPT, Mc, uDiag, oldVs;
+    // Value-set coding of the two diagonals the SpMV epilogues read (ps_blocks.hip:buildDiagonalCodes): when a diagonal takes at
+    // most 256 distinct values (constant viscosity: uInv = invVisc * {volume fractions}; McInv = 1 / (rho * k/64)) the kernels
+    // read a 1-byte code per row and look the fp64 value up in a 256-entry table held in LDS — the same bits, 7 bytes less per
+    // row.  Decided per setup; any 257th value keeps the fp64 array (variable viscosity fields).  PS_NO_DIAG_CODES=1 disables.
+    ps::DevBuf<uint8_t> uCode, mcCode;
+    ps::DevBuf<double> uDict, mcDict;      // 256 entries each
+    bool uCoded = false, mcCoded = false;
+    int32_t diagFlagsHost = 0;
+    void buildDiagonalCodes();
     ps::DevBuf<float> dinvF;   // the Jacobi diagonal as the PCG kernels read it (fp32 storage, see constructPreconditioner)
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
     ps::DevBuf<double> chebPartials, chebPartials2;   // r.z partials of the Chebyshev polynomial's last term

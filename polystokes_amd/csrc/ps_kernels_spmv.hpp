@@ -300,15 +300,18 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
                                                     const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
                                                     int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
-                                                    const int* __restrict__ done, ChunkSched sched, int nChunks, int xcdAware) {
+                                                    const int* __restrict__ done, ChunkSched sched, int nChunks, int xcdAware,
+                                                    const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict) {
     if (done && *done) return;
     constexpr int PL = BS * NV;
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
+    __shared__ double dict[MODE == 0 ? 256 : 1];      // value-set coded McInv (ps_context.hpp: mcCode): first read after the loop's first barrier
+    if (MODE == 0 && mcCode) dict[threadIdx.x] = mcDict[threadIdx.x];
     static_assert(BS == 256, "four waves per block");
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, F64 ? 0 : (size_t)streamLen),
                                  rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
-                                 rOut = bufRsrc(out, (size_t)rows * 8);
+                                 rMcc = bufRsrc(mcCode, mcCode ? (size_t)nA : 0), rOut = bufRsrc(out, (size_t)rows * 8);
     const ChunkWalk W(xcdAware, sched);
     int it = 0;
     int chunk = W.at(0);
@@ -324,7 +327,11 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
         const unsigned row = (unsigned)chunk * BS + threadIdx.x;
         const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
         double sc = 1.;
-        if (MODE == 0) { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
+        int mcc = 0;
+        if (MODE == 0) {
+            if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, 0);
+            else { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
+        }
         double xv[4 * NV];
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
@@ -356,6 +363,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
             const int wv = threadIdx.x >> 6;
             const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
             const double s = rowSum<8, PL>(prod, ea, len);
+            if (MODE == 0 && mcCode) sc = (int)row < nA ? dt * dict[mcc] : 1.;
             bufStoreF64nt(rOut, row * 8u, s * sc);                             // dropped past the last row
         }
         __syncthreads();
@@ -371,18 +379,21 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                                      const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
                                                      double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done,
-                                                     ChunkSched sched, int nChunks, int xcdAware, ChebArgs cheb) {
+                                                     ChunkSched sched, int nChunks, int xcdAware, ChebArgs cheb,
+                                                     const uint8_t* __restrict__ uCode, const double* __restrict__ uDict) {
     if (done && *done) return;
     constexpr int PL = BS * NV;
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
+    __shared__ double dict[MODE != 1 ? 256 : 1];      // value-set coded uInv (ps_context.hpp: uCode)
+    if (MODE != 1 && uCode) dict[threadIdx.x] = uDict[threadIdx.x];
     static_assert(BS == 256, "four waves per block");
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, F64 ? 0 : (size_t)streamLen),
                                  rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(MODE == 1 ? add : xin, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8),
                                  rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
-                                 rCd = bufRsrc(cheb.d, MODE == 2 ? (size_t)rows * 8 : 0);
+                                 rCd = bufRsrc(cheb.d, MODE == 2 ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0);
     const ChunkWalk W(xcdAware, sched);
     int it = 0;
     int chunk = W.at(0);
@@ -400,7 +411,8 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
         const double e0 = bufLoadF64(rE0, row * 8u);                                       // x (MODE 0, 2) / the vector added (MODE 1)
         double e1 = 0., cr = 0., ci = 0., cd = 0.;
-        if (MODE != 1) e1 = bufLoadF64(rE1, row * 8u);
+        int uc = 0;
+        if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, 0); else e1 = bufLoadF64(rE1, row * 8u); }
         if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }
         double xv[4 * NV];
 #pragma unroll
@@ -433,6 +445,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             const int wv = threadIdx.x >> 6;
             const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
             const double s = rowSum<6, PL>(prod, ea, len);
+            if (MODE != 1 && uCode) e1 = dict[uc];
             double y;
             if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
             else if (MODE == 1) y = -s + e0;

@@ -65,7 +65,7 @@ struct Launch {
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
 #define PS_LAUNCH_SP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, sched(M, gr.x), nChunks, xcdAware)
+                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, sched(M, gr.x), nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p)
 #define PS_LAUNCH_SP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_SP(MODE_, NV_, false); else PS_LAUNCH_SP(MODE_, NV_, true); } while (0)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP2(0, 1); else PS_LAUNCH_SP2(1, 1); }
             else { if (mode == 0) PS_LAUNCH_SP2(0, 2); else PS_LAUNCH_SP2(1, 2); }
@@ -113,7 +113,7 @@ struct Launch {
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
 #define PS_LAUNCH_TP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware, ca)
+                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p)
 #define PS_LAUNCH_TP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_TP(MODE_, NV_, false); else PS_LAUNCH_TP(MODE_, NV_, true); } while (0)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP2(0, 1); else if (mode == 1) PS_LAUNCH_TP2(1, 1); else PS_LAUNCH_TP2(2, 1); }
             else { if (mode == 0) PS_LAUNCH_TP2(0, 2); else if (mode == 1) PS_LAUNCH_TP2(1, 2); else PS_LAUNCH_TP2(2, 2); }
