@@ -149,38 +149,42 @@ __device__ inline int blockScanExcl(int v, int* total) {
 }
 template <bool ASSIGN>
 __global__ void __launch_bounds__(BS) k_skin(BlockArgs A, const int32_t* __restrict__ bbox, const int32_t* __restrict__ itemRegion,
-                                             const int32_t* __restrict__ itemAxis, const int32_t* __restrict__ itemStart,
-                                             int32_t* __restrict__ itemCount, int32_t* __restrict__ faceRow0, int32_t* __restrict__ faceRow1,
-                                             int32_t* __restrict__ faceRow2, uint32_t* __restrict__ rrowFace, int32_t* __restrict__ rrowRegion) {
+                                             const int32_t* __restrict__ itemStart, int32_t* __restrict__ itemCount, int32_t* __restrict__ faceRow0,
+                                             int32_t* __restrict__ faceRow1, int32_t* __restrict__ faceRow2, uint32_t* __restrict__ rrowFace,
+                                             int32_t* __restrict__ rrowRegion) {
     const int item = blockIdx.x;
-    const int r = itemRegion[item], axis = itemAxis[item], start = itemStart[item];
+    const int r = itemRegion[item], start = itemStart[item];
     if (A.regionOwned && !A.regionOwned[r]) {   // tile of another rank (halo): no rows here
         if (!ASSIGN && threadIdx.x == 0) itemCount[item] = 0;
         return;
     }
     const int bx0 = bbox[r * 6 + 0], by0 = bbox[r * 6 + 1], bz0 = bbox[r * 6 + 2];
-    int ex = bbox[r * 6 + 3] - bx0 + 1, ey = bbox[r * 6 + 4] - by0 + 1, ez = bbox[r * 6 + 5] - bz0 + 1;
-    if (axis == 0) ex++; else if (axis == 1) ey++; else ez++;
+    const int ex = bbox[r * 6 + 3] - bx0 + 2, ey = bbox[r * 6 + 4] - by0 + 2, ez = bbox[r * 6 + 5] - bz0 + 2;   // union of the three face boxes
     const int total = ex * ey * ez;
     const int end = min(start + FB_CHUNK, total);
-    int32_t* faceRow = axis == 0 ? faceRow0 : (axis == 1 ? faceRow1 : faceRow2);
-    const int3 fd = A.g.dims(1 + axis);
     int running = ASSIGN ? itemCount[item] : 0;   // exclusive offset of this item (after scan)
     for (int base = start; base < end; base += BS) {
         const int pos = base + threadIdx.x;
-        bool fl = false;
+        int fl = 0;                                // bit a: the face of axis a at this position is a skin face
         int i = 0, j = 0, k = 0;
         if (pos < end) {
             i = bx0 + pos % ex; j = by0 + (pos / ex) % ey; k = bz0 + pos / (ex * ey);
-            fl = skinFace(A, axis, r, i, j, k);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) if (skinFace(A, a, r, i, j, k)) fl |= 1 << a;
         }
         int tot;
-        const int off = blockScanExcl(fl ? 1 : 0, &tot);
+        const int off = blockScanExcl(__popc(fl), &tot);
         if (ASSIGN && fl) {
-            const int rr = running + off;
-            faceRow[lin3(fd, i, j, k)] = (int32_t)(A.nA + rr);
-            rrowFace[rr] = packFace(i, j, k, axis);
-            rrowRegion[rr] = r;
+            int rr = running + off;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if (fl & (1 << a)) {
+                    int32_t* faceRow = a == 0 ? faceRow0 : (a == 1 ? faceRow1 : faceRow2);
+                    faceRow[lin3(A.g.dims(1 + a), i, j, k)] = (int32_t)(A.nA + rr);
+                    rrowFace[rr] = packFace(i, j, k, a);
+                    rrowRegion[rr] = r;
+                    ++rr;
+                }
         }
         running += tot;
     }
@@ -691,55 +695,45 @@ void ps_context::constructMatrixBlocks() {
     BlockArgs A = makeArgs(this);
     // reduced rows
     nReducedRows = 0;
-    if (regionCount > 0 && fbItems > 0) {
-        hipLaunchKernelGGL(k_skin<false>, dim3((unsigned)fbItems), dim3(BS), 0, stream, A, bbox.p, fbItemRegion.p, fbItemAxis.p,
-                           fbItemStart.p, fbItemCount.p, faceRow[0].p, faceRow[1].p, faceRow[2].p, (uint32_t*)nullptr, (int32_t*)nullptr);
-        HIP_CHECK(hipMemsetAsync(fbItemCount.p + fbItems, 0, sizeof(int32_t), stream));
-        nReducedRows = exclusiveScanI32(fbItemCount.p, fbItems + 1);
+    maxRegionRows = 0;
+    if (regionCount > 0 && sbItems > 0) {
+        hipLaunchKernelGGL(k_skin<false>, dim3((unsigned)sbItems), dim3(BS), 0, stream, A, bbox.p, sbItemRegion.p, sbItemStart.p, sbItemCount.p,
+                           faceRow[0].p, faceRow[1].p, faceRow[2].p, (uint32_t*)nullptr, (int32_t*)nullptr);
+        HIP_CHECK(hipMemsetAsync(sbItemCount.p + sbItems, 0, sizeof(int32_t), stream));
+        nReducedRows = exclusiveScanI32(sbItemCount.p, sbItems + 1);
         rrowFace.alloc((size_t)nReducedRows);
         rrowRegion.alloc((size_t)nReducedRows);
-        hipLaunchKernelGGL(k_skin<true>, dim3((unsigned)fbItems), dim3(BS), 0, stream, A, bbox.p, fbItemRegion.p, fbItemAxis.p,
-                           fbItemStart.p, fbItemCount.p, faceRow[0].p, faceRow[1].p, faceRow[2].p, rrowFace.p, rrowRegion.p);
-        // region -> row range, and fixed-size row chunks for the per-iteration tile kernels (host built)
-        std::vector<int32_t> itemOff((size_t)fbItems + 1), itemPtr((size_t)regionCount + 1);
-        HIP_CHECK(hipMemcpyAsync(itemOff.data(), fbItemCount.p, itemOff.size() * 4, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(itemPtr.data(), fbRegionItemPtr.p, itemPtr.size() * 4, hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(k_skin<true>, dim3((unsigned)sbItems), dim3(BS), 0, stream, A, bbox.p, sbItemRegion.p, sbItemStart.p, sbItemCount.p,
+                           faceRow[0].p, faceRow[1].p, faceRow[2].p, rrowFace.p, rrowRegion.p);
+        // region -> row range, and equal pieces of <= RC_ROWS rows for the three-kernel tile apply (host built)
+        std::vector<int32_t> itemOff((size_t)sbItems + 1);
+        HIP_CHECK(hipMemcpyAsync(itemOff.data(), sbItemCount.p, itemOff.size() * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        std::vector<int32_t> rptr((size_t)regionCount + 1), cR, cS, cE, cA, cptr((size_t)regionCount + 1);
-        for (int64_t r = 0; r <= regionCount; ++r) rptr[(size_t)r] = itemOff[(size_t)itemPtr[(size_t)r]];
+        std::vector<int32_t> rptr((size_t)regionCount + 1), cR, cS, cE, cptr((size_t)regionCount + 1);
+        for (int64_t r = 0; r <= regionCount; ++r) rptr[(size_t)r] = itemOff[(size_t)sbRegionItemPtrHost[(size_t)r]];
         regionRowPtrHost = rptr;
         for (int64_t r = 0; r < regionCount; ++r) {
             cptr[(size_t)r] = (int32_t)cR.size();
-            // rows are ordered (region, axis, position): cut every axis run into equal pieces of <= RC_ROWS rows
-            int32_t it = itemPtr[(size_t)r];
-            const int32_t itEnd = itemPtr[(size_t)r + 1];
-            while (it < itEnd) {
-                const int32_t a = fbItemAxisHost[(size_t)it];
-                int32_t it2 = it;
-                while (it2 < itEnd && fbItemAxisHost[(size_t)it2] == a) ++it2;
-                const int32_t lo = itemOff[(size_t)it], hi = itemOff[(size_t)it2];
-                const int32_t len = hi - lo;
-                if (len > 0) {
-                    const int32_t pieces = (len + RC_ROWS - 1) / RC_ROWS;
-                    for (int32_t q = 0; q < pieces; ++q) {
-                        cR.push_back((int32_t)r); cA.push_back(a);
-                        cS.push_back(lo + (int32_t)((int64_t)len * q / pieces));
-                        cE.push_back(lo + (int32_t)((int64_t)len * (q + 1) / pieces));
-                    }
+            const int32_t lo = rptr[(size_t)r], hi = rptr[(size_t)r + 1], len = hi - lo;
+            maxRegionRows = std::max<int64_t>(maxRegionRows, len);
+            if (len > 0) {
+                const int32_t pieces = (len + RC_ROWS - 1) / RC_ROWS;
+                for (int32_t q = 0; q < pieces; ++q) {
+                    cR.push_back((int32_t)r);
+                    cS.push_back(lo + (int32_t)((int64_t)len * q / pieces));
+                    cE.push_back(lo + (int32_t)((int64_t)len * (q + 1) / pieces));
                 }
-                it = it2;
             }
         }
         cptr[(size_t)regionCount] = (int32_t)cR.size();
         nRChunks = (int64_t)cR.size();
-        regionRowPtr.alloc(rptr.size()); rchunkRegion.alloc(cR.size()); rchunkStart.alloc(cS.size()); rchunkEnd.alloc(cE.size()); rchunkAxis.alloc(cA.size());
+        regionRowPtr.alloc(rptr.size()); rchunkRegion.alloc(cR.size()); rchunkStart.alloc(cS.size()); rchunkEnd.alloc(cE.size());
         regionChunkPtr.alloc(cptr.size());
         HIP_CHECK(hipMemcpyAsync(regionRowPtr.p, rptr.data(), rptr.size() * 4, hipMemcpyHostToDevice, stream));
         if (nRChunks) {
             HIP_CHECK(hipMemcpyAsync(rchunkRegion.p, cR.data(), cR.size() * 4, hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(rchunkStart.p, cS.data(), cS.size() * 4, hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(rchunkEnd.p, cE.data(), cE.size() * 4, hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(rchunkAxis.p, cA.data(), cA.size() * 4, hipMemcpyHostToDevice, stream));
         }
         HIP_CHECK(hipMemcpyAsync(regionChunkPtr.p, cptr.data(), cptr.size() * 4, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

@@ -109,16 +109,21 @@ struct ps_context {
     // work tables for per-region reductions over the region's face box (host built, small)
     ps::DevBuf<int32_t> fbItemRegion, fbItemAxis, fbItemStart;   // one item = <=FB_CHUNK face-box positions
     ps::DevBuf<int32_t> fbRegionItemPtr;                         // R+1
-    std::vector<int32_t> fbItemAxisHost;                         // host copy of fbItemAxis (axis-pure row chunks)
     int64_t fbItems = 0;
-    ps::DevBuf<int32_t> fbItemCount;                             // skin faces found per item (then scanned)
+    // skin-row enumeration: items of <= FB_CHUNK positions of a region's UNION face box (ex+1)(ey+1)(ez+1); a position yields up
+    // to three rows (its X, Y, Z face) — rows are ordered (region, position x-fastest, axis), so the faces hanging off one
+    // voxel are adjacent rows like the active ones
+    ps::DevBuf<int32_t> sbItemRegion, sbItemStart, sbItemCount;
+    std::vector<int32_t> sbRegionItemPtrHost;                    // R+1
+    int64_t sbItems = 0;
+    int64_t maxRegionRows = 0;                                   // fullest region: decides fused / three-kernel tile apply
     ps::DevBuf<double> partials;                                  // items * 676 (or rows chunks * 26)
 
     // reduced rows of S: region-contiguous, deterministic order
     ps::DevBuf<uint32_t> rrowFace;           // packed (i,j,k,axis)
     ps::DevBuf<int32_t> rrowRegion;
     ps::DevBuf<int32_t> regionRowPtr;        // R+1, offsets into reduced rows
-    ps::DevBuf<int32_t> rchunkRegion, rchunkStart, rchunkEnd, rchunkAxis, regionChunkPtr;  // <=RC rows of ONE face axis per chunk
+    ps::DevBuf<int32_t> rchunkRegion, rchunkStart, rchunkEnd, regionChunkPtr;  // <= RC_ROWS rows of ONE region per chunk (three-kernel tile apply)
     int64_t nRChunks = 0;
     bool bboxValid = false;      // bbox[] holds the boxes of the final regions (set by the small-region fix, cleared per setup)
 
@@ -244,5 +249,6 @@ void ps_dist_release(ps_context* c);                       // ps_solve.hip: dest
 
 namespace ps {
 constexpr int FB_CHUNK = 4096;   // face-box positions per work item (per-region dense reductions)
-constexpr int RC_ROWS = 1280;    // reduced rows per chunk in the per-iteration tile kernels
+constexpr int RC_ROWS = 1280;    // reduced rows per chunk in the three-kernel tile apply (regions too large for one workgroup)
+constexpr int TILE_FUSED_MAX_ROWS = 32768;   // regions up to this many skin rows: one workgroup gathers, solves and expands (k_tile_apply)
 }  // namespace ps

@@ -13,69 +13,208 @@ __device__ inline void rowOffset(uint32_t packed, const double* __restrict__ COM
     o[2] = p[2] * dx - COM[(int64_t)region * 3 + 2];
     *axis = a;
 }
-// partial w (26) of one chunk of <= RC_ROWS reduced rows of ONE face axis:  w += C_f * s_f.  One wavefront per chunk:
-// all RC_ROWS/64 (face, s) pairs of a lane are requested up front (independent loads in flight together), then only
-// the 10 / 10 / 14 non-zero entries of that axis' basis row (buildConversionCoefficients, Solver.cpp:2112-2145) are
-// accumulated in registers and wave-shuffle reduced; no LDS, no barrier.
-template <int AXIS>
-__device__ inline void tileGatherAxis(int b0, int e, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx,
-                                      double cx, double cy, double cz, double* __restrict__ wout) {
-    constexpr int PER = RC_ROWS / 64;
-    constexpr int NW = AXIS == 2 ? 14 : 10;
-    uint32_t fq[PER];
-    double sq[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int rr = b0 + threadIdx.x + q * 64;
-        const bool ok = rr < e;
-        fq[q] = ok ? __builtin_nontemporal_load(rrowFace + rr) : 0u;
-        sq[q] = ok ? __builtin_nontemporal_load(sred + rr) : 0.;     // 0 for the lanes past the end: contributes nothing
+// ---- the basis row through moments ----------------------------------------------------------------------------------
+// Every entry of the 26-entry basis row C_a(o) (buildConversionCoefficients, Solver.cpp:2112-2145) is a constant times one
+// of the ten monomials  mu = (1, ox, oy, oz, ox^2, ox oy, ox oz, oy^2, oy oz, oz^2)  of the face offset o.  So
+//   w = sum_f C_f s_f   needs only the 3 x 10 moments  M_a[m] = sum over faces of axis a of mu_m(o_f) s_f   (30 sums per row
+//   stream instead of 26 axis-dependent ones), mapped to the 26 entries once per region (momentsToW), and
+//   t_f = C_f . v      is the 10-term dot of mu(o_f) with the per-axis coefficient vector V_a of v (vToAxisCoeffs).
+// Rows of the three axes are interleaved (region, position, axis): the axis is a per-lane select, no divergence.
+__device__ inline void faceMonomials(uint32_t f, double dx, double cx, double cy, double cz, double* mu, int* axis) {
+    int i, j, k, a;
+    unpackFace(f, i, j, k, a);
+    const double ox = ((double)i - (a == 0 ? 0.5 : 0.)) * dx - cx;
+    const double oy = ((double)j - (a == 1 ? 0.5 : 0.)) * dx - cy;
+    const double oz = ((double)k - (a == 2 ? 0.5 : 0.)) * dx - cz;
+    mu[0] = 1.; mu[1] = ox; mu[2] = oy; mu[3] = oz; mu[4] = ox * ox; mu[5] = ox * oy; mu[6] = ox * oz; mu[7] = oy * oy; mu[8] = oy * oz; mu[9] = oz * oz;
+    *axis = a;
+}
+// entry e of w from the 30 moments M[a * 10 + m]
+__device__ inline double momentsToW(const double* M, int e) {
+    const double* X = M; const double* Y = M + 10; const double* Z = M + 20;
+    switch (e) {
+        case 0: return X[0];
+        case 1: return Y[0];
+        case 2: return Z[0];
+        case 3: return X[1] - Z[3];
+        case 4: return X[2];
+        case 5: return X[3];
+        case 6: return X[4] - 2. * Z[6];
+        case 7: return X[5] - Z[8];
+        case 8: return X[6] - 0.5 * Z[9];
+        case 9: return X[7];
+        case 10: return X[8];
+        case 11: return X[9];
+        case 12: return Y[1];
+        case 13: return Y[2] - Z[3];
+        case 14: return Y[3];
+        case 15: return Y[4];
+        case 16: return Y[5] - Z[6];
+        case 17: return Y[6];
+        case 18: return Y[7] - 2. * Z[8];
+        case 19: return Y[8] - 0.5 * Z[9];
+        case 20: return Y[9];
+        case 21: return Z[1];
+        case 22: return Z[2];
+        case 23: return Z[4];
+        case 24: return Z[5];
+        default: return Z[7];
     }
-    double w[NW];
+}
+// V[a * 10 + m]: coefficient of monomial m in C_a(o) . v
+__device__ inline double vToAxisCoeff(const double* v, int q) {
+    switch (q) {
+        case 0: return v[0];  case 1: return v[3];  case 2: return v[4];  case 3: return v[5];  case 4: return v[6];
+        case 5: return v[7];  case 6: return v[8];  case 7: return v[9];  case 8: return v[10]; case 9: return v[11];
+        case 10: return v[1]; case 11: return v[12]; case 12: return v[13]; case 13: return v[14]; case 14: return v[15];
+        case 15: return v[16]; case 16: return v[17]; case 17: return v[18]; case 18: return v[19]; case 19: return v[20];
+        case 20: return v[2]; case 21: return v[21]; case 22: return v[22]; case 23: return -v[3] - v[13]; case 24: return v[23];
+        case 25: return v[24]; case 26: return -2. * v[6] - v[16]; case 27: return v[25]; case 28: return -v[7] - 2. * v[18];
+        default: return -0.5 * v[8] - 0.5 * v[19];
+    }
+}
+// one lane's share of the moments over the rows rr = first, first + stride, ... < end
+constexpr int TILE_FACE_CACHE = 16;   // packed faces a lane keeps in registers between the gather and the expand of k_tile_apply
+template <bool CACHE>
+__device__ inline void tileAccumulate(int first, int stride, int end, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx,
+                                      double cx, double cy, double cz, double* __restrict__ M, uint32_t* __restrict__ fcache) {
+    constexpr int U = 4;                           // (face, s) pairs requested together: independent loads in flight, then the arithmetic
+    int it = 0;
+    for (int base = first; base < end; base += U * stride, ++it) {
+        uint32_t f[U];
+        double s[U];
 #pragma unroll
-    for (int n = 0; n < NW; ++n) w[n] = 0.;
+        for (int u = 0; u < U; ++u) {
+            const int rr = base + u * stride;
+            const bool ok = rr < end;
+            f[u] = ok ? __builtin_nontemporal_load(rrowFace + rr) : 0u;
+            s[u] = ok ? __builtin_nontemporal_load(sred + rr) : 0.;   // 0 past the end: contributes nothing
+        }
+        if (CACHE && it < TILE_FACE_CACHE / U) {
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        int i, j, k, axis;
-        unpackFace(fq[q], i, j, k, axis);
-        const double s = sq[q];
-        const double ox = ((double)i - (AXIS == 0 ? 0.5 : 0.)) * dx - cx;
-        const double oy = ((double)j - (AXIS == 1 ? 0.5 : 0.)) * dx - cy;
-        const double oz = ((double)k - (AXIS == 2 ? 0.5 : 0.)) * dx - cz;
-        if constexpr (AXIS != 2) {    // x-row: entries 0,3..11 ; y-row: entries 1,12..20
-            w[0] += s; w[1] += ox * s; w[2] += oy * s; w[3] += oz * s;
-            w[4] += ox * ox * s; w[5] += ox * oy * s; w[6] += ox * oz * s; w[7] += oy * oy * s; w[8] += oy * oz * s; w[9] += oz * oz * s;
-        } else {            // z-row: entries 2,3,6,7,8,13,16,18,19,21..25
-            w[0] += s; w[1] += (-oz) * s; w[2] += (-2. * ox * oz) * s; w[3] += (-1. * oy * oz) * s; w[4] += (-0.5 * oz * oz) * s;
-            w[5] += (-oz) * s; w[6] += (-1. * ox * oz) * s; w[7] += (-2. * oy * oz) * s; w[8] += (-0.5 * oz * oz) * s;
-            w[9] += ox * s; w[10] += oy * s; w[11] += ox * ox * s; w[12] += ox * oy * s; w[13] += oy * oy * s;
+            for (int q = 0; q < TILE_FACE_CACHE / U; ++q)
+                if (q == it) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) fcache[q * U + u] = f[u];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double mu[10];
+            int axis;
+            faceMonomials(f[u], dx, cx, cy, cz, mu, &axis);
+            const double s0 = axis == 0 ? s[u] : 0., s1 = axis == 1 ? s[u] : 0., s2 = axis == 2 ? s[u] : 0.;
+#pragma unroll
+            for (int m = 0; m < 10; ++m) { M[m] += mu[m] * s0; M[10 + m] += mu[m] * s1; M[20 + m] += mu[m] * s2; }
         }
     }
-    constexpr int slotX[10] = {0, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-    constexpr int slotY[10] = {1, 12, 13, 14, 15, 16, 17, 18, 19, 20};
-    constexpr int slotZ[14] = {2, 3, 6, 7, 8, 13, 16, 18, 19, 21, 22, 23, 24, 25};
-    // lane n < 26 ends up holding entry n of the chunk's partial w (0 for the entries this axis never touches): one store
-    double mine = 0.;
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-        const double v = __shfl(waveReduceSum(w[n]), 0);
-        if ((int)threadIdx.x == (AXIS == 0 ? slotX[n] : (AXIS == 1 ? slotY[n] : slotZ[n]))) mine = v;
-    }
-    if (threadIdx.x < PS_RD) wout[threadIdx.x] = mine;
 }
+// three-kernel tile apply, step 1 (regions too large for one workgroup): partial w (26) of one chunk of <= RC_ROWS rows of ONE
+// region.  One wavefront per chunk, lane-strided rows, wave-shuffle reduction of the 30 moments; lane n < 26 stores entry n of w.
 __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ chunkRegion, const int32_t* __restrict__ chunkStart,
-                                                    const int32_t* __restrict__ chunkEnd, const int32_t* __restrict__ chunkAxis,
-                                                    const uint32_t* __restrict__ rrowFace, const double* __restrict__ COM, double dx,
-                                                    const double* __restrict__ sred, double* __restrict__ wpart, const int* __restrict__ done) {
+                                                    const int32_t* __restrict__ chunkEnd, const uint32_t* __restrict__ rrowFace,
+                                                    const double* __restrict__ COM, double dx, const double* __restrict__ sred,
+                                                    double* __restrict__ wpart, const int* __restrict__ done) {
     if (done && *done) return;
+    __shared__ double Ms[30];
     const int ch = blockIdx.x;
     const int r = chunkRegion[ch];
-    const double cx = COM[(int64_t)r * 3 + 0], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
-    const int e = chunkEnd[ch], b0 = chunkStart[ch], axis = chunkAxis[ch];
-    double* wout = wpart + (int64_t)ch * PS_RD;
-    if (axis == 0) tileGatherAxis<0>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
-    else if (axis == 1) tileGatherAxis<1>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
-    else tileGatherAxis<2>(b0, e, rrowFace, sred, dx, cx, cy, cz, wout);
+    double M[30];
+#pragma unroll
+    for (int n = 0; n < 30; ++n) M[n] = 0.;
+    tileAccumulate<false>(chunkStart[ch] + (int)threadIdx.x, 64, chunkEnd[ch], rrowFace, sred, dx, COM[(int64_t)r * 3], COM[(int64_t)r * 3 + 1], COM[(int64_t)r * 3 + 2], M, nullptr);
+#pragma unroll
+    for (int n = 0; n < 30; ++n) {
+        const double v = waveReduceSum(M[n]);
+        if (threadIdx.x == 0) Ms[n] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PS_RD) wpart[(int64_t)ch * PS_RD + threadIdx.x] = momentsToW(Ms, (int)threadIdx.x);
+}
+// Fused tile apply: ONE workgroup per region gathers w = J^T s over the region's skin rows, multiplies by the 26x26 block and
+// expands t = J v in place — no partial-w round trip, one launch instead of three (regions up to TILE_FUSED_MAX_ROWS rows).
+//   MODE 0: v = BInv w, t = J v                         (operator apply)
+//   MODE 1: v = BInv (invDt rhsR - w) -> vreg, no expand (velocity recovery, Solver.cpp:509)
+//   MODE 2: v = invDt BInv rhsR, t = J v, no gather      (right-hand side, AssembleSystem.cpp:448-452)
+template <int MODE, int TB>
+__global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ regionRowPtr, const uint32_t* __restrict__ rrowFace,
+                                                   const double* __restrict__ COM, double dx, const double* __restrict__ Binv,
+                                                   const double* __restrict__ rhsR, double invDt, double* __restrict__ sred,
+                                                   double* __restrict__ vreg, const int* __restrict__ done) {
+    if (done && *done) return;
+    __shared__ double msum[TB / 64][30];
+    __shared__ double Ms[30], wv[PS_RD], vv[PS_RD], Vs[30];
+    const int r = blockIdx.x;
+    const int r0 = regionRowPtr[r], r1 = regionRowPtr[r + 1];
+    const double cx = COM[(int64_t)r * 3], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t fcache[TILE_FACE_CACHE];
+    if (MODE != 2) {
+        double M[30];
+#pragma unroll
+        for (int n = 0; n < 30; ++n) M[n] = 0.;
+        tileAccumulate<MODE == 0>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, cx, cy, cz, M, fcache);
+#pragma unroll
+        for (int n = 0; n < 30; ++n) {
+            const double v = waveReduceSum(M[n]);
+            if (lane == 0) msum[wave][n] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 30) {
+            double s = 0.;
+#pragma unroll
+            for (int q = 0; q < TB / 64; ++q) s += msum[q][threadIdx.x];
+            Ms[threadIdx.x] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < PS_RD) {
+            double s = momentsToW(Ms, (int)threadIdx.x);
+            if (MODE == 1) s = invDt * rhsR[(int64_t)r * PS_RD + threadIdx.x] - s;
+            wv[threadIdx.x] = s;
+        }
+    } else if (threadIdx.x < PS_RD) wv[threadIdx.x] = rhsR[(int64_t)r * PS_RD + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < PS_RD) {
+        const double* B = Binv + (int64_t)r * PS_RD * PS_RD + threadIdx.x * PS_RD;
+        double s = 0.;
+#pragma unroll
+        for (int n = 0; n < PS_RD; ++n) s += B[n] * wv[n];
+        if (MODE == 2) s *= invDt;
+        vv[threadIdx.x] = s;
+        if (MODE == 1) vreg[(int64_t)r * PS_RD + threadIdx.x] = s;
+    }
+    if (MODE == 1) return;
+    __syncthreads();
+    if (threadIdx.x < 30) Vs[threadIdx.x] = vToAxisCoeff(vv, (int)threadIdx.x);
+    __syncthreads();
+    constexpr int U = 4;
+    int it = 0;
+    for (int base = r0 + (int)threadIdx.x; base < r1; base += U * TB, ++it) {
+        uint32_t f[U];
+        if (MODE == 0 && it < TILE_FACE_CACHE / U) {   // the faces this lane already decoded in the gather
+#pragma unroll
+            for (int q = 0; q < TILE_FACE_CACHE / U; ++q)
+                if (q == it) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) f[u] = fcache[q * U + u];
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) f[u] = base + u * TB < r1 ? rrowFace[base + u * TB] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u * TB >= r1) break;
+            double mu[10];
+            int axis;
+            faceMonomials(f[u], dx, cx, cy, cz, mu, &axis);
+            const double* V = Vs + 10 * axis;                        // LDS broadcast-ish reads (3 distinct rows per wave)
+            double t = 0.;
+#pragma unroll
+            for (int m = 0; m < 10; ++m) t += mu[m] * V[m];
+            sred[base + u * TB] = t;
+        }
+    }
 }
 // MODE 0: v = BInv w ;  MODE 1: v = BInv (invDt*rhsR - w)  (velocity recovery, Solver.cpp:509)
 // MODE 2: v = invDt * BInv rhsR  (right-hand side, AssembleSystem.cpp:448-452; no gather)

@@ -78,10 +78,24 @@ struct Launch {
     void tiles(int mode, double* ts) const {   // ts: face-row vector; reduced part rewritten in place
         if (c->regionCount == 0) return;
         double* sred = ts + nA;
+        const dim3 gr((unsigned)c->regionCount);
+        static const bool noFuse = getenv("PS_TILE_SPLIT") && atoi(getenv("PS_TILE_SPLIT")) != 0;   // A/B: force the three-kernel form
+        if (c->maxRegionRows <= TILE_FUSED_MAX_ROWS && !noFuse) {   // one workgroup per region: gather, 26x26 block, expand
+#define PS_TILE_APPLY(MODE_, TB_) hipLaunchKernelGGL((k_tile_apply<MODE_, TB_>), gr, dim3(TB_), 0, c->stream, c->regionRowPtr.p, c->rrowFace.p, c->COM.p, c->dx, c->Binv.p, \
+                                                c->rhsR.p, c->invDt, sred, c->vreg.p, done)
+            // threads per region: one wavefront up to 4096 rows (measured at 256^3, 3204 rows per tile: 0.080 ms with 64 threads,
+            // 0.087 / 0.106 / 0.166 with 128 / 256 / 512), more for larger regions
+            static const int tbEnv = getenv("PS_TILE_TB") ? atoi(getenv("PS_TILE_TB")) : 0;
+            const int tb = tbEnv ? tbEnv : (c->maxRegionRows <= 4096 ? 64 : (c->maxRegionRows <= 8192 ? 128 : 256));
+            if (mode == 0) { if (tb == 128) PS_TILE_APPLY(0, 128); else if (tb == 512) PS_TILE_APPLY(0, 512); else if (tb == 64) PS_TILE_APPLY(0, 64); else PS_TILE_APPLY(0, 256); }
+            else if (mode == 1) PS_TILE_APPLY(1, 256); else PS_TILE_APPLY(2, 256);
+#undef PS_TILE_APPLY
+            return;
+        }
         if (mode != 2 && c->nRChunks > 0)
             hipLaunchKernelGGL(k_tile_gather, dim3((unsigned)c->nRChunks), dim3(64), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
-                               c->rchunkEnd.p, c->rchunkAxis.p, c->rrowFace.p, c->COM.p, c->dx, sred, c->wreg.p, done);
-        const dim3 gr((unsigned)c->regionCount), bl(64);
+                               c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, sred, c->wreg.p, done);
+        const dim3 bl(64);
         if (mode == 0)
             hipLaunchKernelGGL(k_tile_solve<0>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
         else if (mode == 1)

@@ -542,9 +542,24 @@ void ps_context::computeCenterOfMasses() {
     }
     ptr[(size_t)R] = (int32_t)iR.size();
     fbItems = (int64_t)iR.size();
-    fbItemAxisHost = iA;
     fbItemRegion.alloc(iR.size()); fbItemAxis.alloc(iR.size()); fbItemStart.alloc(iR.size()); fbRegionItemPtr.alloc(ptr.size());
-    fbItemCount.alloc(iR.size() + 1);
+    {   // skin-row enumeration items: the union face box of each region, FB_CHUNK positions per item
+        std::vector<int32_t> sR, sS;
+        sbRegionItemPtrHost.assign((size_t)R + 1, 0);
+        for (int64_t r = 0; r < R; ++r) {
+            sbRegionItemPtrHost[(size_t)r] = (int32_t)sR.size();
+            int64_t total = 1;
+            for (int q = 0; q < 3; ++q) total *= (int64_t)hbbox[(size_t)r * 6 + 3 + q] - hbbox[(size_t)r * 6 + q] + 2;
+            if (total > 0x7fffffff) throw Error("region face box too large");
+            for (int64_t st = 0; st < total; st += FB_CHUNK) { sR.push_back((int32_t)r); sS.push_back((int32_t)st); }
+        }
+        sbRegionItemPtrHost[(size_t)R] = (int32_t)sR.size();
+        sbItems = (int64_t)sR.size();
+        sbItemRegion.alloc(sR.size()); sbItemStart.alloc(sS.size()); sbItemCount.alloc(sR.size() + 1);
+        HIP_CHECK(hipMemcpyAsync(sbItemRegion.p, sR.data(), sR.size() * 4, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(sbItemStart.p, sS.data(), sS.size() * 4, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));   // sR / sS are locals
+    }
     HIP_CHECK(hipMemcpyAsync(fbItemRegion.p, iR.data(), iR.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(fbItemAxis.p, iA.data(), iA.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(fbItemStart.p, iS.data(), iS.size() * 4, hipMemcpyHostToDevice, stream));
