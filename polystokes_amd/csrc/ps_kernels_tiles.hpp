@@ -75,10 +75,10 @@ __device__ inline double vToAxisCoeff(const double* v, int q) {
 }
 // one lane's share of the moments over the rows rr = first, first + stride, ... < end
 constexpr int TILE_FACE_CACHE = 16;   // packed faces a lane keeps in registers between the gather and the expand of k_tile_apply
-template <bool CACHE>
+template <bool CACHE, int U>
 __device__ inline void tileAccumulate(int first, int stride, int end, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx,
                                       double cx, double cy, double cz, double* __restrict__ M, uint32_t* __restrict__ fcache) {
-    constexpr int U = 4;                           // (face, s) pairs requested together: independent loads in flight, then the arithmetic
+    // U (face, s) pairs are requested together: independent loads in flight, then the arithmetic
     int it = 0;
     for (int base = first; base < end; base += U * stride, ++it) {
         uint32_t f[U];
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ 
     double M[30];
 #pragma unroll
     for (int n = 0; n < 30; ++n) M[n] = 0.;
-    tileAccumulate<false>(chunkStart[ch] + (int)threadIdx.x, 64, chunkEnd[ch], rrowFace, sred, dx, COM[(int64_t)r * 3], COM[(int64_t)r * 3 + 1], COM[(int64_t)r * 3 + 2], M, nullptr);
+    tileAccumulate<false, 4>(chunkStart[ch] + (int)threadIdx.x, 64, chunkEnd[ch], rrowFace, sred, dx, COM[(int64_t)r * 3], COM[(int64_t)r * 3 + 1], COM[(int64_t)r * 3 + 2], M, nullptr);
 #pragma unroll
     for (int n = 0; n < 30; ++n) {
         const double v = waveReduceSum(M[n]);
@@ -148,12 +148,15 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
     const int r0 = regionRowPtr[r], r1 = regionRowPtr[r + 1];
     const double cx = COM[(int64_t)r * 3], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // few regions (TB = 256: small grids, latency bound): a lane requests all its ~13 rows at once; many regions (TB = 64): 4 at a
+    // time, occupancy hides the latency
+    constexpr int U = TB >= 256 ? 16 : 4;
     uint32_t fcache[TILE_FACE_CACHE];
     if (MODE != 2) {
         double M[30];
 #pragma unroll
         for (int n = 0; n < 30; ++n) M[n] = 0.;
-        tileAccumulate<MODE == 0>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, cx, cy, cz, M, fcache);
+        tileAccumulate<MODE == 0, U>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, cx, cy, cz, M, fcache);
 #pragma unroll
         for (int n = 0; n < 30; ++n) {
             const double v = waveReduceSum(M[n]);
@@ -187,7 +190,6 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
     __syncthreads();
     if (threadIdx.x < 30) Vs[threadIdx.x] = vToAxisCoeff(vv, (int)threadIdx.x);
     __syncthreads();
-    constexpr int U = 4;
     int it = 0;
     for (int base = r0 + (int)threadIdx.x; base < r1; base += U * TB, ++it) {
         uint32_t f[U];

@@ -83,12 +83,20 @@ struct Launch {
         if (c->maxRegionRows <= TILE_FUSED_MAX_ROWS && !noFuse) {   // one workgroup per region: gather, 26x26 block, expand
 #define PS_TILE_APPLY(MODE_, TB_) hipLaunchKernelGGL((k_tile_apply<MODE_, TB_>), gr, dim3(TB_), 0, c->stream, c->regionRowPtr.p, c->rrowFace.p, c->COM.p, c->dx, c->Binv.p, \
                                                 c->rhsR.p, c->invDt, sred, c->vreg.p, done)
-            // threads per region: one wavefront up to 4096 rows (measured at 256^3, 3204 rows per tile: 0.080 ms with 64 threads,
-            // 0.087 / 0.106 / 0.166 with 128 / 256 / 512), more for larger regions
+            // threads per region: enough threads in flight chip-wide (~256 K) without starving a region of work.  Measured
+            // at 256^3 (4096 tiles of 3204 rows): 0.080 ms with 64 threads, 0.087 / 0.106 / 0.166 with 128 / 256 / 512; at 32^3
+            // (8 tiles) one wavefront per tile serialises 50 rows per lane behind memory latency (60 us per CG iteration
+            // against 43 with 256 threads per tile; 1024 threads: 50, the block reduction over 16 waves costs more than it hides).
             static const int tbEnv = getenv("PS_TILE_TB") ? atoi(getenv("PS_TILE_TB")) : 0;
-            const int tb = tbEnv ? tbEnv : (c->maxRegionRows <= 4096 ? 64 : (c->maxRegionRows <= 8192 ? 128 : 256));
-            if (mode == 0) { if (tb == 128) PS_TILE_APPLY(0, 128); else if (tb == 512) PS_TILE_APPLY(0, 512); else if (tb == 64) PS_TILE_APPLY(0, 64); else PS_TILE_APPLY(0, 256); }
-            else if (mode == 1) PS_TILE_APPLY(1, 256); else PS_TILE_APPLY(2, 256);
+            int tb = tbEnv;
+            if (!tb) {
+                tb = 64;
+                while (tb < 256 && (int64_t)tb * c->regionCount < 262144 && (int64_t)tb * 2 < c->maxRegionRows) tb *= 2;
+            }
+#define PS_TILE_APPLY_TB(MODE_) do { if (tb >= 1024) PS_TILE_APPLY(MODE_, 1024); else if (tb >= 512) PS_TILE_APPLY(MODE_, 512); else if (tb >= 256) PS_TILE_APPLY(MODE_, 256); \
+                                     else if (tb >= 128) PS_TILE_APPLY(MODE_, 128); else PS_TILE_APPLY(MODE_, 64); } while (0)
+            if (mode == 0) PS_TILE_APPLY_TB(0); else if (mode == 1) PS_TILE_APPLY_TB(1); else PS_TILE_APPLY_TB(2);
+#undef PS_TILE_APPLY_TB
 #undef PS_TILE_APPLY
             return;
         }
