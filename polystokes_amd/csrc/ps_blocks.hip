@@ -592,6 +592,38 @@ void ps_context::buildChunkSchedule(ps::DevCSR& M, bool faceRows) {
     if (!M.col16ok || mode == 0 || ilBlocks == 0) return;
     const int nChunks = gridFor(M.rows, BS);
     if (nChunks < 64) return;
+    if (mode == 3) {
+        // "sweep" walk (A/B): every XCD owns one contiguous eighth of the chunks, and inside it every group of 16 workgroups (the
+        // domain in which fills are shared) sweeps its own contiguous sub-span: at iteration it the group works on 16 consecutive
+        // chunks, at it + 1 on the next 16 — the neighbours in k of one iteration are the rows of the next
+        const char* pgE = getenv("PS_PIPE_GRID");
+        const int grid = std::min(nChunks, pgE ? atoi(pgE) : 4096) & ~7;
+        if (grid < 128) return;
+        const int per = grid / 8, groups = per / 16;
+        if (groups < 1 || per % 16) return;
+        std::vector<int32_t> list;
+        int lo = 0;
+        for (int x = 0; x < 8; ++x) {
+            M.schedOff[x] = (int)list.size();
+            const int hi = (int)((int64_t)nChunks * (x + 1) / 8);
+            const int cnt = hi - lo;
+            const int span = (cnt + groups - 1) / groups;            // chunks per group
+            const int iters = (span + 15) / 16;
+            for (int it = 0; it < iters; ++it)
+                for (int l = 0; l < per; ++l) {
+                    const int g = l / 16, j = l % 16;
+                    const int c = g * span + it * 16 + j;
+                    list.push_back((it * 16 + j < span && c < cnt) ? lo + c : 0x7fffffff);   // holes: the kernels skip chunk ids >= nChunks
+                }
+            lo = hi;
+        }
+        M.schedOff[8] = (int)list.size();
+        M.sched.alloc(list.size());
+        HIP_CHECK(hipMemcpyAsync(M.sched.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        M.schedOk = true;
+        return;
+    }
     const std::vector<int32_t>& bs = faceRows ? blockStartRow : blockStartSys;
     const int sbv = ilSuper[0] * ilSuper[1] * ilSuper[2];
     const int nSB = ilBlocks / sbv;
