@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--precond", choices=["jacobi", "identity"], default="jacobi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-res", type=int, default=128)
+    ap.add_argument("--transport", choices=["rccl", "tcp"], default="rccl",
+                    help="N > 1: rccl = one GPU per rank over RCCL/xGMI (the measured configuration); tcp = host-staged sockets, all ranks "
+                         "may share GPU 0 — a REHEARSAL of the multi-process path on a single-GPU box, not a performance number")
     ap.add_argument("--maxit", type=int, default=0, help="cap on solver iterations (profiling runs only; 0 = node default 5000)")
     args = ap.parse_args()
 
@@ -143,6 +146,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1):
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    # stdout carries exactly ONE line (the JSON): everything else any library writes to fd 1 (gloo announces its connections
+    # there) goes to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import polystokes_amd
@@ -159,6 +168,8 @@ def main():
         dist.init_process_group(backend="gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if args.transport == "tcp":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: ranks share the GPUs there are
     torch.cuda.set_device(local_rank)
 
     strong = args.scaling == "strong"
@@ -191,12 +202,22 @@ def main():
         p.maxSolverIterations = args.maxit   # the BiCGStab fallback then runs too: use for kernel profiling only
     solver.upload(sc, p)           # host -> HBM, outside the timed region
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid.copy_(torch.tensor(list(polystokes_amd.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
         solver.set_slab(slab)
-        solver.comm_init(bytes(uid.tolist()), rank, world)
+        if args.transport == "tcp":
+            port = torch.zeros(1, dtype=torch.int64)
+            if rank == 0:
+                import socket
+                with socket.socket() as so:      # a free base port; the ranks listen on port + rank
+                    so.bind(("127.0.0.1", 0))
+                    port[0] = 20000 + so.getsockname()[1] % 20000
+            dist.broadcast(port, 0)
+            solver.comm_init_tcp(rank, world, "127.0.0.1", int(port.item()))
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid.copy_(torch.tensor(list(polystokes_amd.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            solver.comm_init(bytes(uid.tolist()), rank, world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -259,7 +280,7 @@ def main():
     csr = kern[dom + "_csr"]["algorithmic_bytes"]
     csr_gbps = csr / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {
-        "bound": "hbm", "kernel": "k_spmv_St_pipe<0,2,%s>" % ("false" if coded else "true") if c16 else "k_spmv_St<0,6,%s>" % ("true" if coded else "false"),
+        "bound": "hbm", "kernel": "k_spmv_St_pipe<0,NV,%s> (NV = 1 or 2 four-entry groups per lane, by the fullest chunk)" % ("false" if coded else "true") if c16 else "k_spmv_St<0,6,%s>" % ("true" if coded else "false"),
         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
         "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_ms": ms,
@@ -273,8 +294,9 @@ def main():
         "other_kernels": {k: v for k, v in kern.items() if k != dom},
     }
 
-    par = "1 GPU" if world == 1 else ("%d z-slabs of one %d^3 scene (strong), RCCL halo exchange + all-reduce" % (world, n) if strong
-                                       else "%d z-slabs, one %d-layer slab per GPU (weak), RCCL halo exchange + all-reduce" % (world, n))
+    link = "RCCL halo exchange + all-reduce" if args.transport == "rccl" else "host-staged TCP transport (REHEARSAL: ranks share GPUs, not a performance number)"
+    par = "1 GPU" if world == 1 else ("%d z-slabs of one %d^3 scene (strong), %s" % (world, n, link) if strong
+                                       else "%d z-slabs, one %d-layer slab per GPU (weak), %s" % (world, n, link))
     workload = {"cavity": "synthetic lid-driven cavity", "coil": "synthetic coiling column (honey_coil stand-in)", "spheres": "pool with 8 moving solid spheres (armadillos stand-in)"}[scene_name]
     out = {
         "metric": "Stokes-solve wall ms/step (assembly+PCG) on 256^3 grid; CG iters/sec",
@@ -296,7 +318,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n ** 3, nsys, iters, dict(tile=16, pad=2, precond=kw["precond"]), args.cpu_sample_res)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     solver.close()
     if dist is not None:
         dist.barrier()
