@@ -710,6 +710,56 @@ void ps_context::buildChunkSchedule(ps::DevCSR& M, bool faceRows) {
                                            faceRows ? "S" : "St", nChunks, nSB, (long long)mx);
 }
 
+// Units of the block-resident S kernel (k_spmv_S_blk): one per non-empty lattice block — the 256-row chunks whose first row lies
+// in the block, then the skin-row chunks of the regions whose box starts in it — with the block's contiguous DOF range as the
+// window the workgroup keeps in LDS (capped: a denser block than the window holds is still correct, its tail is gathered).
+void ps_context::buildBlockUnits(ps::DevCSR& M) {
+    M.nUnits = 0;
+    const char* e = getenv("PS_BLK");
+    if (!(e && atoi(e) != 0) || !M.col16ok || !M.packed || ilBlocks == 0 || slabEnabled) return;
+    if (ilSuper[0] * ilSuper[1] * ilSuper[2] != 1) return;
+    constexpr int WCAP = 11776;
+    const int nChunks = gridFor(M.rows, BS);
+    const int nB = ilBlocks;
+    std::vector<std::vector<int32_t>> per((size_t)nB);
+    {
+        size_t b = 0;
+        const int firstSkin = (int)((nActiveVs + BS - 1) / BS);
+        for (int ch = 0; ch < firstSkin && ch < nChunks; ++ch) {
+            const int64_t r0 = (int64_t)ch * BS;
+            while (b + 1 < blockStartRow.size() - 1 && blockStartRow[b + 1] <= r0) ++b;
+            per[b].push_back(ch);
+        }
+        if (nReducedRows > 0) {
+            const int LBx = (g.nx + 1 + ilOrigin[0] + 15) / 16, LBy = (g.ny + 1 + ilOrigin[1] + 15) / 16;
+            size_t r = 0;
+            for (int ch = firstSkin; ch < nChunks; ++ch) {
+                const int64_t rr = (int64_t)ch * BS - nActiveVs;
+                while (r + 1 < regionRowPtrHost.size() - 1 && regionRowPtrHost[r + 1] <= rr) ++r;
+                const int bx = (hbbox[r * 6 + 0] + ilOrigin[0]) / 16, by = (hbbox[r * 6 + 1] + ilOrigin[1]) / 16, bz = (hbbox[r * 6 + 2] + ilOrigin[2]) / 16;
+                per[(size_t)std::min((bz * LBy + by) * LBx + bx, nB - 1)].push_back(ch);
+            }
+        }
+    }
+    std::vector<int32_t> chunks;
+    std::vector<int4> units;
+    chunks.reserve((size_t)nChunks);
+    for (int b = 0; b < nB; ++b) {
+        if (per[(size_t)b].empty()) continue;
+        int4 u;
+        u.x = (int)chunks.size(); u.y = (int)per[(size_t)b].size();
+        u.z = blockStartSys[(size_t)b]; u.w = std::min(WCAP, blockStartSys[(size_t)b + 1] - blockStartSys[(size_t)b]);
+        units.push_back(u);
+        chunks.insert(chunks.end(), per[(size_t)b].begin(), per[(size_t)b].end());
+    }
+    if (units.empty()) return;
+    M.unitChunks.alloc(chunks.size()); M.units.alloc(units.size());
+    HIP_CHECK(hipMemcpyAsync(M.unitChunks.p, chunks.data(), chunks.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(M.units.p, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    M.nUnits = (int)units.size();
+}
+
 // ConstructMatrixBlocks.cpp:9-292
 void ps_context::constructMatrixBlocks() {
     nActiveVs = nFace[0] + nFace[1] + nFace[2];
@@ -841,6 +891,7 @@ void ps_context::constructMatrixBlocks() {
         buildCol16(St, 23);
         buildChunkSchedule(S, true);
         buildChunkSchedule(St, false);
+        buildBlockUnits(S);
         buildDiagonalCodes();
         const int32_t c16 = (S.col16ok ? 1 : 0) | (St.col16ok ? 2 : 0);
         HIP_CHECK(hipMemcpyAsync(counters.p + 24, &c16, sizeof(c16), hipMemcpyHostToDevice, stream));

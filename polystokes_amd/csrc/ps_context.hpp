@@ -30,6 +30,10 @@ struct DevCSR {
     bool col16ok = false;
     // Scheduled walk of the persistent kernels: the chunks of one super-block of the numbering lattice (and, for S, the skin
     // rows of its tiles) go to ONE XCD, back to back, so the x / t lines they share are filled into one L2 once.
+    // Block-resident walk (k_spmv_S_blk): units = lattice blocks, each with its chunk list and the DOF window it keeps in LDS
+    DevBuf<int32_t> unitChunks;  // chunk ids, unit after unit
+    DevBuf<int4> units;          // (chunkBegin, chunkCount, winLo, winLen)
+    int nUnits = 0;
     DevBuf<int32_t> sched;       // 8 lists, concatenated
     int schedOff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool schedOk = false;
@@ -210,6 +214,7 @@ struct ps_context {
     void buildCol16(ps::DevCSR& M, int counterSlot);      // ps_blocks.hip
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
     void buildChunkSchedule(ps::DevCSR& M, bool faceRows);
+    void buildBlockUnits(ps::DevCSR& M);
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();

@@ -243,10 +243,11 @@ __device__ inline void loadVals4(const double* val4, int p0, int p1, Vals4<NV>& 
 }
 // (the fp64 value array can exceed the 4 GiB a buffer descriptor spans: its descriptor is rebuilt per chunk on the chunk's base)
 template <int NV, bool F64>
-__device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, const double* val4, int p0, int p1, Stream4<NV, F64>& s) {
+__device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, const double* val4, int p0, int p1, Stream4<NV, F64>& s,
+                                   unsigned tid = threadIdx.x) {               // tid: the thread's index inside its 256-thread group
 #pragma unroll
     for (int w = 0; w < NV; ++w) {
-        const unsigned first = (unsigned)p0 + 4u * (threadIdx.x + w * BS);     // p0 is a multiple of 4
+        const unsigned first = (unsigned)p0 + 4u * (tid + w * BS);     // p0 is a multiple of 4
         // groups past the end of the chunk: offset 0xffffffff is out of range -> zeros without a memory access
         // (zeros decode to window 0 / offset 0 / value 0, like the padding inside the last group)
         const bool in = (int)first < p1;
@@ -371,6 +372,101 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
         chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
         nchunk = nn; npr = nnpr;
         ++it;
+    }
+}
+// ---- block-resident variant of S: x of a lattice block lives in LDS ------------------------------------------------------
+// A 1024-thread workgroup owns one UNIT at a time — the chunks of one 16^3 lattice block (its active rows and the skin rows of its
+// tiles, ps_context::buildBlockUnits) — and first copies the block's contiguous DOF range x[winLo, winLo + winLen) into LDS with
+// coalesced loads.  The four 256-thread groups then each process chunks of the unit exactly like k_spmv_S_pipe, except that a
+// gather whose column falls inside the window reads LDS; the others (neighbour blocks) go to memory as before.  The window is a
+// cache, not an assumption: any column outside it is simply fetched, so results are those of the pipelined kernel bit for bit.
+struct BlkUnit { int chunkBegin, chunkCount, winLo, winLen; };
+constexpr int BLK_T = 1024, BLK_G = BLK_T / BS;
+constexpr int BLK_WCAP = 11776;                      // doubles of x per unit (92 KB; + 64 KB of product slots + tables < 160 KB)
+template <int MODE, int NV>
+__global__ void __launch_bounds__(BLK_T) k_spmv_S_blk(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
+                                                      const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
+                                                      const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
+                                                      int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
+                                                      const int* __restrict__ done, const BlkUnit* __restrict__ units, int nUnits,
+                                                      const int32_t* __restrict__ unitChunks, const uint8_t* __restrict__ mcCode,
+                                                      const double* __restrict__ mcDict) {
+    if (done && *done) return;
+    constexpr int PL = BS * NV;
+    __shared__ double xw[BLK_WCAP];
+    __shared__ double prodAll[BLK_G][4 * PL];
+    __shared__ __align__(16) int wtotAll[BLK_G][BS / 64];
+    __shared__ double dict[MODE == 0 ? 256 : 1];
+    const int g = threadIdx.x >> 8, t = threadIdx.x & 255;
+    double* prod = prodAll[g];
+    int* wtot = wtotAll[g];
+    if (MODE == 0 && mcCode && threadIdx.x < 256) dict[threadIdx.x] = mcDict[threadIdx.x];
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
+                                 rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
+                                 rMcc = bufRsrc(mcCode, mcCode ? (size_t)nA : 0), rOut = bufRsrc(out, (size_t)rows * 8);
+    for (int u = blockIdx.x; u < nUnits; u += gridDim.x) {
+        const BlkUnit U = units[u];
+        // this group's first chunk and its stream: requested before the window copy so that the two latencies overlap
+        int ci = g;
+        int chunk = ci < U.chunkCount ? unitChunks[U.chunkBegin + ci] : -1;
+        int2 pr = {0, 0};
+        if (chunk >= 0) pr = chunkRange[chunk];
+        Stream4<NV, false> cur, nxt;
+        loadStream4<NV, false>(rCol, rCode, nullptr, pr.x, pr.y, cur, (unsigned)t);
+        int myBase = chunk >= 0 ? winBase[chunk * 16 + (t & 15)] : 0, nBase = 0;
+        for (int i = threadIdx.x; i < U.winLen; i += BLK_T) xw[i] = x[U.winLo + i];
+        __syncthreads();
+        const int rounds = (U.chunkCount + BLK_G - 1) / BLK_G;
+        for (int q = 0; q < rounds; ++q) {
+            const unsigned row = chunk >= 0 ? (unsigned)chunk * BS + t : 0xffffffffu;
+            const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row / for an idle group
+            double sc = 1.;
+            int mcc = 0;
+            if (MODE == 0) {
+                if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, 0);
+                else { const double m = bufLoadF64(rMc, row * 8u); sc = row < (unsigned)nA ? dt * m : 1.; }
+            }
+            double xv[4 * NV];
+            unsigned rel[4 * NV];
+#pragma unroll
+            for (int w = 0; w < NV; ++w) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned c = streamCol(cur.c[w], j, myBase);
+                    rel[4 * w + j] = c - (unsigned)U.winLo;
+                    const bool inWin = rel[4 * w + j] < (unsigned)U.winLen;
+                    xv[4 * w + j] = bufGatherF64(rX, inWin ? 0xffffffffu : c * 8u);       // out of range: 0, no memory access
+                }
+            }
+            // next chunk of this group
+            const int nci = ci + BLK_G;
+            const int nchunk = nci < U.chunkCount ? unitChunks[U.chunkBegin + nci] : -1;
+            int2 npr = {0, 0};
+            if (nchunk >= 0) { npr = chunkRange[nchunk]; nBase = winBase[nchunk * 16 + (t & 15)]; }
+            loadStream4<NV, false>(rCol, rCode, nullptr, npr.x, npr.y, nxt, (unsigned)t);
+#pragma unroll
+            for (int w = 0; w < NV; ++w) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned r = rel[4 * w + j];
+                    const double xx = r < (unsigned)U.winLen ? xw[r] : xv[4 * w + j];
+                    prod[j * PL + t + w * BS] = streamVal(cur.v[w], j, scale) * xx;
+                }
+            }
+            const int incl = waveInclusiveScan(len);
+            if ((t & 63) == 63) wtot[t >> 6] = incl;
+            __syncthreads();
+            {
+                const int4 wt = *reinterpret_cast<const int4*>(wtot);
+                const int wv = t >> 6;
+                const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
+                const double s = rowSum<8, PL>(prod, ea, len);
+                if (MODE == 0 && mcCode) sc = row < (unsigned)nA ? dt * dict[mcc] : 1.;
+                bufStoreF64nt(rOut, row * 8u, s * sc);                         // dropped past the last row / for an idle group
+            }
+            __syncthreads();
+            ci = nci; chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
+        }
     }
 }
 template <int MODE, int NV, bool F64>

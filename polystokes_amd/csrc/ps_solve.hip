@@ -60,6 +60,17 @@ struct Launch {
     void spmvS(int mode, const double* x, double* out) const {
         if (rowsS == 0) return;
         const ps::DevCSR& M = c->S;
+        if (pipeGrid > 0 && M.col16ok && M.packed && M.nUnits > 0) {   // block-resident x (PS_BLK=1)
+            static const int blkGrid = getenv("PS_BLK_GRID") ? atoi(getenv("PS_BLK_GRID")) : 256;
+            const dim3 gr((unsigned)std::min(M.nUnits, blkGrid)), bl(BLK_T);
+#define PS_LAUNCH_SB(MODE_, NV_) hipLaunchKernelGGL((k_spmv_S_blk<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
+                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, \
+                                                    (const BlkUnit*)M.units.p, M.nUnits, M.unitChunks.p, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p)
+            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SB(0, 1); else PS_LAUNCH_SB(1, 1); }
+            else { if (mode == 0) PS_LAUNCH_SB(0, 2); else PS_LAUNCH_SB(1, 2); }
+#undef PS_LAUNCH_SB
+            return;
+        }
         if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
             const int nChunks = gridFor(rowsS, BS);
             int xcdAware = this->xcdAware;

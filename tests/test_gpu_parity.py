@@ -507,7 +507,8 @@ def test_exported_system_import_errors(gpu, tmp_path):
 
 @pytest.mark.parametrize("env", [{"PS_COL32": "1"}, {"PS_FORCE_FP64_VALUES": "1"}, {"PS_FORCE_FP64_VALUES": "1", "PS_COL32": "1"},
                                  {"PS_PIPE_GRID": "0"}, {"PS_XCD": "0"}, {"PS_SCHED": "1", "PS_IL_SUPER": "2"},
-                                 {"PS_IL_ORIGIN": "8", "PS_IL_SUPER": "2,2,1"}, {"PS_NO_DIAG_CODES": "1"}])
+                                 {"PS_IL_ORIGIN": "8", "PS_IL_SUPER": "2,2,1"}, {"PS_NO_DIAG_CODES": "1"}, {"PS_TILE_SPLIT": "1"},
+                                 {"PS_BLK": "1"}, {"PS_SCHED": "3"}])
 def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     """The SpMV has four storage formats chosen at setup — compressed stream with int8 value codes (3 B/nnz) or with fp64
     values (10 B/nnz: values that are not code * scale), both on the pipelined kernels; int8-coded CSR and fp64 CSR on the
