@@ -24,7 +24,14 @@
 extern "C" {
 #endif
 
-#define PS_REDUCED_DOF 26 /* lib/include/units.h:13-15 (QUADRATIC_REGIONS) */
+/* Reduced model per tile: a compile-time choice, as in the reference (lib/include/units.h:9-18).  Default QUADRATIC_REGIONS,
+ * 26 divergence-free quadratic DOFs; -DPS_AFFINE_REGIONS builds the AFFINE_REGIONS variant, 11 DOFs
+ * (exec/HDK_PolyStokesSolver.cpp:2153-2184) -> libpolystokes_hip_affine.so, same ABI, ps_reduced_dof() tells which. */
+#ifdef PS_AFFINE_REGIONS
+#define PS_REDUCED_DOF 11
+#else
+#define PS_REDUCED_DOF 26
+#endif
 
 /* exec/HDK_PolyStokesSolver.h:61-70  enum class SolverResult */
 enum ps_result {
@@ -145,6 +152,7 @@ typedef struct ps_context ps_context;
 
 /* Library/ABI version and a loud availability check (0 devices -> error string). */
 int32_t ps_abi_version(void);
+int32_t ps_reduced_dof(void);                     /* REDUCED_DOF of this build: 26 (quadratic) or 11 (affine) */
 
 /* Context = what `Solver mySolver(...)` owns for one call (HDK_PolyStokes.C:333-343), kept alive
  * across steps so device buffers are reused.  One context per GPU. */

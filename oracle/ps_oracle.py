@@ -11,7 +11,7 @@ import numpy as np
 from polystokes_amd._abi import FieldsIn, Params, Stats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libps_oracle.so")
+_LIB_PATH = os.environ.get("PS_ORACLE_LIB") or os.path.join(_HERE, "_build", "libps_oracle.so")   # PS_ORACLE_LIB: the affine build
 _lib = None
 
 
@@ -164,9 +164,15 @@ class Oracle:
         return ms, int(used.value)
 
 
+def reduced_dof():
+    L = lib()
+    L.po_reduced_dof.restype = C.c_int32
+    return int(L.po_reduced_dof())
+
+
 def basis(off, axis):
     off = np.ascontiguousarray(off, dtype=np.float64)
-    out = np.empty(26)
+    out = np.empty(reduced_dof())
     lib().po_basis(off.ctypes.data, axis, out.ctypes.data)
     return out
 

@@ -67,6 +67,14 @@ CSR CSR::transposed() const {
 // ---------------------------------------------------------------------------------------------
 void buildConversionCoefficients(const double o[3], int axis, double v[RD]) {
     for (int n = 0; n < RD; ++n) v[n] = 0.;
+#ifdef PS_AFFINE_REGIONS
+    switch (axis) {   // AFFINE_REGIONS, exec/HDK_PolyStokesSolver.cpp:2153-2184
+        case 0: v[0] = 1.; v[3] = o[0]; v[4] = o[1]; v[5] = o[2]; break;
+        case 1: v[1] = 1.; v[6] = o[0]; v[7] = o[1]; v[8] = o[2]; break;
+        case 2: v[2] = 1.; v[3] = -o[2]; v[7] = -o[2]; v[9] = o[0]; v[10] = o[1]; break;
+    }
+    return;
+#endif
     switch (axis) {
         case 0:
             v[0] = 1.;

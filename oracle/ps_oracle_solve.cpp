@@ -628,6 +628,7 @@ void po_precondition(void* h, const double* r, double* z) {
     std::copy(out.begin(), out.end(), z);
 }
 double po_cheb_lmax(void* h) { return ((Oracle*)h)->chebLmax; }
+int32_t po_reduced_dof(void) { return psoracle::RD; }
 void po_basis(const double* off, int32_t axis, double* out) { psoracle::buildConversionCoefficients(off, axis, out); }
 int32_t po_fullpivlu_solve(const double* N, const double* rhs, double* x) { return psoracle::fullPivLuSolve(N, rhs, x) ? 1 : 0; }
 int32_t po_partialpiv_inverse(const double* B, double* Binv) { return psoracle::partialPivInverse(B, Binv) ? 1 : 0; }

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("PS_LIB") or os.path.join(_HERE, "libpolystokes_hip.so
 _lib = None
 
 EXPORTED_SYMBOLS = [
-    "ps_abi_version", "ps_context_create", "ps_context_destroy", "ps_last_error", "ps_params_default",
+    "ps_abi_version", "ps_reduced_dof", "ps_context_create", "ps_context_destroy", "ps_last_error", "ps_params_default",
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
     "polystokes_step", "ps_apply_operator", "ps_apply_preconditioner", "ps_query_array", "ps_read_array",
     "ps_export_component_matrices", "ps_export_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt", "ps_solve_exported_system",
@@ -46,6 +46,7 @@ def lib():
                 "(__graft_entry__.build()).  There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
         L.ps_abi_version.restype = C.c_int32
+        L.ps_reduced_dof.restype = C.c_int32
         L.ps_context_create.argtypes = [C.c_int32]
         L.ps_context_create.restype = C.c_void_p
         L.ps_context_destroy.argtypes = [C.c_void_p]

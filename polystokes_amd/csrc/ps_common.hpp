@@ -13,7 +13,7 @@
 
 #include "../../include/polystokes.h"
 
-#define PS_RD 26
+#define PS_RD PS_REDUCED_DOF   // 26 (quadratic regions) or 11 (-DPS_AFFINE_REGIONS)
 
 #define HIP_CHECK(x)                                                                              \
     do {                                                                                          \
@@ -112,6 +112,28 @@ struct Own {
     __host__ __device__ bool sample(int s, int k) const { return (s == 3 || s == 4 || s == 5) ? plane(k) : layer(k); }
 };
 
+#ifdef PS_AFFINE_REGIONS
+// Affine basis row C_a(x), exec/HDK_PolyStokesSolver.cpp:2153-2184 (AFFINE_REGIONS, 11 DOF): branch-free selects as below.
+__host__ __device__ inline void basisRow(const double ox, const double oy, const double oz, int axis, double* v) {
+    const bool a0 = axis == 0, a1 = axis == 1, a2 = axis == 2;
+    v[0] = a0 ? 1. : 0.;
+    v[1] = a1 ? 1. : 0.;
+    v[2] = a2 ? 1. : 0.;
+    v[3] = a0 ? ox : (a2 ? -oz : 0.);
+    v[4] = a0 ? oy : 0.;
+    v[5] = a0 ? oz : 0.;
+    v[6] = a1 ? ox : 0.;
+    v[7] = a1 ? oy : (a2 ? -oz : 0.);
+    v[8] = a1 ? oz : 0.;
+    v[9] = a2 ? ox : 0.;
+    v[10] = a2 ? oy : 0.;
+}
+__host__ __device__ inline double basisDot(const double ox, const double oy, const double oz, int axis, const double* c) {
+    if (axis == 0) return c[0] + ox * c[3] + oy * c[4] + oz * c[5];
+    if (axis == 1) return c[1] + ox * c[6] + oy * c[7] + oz * c[8];
+    return c[2] - oz * c[3] - oz * c[7] + ox * c[9] + oy * c[10];
+}
+#else
 // Polynomial basis row C_a(x), exec/HDK_PolyStokesSolver.cpp:2105-2149 (QUADRATIC_REGIONS, 26 DOF).
 __host__ __device__ inline void basisRow(const double ox, const double oy, const double oz, int axis, double* v) {
     const double qx[9] = {ox, oy, oz, ox * ox, ox * oy, ox * oz, oy * oy, oy * oz, oz * oz};
@@ -157,6 +179,8 @@ __host__ __device__ inline double basisDot(const double ox, const double oy, con
            ox * oz * c[16] - 2. * oy * oz * c[18] - 0.5 * oz * oz * c[19] + ox * c[21] + oy * c[22] +
            ox * ox * c[23] + ox * oy * c[24] + oy * oy * c[25];
 }
+
+#endif
 
 // face position packed in 32 bits: 10 bits per coordinate + 2 bits axis (grids up to 1023^3)
 __host__ __device__ inline uint32_t packFace(int i, int j, int k, int axis) {

@@ -430,6 +430,7 @@ void ps_context::buildExplicitA(std::vector<int64_t>& aptr, std::vector<int32_t>
 extern "C" {
 
 int32_t ps_abi_version(void) { return 1; }
+int32_t ps_reduced_dof(void) { return PS_RD; }
 
 ps_context* ps_context_create(int32_t device) {
     int count = 0;

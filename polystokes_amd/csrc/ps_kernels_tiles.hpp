@@ -29,6 +29,33 @@ __device__ inline void faceMonomials(uint32_t f, double dx, double cx, double cy
     mu[0] = 1.; mu[1] = ox; mu[2] = oy; mu[3] = oz; mu[4] = ox * ox; mu[5] = ox * oy; mu[6] = ox * oz; mu[7] = oy * oy; mu[8] = oy * oz; mu[9] = oz * oz;
     *axis = a;
 }
+#ifdef PS_AFFINE_REGIONS
+// AFFINE_REGIONS (11 DOF): only the monomials 1, ox, oy, oz enter
+__device__ inline double momentsToW(const double* M, int e) {
+    const double* X = M; const double* Y = M + 10; const double* Z = M + 20;
+    switch (e) {
+        case 0: return X[0];
+        case 1: return Y[0];
+        case 2: return Z[0];
+        case 3: return X[1] - Z[3];
+        case 4: return X[2];
+        case 5: return X[3];
+        case 6: return Y[1];
+        case 7: return Y[2] - Z[3];
+        case 8: return Y[3];
+        case 9: return Z[1];
+        default: return Z[2];
+    }
+}
+__device__ inline double vToAxisCoeff(const double* v, int q) {
+    switch (q) {
+        case 0: return v[0];  case 1: return v[3];  case 2: return v[4];  case 3: return v[5];
+        case 10: return v[1]; case 11: return v[6]; case 12: return v[7]; case 13: return v[8];
+        case 20: return v[2]; case 21: return v[9]; case 22: return v[10]; case 23: return -v[3] - v[7];
+        default: return 0.;
+    }
+}
+#else
 // entry e of w from the 30 moments M[a * 10 + m]
 __device__ inline double momentsToW(const double* M, int e) {
     const double* X = M; const double* Y = M + 10; const double* Z = M + 20;
@@ -73,6 +100,7 @@ __device__ inline double vToAxisCoeff(const double* v, int q) {
         default: return -0.5 * v[8] - 0.5 * v[19];
     }
 }
+#endif
 // one lane's share of the moments over the rows rr = first, first + stride, ... < end
 constexpr int TILE_FACE_CACHE = 16;   // packed faces a lane keeps in registers between the gather and the expand of k_tile_apply
 template <bool CACHE, int U>
