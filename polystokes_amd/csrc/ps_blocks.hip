@@ -531,16 +531,27 @@ namespace {
 constexpr unsigned long long DICT_EMPTY = 0xfff8dead0000beefull;   // a NaN payload no diagonal value takes
 __device__ inline int dictHash(unsigned long long k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 29; return (int)(k & 255ull); }
 // insert every value into a 256-slot open-addressing table (linear probing); slot index = the value's code
-__global__ void k_dict_build(const double* __restrict__ v, int64_t n, unsigned long long* __restrict__ table, int32_t* __restrict__ overflow) {
+__global__ void __launch_bounds__(BS) k_dict_build(const double* __restrict__ v, int64_t n, unsigned long long* __restrict__ table, int32_t* __restrict__ overflow) {
+    // a block works from an LDS snapshot of the table (refreshed when a value is missing from it): after the first few hundred
+    // values every lookup is an LDS hit; only unseen values take the global probe / CAS path
+    __shared__ unsigned long long snap[256];
+    snap[threadIdx.x] = __hip_atomic_load(&table[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
         if (key == DICT_EMPTY) { *overflow = 1; continue; }
         int h = dictHash(key);
         bool placed = false;
+        for (int probe = 0; probe < 256 && !placed; ++probe) {      // LDS snapshot first
+            const unsigned long long cur = snap[(h + probe) & 255];
+            if (cur == key) placed = true;
+            else if (cur == DICT_EMPTY) break;
+        }
         for (int probe = 0; probe < 256 && !placed; ++probe) {
             unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == DICT_EMPTY) cur = atomicCAS(&table[h], DICT_EMPTY, key), cur = (cur == DICT_EMPTY) ? key : cur;
-            if (cur == key) placed = true; else h = (h + 1) & 255;
+            if (cur == key) { placed = true; snap[h] = key; }         // benign race: every writer of a slot writes the slot's one key
+            else h = (h + 1) & 255;
         }
         if (!placed) *overflow = 1;
     }
@@ -566,7 +577,7 @@ void ps_context::buildDiagonalCodes() {
         unsigned long long* table = (unsigned long long*)dict.p;
         HIP_CHECK(hipMemsetAsync(counters.p + 26, 0, sizeof(int32_t), stream));
         hipLaunchKernelGGL(k_dict_init, dim3(1), dim3(256), 0, stream, table);
-        hipLaunchKernelGGL(k_dict_build, dim3(1024), dim3(BS), 0, stream, vals.p, n, table, counters.p + 26);
+        hipLaunchKernelGGL(k_dict_build, dim3(2048), dim3(BS), 0, stream, vals.p, n, table, counters.p + 26);
         if (readCounter(26) != 0) return false;
         hipLaunchKernelGGL(k_dict_code, dim3(1024), dim3(BS), 0, stream, vals.p, n, (const unsigned long long*)table, code.p);
         hipLaunchKernelGGL(k_dict_finish, dim3(1), dim3(256), 0, stream, table);
