@@ -283,6 +283,21 @@ __device__ inline int waveInclusiveScan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
+// wave sum of a double with DPP moves only (no LDS-pipe bpermutes): same row_shr / row_bcast ladder as the scan above on the two
+// 32-bit halves; the total lands in lane 63 (the other lanes hold partial prefix sums)
+__device__ inline double waveSumToLane63(double v) {
+#define PS_DPP_STEP(CTRL, RMASK)                                                                                   \
+    {                                                                                                               \
+        const long long b = __double_as_longlong(v);                                                                \
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, RMASK, 0xf, false);            \
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, RMASK, 0xf, false);                     \
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                                            \
+    }
+    PS_DPP_STEP(0x111, 0xf) PS_DPP_STEP(0x112, 0xf) PS_DPP_STEP(0x114, 0xf) PS_DPP_STEP(0x118, 0xf)
+    PS_DPP_STEP(0x142, 0xa) PS_DPP_STEP(0x143, 0xc)
+#undef PS_DPP_STEP
+    return v;
+}
 // sum of the row's products prod[ea .. ea+len) in entry order; all (<= ML) LDS reads are issued up front
 template <int ML, int PL>
 __device__ inline double rowSum(const double* prod, int ea, int len) {

@@ -153,8 +153,8 @@ __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ 
     tileAccumulate<false, 4>(chunkStart[ch] + (int)threadIdx.x, 64, chunkEnd[ch], rrowFace, sred, dx, COM[(int64_t)r * 3], COM[(int64_t)r * 3 + 1], COM[(int64_t)r * 3 + 2], M, nullptr);
 #pragma unroll
     for (int n = 0; n < 30; ++n) {
-        const double v = waveReduceSum(M[n]);
-        if (threadIdx.x == 0) Ms[n] = v;
+        const double v = waveSumToLane63(M[n]);
+        if (threadIdx.x == 63) Ms[n] = v;
     }
     __syncthreads();
     if (threadIdx.x < PS_RD) wpart[(int64_t)ch * PS_RD + threadIdx.x] = momentsToW(Ms, (int)threadIdx.x);
@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
         tileAccumulate<MODE == 0, U>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, cx, cy, cz, M, fcache);
 #pragma unroll
         for (int n = 0; n < 30; ++n) {
-            const double v = waveReduceSum(M[n]);
-            if (lane == 0) msum[wave][n] = v;
+            const double v = waveSumToLane63(M[n]);
+            if (lane == 63) msum[wave][n] = v;
         }
         __syncthreads();
         if (threadIdx.x < 30) {

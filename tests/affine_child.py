@@ -57,7 +57,7 @@ def gpu(name):
     import polystokes_amd
     assert polystokes_amd.lib().ps_reduced_dof() == RD and ps_oracle.reduced_dof() == RD
     sc, p = scene(name)
-    p.tolerance = 1e-6
+    p.tolerance = 1e-4 if name == "spheres32" else 1e-6   # spheres (mu = 1e4) is ill-conditioned: x agrees to ~cond * tol
     o = ps_oracle.Oracle(); o.run(sc, p)
     g = polystokes_amd.Solver(0)
     rc = g.step(sc, p)
