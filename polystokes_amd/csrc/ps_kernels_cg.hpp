@@ -3,6 +3,47 @@
 #pragma once
 
 // ---- CG vector kernels ---------------------------------------------------------------------------
+// Cache policy of the streams these kernels touch once per iteration (compile-time, scripts/build_variant.sh builds A/B copies).
+// Measured at 256^3: x, Ap and r non-temporal (read / written once per iteration, next use a whole iteration away) take
+// k_cg_update_xp from 0.345 to 0.30 ms and the step from 1378 to 1319 ms; p stays default-policy (the next S gathers it).
+#ifndef PS_VEC_NT_X
+#define PS_VEC_NT_X 1      // x: read and written only by k_cg_update_xp
+#endif
+#ifndef PS_VEC_NT_AP
+#define PS_VEC_NT_AP 1     // Ap: written by St, read once by k_cg_update_r
+#endif
+#ifndef PS_VEC_NT_R
+#define PS_VEC_NT_R 1      // r in k_cg_update_r (read + written)
+#endif
+#ifndef PS_VEC_NT_RX
+#define PS_VEC_NT_RX 1     // r as read by k_cg_update_xp
+#endif
+#ifndef PS_VEC_NT_P
+#define PS_VEC_NT_P 0      // p as written by k_cg_update_xp (gathered by the next S)
+#endif
+#ifndef PS_VEC_NT_PL
+#define PS_VEC_NT_PL 0     // p as read by k_cg_update_xp
+#endif
+#ifndef PS_VEC_NT_D
+#define PS_VEC_NT_D 1      // the fp32 Jacobi diagonal (read by both step kernels, half an iteration apart)
+#endif
+__device__ inline float2 ldF2(const float2* p, bool nt) {
+    if (!nt) return *p;
+    typedef float psf2 __attribute__((ext_vector_type(2)));
+    const psf2 v = __builtin_nontemporal_load(reinterpret_cast<const psf2*>(p));
+    return make_float2(v.x, v.y);
+}
+typedef double psd2 __attribute__((ext_vector_type(2)));
+__device__ inline double2 ldD2(const double2* p, bool nt) {
+    if (!nt) return *p;
+    const psd2 v = __builtin_nontemporal_load(reinterpret_cast<const psd2*>(p));
+    return make_double2(v.x, v.y);
+}
+__device__ inline void stD2(double2* p, double2 v, bool nt) {
+    if (!nt) { *p = v; return; }
+    psd2 q; q.x = v.x; q.y = v.y;
+    __builtin_nontemporal_store(q, reinterpret_cast<psd2*>(p));
+}
 __global__ void k_scale_rows(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
 }
@@ -188,12 +229,12 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double*
     const double2* A2 = (const double2*)Ap; const float2* d2 = (const float2*)dinv;
     double2* r2 = (double2*)r;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        const double2 av = A2[i];
-        double2 rv = r2[i];
+        const double2 av = ldD2(A2 + i, PS_VEC_NT_AP);
+        double2 rv = ldD2(r2 + i, PS_VEC_NT_R);
         rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
-        r2[i] = rv;
+        stD2(r2 + i, rv, PS_VEC_NT_R);
         arr += rv.x * rv.x; arr += rv.y * rv.y;
-        if (dinv) { const float2 dv = d2[i]; arz += rv.x * ((double)dv.x * rv.x); arz += rv.y * ((double)dv.y * rv.y); }
+        if (dinv) { const float2 dv = ldF2(d2 + i, PS_VEC_NT_D); arz += rv.x * ((double)dv.x * rv.x); arz += rv.y * ((double)dv.y * rv.y); }
     }
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = r[i] - alpha * Ap[i];
@@ -223,12 +264,12 @@ __global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double
     const double2* r2 = (const double2*)r; const float2* d2 = (const float2*)dinv;
     double2* p2 = (double2*)p; double2* x2 = (double2*)x;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        double2 z = r2[i];
-        if (dinv) { const float2 dv = d2[i]; z.x = (double)dv.x * z.x; z.y = (double)dv.y * z.y; }
-        double2 pv = p2[i], xv = x2[i];
+        double2 z = ldD2(r2 + i, PS_VEC_NT_RX);
+        if (dinv) { const float2 dv = ldF2(d2 + i, PS_VEC_NT_D); z.x = (double)dv.x * z.x; z.y = (double)dv.y * z.y; }
+        double2 pv = ldD2(p2 + i, PS_VEC_NT_PL), xv = ldD2(x2 + i, PS_VEC_NT_X);
         xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
         pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
-        x2[i] = xv; p2[i] = pv;
+        stD2(x2 + i, xv, PS_VEC_NT_X); stD2(p2 + i, pv, PS_VEC_NT_P);
         axx += xv.x * xv.x; axx += xv.y * xv.y;
     }
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
