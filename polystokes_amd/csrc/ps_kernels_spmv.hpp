@@ -199,6 +199,7 @@ __device__ inline __amdgpu_buffer_rsrc_t bufRsrc(const void* p, size_t bytes) {
 __device__ inline double bufLoadF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, 0));
 }
+__device__ inline double bufLoadF64epi(__amdgpu_buffer_rsrc_t r, unsigned byteOff);
 __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, 0);
 }
@@ -215,6 +216,12 @@ __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, d
 #ifndef PS_GATHER_AUX
 #define PS_GATHER_AUX 0
 #endif
+#ifndef PS_EPI_AUX
+#define PS_EPI_AUX 2       // the per-row streams of the epilogues (row length, x, uInv / codes): read once per launch -> nt (St -3 %)
+#endif
+__device__ inline double bufLoadF64epi(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, PS_EPI_AUX));
+}
 __device__ inline void bufStoreF64nt(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, PS_STORE_AUX);
 }
@@ -341,11 +348,11 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     if (nchunk < nChunks) npr = chunkRange[nchunk];
     while (true) {
         const unsigned row = (unsigned)chunk * BS + threadIdx.x;
-        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, PS_EPI_AUX);   // 0 past the last row
         double sc = 1.;
         int mcc = 0;
         if (MODE == 0) {
-            if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, 0);
+            if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, PS_EPI_AUX);
             else { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
         }
         double xv[4 * NV];
@@ -519,11 +526,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
     if (nchunk < nChunks) npr = chunkRange[nchunk];
     while (true) {
         const unsigned row = (unsigned)chunk * BS + threadIdx.x;
-        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row
-        const double e0 = bufLoadF64(rE0, row * 8u);                                       // x (MODE 0, 2) / the vector added (MODE 1)
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, PS_EPI_AUX);   // 0 past the last row
+        const double e0 = bufLoadF64epi(rE0, row * 8u);                                       // x (MODE 0, 2) / the vector added (MODE 1)
         double e1 = 0., cr = 0., ci = 0., cd = 0.;
         int uc = 0;
-        if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, 0); else e1 = bufLoadF64(rE1, row * 8u); }
+        if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, PS_EPI_AUX); else e1 = bufLoadF64epi(rE1, row * 8u); }
         if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }
         double xv[4 * NV];
 #pragma unroll
