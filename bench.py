@@ -93,7 +93,7 @@ def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw, sample_res=128):
     }
 
 
-def _latest_traffic():
+def _latest_traffic(kernel="k_spmv_St"):
     """Newest committed PMC summary (profiles/rNN_pmc_traffic.json, written by scripts/profile_round.sh).  The counters
     cannot be collected inside this process: traffic is a pointer to that measurement, and says which."""
     import glob
@@ -102,7 +102,7 @@ def _latest_traffic():
         return None, None
     try:
         d = json.load(open(files[-1]))
-        return d.get("k_spmv_St", {}).get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+        return d.get(kernel, {}).get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
 
@@ -255,21 +255,26 @@ def main():
     coded = bool(solver.array("valuesCoded")[0])
     c16 = int(solver.array("columns16")[0]) == 3
     kern = {}
-    names = ["spmv_St", "spmv_S", "apply", "tiles", "cg_update_r", "cg_update_xp"]
+    # the PCG step as the solve ran it: four kernels (S, tiles, St with the residual update in its epilogue, x/p update) on
+    # the coded stream, five (S, tiles, St, r update, x/p update) otherwise — the five-kernel ones stay listed: they are what
+    # the distributed, Chebyshev and fallback-stream solves launch
+    fused = int(solver.array("fusedStep")[0]) == 1
+    names = (["spmv_St_r", "cg_update_xp_u"] if fused else []) + ["spmv_St", "spmv_S", "apply", "tiles", "cg_update_r", "cg_update_xp"]
     if coded and c16:
         names += ["spmv_St_fp64", "spmv_S_fp64"]     # the pipelined kernels on fp64 values (10 B/nnz): the non-dyadic-weights fallback
     names += ["spmv_St_csr", "spmv_S_csr"]            # the one-shot kernels on the plain CSR (12 B/nnz): the last-resort fallback
     # the five kernels of a CG iteration are timed IN SEQUENCE ("seq:": the loop's predecessor kernel runs, untimed, before
     # every timed launch: what rocprof sees in a real solve); "replayed_ms" is the same kernel launched back to back
-    in_loop = ("spmv_St", "spmv_S", "tiles", "cg_update_r", "cg_update_xp")
+    in_loop = ("spmv_St_r", "cg_update_xp_u", "spmv_St", "spmv_S", "tiles", "cg_update_r", "cg_update_xp")
     for name in names:
         ms, by = solver.bench_kernel(("seq:" + name) if name in in_loop else name, 20)
         kern[name] = {"ms": ms, "algorithmic_bytes": by, "GBps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                       "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0}
         if name in in_loop:
             kern[name]["replayed_ms"] = solver.bench_kernel(name, 20)[0]
-    dom = "spmv_St"
-    traffic, traffic_source = _latest_traffic() if (n == 256 and world == 1 and scene_name == "cavity") else (None, None)
+    dom = "spmv_St_r" if fused else "spmv_St"
+    mode = 3 if fused else 0
+    traffic, traffic_source = _latest_traffic("k_spmv_St_r" if fused else "k_spmv_St") if (n == 256 and world == 1 and scene_name == "cavity") else (None, None)
     # achieved = the bytes the production kernel has to move per launch (its stored matrix format + the vectors, each once)
     # / its launch duration: the HBM utilisation of the kernel as it runs.  The production kernel streams a lossless 3 B/nnz
     # encoding of the matrix, so this is FEWER bytes than SURVEY section 8(d)'s CSR figure (12 B/nnz + row pointers +
@@ -277,15 +282,15 @@ def main():
     # HBM peak, which only says the kernel beats a CSR SpMV running at the roofline).  Every fraction in "other_kernels" is
     # that kernel's OWN stored bytes over its OWN measured duration (the fallbacks are timed as themselves).
     ms = kern[dom]["ms"]
-    csr = kern[dom + "_csr"]["algorithmic_bytes"]
+    csr = kern["spmv_St_csr"]["algorithmic_bytes"]
     csr_gbps = csr / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {
-        "bound": "hbm", "kernel": "k_spmv_St_pipe<0,NV,%s> (NV = 1 or 2 four-entry groups per lane, by the fullest chunk)" % ("false" if coded else "true") if c16 else "k_spmv_St<0,6,%s>" % ("true" if coded else "false"),
+        "bound": "hbm", "kernel": "k_spmv_St_pipe<%d,NV,%s> (NV = 1 or 2 four-entry groups per lane, by the fullest chunk%s)" % (mode, "false" if coded else "true", "; MODE 3: r -= alpha A p in the epilogue" if fused else "") if c16 else "k_spmv_St<0,6,%s>" % ("true" if coded else "false"),
         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
         "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_ms": ms,
         "algorithmic_bytes_definition": ("stored format: 3*nnz (16-bit windowed column + int8 value code) + 1*rows (row length) + 72 B per 256-row chunk "
-                                         "+ 8*rows (y) + 8*cols (x once) + 16*rows (fused -1/2 uInv x epilogue)") if (coded and c16) else
+                                         "+ 8*cols (t once) + 8*rows (p) + 1*rows (coded uInv) + %s") % ("16*rows (r read + written) + 4*rows (fp32 Jacobi diagonal); A p is not stored" if fused else "8*rows (y)") if (coded and c16) else
                                         "CSR: (12 | 10 | 5)*nnz + 4*(rows+1) + 8*rows (y) + 8*cols (x once) + 16*rows (fused epilogue)",
         "value_format": ("16-bit windowed col + int8 value code (3 B/nnz, lossless)" if c16 else "int32 col + int8 value code (5 B/nnz, lossless)") if coded
                         else ("16-bit windowed col + fp64 value (10 B/nnz)" if c16 else "int32 col + fp64 value (12 B/nnz)"),

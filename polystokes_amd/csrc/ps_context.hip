@@ -278,6 +278,9 @@ void ps_context::registerArrays() {
     HIP_CHECK(hipMemcpyAsync(counters.p + 27, &diagFlagsHost, sizeof(int32_t), hipMemcpyHostToDevice, stream));
     reg("diagonalsCoded", counters.p + 27, 1, 4);
     reg("columns16", counters.p + 24, 1, 4);
+    // 1: the last PCG solve ran the four-kernel step (residual update inside the St kernel, ps_solve.hip)
+    HIP_CHECK(hipMemcpyAsync(counters.p + 28, &fusedStepHost, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    reg("fusedStep", counters.p + 28, 1, 4);
     reg("sysPerm", permSys.p, nSystem, 4);
     reg("rowPerm", permRow.p, nActiveVs, 4);
     reg("S.ptr", S.ptr.p, S.rows + 1, 4); reg("S.col", S.col.p, S.nnz, 4); reg("S.val", S.val.p, S.nnz, 8);
@@ -629,7 +632,8 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
         if (seq) k = k.substr(4);
         std::vector<std::string> pred;
         if (seq) {
-            if (k == "spmv_St") pred = {"spmv_S", "tiles"};
+            if (k == "spmv_St" || k == "spmv_St_r") pred = {"spmv_S", "tiles"};
+            else if (k == "cg_update_xp_u") pred = {"spmv_St_r"};
             else if (k == "spmv_S") pred = {"cg_update_xp"};
             else if (k == "tiles") pred = {"spmv_S"};
             else if (k == "cg_update_r") pred = {"spmv_St"};
@@ -683,6 +687,9 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             const double bT = winT + perNnzT * nnz + ptrT * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + dU * rowsT;
             if (kb == "spmv_S") *algorithmic_bytes = bS;
             else if (kb == "spmv_St") *algorithmic_bytes = bT;
+            // fused residual update: r read and written in place of the A p store, + the fp32 Jacobi diagonal
+            else if (kb == "spmv_St_r") *algorithmic_bytes = bT + (c->P.preconditioner == PS_PRE_DIAGONAL ? 12. : 8.) * rowsT;
+            else if (kb == "cg_update_xp_u") *algorithmic_bytes = ((c->P.preconditioner == PS_PRE_DIAGONAL ? 44. : 40.) + (c->uCoded ? 1. : 8.)) * rowsT;
             else if (kb == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);
             else if (kb == "tiles") *algorithmic_bytes = (double)c->nReducedRows * (8. + 4. + 8. + 4.);   // s in, t out, packed face x2
             else if (kb == "cg_update_r") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 28. : 24.) * rowsT;   // fp32 diagonal

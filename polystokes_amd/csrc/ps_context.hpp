@@ -142,6 +142,7 @@ struct ps_context {
     ps::DevBuf<double> uDict, mcDict;      // 256 entries each
     bool uCoded = false, mcCoded = false;
     int32_t diagFlagsHost = 0;
+    int32_t fusedStepHost = 0;
     void buildDiagonalCodes();
     ps::DevBuf<float> dinvF;   // the Jacobi diagonal as the PCG kernels read it (fp32 storage, see constructPreconditioner)
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
@@ -152,6 +153,7 @@ struct ps_context {
     // dotPartialsR: r.r / r.z partials of k_cg_update_r; dotPartials3: x.x partials of k_cg_update_xp.  Separate buffers:
     // every block of a step kernel sums its predecessor's partials while other blocks already write this kernel's.
     ps::DevBuf<double> dotPartials, dotPartials2, dotPartials3, dotPartialsR;
+    ps::DevBuf<double> fusedPart;   // fused step (ps_solve.hip): S-kernel, tile, uInv p^2 and r.r/r.z partials, in that order
     ps::DevBuf<ps::CGScalars> scal;
 
     // ---- multi-GPU (slab decomposition; ps_dist.hip) ----

@@ -246,20 +246,28 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double*
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s2; }
 }
 // beta ; x += alpha p ; p = z + beta p (z = D^-1 r) ; partials of x.x
-__global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
-                                                     int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
-                                                     double* __restrict__ p, int64_t n, double* __restrict__ partial) {
+// UPP (fused residual update, FusedR in ps_kernels_spmv.hpp): also the partials of sum_j uInv_j p_j^2 of the NEW p — the diagonal
+// share of the next p . A p — from the coded diagonal (1 B per entry + 256-entry table in LDS) or the fp64 one.
+template <bool UPP>
+__device__ inline void cgUpdateXp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
+                                  int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
+                                  double* __restrict__ p, int64_t n, double* __restrict__ partial,
+                                  const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
     if (sc->done) return;
+    __shared__ double dict[UPP ? 256 : 1];
+    if (UPP && uCode) dict[threadIdx.x] = uDict[threadIdx.x];   // visible after the barriers of blockSumAll below
     double rr, rz;
     if (red) { rr = red[0]; rz = jacobi ? red[1] : red[0]; }
     else {
         rr = blockSumAll(sumLocal(rPartial, rCount));
         rz = jacobi ? blockSumAll(sumLocal(rPartial + rCount, rCount)) : rr;
     }
+    if (UPP && red) __syncthreads();
     const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
-    double axx = 0.;
-    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x) & 15) == 0) && (((uintptr_t)dinv & 7) == 0);
+    double axx = 0., aup = 0.;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x) & 15) == 0) && (((uintptr_t)dinv & 7) == 0) &&
+                     (!UPP || ((((uintptr_t)uCode & 1) == 0) && (((uintptr_t)uInv & 15) == 0)));
     const int64_t n2 = vec ? n / 2 : 0;
     const double2* r2 = (const double2*)r; const float2* d2 = (const float2*)dinv;
     double2* p2 = (double2*)p; double2* x2 = (double2*)x;
@@ -271,16 +279,53 @@ __global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double
         pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
         stD2(x2 + i, xv, PS_VEC_NT_X); stD2(p2 + i, pv, PS_VEC_NT_P);
         axx += xv.x * xv.x; axx += xv.y * xv.y;
+        if (UPP) {
+            double u0, u1;
+            if (uCode) { const uint16_t cc = __builtin_nontemporal_load((const uint16_t*)uCode + i); u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
+            else { const double2 uv = ldD2((const double2*)uInv + i, 1); u0 = uv.x; u1 = uv.y; }
+            aup += u0 * (pv.x * pv.x); aup += u1 * (pv.y * pv.y);
+        }
     }
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double z = dinv ? (double)dinv[i] * r[i] : r[i];
         const double pv = p[i];
         const double xv = x[i] + alpha * pv;
-        x[i] = xv; p[i] = z + beta * pv;
+        const double pn = z + beta * pv;
+        x[i] = xv; p[i] = pn;
         axx += xv * xv;
+        if (UPP) aup += (uCode ? dict[uCode[i]] : uInv[i]) * (pn * pn);
     }
     const double s1 = blockReduceSum(axx);
     if (threadIdx.x == 0) partial[blockIdx.x] = s1;
+    if (UPP) {
+        const double s2 = blockReduceSum(aup);
+        if (threadIdx.x == 0) uPart[blockIdx.x] = s2;
+    }
+}
+__global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
+                                                     int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
+                                                     double* __restrict__ p, int64_t n, double* __restrict__ partial) {
+    cgUpdateXp<false>(sc, red, rPartial, rCount, jacobi, it, r, dinv, x, p, n, partial, nullptr, nullptr, nullptr, nullptr);
+}
+__global__ void __launch_bounds__(BS) k_cg_update_xp_u(CGScalars* sc, const double* __restrict__ rPartial, int rCount, int jacobi,
+                                                       int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
+                                                       double* __restrict__ p, int64_t n, double* __restrict__ partial,
+                                                       const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
+    cgUpdateXp<true>(sc, nullptr, rPartial, rCount, jacobi, it, r, dinv, x, p, n, partial, uCode, uDict, uInv, uPart);
+}
+// partials of sum_j uInv_j p_j^2 (the first search direction of a fused-step solve)
+__global__ void __launch_bounds__(BS) k_uinv_pp(const double* __restrict__ p, const uint8_t* __restrict__ uCode, const double* __restrict__ uDict,
+                                                const double* __restrict__ uInv, int64_t n, double* __restrict__ uPart) {
+    __shared__ double dict[256];
+    if (uCode) dict[threadIdx.x] = uDict[threadIdx.x];
+    __syncthreads();
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double pv = p[i];
+        acc += (uCode ? dict[uCode[i]] : uInv[i]) * (pv * pv);
+    }
+    const double s = blockReduceSum(acc);
+    if (threadIdx.x == 0) uPart[blockIdx.x] = s;
 }
 
 // ---- generic vector helpers (BiCGStab fallback, rare) -----------------------------------------------

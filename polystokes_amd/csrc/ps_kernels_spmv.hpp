@@ -173,6 +173,20 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 // MODE 2 of the St kernel: one term of the Chebyshev preconditioner fused into the epilogue (ps_context::solve):
 //   Az = (A z)[row];  d[row] = c1 d[row] + c2 dinv[row] (r[row] - Az);  z[row] += d[row];  partial += r[row] z[row]
 struct ChebArgs { const double* r; const double* dinv; double* d; double c1, c2; };
+// MODE 3 of the St kernel: the residual update of the PCG step inside the epilogue.  x . A x is known BEFORE the kernel starts,
+// from the factored form:  x.Ax = -( sum_active s_f t_f  +  sum_tiles w.v  +  1/2 sum_j uInv_j x_j^2 )  (partials of the S kernel,
+// of the tile kernel and of k_cg_update_xp) — so every workgroup forms alpha itself and does r -= alpha (A p) on its rows with
+// (A p)[row] still in a register: A p is never written or read back, and k_cg_update_r is not launched.
+struct FusedR {
+    CGScalars* sc;
+    const double* sPart; int sCount;      // k_spmv_S_pipe: active-face share
+    const double* tPart; int tCount;      // k_tile_apply: one value per region
+    const double* uPart; int uCount;      // k_cg_update_xp / k_uinv_pp: 1/2 sum uInv p^2 is formed here (partials hold sum uInv p^2)
+    const double* xxPart; int xxCount;    // ||x||^2 partials of the previous k_cg_update_xp (stop test of the previous iteration)
+    int it;
+    double* r; const float* dinvF;        // residual (updated in place), fp32 Jacobi diagonal (null: identity)
+    double* rPart;                        // out: partials of r.r at [block], of r.z at [gridDim + block]
+};
 struct ChunkSched { const int32_t* list; int off[9]; };   // per-XCD chunk lists (ps_context::buildChunkSchedule); list == null: computed walk
 struct ChunkWalk {
     int sh, x, l, per;   // G = 1 << sh chunks per run; sh < 0: plain walk
@@ -324,7 +338,9 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
                                                     int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
                                                     const int* __restrict__ done, ChunkSched sched, int nChunks, int xcdAware,
-                                                    const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict) {
+                                                    const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict, double* __restrict__ stPart) {
+    // stPart (MODE 0, may be null): per workgroup, the sum over its ACTIVE rows of s_f t_f = dt McInv_f s_f^2 — the active-face
+    // share of x . A x, so that the residual update can run inside the St kernel (ps_solve.hip: fused step)
     if (done && *done) return;
     constexpr int PL = BS * NV;
     __shared__ double prod[4 * PL];
@@ -338,7 +354,8 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     const ChunkWalk W(xcdAware, sched);
     int it = 0;
     int chunk = W.at(0);
-    if (chunk >= nChunks) return;
+    if (chunk >= nChunks) { if (MODE == 0 && stPart && threadIdx.x == 0) stPart[blockIdx.x] = 0.; return; }
+    double stAcc = 0.;
     int2 pr = chunkRange[chunk];
     Stream4<NV, F64> cur, nxt;
     loadStream4<NV, F64>(rCol, rCode, val4, pr.x, pr.y, cur);
@@ -387,6 +404,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
             const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
             const double s = rowSum<8, PL>(prod, ea, len);
             if (MODE == 0 && mcCode) sc = (int)row < nA ? dt * dict[mcc] : 1.;
+            if (MODE == 0) stAcc += (int)row < nA ? s * (s * sc) : 0.;
             bufStoreF64nt(rOut, row * 8u, s * sc);                             // dropped past the last row
         }
         __syncthreads();
@@ -394,6 +412,10 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
         chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
         nchunk = nn; npr = nnpr;
         ++it;
+    }
+    if (MODE == 0 && stPart) {
+        const double bs = blockReduceSum(stAcc);
+        if (threadIdx.x == 0) stPart[blockIdx.x] = bs;
     }
 }
 // ---- block-resident variant of S: x of a lattice block lives in LDS ------------------------------------------------------
@@ -498,25 +520,49 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
                                                      double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done,
                                                      ChunkSched sched, int nChunks, int xcdAware, ChebArgs cheb,
-                                                     const uint8_t* __restrict__ uCode, const double* __restrict__ uDict) {
+                                                     const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr) {
     if (done && *done) return;
     constexpr int PL = BS * NV;
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
     __shared__ double dict[MODE != 1 ? 256 : 1];      // value-set coded uInv (ps_context.hpp: uCode)
     if (MODE != 1 && uCode) dict[threadIdx.x] = uDict[threadIdx.x];
+    double alpha = 0.;
+    if (MODE == 3) {
+        // same prologue as k_cg_update_r: [stop test of iteration it-1], alpha = rsold / p.Ap — identical in every workgroup
+        CGScalars* sc = fr.sc;
+        auto sumArr = [&](const double* a, int cnt) { double acc = 0.; for (int i = threadIdx.x; i < cnt; i += BS) acc += a[i]; return blockSumAll(acc); };
+        const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+        if (fr.it > 0) {
+            const double xx = sumArr(fr.xxPart, fr.xxCount);
+            const double rr = sc->rr;
+            double rre = rr;                               // pcg.h:319-325
+            if (rr / xx < rre) rre = rr / xx;
+            const bool fire = rre < sc->tol2;
+            if (writer) { sc->xx = xx; sc->rre = rre; if (fire) { sc->done = 1; sc->iter = fr.it - 1; } }
+            if (fire) return;                              // same verdict in every workgroup
+        }
+        const double pAp = -(sumArr(fr.sPart, fr.sCount) + sumArr(fr.tPart, fr.tCount) + 0.5 * sumArr(fr.uPart, fr.uCount));
+        alpha = sc->rsold2[fr.it & 1] / pAp;               // pcg.h:314
+        if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
+    }
     static_assert(BS == 256, "four waves per block");
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, F64 ? 0 : (size_t)streamLen),
                                  rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(MODE == 1 ? add : xin, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8),
                                  rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
-                                 rCd = bufRsrc(cheb.d, MODE == 2 ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0);
+                                 rCd = bufRsrc(cheb.d, MODE == 2 ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
+                                 rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0);
     const ChunkWalk W(xcdAware, sched);
     int it = 0;
     int chunk = W.at(0);
-    if (chunk >= nChunks) { if (MODE != 1 && threadIdx.x == 0) partial[blockIdx.x] = 0.; return; }
-    double dacc = 0.;
+    if (chunk >= nChunks) {
+        if ((MODE == 0 || MODE == 2) && threadIdx.x == 0) partial[blockIdx.x] = 0.;
+        if (MODE == 3 && threadIdx.x == 0) { fr.rPart[blockIdx.x] = 0.; fr.rPart[gridDim.x + blockIdx.x] = 0.; }
+        return;
+    }
+    double dacc = 0., dacc2 = 0.;
     int2 pr = chunkRange[chunk];
     Stream4<NV, F64> cur, nxt;
     loadStream4<NV, F64>(rCol, rCode, val4, pr.x, pr.y, cur);
@@ -532,6 +578,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         int uc = 0;
         if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, PS_EPI_AUX); else e1 = bufLoadF64epi(rE1, row * 8u); }
         if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }
+        float fdv = 1.f;
+        if (MODE == 3) {
+            cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, PS_EPI_AUX));
+            if (fr.dinvF) fdv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(row * 4u), 0, PS_EPI_AUX));
+        }
         double xv[4 * NV];
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
@@ -567,6 +618,13 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             double y;
             if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
             else if (MODE == 1) y = -s + e0;
+            else if (MODE == 3) {
+                y = -s; y -= 0.5 * e1 * e0;                                      // (A p)[row], not stored
+                const double rv = cr - alpha * y;                                // pcg.h:316
+                dacc += rv * rv;
+                dacc2 += fr.dinvF ? rv * ((double)fdv * rv) : 0.;
+                y = rv;
+            }
             else {
                 double az = -s; az -= 0.5 * e1 * e0;
                 const double dn = cheb.c1 * cd + cheb.c2 * (ci * (cr - az));
@@ -574,7 +632,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                 y = e0 + dn;
                 dacc += cr * y;                                                  // r.z of the updated z
             }
-            bufStoreF64nt(rOut, row * 8u, y);
+            if (MODE == 3) bufStoreF64nt(rFr, row * 8u, y); else bufStoreF64nt(rOut, row * 8u, y);
         }
         __syncthreads();    // protects the LDS reuse
         if (!hasNext) break;
@@ -582,9 +640,13 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         nchunk = nn; npr = nnpr;
         ++it;
     }
-    if (MODE != 1) {
+    if (MODE == 0 || MODE == 2) {
         const double bs = blockReduceSum(dacc);
         if (threadIdx.x == 0) partial[blockIdx.x] = bs;   // gridDim.x partials (Launch::stBlocks)
+    }
+    if (MODE == 3) {
+        const double b0 = blockReduceSum(dacc), b1 = fr.dinvF ? blockReduceSum(dacc2) : 0.;
+        if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[gridDim.x + blockIdx.x] = b1; }
     }
 }
 

@@ -168,7 +168,7 @@ template <int MODE, int TB>
 __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ regionRowPtr, const uint32_t* __restrict__ rrowFace,
                                                    const double* __restrict__ COM, double dx, const double* __restrict__ Binv,
                                                    const double* __restrict__ rhsR, double invDt, double* __restrict__ sred,
-                                                   double* __restrict__ vreg, const int* __restrict__ done) {
+                                                   double* __restrict__ vreg, const int* __restrict__ done, double* __restrict__ wvPart) {
     if (done && *done) return;
     __shared__ double msum[TB / 64][30];
     __shared__ double Ms[30], wv[PS_RD], vv[PS_RD], Vs[30];
@@ -216,6 +216,13 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
     }
     if (MODE == 1) return;
     __syncthreads();
+    // w . v = w^T BInv w = sum over the tile's rows of s_f t_f: the tile's share of x . A x (fused residual update, ps_solve.hip)
+    if (MODE == 0 && wvPart && threadIdx.x == 0) {
+        double s = 0.;
+#pragma unroll
+        for (int n = 0; n < PS_RD; ++n) s += wv[n] * vv[n];
+        wvPart[r] = s;
+    }
     if (threadIdx.x < 30) Vs[threadIdx.x] = vToAxisCoeff(vv, (int)threadIdx.x);
     __syncthreads();
     int it = 0;
@@ -251,9 +258,10 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
 template <int MODE>
 __global__ void __launch_bounds__(64) k_tile_solve(const int32_t* __restrict__ regionChunkPtr, const double* __restrict__ wpart,
                                                    const double* __restrict__ Binv, const double* __restrict__ rhsR, double invDt,
-                                                   double* __restrict__ vreg, const int* __restrict__ done) {
+                                                   double* __restrict__ vreg, const int* __restrict__ done, double* __restrict__ wvPart) {
     if (done && *done) return;
     __shared__ double w[PS_RD];
+    __shared__ double vloc[PS_RD];
     const int r = blockIdx.x, lane = threadIdx.x;
     if (lane < PS_RD) {
         double s = 0.;
@@ -271,6 +279,16 @@ __global__ void __launch_bounds__(64) k_tile_solve(const int32_t* __restrict__ r
         for (int n = 0; n < PS_RD; ++n) s += B[n] * w[n];
         if (MODE == 2) s *= invDt;
         vreg[(int64_t)r * PS_RD + lane] = s;
+        vloc[lane] = s;
+    }
+    if (MODE == 0 && wvPart) {
+        __syncthreads();
+        if (lane == 0) {
+            double s = 0.;
+#pragma unroll
+            for (int n = 0; n < PS_RD; ++n) s += w[n] * vloc[n];
+            wvPart[r] = s;
+        }
     }
 }
 // t_f = C_f . v_region(f).  One block per chunk of <= RC_ROWS rows of ONE region: the 26 coefficients are block-uniform

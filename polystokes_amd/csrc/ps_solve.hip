@@ -55,6 +55,9 @@ struct Launch {
         for (int q = 0; q < 9; ++q) s.off[q] = M.schedOff[q];
         return s;
     }
+    // fused residual update (solve(): FusedR): where the S and tile kernels leave their shares of p.Ap (null: not asked for)
+    double* sPart = nullptr;
+    double* wvPart = nullptr;
     int pipeGrid;   // 0: one-shot kernels; >0: persistent software-pipelined kernels with this many blocks
     int xcdAware;   // pipelined kernels: runs of this many chunks are dealt to the XCDs round robin (ChunkWalk); 0 = plain walk
     void spmvS(int mode, const double* x, double* out) const {
@@ -76,7 +79,7 @@ struct Launch {
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
 #define PS_LAUNCH_SP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, sched(M, gr.x), nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p)
+                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, sched(M, gr.x), nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart)
 #define PS_LAUNCH_SP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_SP(MODE_, NV_, false); else PS_LAUNCH_SP(MODE_, NV_, true); } while (0)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP2(0, 1); else PS_LAUNCH_SP2(1, 1); }
             else { if (mode == 0) PS_LAUNCH_SP2(0, 2); else PS_LAUNCH_SP2(1, 2); }
@@ -93,7 +96,7 @@ struct Launch {
         static const bool noFuse = getenv("PS_TILE_SPLIT") && atoi(getenv("PS_TILE_SPLIT")) != 0;   // A/B: force the three-kernel form
         if (c->maxRegionRows <= TILE_FUSED_MAX_ROWS && !noFuse) {   // one workgroup per region: gather, 26x26 block, expand
 #define PS_TILE_APPLY(MODE_, TB_) hipLaunchKernelGGL((k_tile_apply<MODE_, TB_>), gr, dim3(TB_), 0, c->stream, c->regionRowPtr.p, c->rrowFace.p, c->COM.p, c->dx, c->Binv.p, \
-                                                c->rhsR.p, c->invDt, sred, c->vreg.p, done)
+                                                c->rhsR.p, c->invDt, sred, c->vreg.p, done, wvPart)
             // threads per region: enough threads in flight chip-wide (~256 K) without starving a region of work.  Measured
             // at 256^3 (4096 tiles of 3204 rows): 0.080 ms with 64 threads, 0.087 / 0.106 / 0.166 with 128 / 256 / 512; at 32^3
             // (8 tiles) one wavefront per tile serialises 50 rows per lane behind memory latency (60 us per CG iteration
@@ -116,11 +119,11 @@ struct Launch {
                                c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, sred, c->wreg.p, done);
         const dim3 bl(64);
         if (mode == 0)
-            hipLaunchKernelGGL(k_tile_solve<0>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
+            hipLaunchKernelGGL(k_tile_solve<0>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done, wvPart);
         else if (mode == 1)
-            hipLaunchKernelGGL(k_tile_solve<1>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
+            hipLaunchKernelGGL(k_tile_solve<1>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done, (double*)nullptr);
         else
-            hipLaunchKernelGGL(k_tile_solve<2>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done);
+            hipLaunchKernelGGL(k_tile_solve<2>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done, (double*)nullptr);
         if (mode != 1 && c->nRChunks > 0)
             hipLaunchKernelGGL(k_tile_expand, dim3((unsigned)c->nRChunks), dim3(BS), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
                                c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, c->vreg.p, sred, done);
@@ -136,25 +139,34 @@ struct Launch {
     }
     bool stOnPipe() const { return pipeGrid > 0 && c->St.col16ok && (c->St.packed || c->St.val4.p); }
     // mode 2 (Chebyshev term fused into the epilogue, ChebArgs) exists on the pipelined kernels only: callers check stOnPipe()
-    void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial, const ChebArgs* cheb = nullptr) const {
+    // mode 3 (residual update fused into the epilogue, FusedR): pipelined kernels on the coded stream only — callers check fusedOk()
+    void spmvSt(int mode, const double* t, const double* xin, const double* add, double* out, double* partial, const ChebArgs* cheb = nullptr,
+                const FusedR* fused = nullptr) const {
         if (rowsSt == 0) return;
         const ps::DevCSR& M = c->St;
         ChebArgs ca{nullptr, nullptr, nullptr, 0., 0.};
         if (cheb) ca = *cheb;
+        FusedR fr{};
+        if (fused) fr = *fused;
         if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
             const int nChunks = gridFor(rowsSt, BS);
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
 #define PS_LAUNCH_TP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p)
+                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr)
 #define PS_LAUNCH_TP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_TP(MODE_, NV_, false); else PS_LAUNCH_TP(MODE_, NV_, true); } while (0)
+            if (mode == 3) {
+                if (!M.packed) throw Error("internal: fused residual update on the fp64 stream");
+                if (M.nv == 1) PS_LAUNCH_TP(3, 1, false); else PS_LAUNCH_TP(3, 2, false);
+                return;
+            }
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP2(0, 1); else if (mode == 1) PS_LAUNCH_TP2(1, 1); else PS_LAUNCH_TP2(2, 1); }
             else { if (mode == 0) PS_LAUNCH_TP2(0, 2); else if (mode == 1) PS_LAUNCH_TP2(1, 2); else PS_LAUNCH_TP2(2, 2); }
 #undef PS_LAUNCH_TP2
 #undef PS_LAUNCH_TP
             return;
         }
-        if (mode == 2) throw Error("internal: fused Chebyshev term without the pipelined St kernel");
+        if (mode >= 2) throw Error("internal: fused St epilogue without the pipelined St kernel");
         spmvSt_(mode, t, xin, add, out, partial);
     }
     // grid of a persistent kernel; the XCD-grouped walk needs a multiple of 8 blocks (workgroup b runs on XCD b & 7)
@@ -165,6 +177,16 @@ struct Launch {
         int g = std::min(nChunks, pipeGrid);
         if (xcd > 0) { if (g >= 8) g &= ~7; else xcd = 0; }
         return g;
+    }
+    // the fused step needs both products on the persistent coded-stream kernels (their per-workgroup partials) and the S kernel
+    // not on the block-resident prototype
+    bool fusedOk() const {
+        return stOnPipe() && c->St.packed && pipeGrid > 0 && c->S.col16ok && c->S.packed && c->S.nUnits == 0 && rowsS > 0;
+    }
+    int sBlocks() const {
+        const int nChunks = gridFor(rowsS, BS);
+        int xcd = xcdAware;
+        return pipeBlocks(nChunks, xcd, true);
     }
     int stBlocks() const {   // number of p.Ap partials the St kernel writes: one per block
         const int nChunks = gridFor(rowsSt, BS);
@@ -354,8 +376,24 @@ int ps_context::solve() {
         }
     };
 
+    // Fused step (default on the coded stream; PS_FUSED_R=0 keeps the five-kernel step): p.Ap = -(sum_active s.t + sum_tiles w.v
+    // + 1/2 sum uInv p^2) is complete before the St kernel starts, so that kernel forms alpha and updates r in its epilogue —
+    // A p is neither written nor read back (16 B per row less) and the step is four launches (FusedR, ps_kernels_spmv.hpp).
+    static const bool fusedEnv = !(getenv("PS_FUSED_R") && atoi(getenv("PS_FUSED_R")) == 0);
+    const bool fused = fusedEnv && !cheb && L.fusedOk();
+    fusedStepHost = fused ? 1 : 0;
+    const int sBlocks = fused ? L.sBlocks() : 0;
+    double *fS = nullptr, *fT = nullptr, *fU = nullptr, *fR = nullptr;
+    const uint8_t* ucode = uCoded ? uCode.p : nullptr;
+    if (fused) {
+        fusedPart.alloc((size_t)sBlocks + (size_t)regionCount + VGRID + 2 * (size_t)stBlocks + 16);
+        fS = fusedPart.p; fT = fS + sBlocks; fU = fT + regionCount; fR = fU + VGRID;
+        L.sPart = fS; L.wvPart = fT;
+    }
+
     HIP_CHECK(hipMemsetAsync(dotPartials3.p, 0, VGRID * sizeof(double), stream));
     hipLaunchKernelGGL(k_cg_init_f, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
+    if (fused) hipLaunchKernelGGL(k_uinv_pp, dim3(vb), dim3(BS), 0, stream, (const double*)pvec.p, ucode, (const double*)uDict.p, (const double*)uInv.p, n, fU);
     if (cheb) {   // z = M^-1 r, p = z, rsold = r.z
         HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(CGScalars), stream));   // `done` must read 0 inside the polynomial's kernels
         const int cnt0 = chebyshevApply(r.p, zvec, dvec, rzPart, nullptr);
@@ -373,6 +411,13 @@ int ps_context::solve() {
         for (; it < upto; ++it) {
             L.spmvS(0, pvec.p, ts.p);
             L.tiles(0, ts.p);
+            if (fused) {
+                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, dv, fR};
+                L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
+                hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBlocks, dv ? 1 : 0, it, (const double*)r.p, dv, x.p,
+                                   pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
+                continue;
+            }
             L.spmvSt(0, ts.p, pvec.p, nullptr, Ap.p, dotPartials.p);
             const double* pApPart = dotPartials.p;
             int pApCount = stBlocks;
@@ -575,13 +620,13 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
     else if (base == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
     else if (base == "apply") c->applyOperator(x, y, c->dotPartials.p);
     else if (base == "tiles") L.tiles(0, c->ts.p);
-    else if (base == "cg_update_xr" || base == "cg_update_p" || base == "cg_update_r" || base == "cg_update_xp") {
+    else if (base == "cg_update_xr" || base == "cg_update_p" || base == "cg_update_r" || base == "cg_update_xp" || base == "cg_update_xp_u" || base == "spmv_St_r") {
         // streaming vector kernels on scratch vectors (alpha = beta = 0 keeps them finite over many launches)
         ps::DevBuf<CGScalars>& scratch = c->benchScal;
         scratch.alloc(1);
         CGScalars h{};
         h.tol2 = -1.;                                  // the stop test never fires
-        if (base == "cg_update_xp") h.rsold2[0] = 1.;   // beta = 0 / 1 ; (cg_update_r: alpha = 0 / p.Ap with p.Ap = 1024 below)
+        if (base == "cg_update_xp" || base == "cg_update_xp_u") h.rsold2[0] = 1.;   // beta = 0 / 1 ; (cg_update_r, spmv_St_r: alpha = 0 / p.Ap with p.Ap = +-1024 below)
         HIP_CHECK(hipMemcpyAsync(scratch.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
         ps::DevBuf<double>& ones = c->benchOnes;       // input partials of the fused scalar prologues
         if (ones.n < (size_t)2 * VGRID) {
@@ -597,8 +642,17 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         const double* dv = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinv.p : nullptr;
         const float* dvf = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinvF.p : nullptr;
         c->tmp4.alloc((size_t)n); c->tmp5.alloc((size_t)n);
-        c->dotPartials.alloc((size_t)3 * std::max(vb, VGRID) + 16);
-        if (base == "cg_update_xr")
+        c->dotPartials.alloc((size_t)std::max(3 * std::max(vb, VGRID), 2 * L.stBlocks()) + 16);
+        const uint8_t* ucode = c->uCoded ? c->uCode.p : nullptr;
+        if (base == "spmv_St_r") {   // the St kernel of the four-kernel step: r (scratch) -= 0 * A x in the epilogue
+            if (!L.fusedOk()) throw Error("no fused step on this system");
+            const FusedR fr{scratch.p, ones.p, VGRID, zeros.p, 0, zeros.p, 0, ones.p, 0, 0, c->tmp5.p, dvf, c->dotPartials.p};
+            L.spmvSt(3, c->ts.p, x, nullptr, nullptr, nullptr, nullptr, &fr);
+        }
+        else if (base == "cg_update_xp_u")
+            hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)zeros.p, VGRID, dvf ? 1 : 0, 0, x, dvf,
+                               c->tmp4.p, c->tmp5.p, n, c->dotPartials.p, ucode, (const double*)c->uDict.p, (const double*)c->uInv.p, c->dotPartials.p + VGRID);
+        else if (base == "cg_update_xr")
             hipLaunchKernelGGL(k_cg_update_xr, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, y, dv, c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);
         else if (base == "cg_update_p")
             hipLaunchKernelGGL(k_cg_update_p, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, dv, c->tmp4.p, n);

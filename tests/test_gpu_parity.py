@@ -508,7 +508,7 @@ def test_exported_system_import_errors(gpu, tmp_path):
 @pytest.mark.parametrize("env", [{"PS_COL32": "1"}, {"PS_FORCE_FP64_VALUES": "1"}, {"PS_FORCE_FP64_VALUES": "1", "PS_COL32": "1"},
                                  {"PS_PIPE_GRID": "0"}, {"PS_XCD": "0"}, {"PS_SCHED": "1", "PS_IL_SUPER": "2"},
                                  {"PS_IL_ORIGIN": "8", "PS_IL_SUPER": "2,2,1"}, {"PS_NO_DIAG_CODES": "1"}, {"PS_TILE_SPLIT": "1"},
-                                 {"PS_BLK": "1"}, {"PS_SCHED": "3"}])
+                                 {"PS_BLK": "1"}, {"PS_SCHED": "3"}, {"PS_FUSED_R": "0"}])
 def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     """The SpMV has four storage formats chosen at setup — compressed stream with int8 value codes (3 B/nnz) or with fp64
     values (10 B/nnz: values that are not code * scale), both on the pipelined kernels; int8-coded CSR and fp64 CSR on the
@@ -522,6 +522,7 @@ def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     p.tolerance = 1e-8
     p.maxSolverIterations = 20000
     assert gpu.step(sc, p) == abi.SUCCESS
+    assert int(gpu.array("fusedStep")[0]) == 1    # default: residual update inside the St kernel (four-kernel PCG step)
     out = str(tmp_path / "alt.npz")
     code = (
         "import sys, numpy as np\n"
@@ -529,12 +530,15 @@ def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
         "import polystokes_amd\nfrom polystokes_amd import scenes\n"
         "sc, p = scenes.blob(20, 18, 22, seed=9, tile=8)\np.tolerance = 1e-8\np.maxSolverIterations = 20000\n"
         "s = polystokes_amd.Solver(0)\nrc = s.step(sc, p)\n"
-        f"np.savez({out!r}, rc=rc, it=s.stats.solveData[1], vx=s.vel[0], vy=s.vel[1], vz=s.vel[2], c16=s.array('columns16'), coded=s.array('valuesCoded'), dc=s.array('diagonalsCoded'))\n"
+        f"np.savez({out!r}, rc=rc, it=s.stats.solveData[1], vx=s.vel[0], vy=s.vel[1], vz=s.vel[2], c16=s.array('columns16'), coded=s.array('valuesCoded'), dc=s.array('diagonalsCoded'), fused=s.array('fusedStep'))\n"
     )
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), timeout=300)
     alt = np.load(out)
     assert int(alt["rc"]) == abi.SUCCESS
     assert int(alt["dc"][0]) == (0 if "PS_NO_DIAG_CODES" in env else 2)   # blob: variable viscosity -> uInv stays fp64, McInv is coded
+    # the four-kernel step needs both products on the persistent coded-stream kernels
+    unfused = any(k in env for k in ("PS_FUSED_R", "PS_COL32", "PS_FORCE_FP64_VALUES", "PS_PIPE_GRID", "PS_BLK"))
+    assert int(alt["fused"][0]) == (0 if unfused else 1)
     if "PS_COL32" in env:
         assert int(alt["c16"][0]) == 0
     if "PS_FORCE_FP64_VALUES" in env:
