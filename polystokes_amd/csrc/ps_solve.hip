@@ -209,6 +209,7 @@ Launch mk(ps_context* c, const int* done) {
     L.xcdAware = xa > 0 ? xa : 0;
     return L;
 }
+constexpr int64_t FUSED_STEP_MIN_ROWS = 10000000;   // see solve()
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
 }  // namespace
 
@@ -379,8 +380,14 @@ int ps_context::solve() {
     // Fused step (default on the coded stream; PS_FUSED_R=0 keeps the five-kernel step): p.Ap = -(sum_active s.t + sum_tiles w.v
     // + 1/2 sum uInv p^2) is complete before the St kernel starts, so that kernel forms alpha and updates r in its epilogue —
     // A p is neither written nor read back (16 B per row less) and the step is four launches (FusedR, ps_kernels_spmv.hpp).
-    static const bool fusedEnv = !(getenv("PS_FUSED_R") && atoi(getenv("PS_FUSED_R")) == 0);
-    const bool fused = fusedEnv && !cheb && L.fusedOk();
+    // Every St workgroup sums the partials of three producers in its prologue (up to 4096 + regions + 1024 + 1024 values, from
+    // L2): a fixed ~15 us per iteration, against 16 B per row saved.  Measured us per iteration, fused / five-kernel: 64^3
+    // (0.8 M rows) 71 / 63, 128^3 (5.9 M) 206 / 197, 256^3 (45 M) 1147 / 1248 -> on from 10 M rows.  (Folding the partials 64 to
+    // 1 in the producers with a ticket per group costs more than it saves: one device-scope atomic per workgroup, +30 us per
+    // iteration with write-through stores and no fence, +650 us with __threadfence(), which flushes the XCD's L2.)
+    // PS_FUSED_R = 0 / 1 forces it off / on (on only where the kernels exist).
+    static const int fusedEnv = getenv("PS_FUSED_R") ? atoi(getenv("PS_FUSED_R")) : -1;
+    const bool fused = fusedEnv != 0 && (fusedEnv > 0 || n >= FUSED_STEP_MIN_ROWS) && !cheb && L.fusedOk();
     fusedStepHost = fused ? 1 : 0;
     const int sBlocks = fused ? L.sBlocks() : 0;
     double *fS = nullptr, *fT = nullptr, *fU = nullptr, *fR = nullptr;

@@ -508,7 +508,8 @@ def test_exported_system_import_errors(gpu, tmp_path):
 @pytest.mark.parametrize("env", [{"PS_COL32": "1"}, {"PS_FORCE_FP64_VALUES": "1"}, {"PS_FORCE_FP64_VALUES": "1", "PS_COL32": "1"},
                                  {"PS_PIPE_GRID": "0"}, {"PS_XCD": "0"}, {"PS_SCHED": "1", "PS_IL_SUPER": "2"},
                                  {"PS_IL_ORIGIN": "8", "PS_IL_SUPER": "2,2,1"}, {"PS_NO_DIAG_CODES": "1"}, {"PS_TILE_SPLIT": "1"},
-                                 {"PS_BLK": "1"}, {"PS_SCHED": "3"}, {"PS_FUSED_R": "0"}])
+                                 {"PS_BLK": "1"}, {"PS_SCHED": "3"}, {"PS_FUSED_R": "1"},
+                                 {"PS_FUSED_R": "1", "PS_TILE_SPLIT": "1"}, {"PS_FUSED_R": "1", "PS_NO_DIAG_CODES": "1"}])
 def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     """The SpMV has four storage formats chosen at setup — compressed stream with int8 value codes (3 B/nnz) or with fp64
     values (10 B/nnz: values that are not code * scale), both on the pipelined kernels; int8-coded CSR and fp64 CSR on the
@@ -522,7 +523,7 @@ def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     p.tolerance = 1e-8
     p.maxSolverIterations = 20000
     assert gpu.step(sc, p) == abi.SUCCESS
-    assert int(gpu.array("fusedStep")[0]) == 1    # default: residual update inside the St kernel (four-kernel PCG step)
+    assert int(gpu.array("fusedStep")[0]) == 0    # small system: five-kernel PCG step (the four-kernel one runs from 10 M rows, or PS_FUSED_R=1)
     out = str(tmp_path / "alt.npz")
     code = (
         "import sys, numpy as np\n"
@@ -536,9 +537,7 @@ def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     alt = np.load(out)
     assert int(alt["rc"]) == abi.SUCCESS
     assert int(alt["dc"][0]) == (0 if "PS_NO_DIAG_CODES" in env else 2)   # blob: variable viscosity -> uInv stays fp64, McInv is coded
-    # the four-kernel step needs both products on the persistent coded-stream kernels
-    unfused = any(k in env for k in ("PS_FUSED_R", "PS_COL32", "PS_FORCE_FP64_VALUES", "PS_PIPE_GRID", "PS_BLK"))
-    assert int(alt["fused"][0]) == (0 if unfused else 1)
+    assert int(alt["fused"][0]) == (1 if "PS_FUSED_R" in env else 0)
     if "PS_COL32" in env:
         assert int(alt["c16"][0]) == 0
     if "PS_FORCE_FP64_VALUES" in env:
@@ -565,6 +564,39 @@ def test_repeated_solves_are_bit_identical(gpu, precond):
     vel1, _ = gpu.download()
     for a in range(3):
         assert np.array_equal(vel0[a], vel1[a])
+
+
+@pytest.mark.parametrize("precond", [abi.PRE_IDENTITY, abi.PRE_DIAGONAL])
+def test_four_kernel_step_matches_and_is_reproducible(gpu, tmp_path, precond):
+    """The four-kernel PCG step (residual update inside the St kernel, p.Ap from the factored form; default from 10 M rows)
+    forced on a small grid in a child process: same iteration count as the five-kernel step to +-1, same x to rounding,
+    and 100 solves give one outcome bit for bit."""
+    import os
+    import subprocess
+    import sys
+    sc, p = scenes.cavity(32, precond=precond)
+    p.tolerance = 1e-8
+    assert gpu.step(sc, p) == abi.SUCCESS
+    assert int(gpu.array("fusedStep")[0]) == 0
+    x_ref = gpu.array("solutionVector").copy()
+    out = str(tmp_path / "fused.npz")
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import polystokes_amd\nfrom polystokes_amd import scenes\n"
+        f"sc, p = scenes.cavity(32, precond={int(precond)})\np.tolerance = 1e-8\n"
+        "s = polystokes_amd.Solver(0)\ns.upload(sc, p)\nseen = set()\n"
+        "for _ in range(100):\n"
+        "    rc = s.step_device()\n"
+        "    seen.add((rc, int(s.stats.solveData[1]), float(s.stats.solveData[0]).hex(), s.array('solutionVector').tobytes()))\n"
+        f"np.savez({out!r}, outcomes=len(seen), rc=rc, it=s.stats.solveData[1], x=s.array('solutionVector'), fused=s.array('fusedStep'))\n"
+    )
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PS_FUSED_R="1"), timeout=300)
+    alt = np.load(out)
+    assert int(alt["fused"][0]) == 1 and int(alt["rc"]) == abi.SUCCESS
+    assert int(alt["outcomes"]) == 1
+    assert abs(float(alt["it"]) - gpu.stats.solveData[1]) <= 1
+    assert np.linalg.norm(alt["x"] - x_ref) <= 1e-6 * np.linalg.norm(x_ref)
 
 
 def test_bad_parameters_are_refused(gpu):
