@@ -223,7 +223,8 @@ struct ps_context {
     int solve();
     void estimateLambdaMax();
     void applyPreconditionerDevice(const double* r, double* z, double* scratch);   // z = M^-1 r (parity hook, ps_apply_preconditioner)
-    int chebyshevApply(const double* r, double* z, double* d, double* rzPartial, const ps::CGScalars* sc);
+    int chebyshevApply(const double* rvec, double* z, double* d, double* rzPartial, const ps::CGScalars* sc, bool firstDone = false);
+    double chebTheta() const;
     int solveEigenCG();                                   // Solver.cpp:814-862 on the factored device operator
     void constructGuessVectors();                         // Solver.cpp:512-531
     // explicit A (AssembleSystem.cpp:351-430) in reference numbering, assembled on the host from the device blocks (export only)

@@ -371,23 +371,75 @@ __global__ void __launch_bounds__(BS) k_cheb_step(const CGScalars* __restrict__ 
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 // beta = r.z / rsold ; x += alpha p ; p = z + beta p with z a VECTOR (polynomial preconditioner) ; partials of x.x
-__global__ void __launch_bounds__(BS) k_cg_update_xp_z(CGScalars* sc, const double* __restrict__ rrPartial, int rrCount, const double* __restrict__ rzPartial,
-                                                       int rzCount, int it, const double* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
-                                                       int64_t n, double* __restrict__ partial) {
+// UPP: also the partials of sum uInv p^2 of the new p (four-kernel step, see cgUpdateXp)
+template <bool UPP>
+__device__ inline void cgUpdateXpZ(CGScalars* sc, const double* __restrict__ rrPartial, int rrCount, const double* __restrict__ rzPartial,
+                                   int rzCount, int it, const double* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
+                                   int64_t n, double* __restrict__ partial,
+                                   const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
     if (sc->done) return;
+    __shared__ double dict[UPP ? 256 : 1];
+    if (UPP && uCode) dict[threadIdx.x] = uDict[threadIdx.x];   // visible after the barriers of blockSumAll below
     const double rr = blockSumAll(sumLocal(rrPartial, rrCount));
     const double rz = blockSumAll(sumLocal(rzPartial, rzCount));
     const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
-    double axx = 0.;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+    double axx = 0., aup = 0.;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)z | (uintptr_t)x) & 15) == 0) && (!UPP || ((((uintptr_t)uCode & 1) == 0) && (((uintptr_t)uInv & 15) == 0)));
+    const int64_t n2 = vec ? n / 2 : 0;
+    const double2* z2 = (const double2*)z;
+    double2* p2 = (double2*)p; double2* x2 = (double2*)x;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        const double2 zv = ldD2(z2 + i, 1);
+        double2 pv = ldD2(p2 + i, PS_VEC_NT_PL), xv = ldD2(x2 + i, PS_VEC_NT_X);
+        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
+        pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y;
+        stD2(x2 + i, xv, PS_VEC_NT_X); stD2(p2 + i, pv, PS_VEC_NT_P);
+        axx += xv.x * xv.x; axx += xv.y * xv.y;
+        if (UPP) {
+            double u0, u1;
+            if (uCode) { const uint16_t cc = __builtin_nontemporal_load((const uint16_t*)uCode + i); u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
+            else { const double2 uv = ldD2((const double2*)uInv + i, 1); u0 = uv.x; u1 = uv.y; }
+            aup += u0 * (pv.x * pv.x); aup += u1 * (pv.y * pv.y);
+        }
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double pv = p[i];
         const double xv = x[i] + alpha * pv;
-        x[i] = xv; p[i] = z[i] + beta * pv;
+        const double pn = z[i] + beta * pv;
+        x[i] = xv; p[i] = pn;
         axx += xv * xv;
+        if (UPP) aup += (uCode ? dict[uCode[i]] : uInv[i]) * (pn * pn);
     }
     const double s1 = blockReduceSum(axx);
     if (threadIdx.x == 0) partial[blockIdx.x] = s1;
+    if (UPP) {
+        const double s2 = blockReduceSum(aup);
+        if (threadIdx.x == 0) uPart[blockIdx.x] = s2;
+    }
+}
+__global__ void __launch_bounds__(BS) k_cg_update_xp_z(CGScalars* sc, const double* __restrict__ rrPartial, int rrCount, const double* __restrict__ rzPartial,
+                                                       int rzCount, int it, const double* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
+                                                       int64_t n, double* __restrict__ partial) {
+    cgUpdateXpZ<false>(sc, rrPartial, rrCount, rzPartial, rzCount, it, z, x, p, n, partial, nullptr, nullptr, nullptr, nullptr);
+}
+__global__ void __launch_bounds__(BS) k_cg_update_xp_z_u(CGScalars* sc, const double* __restrict__ rrPartial, int rrCount, const double* __restrict__ rzPartial,
+                                                         int rzCount, int it, const double* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
+                                                         int64_t n, double* __restrict__ partial,
+                                                         const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
+    cgUpdateXpZ<true>(sc, rrPartial, rrCount, rzPartial, rzCount, it, z, x, p, n, partial, uCode, uDict, uInv, uPart);
+}
+// one step of the power iteration on D^-1 A (ps_context::estimateLambdaMax): w = dinv .* Av ; partials of v.v and v.w
+__global__ void __launch_bounds__(BS) k_power_step(const double* __restrict__ v, const double* __restrict__ Av, const double* __restrict__ dinv,
+                                                   double* __restrict__ w, int64_t n, double* __restrict__ partial) {
+    double avv = 0., avw = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double vi = v[i], wi = dinv[i] * Av[i];
+        w[i] = wi;
+        avv += vi * vi; avw += vi * wi;
+    }
+    const double s0 = blockReduceSum(avv), s1 = blockReduceSum(avw);
+    if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
 }
 __global__ void k_fill_f64(double* __restrict__ a, double v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = v;

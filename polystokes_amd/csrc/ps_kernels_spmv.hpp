@@ -186,6 +186,9 @@ struct FusedR {
     int it;
     double* r; const float* dinvF;        // residual (updated in place), fp32 Jacobi diagonal (null: identity)
     double* rPart;                        // out: partials of r.r at [block], of r.z at [gridDim + block]
+    // Chebyshev preconditioner: the polynomial's first term on the new r, d = z = dinv r / theta (null: not asked for; then r.z
+    // above is that of the Jacobi diagonal)
+    const double* dinv64; double invTheta; double* cd; double* cz;
 };
 struct ChunkSched { const int32_t* list; int off[9]; };   // per-XCD chunk lists (ps_context::buildChunkSchedule); list == null: computed walk
 struct ChunkWalk {
@@ -553,7 +556,9 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                  rOut = bufRsrc(out, (size_t)rows * 8),
                                  rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
                                  rCd = bufRsrc(cheb.d, MODE == 2 ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
-                                 rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0);
+                                 rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0),
+                                 rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0), rFcd = bufRsrc(fr.cd, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0),
+                                 rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0);
     const ChunkWalk W(xcdAware, sched);
     int it = 0;
     int chunk = W.at(0);
@@ -582,6 +587,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         if (MODE == 3) {
             cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, PS_EPI_AUX));
             if (fr.dinvF) fdv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(row * 4u), 0, PS_EPI_AUX));
+            if (fr.cd) ci = bufLoadF64epi(rF64, row * 8u);
         }
         double xv[4 * NV];
 #pragma unroll
@@ -623,6 +629,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                 const double rv = cr - alpha * y;                                // pcg.h:316
                 dacc += rv * rv;
                 dacc2 += fr.dinvF ? rv * ((double)fdv * rv) : 0.;
+                if (fr.cd) {                                                     // k_cheb_first on this row
+                    const double v = ci * rv * fr.invTheta;
+                    bufStoreF64nt(rFcd, row * 8u, v); bufStoreF64nt(rFcz, row * 8u, v);
+                    dacc2 += rv * v;
+                }
                 y = rv;
             }
             else {
@@ -645,7 +656,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         if (threadIdx.x == 0) partial[blockIdx.x] = bs;   // gridDim.x partials (Launch::stBlocks)
     }
     if (MODE == 3) {
-        const double b0 = blockReduceSum(dacc), b1 = fr.dinvF ? blockReduceSum(dacc2) : 0.;
+        const double b0 = blockReduceSum(dacc), b1 = (fr.dinvF || fr.cd) ? blockReduceSum(dacc2) : 0.;
         if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[gridDim.x + blockIdx.x] = b1; }
     }
 }

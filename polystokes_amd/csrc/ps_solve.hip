@@ -265,32 +265,31 @@ void ps_context::constructPreconditioner() {
 // last iterate, then max(8.4, 1.25 * estimate) — same procedure as the oracle (ps_oracle_solve.cpp:estimateLambdaMax).
 // The stencil part of A is a sum of rank-one face terms with <= 8 entries, so its lambda_max(D^-1 A) <= 8 by Cauchy-Schwarz;
 // the measurement covers the tile part.  10 applies at setup (~1 % of a 256^3 step).
+double ps_context::chebTheta() const { return 0.5 * (chebLmax + chebLmax / 30.); }   // centre of the interval [lmax/30, lmax]
+
 void ps_context::estimateLambdaMax() {
+    // 10 steps of the power iteration on D^-1 A from the ones vector, Rayleigh quotient of the last step (oracle:
+    // estimateLambdaMax).  The iterate is not normalised between steps (the quotient does not depend on its length and the
+    // spectrum lies in (0, ~8]: ten steps grow it by < 1e10), so nothing comes back to the host until the end.
     const int64_t n = nSystem;
     chebLmax = 8.4;
     if (n == 0) return;
     const int vb = dotBlocks(n);
     tmp1.alloc((size_t)n); tmp2.alloc((size_t)n); tmp3.alloc((size_t)n);
     double* v = tmp1.p; double* w = tmp2.p; double* Av = tmp3.p;
-    auto dotH = [&](const double* a, const double* bb) {
-        hipLaunchKernelGGL(k_dot, dim3(vb), dim3(BS), 0, stream, a, bb, n, dotPartials.p);
-        hipLaunchKernelGGL(k_sum1, dim3(1), dim3(BS), 0, stream, dotPartials.p, vb, dotPartials.p + 3 * VGRID);
-        double out;
-        HIP_CHECK(hipMemcpyAsync(&out, dotPartials.p + 3 * VGRID, sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        return out;
-    };
+    chebPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(n, BS)) + 16);
     hipLaunchKernelGGL(k_fill_f64, dim3(vb), dim3(BS), 0, stream, v, 1., n);
-    double lam = 0.;
     for (int it = 0; it < 10; ++it) {
         applyOperator(v, Av, dotPartials.p);
-        hipLaunchKernelGGL(k_mulv, dim3(vb), dim3(BS), 0, stream, w, dinv.p, Av, n);
-        const double vv = dotH(v, v);
-        lam = dotH(v, w) / vv;
-        const double nw = std::sqrt(dotH(w, w));
-        if (nw == 0.) break;
-        hipLaunchKernelGGL(k_lin, dim3(vb), dim3(BS), 0, stream, v, 1. / nw, (const double*)w, 0., (const double*)nullptr, 0., (const double*)nullptr, n);
+        hipLaunchKernelGGL(k_power_step, dim3(vb), dim3(BS), 0, stream, (const double*)v, (const double*)Av, (const double*)dinv.p, w, n, chebPartials.p);
+        std::swap(v, w);
     }
+    hipLaunchKernelGGL(k_sum1, dim3(1), dim3(BS), 0, stream, chebPartials.p, vb, chebPartials.p + 2 * vb);
+    hipLaunchKernelGGL(k_sum1, dim3(1), dim3(BS), 0, stream, chebPartials.p + vb, vb, chebPartials.p + 2 * vb + 1);
+    double h[2];
+    HIP_CHECK(hipMemcpyAsync(h, chebPartials.p + 2 * vb, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const double lam = (h[0] > 0. && std::isfinite(h[1] / h[0])) ? h[1] / h[0] : 0.;   // A v = 0 on the way: the floor below
     chebLmax = std::max(8.4, 1.25 * lam);
 }
 
@@ -298,7 +297,9 @@ void ps_context::estimateLambdaMax() {
 // Terms 2..k run as S, tiles and the St kernel with the update fused into its epilogue (MODE 2): per term the St kernel reads
 // r, dinv, d besides its own operands and writes d and z in place — no separate vector pass.  rzPartial receives the partials
 // of r.z of the final z (count returned); `sc` (may be null) lets the kernels of a converged solve exit early.
-int ps_context::chebyshevApply(const double* rvec, double* z, double* d, double* rzPartial, const ps::CGScalars* sc) {
+// firstDone: the caller already holds the first term d = z = dinv r / theta (the St kernel of the four-kernel PCG step forms it
+// on the rows it updates) — with a one-term polynomial nothing is launched and 0 is returned.
+int ps_context::chebyshevApply(const double* rvec, double* z, double* d, double* rzPartial, const ps::CGScalars* sc, bool firstDone) {
     const int64_t n = nSystem;
     const int k = P.preconditionerDegree > 0 ? P.preconditionerDegree : 4;
     const double lmax = chebLmax, lmin = lmax / 30.;
@@ -307,8 +308,8 @@ int ps_context::chebyshevApply(const double* rvec, double* z, double* d, double*
     const int vb = dotBlocks(n);
     const int* done = sc ? &sc->done : nullptr;
     Launch L = mk(this, done);
-    hipLaunchKernelGGL(k_cheb_first, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, 1. / theta, d, z, n, rzPartial);
-    int count = vb;
+    if (!firstDone) hipLaunchKernelGGL(k_cheb_first, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, 1. / theta, d, z, n, rzPartial);
+    int count = firstDone ? 0 : vb;
     for (int j = 1; j < k; ++j) {
         const double rhoN = 1. / (2. * sigma - rho);
         const double c1 = rhoN * rho, c2 = 2. * rhoN / delta;
@@ -369,10 +370,10 @@ int ps_context::solve() {
         rzPart = chebPartials.p;
     }
     // r.z partials of the polynomial's last term, reduced to <= RED_BLOCKS values when there is one per 256-row chunk
-    auto rzReduce = [&](int count, const double*& part, int& cnt) {
-        part = rzPart; cnt = count;
+    auto rzReduce = [&](const double* src, int count, const double*& part, int& cnt) {
+        part = src; cnt = count;
         if (count > 8192) {
-            hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, stream, sc, rzPart, count, chebPartials2.p);
+            hipLaunchKernelGGL(k_reduce_partials, dim3(RED_BLOCKS), dim3(BS), 0, stream, sc, src, count, chebPartials2.p);
             part = chebPartials2.p; cnt = RED_BLOCKS;
         }
     };
@@ -387,7 +388,7 @@ int ps_context::solve() {
     // iteration with write-through stores and no fence, +650 us with __threadfence(), which flushes the XCD's L2.)
     // PS_FUSED_R = 0 / 1 forces it off / on (on only where the kernels exist).
     static const int fusedEnv = getenv("PS_FUSED_R") ? atoi(getenv("PS_FUSED_R")) : -1;
-    const bool fused = fusedEnv != 0 && (fusedEnv > 0 || n >= FUSED_STEP_MIN_ROWS) && !cheb && L.fusedOk();
+    const bool fused = fusedEnv != 0 && (fusedEnv > 0 || n >= FUSED_STEP_MIN_ROWS) && L.fusedOk();
     fusedStepHost = fused ? 1 : 0;
     const int sBlocks = fused ? L.sBlocks() : 0;
     double *fS = nullptr, *fT = nullptr, *fU = nullptr, *fR = nullptr;
@@ -400,7 +401,6 @@ int ps_context::solve() {
 
     HIP_CHECK(hipMemsetAsync(dotPartials3.p, 0, VGRID * sizeof(double), stream));
     hipLaunchKernelGGL(k_cg_init_f, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
-    if (fused) hipLaunchKernelGGL(k_uinv_pp, dim3(vb), dim3(BS), 0, stream, (const double*)pvec.p, ucode, (const double*)uDict.p, (const double*)uInv.p, n, fU);
     if (cheb) {   // z = M^-1 r, p = z, rsold = r.z
         HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(CGScalars), stream));   // `done` must read 0 inside the polynomial's kernels
         const int cnt0 = chebyshevApply(r.p, zvec, dvec, rzPart, nullptr);
@@ -409,6 +409,8 @@ int ps_context::solve() {
         hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, 1, tol, maxit);
     } else
     hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, tol, maxit);
+    // the first direction's share of p.Ap on the diagonal
+    if (fused) hipLaunchKernelGGL(k_uinv_pp, dim3(vb), dim3(BS), 0, stream, (const double*)pvec.p, ucode, (const double*)uDict.p, (const double*)uInv.p, n, fU);
     CGScalars h{};
     const int batch = 25;
     int it = 0;
@@ -418,8 +420,18 @@ int ps_context::solve() {
         for (; it < upto; ++it) {
             L.spmvS(0, pvec.p, ts.p);
             L.tiles(0, ts.p);
+            if (fused && cheb) {   // St kernel: r -= alpha A p and the polynomial's first term on the new r; then terms 2..k; then x, p
+                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, nullptr, fR, dinv.p, 1. / chebTheta(), dvec, zvec};
+                L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
+                const int c2 = chebyshevApply(r.p, zvec, dvec, rzPart, sc, true);
+                const double* part; int cnt;
+                if (c2 > 0) rzReduce(rzPart, c2, part, cnt); else { part = fR + stBlocks; cnt = stBlocks; }
+                hipLaunchKernelGGL(k_cg_update_xp_z_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBlocks, part, cnt, it, (const double*)zvec,
+                                   x.p, pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
+                continue;
+            }
             if (fused) {
-                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, dv, fR};
+                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, dv, fR, nullptr, 0., nullptr, nullptr};
                 L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                 hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBlocks, dv ? 1 : 0, it, (const double*)r.p, dv, x.p,
                                    pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
@@ -436,7 +448,7 @@ int ps_context::solve() {
                                r.p, n, dotPartialsR.p);
             if (cheb) {
                 const double* part; int cnt;
-                rzReduce(chebyshevApply(r.p, zvec, dvec, rzPart, sc), part, cnt);
+                rzReduce(rzPart, chebyshevApply(r.p, zvec, dvec, rzPart, sc), part, cnt);
                 hipLaunchKernelGGL(k_cg_update_xp_z, dim3(vb), dim3(BS), 0, stream, sc, (const double*)dotPartialsR.p, vb, part, cnt, it, (const double*)zvec,
                                    x.p, pvec.p, n, dotPartials3.p);
             } else
@@ -653,7 +665,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         const uint8_t* ucode = c->uCoded ? c->uCode.p : nullptr;
         if (base == "spmv_St_r") {   // the St kernel of the four-kernel step: r (scratch) -= 0 * A x in the epilogue
             if (!L.fusedOk()) throw Error("no fused step on this system");
-            const FusedR fr{scratch.p, ones.p, VGRID, zeros.p, 0, zeros.p, 0, ones.p, 0, 0, c->tmp5.p, dvf, c->dotPartials.p};
+            const FusedR fr{scratch.p, ones.p, VGRID, zeros.p, 0, zeros.p, 0, ones.p, 0, 0, c->tmp5.p, dvf, c->dotPartials.p, nullptr, 0., nullptr, nullptr};
             L.spmvSt(3, c->ts.p, x, nullptr, nullptr, nullptr, nullptr, &fr);
         }
         else if (base == "cg_update_xp_u")

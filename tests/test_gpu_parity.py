@@ -566,16 +566,18 @@ def test_repeated_solves_are_bit_identical(gpu, precond):
         assert np.array_equal(vel0[a], vel1[a])
 
 
-@pytest.mark.parametrize("precond", [abi.PRE_IDENTITY, abi.PRE_DIAGONAL])
-def test_four_kernel_step_matches_and_is_reproducible(gpu, tmp_path, precond):
+@pytest.mark.parametrize("precond,degree", [(abi.PRE_IDENTITY, 0), (abi.PRE_DIAGONAL, 0), (abi.PRE_CHEBYSHEV, 4), (abi.PRE_CHEBYSHEV, 1)])
+def test_four_kernel_step_matches_and_is_reproducible(gpu, tmp_path, precond, degree):
     """The four-kernel PCG step (residual update inside the St kernel, p.Ap from the factored form; default from 10 M rows)
     forced on a small grid in a child process: same iteration count as the five-kernel step to +-1, same x to rounding,
-    and 100 solves give one outcome bit for bit."""
+    and 100 solves give one outcome bit for bit.  With the Chebyshev preconditioner the same St kernel also forms the
+    polynomial's first term on the rows it updates (degree 1: that term is the whole preconditioner)."""
     import os
     import subprocess
     import sys
     sc, p = scenes.cavity(32, precond=precond)
     p.tolerance = 1e-8
+    p.preconditionerDegree = degree
     assert gpu.step(sc, p) == abi.SUCCESS
     assert int(gpu.array("fusedStep")[0]) == 0
     x_ref = gpu.array("solutionVector").copy()
@@ -584,7 +586,7 @@ def test_four_kernel_step_matches_and_is_reproducible(gpu, tmp_path, precond):
         "import sys, numpy as np\n"
         f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
         "import polystokes_amd\nfrom polystokes_amd import scenes\n"
-        f"sc, p = scenes.cavity(32, precond={int(precond)})\np.tolerance = 1e-8\n"
+        f"sc, p = scenes.cavity(32, precond={int(precond)})\np.tolerance = 1e-8\np.preconditionerDegree = {int(degree)}\n"
         "s = polystokes_amd.Solver(0)\ns.upload(sc, p)\nseen = set()\n"
         "for _ in range(100):\n"
         "    rc = s.step_device()\n"
