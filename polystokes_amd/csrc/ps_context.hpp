@@ -49,7 +49,8 @@ struct CGScalars {
     int maxit;
     int pend;        // the stop test of iteration `pendIter` waits for ||x||^2 of the x it updated (deferred-x step)
     double tol2;
-    int pendIter, pad;
+    int pendIter;
+    int vecNT;       // 1: the vector kernels use non-temporal loads / stores (ps_context::ntLevel() == 2)
     double rsold2[2];   // r.z of the previous iteration, double-buffered by iteration parity (fused-scalar step kernels)
 };
 
@@ -225,6 +226,7 @@ struct ps_context {
     void applyPreconditionerDevice(const double* r, double* z, double* scratch);   // z = M^-1 r (parity hook, ps_apply_preconditioner)
     int chebyshevApply(const double* rvec, double* z, double* d, double* rzPartial, const ps::CGScalars* sc, bool firstDone = false);
     double chebTheta() const;
+    int ntLevel() const;
     int solveEigenCG();                                   // Solver.cpp:814-862 on the factored device operator
     void constructGuessVectors();                         // Solver.cpp:512-531
     // explicit A (AssembleSystem.cpp:351-430) in reference numbering, assembled on the host from the device blocks (export only)

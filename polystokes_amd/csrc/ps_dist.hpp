@@ -49,13 +49,13 @@ __global__ void __launch_bounds__(BS) k_sumq(const CGScalars* __restrict__ sc, c
         __syncthreads();
     }
 }
-__global__ void k_dscal0(CGScalars* sc, const double* __restrict__ red, double tol, int maxit) {
+__global__ void k_dscal0(CGScalars* sc, const double* __restrict__ red, double tol, int maxit, int vecNT) {
     const double s = red[0];
     sc->rsold = s; sc->rsold2[0] = s; sc->rsold2[1] = 0.; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
     sc->done = (s == 0.) ? 1 : 0;
     if (s == 0.) sc->iter = 0;
     sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
-    sc->pend = 0; sc->pendIter = 0;
+    sc->pend = 0; sc->pendIter = 0; sc->vecNT = vecNT;
 }
 __global__ void k_invert_diag(double* __restrict__ d, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -401,7 +401,7 @@ struct Dist {
         }
         allreduce(1);
         for (size_t q = 0; q < R.size(); ++q)
-            hipLaunchKernelGGL(k_dscal0, dim3(1), dim3(1), 0, R[q]->stream, loc[q].sc, R[q]->redbuf.p, tol, maxit);
+            hipLaunchKernelGGL(k_dscal0, dim3(1), dim3(1), 0, R[q]->stream, loc[q].sc, R[q]->redbuf.p, tol, maxit, R[q]->ntLevel() >= 2 ? 1 : 0);
         CGScalars h{};
         const int batch = 25;
         int it = 0;

@@ -253,7 +253,7 @@ extern "C" int32_t ps_solve_exported_system(ps_context* c, const char* prefix, c
         const double* dvp = jac ? ddinv.p : nullptr;
         const int maxit = params->maxSolverIterations;
         hipLaunchKernelGGL(k_cg_init, dim3(vb), dim3(BS), 0, st, db.p, dvp, dx.p, dr.p, dp.p, n, part.p);
-        hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, st, dsc.p, part.p, vb, params->tolerance, maxit);
+        hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, st, dsc.p, part.p, vb, params->tolerance, maxit, 1);
         CGScalars h{};
         int it = 0;
         bool finished = false;

@@ -86,14 +86,14 @@ __device__ inline double sumPartials(const double* __restrict__ partial, int cou
     for (int i = threadIdx.x; i < count; i += BS) acc += partial[i];
     return blockReduceSum(acc);
 }
-__global__ void __launch_bounds__(BS) k_cg_scal0(CGScalars* sc, const double* __restrict__ partial, int count, double tol, int maxit) {
+__global__ void __launch_bounds__(BS) k_cg_scal0(CGScalars* sc, const double* __restrict__ partial, int count, double tol, int maxit, int vecNT) {
     const double s = sumPartials(partial, count);
     if (threadIdx.x == 0) {
         sc->rsold = s; sc->rsold2[0] = s; sc->rsold2[1] = 0.; sc->rre = 0.; sc->iter = maxit; sc->maxit = maxit; sc->tol2 = tol * tol;
         sc->done = (s == 0.) ? 1 : 0;      // deviation: b == 0 -> return at once (reference divides 0/0, pcg.h:314)
         if (s == 0.) sc->iter = 0;
         sc->alpha = sc->beta = sc->pAp = sc->rr = sc->xx = sc->rz = 0.;
-        sc->pend = 0; sc->pendIter = 0;
+        sc->pend = 0; sc->pendIter = 0; sc->vecNT = vecNT;
     }
 }
 // stage A of the p.Ap reduction: RED_BLOCKS blocks each sum a contiguous slice of the SpMV block partials
@@ -224,17 +224,18 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double*
     const double alpha = sc->rsold2[it & 1] / pAp;                      // pcg.h:314
     if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
     double arr = 0., arz = 0.;
+    const bool nt = sc->vecNT != 0;
     const bool vec = ((((uintptr_t)Ap | (uintptr_t)r) & 15) == 0) && (((uintptr_t)dinv & 7) == 0);
     const int64_t n2 = vec ? n / 2 : 0;
     const double2* A2 = (const double2*)Ap; const float2* d2 = (const float2*)dinv;
     double2* r2 = (double2*)r;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        const double2 av = ldD2(A2 + i, PS_VEC_NT_AP);
-        double2 rv = ldD2(r2 + i, PS_VEC_NT_R);
+        const double2 av = ldD2(A2 + i, nt && PS_VEC_NT_AP);
+        double2 rv = ldD2(r2 + i, nt && PS_VEC_NT_R);
         rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
-        stD2(r2 + i, rv, PS_VEC_NT_R);
+        stD2(r2 + i, rv, nt && PS_VEC_NT_R);
         arr += rv.x * rv.x; arr += rv.y * rv.y;
-        if (dinv) { const float2 dv = ldF2(d2 + i, PS_VEC_NT_D); arz += rv.x * ((double)dv.x * rv.x); arz += rv.y * ((double)dv.y * rv.y); }
+        if (dinv) { const float2 dv = ldF2(d2 + i, nt && PS_VEC_NT_D); arz += rv.x * ((double)dv.x * rv.x); arz += rv.y * ((double)dv.y * rv.y); }
     }
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = r[i] - alpha * Ap[i];
@@ -264,6 +265,7 @@ __device__ inline void cgUpdateXp(CGScalars* sc, const double* __restrict__ red,
     }
     if (UPP && red) __syncthreads();
     const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
+    const bool nt = sc->vecNT != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
     double axx = 0., aup = 0.;
     const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x) & 15) == 0) && (((uintptr_t)dinv & 7) == 0) &&
@@ -272,17 +274,17 @@ __device__ inline void cgUpdateXp(CGScalars* sc, const double* __restrict__ red,
     const double2* r2 = (const double2*)r; const float2* d2 = (const float2*)dinv;
     double2* p2 = (double2*)p; double2* x2 = (double2*)x;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        double2 z = ldD2(r2 + i, PS_VEC_NT_RX);
-        if (dinv) { const float2 dv = ldF2(d2 + i, PS_VEC_NT_D); z.x = (double)dv.x * z.x; z.y = (double)dv.y * z.y; }
-        double2 pv = ldD2(p2 + i, PS_VEC_NT_PL), xv = ldD2(x2 + i, PS_VEC_NT_X);
+        double2 z = ldD2(r2 + i, nt && PS_VEC_NT_RX);
+        if (dinv) { const float2 dv = ldF2(d2 + i, nt && PS_VEC_NT_D); z.x = (double)dv.x * z.x; z.y = (double)dv.y * z.y; }
+        double2 pv = ldD2(p2 + i, nt && PS_VEC_NT_PL), xv = ldD2(x2 + i, nt && PS_VEC_NT_X);
         xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
         pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
-        stD2(x2 + i, xv, PS_VEC_NT_X); stD2(p2 + i, pv, PS_VEC_NT_P);
+        stD2(x2 + i, xv, nt && PS_VEC_NT_X); stD2(p2 + i, pv, nt && PS_VEC_NT_P);
         axx += xv.x * xv.x; axx += xv.y * xv.y;
         if (UPP) {
             double u0, u1;
-            if (uCode) { const uint16_t cc = __builtin_nontemporal_load((const uint16_t*)uCode + i); u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
-            else { const double2 uv = ldD2((const double2*)uInv + i, 1); u0 = uv.x; u1 = uv.y; }
+            if (uCode) { const uint16_t cc = nt ? __builtin_nontemporal_load((const uint16_t*)uCode + i) : ((const uint16_t*)uCode)[i]; u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
+            else { const double2 uv = ldD2((const double2*)uInv + i, nt); u0 = uv.x; u1 = uv.y; }
             aup += u0 * (pv.x * pv.x); aup += u1 * (pv.y * pv.y);
         }
     }
@@ -383,6 +385,7 @@ __device__ inline void cgUpdateXpZ(CGScalars* sc, const double* __restrict__ rrP
     const double rr = blockSumAll(sumLocal(rrPartial, rrCount));
     const double rz = blockSumAll(sumLocal(rzPartial, rzCount));
     const double alpha = sc->alpha, beta = rz / sc->rsold2[it & 1];      // pcg.h:331-335
+    const bool nt = sc->vecNT != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
     double axx = 0., aup = 0.;
     const bool vec = ((((uintptr_t)p | (uintptr_t)z | (uintptr_t)x) & 15) == 0) && (!UPP || ((((uintptr_t)uCode & 1) == 0) && (((uintptr_t)uInv & 15) == 0)));
@@ -390,16 +393,16 @@ __device__ inline void cgUpdateXpZ(CGScalars* sc, const double* __restrict__ rrP
     const double2* z2 = (const double2*)z;
     double2* p2 = (double2*)p; double2* x2 = (double2*)x;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        const double2 zv = ldD2(z2 + i, 1);
-        double2 pv = ldD2(p2 + i, PS_VEC_NT_PL), xv = ldD2(x2 + i, PS_VEC_NT_X);
+        const double2 zv = ldD2(z2 + i, nt);
+        double2 pv = ldD2(p2 + i, nt && PS_VEC_NT_PL), xv = ldD2(x2 + i, nt && PS_VEC_NT_X);
         xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
         pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y;
-        stD2(x2 + i, xv, PS_VEC_NT_X); stD2(p2 + i, pv, PS_VEC_NT_P);
+        stD2(x2 + i, xv, nt && PS_VEC_NT_X); stD2(p2 + i, pv, nt && PS_VEC_NT_P);
         axx += xv.x * xv.x; axx += xv.y * xv.y;
         if (UPP) {
             double u0, u1;
-            if (uCode) { const uint16_t cc = __builtin_nontemporal_load((const uint16_t*)uCode + i); u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
-            else { const double2 uv = ldD2((const double2*)uInv + i, 1); u0 = uv.x; u1 = uv.y; }
+            if (uCode) { const uint16_t cc = nt ? __builtin_nontemporal_load((const uint16_t*)uCode + i) : ((const uint16_t*)uCode)[i]; u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
+            else { const double2 uv = ldD2((const double2*)uInv + i, nt); u0 = uv.x; u1 = uv.y; }
             aup += u0 * (pv.x * pv.x); aup += u1 * (pv.y * pv.y);
         }
     }

@@ -216,7 +216,7 @@ __device__ inline __amdgpu_buffer_rsrc_t bufRsrc(const void* p, size_t bytes) {
 __device__ inline double bufLoadF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, 0));
 }
-__device__ inline double bufLoadF64epi(__amdgpu_buffer_rsrc_t r, unsigned byteOff);
+template <bool NT> __device__ inline double bufLoadF64epi(__amdgpu_buffer_rsrc_t r, unsigned byteOff);
 __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, 0);
 }
@@ -236,11 +236,14 @@ __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, d
 #ifndef PS_EPI_AUX
 #define PS_EPI_AUX 2       // the per-row streams of the epilogues (row length, x, uInv / codes): read once per launch -> nt (St -3 %)
 #endif
-__device__ inline double bufLoadF64epi(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, PS_EPI_AUX));
+// NT (template parameter of the pipelined kernels): the non-temporal policies above, or default policy everywhere.  Chosen per
+// system size (ps_context::ntLevel): streams that are touched once per launch should not sweep the caches of a 45 M-row system,
+// but a system that fits in the 256 MB memory-side cache (or nearly) is served from it between kernels if they are allowed to stay.
+template <bool NT> __device__ inline double bufLoadF64epi(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, NT ? PS_EPI_AUX : 0));
 }
-__device__ inline void bufStoreF64nt(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, PS_STORE_AUX);
+template <bool NT> __device__ inline void bufStoreF64nt(__amdgpu_buffer_rsrc_t r, unsigned byteOff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, NT ? PS_STORE_AUX : 0);
 }
 __device__ inline double bufGatherF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, PS_GATHER_AUX));
@@ -254,19 +257,19 @@ template <int NV> struct Stream4<NV, false> { u32x2 c[NV]; unsigned v[NV]; };
 template <int NV> struct Stream4<NV, true> { u32x2 c[NV]; };   // the fp64 values are fetched for the CURRENT chunk only (below):
 // double-buffering 16 more VGPR pairs per lane costs more occupancy than the prefetch buys
 template <int NV> struct Vals4 { u32x4 v[NV][2]; };
-template <int NV>
+template <int NV, bool NT>
 __device__ inline void loadVals4(const double* val4, int p0, int p1, Vals4<NV>& s) {
     const __amdgpu_buffer_rsrc_t rVal = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(val4 + p0), 0, (int)(((unsigned)(p1 - p0 + 3) & ~3u) * 8u), 0x00020000);
 #pragma unroll
     for (int w = 0; w < NV; ++w) {
         const unsigned rel = 4u * (threadIdx.x + w * BS) * 8u;                   // byte offset inside this chunk's values
         const bool in = (int)(p0 + 4 * (threadIdx.x + w * BS)) < p1;
-        s.v[w][0] = __builtin_amdgcn_raw_buffer_load_b128(rVal, in ? (int)rel : -1, 0, PS_STREAM_AUX);
-        s.v[w][1] = __builtin_amdgcn_raw_buffer_load_b128(rVal, in ? (int)(rel + 16u) : -1, 0, PS_STREAM_AUX);
+        s.v[w][0] = __builtin_amdgcn_raw_buffer_load_b128(rVal, in ? (int)rel : -1, 0, NT ? PS_STREAM_AUX : 0);
+        s.v[w][1] = __builtin_amdgcn_raw_buffer_load_b128(rVal, in ? (int)(rel + 16u) : -1, 0, NT ? PS_STREAM_AUX : 0);
     }
 }
 // (the fp64 value array can exceed the 4 GiB a buffer descriptor spans: its descriptor is rebuilt per chunk on the chunk's base)
-template <int NV, bool F64>
+template <int NV, bool F64, bool NT>
 __device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, const double* val4, int p0, int p1, Stream4<NV, F64>& s,
                                    unsigned tid = threadIdx.x) {               // tid: the thread's index inside its 256-thread group
 #pragma unroll
@@ -275,8 +278,8 @@ __device__ inline void loadStream4(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_
         // groups past the end of the chunk: offset 0xffffffff is out of range -> zeros without a memory access
         // (zeros decode to window 0 / offset 0 / value 0, like the padding inside the last group)
         const bool in = (int)first < p1;
-        s.c[w] = __builtin_amdgcn_raw_buffer_load_b64(rCol, in ? (int)(first * 2u) : -1, 0, PS_STREAM_AUX);
-        if constexpr (!F64) s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, PS_STREAM_AUX);
+        s.c[w] = __builtin_amdgcn_raw_buffer_load_b64(rCol, in ? (int)(first * 2u) : -1, 0, NT ? PS_STREAM_AUX : 0);
+        if constexpr (!F64) s.v[w] = __builtin_amdgcn_raw_buffer_load_b32(rCode, in ? (int)first : -1, 0, NT ? PS_STREAM_AUX : 0);
     }
 }
 __device__ inline unsigned streamCol(u32x2 c, int j, int myBase) {   // window base (lane `window` of every 16-lane group) + 12-bit offset
@@ -335,7 +338,7 @@ __device__ inline double rowSum(const double* prod, int ea, int len) {
 }
 // Both kernels: gathers of the current chunk, prefetch of the next, products to LDS (entry e of the chunk at
 // prod[(e & 3) * PL + (e >> 2)]: conflict-free writes), row offsets from the length bytes (wave scans + 4 wave totals).
-template <int MODE, int NV, bool F64>
+template <int MODE, int NV, bool F64, bool NT>
 __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, const double* __restrict__ val4, int streamLen,
                                                     const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
@@ -361,18 +364,18 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     double stAcc = 0.;
     int2 pr = chunkRange[chunk];
     Stream4<NV, F64> cur, nxt;
-    loadStream4<NV, F64>(rCol, rCode, val4, pr.x, pr.y, cur);
+    loadStream4<NV, F64, NT>(rCol, rCode, val4, pr.x, pr.y, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = W.at(1);
     int2 npr = {0, 0};
     if (nchunk < nChunks) npr = chunkRange[nchunk];
     while (true) {
         const unsigned row = (unsigned)chunk * BS + threadIdx.x;
-        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, PS_EPI_AUX);   // 0 past the last row
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, NT ? PS_EPI_AUX : 0);   // 0 past the last row
         double sc = 1.;
         int mcc = 0;
         if (MODE == 0) {
-            if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, PS_EPI_AUX);
+            if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, NT ? PS_EPI_AUX : 0);
             else { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
         }
         double xv[4 * NV];
@@ -383,10 +386,10 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
             for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
         }
         Vals4<F64 ? NV : 0> cv;
-        if constexpr (F64) loadVals4<NV>(val4, pr.x, pr.y, cv);
+        if constexpr (F64) loadVals4<NV, NT>(val4, pr.x, pr.y, cv);
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream4<NV, F64>(rCol, rCode, val4, npr.x, npr.y, nxt);
+            loadStream4<NV, F64, NT>(rCol, rCode, val4, npr.x, npr.y, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = W.at(it + 2);
@@ -408,7 +411,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
             const double s = rowSum<8, PL>(prod, ea, len);
             if (MODE == 0 && mcCode) sc = (int)row < nA ? dt * dict[mcc] : 1.;
             if (MODE == 0) stAcc += (int)row < nA ? s * (s * sc) : 0.;
-            bufStoreF64nt(rOut, row * 8u, s * sc);                             // dropped past the last row
+            bufStoreF64nt<NT>(rOut, row * 8u, s * sc);                             // dropped past the last row
         }
         __syncthreads();
         if (!hasNext) break;
@@ -459,7 +462,7 @@ __global__ void __launch_bounds__(BLK_T) k_spmv_S_blk(const uint16_t* __restrict
         int2 pr = {0, 0};
         if (chunk >= 0) pr = chunkRange[chunk];
         Stream4<NV, false> cur, nxt;
-        loadStream4<NV, false>(rCol, rCode, nullptr, pr.x, pr.y, cur, (unsigned)t);
+        loadStream4<NV, false, true>(rCol, rCode, nullptr, pr.x, pr.y, cur, (unsigned)t);
         int myBase = chunk >= 0 ? winBase[chunk * 16 + (t & 15)] : 0, nBase = 0;
         for (int i = threadIdx.x; i < U.winLen; i += BLK_T) xw[i] = x[U.winLo + i];
         __syncthreads();
@@ -490,7 +493,7 @@ __global__ void __launch_bounds__(BLK_T) k_spmv_S_blk(const uint16_t* __restrict
             const int nchunk = nci < U.chunkCount ? unitChunks[U.chunkBegin + nci] : -1;
             int2 npr = {0, 0};
             if (nchunk >= 0) { npr = chunkRange[nchunk]; nBase = winBase[nchunk * 16 + (t & 15)]; }
-            loadStream4<NV, false>(rCol, rCode, nullptr, npr.x, npr.y, nxt, (unsigned)t);
+            loadStream4<NV, false, true>(rCol, rCode, nullptr, npr.x, npr.y, nxt, (unsigned)t);
 #pragma unroll
             for (int w = 0; w < NV; ++w) {
 #pragma unroll
@@ -509,14 +512,14 @@ __global__ void __launch_bounds__(BLK_T) k_spmv_S_blk(const uint16_t* __restrict
                 const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
                 const double s = rowSum<8, PL>(prod, ea, len);
                 if (MODE == 0 && mcCode) sc = row < (unsigned)nA ? dt * dict[mcc] : 1.;
-                bufStoreF64nt(rOut, row * 8u, s * sc);                         // dropped past the last row / for an idle group
+                bufStoreF64nt<true>(rOut, row * 8u, s * sc);                         // dropped past the last row / for an idle group
             }
             __syncthreads();
             ci = nci; chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
         }
     }
 }
-template <int MODE, int NV, bool F64>
+template <int MODE, int NV, bool F64, bool NT>
 __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, const double* __restrict__ val4, int streamLen,
                                                      const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
                                                      const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
@@ -570,24 +573,24 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
     double dacc = 0., dacc2 = 0.;
     int2 pr = chunkRange[chunk];
     Stream4<NV, F64> cur, nxt;
-    loadStream4<NV, F64>(rCol, rCode, val4, pr.x, pr.y, cur);
+    loadStream4<NV, F64, NT>(rCol, rCode, val4, pr.x, pr.y, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = W.at(1);
     int2 npr = {0, 0};
     if (nchunk < nChunks) npr = chunkRange[nchunk];
     while (true) {
         const unsigned row = (unsigned)chunk * BS + threadIdx.x;
-        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, PS_EPI_AUX);   // 0 past the last row
-        const double e0 = bufLoadF64epi(rE0, row * 8u);                                       // x (MODE 0, 2) / the vector added (MODE 1)
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, NT ? PS_EPI_AUX : 0);   // 0 past the last row
+        const double e0 = bufLoadF64epi<NT>(rE0, row * 8u);                                       // x (MODE 0, 2) / the vector added (MODE 1)
         double e1 = 0., cr = 0., ci = 0., cd = 0.;
         int uc = 0;
-        if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, PS_EPI_AUX); else e1 = bufLoadF64epi(rE1, row * 8u); }
+        if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, NT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
         if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }
         float fdv = 1.f;
         if (MODE == 3) {
-            cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, PS_EPI_AUX));
-            if (fr.dinvF) fdv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(row * 4u), 0, PS_EPI_AUX));
-            if (fr.cd) ci = bufLoadF64epi(rF64, row * 8u);
+            cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, NT ? PS_EPI_AUX : 0));
+            if (fr.dinvF) fdv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(row * 4u), 0, NT ? PS_EPI_AUX : 0));
+            if (fr.cd) ci = bufLoadF64epi<NT>(rF64, row * 8u);
         }
         double xv[4 * NV];
 #pragma unroll
@@ -597,10 +600,10 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
         }
         Vals4<F64 ? NV : 0> cv;
-        if constexpr (F64) loadVals4<NV>(val4, pr.x, pr.y, cv);
+        if constexpr (F64) loadVals4<NV, NT>(val4, pr.x, pr.y, cv);
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream4<NV, F64>(rCol, rCode, val4, npr.x, npr.y, nxt);
+            loadStream4<NV, F64, NT>(rCol, rCode, val4, npr.x, npr.y, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = W.at(it + 2);
@@ -631,7 +634,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                 dacc2 += fr.dinvF ? rv * ((double)fdv * rv) : 0.;
                 if (fr.cd) {                                                     // k_cheb_first on this row
                     const double v = ci * rv * fr.invTheta;
-                    bufStoreF64nt(rFcd, row * 8u, v); bufStoreF64nt(rFcz, row * 8u, v);
+                    bufStoreF64nt<NT>(rFcd, row * 8u, v); bufStoreF64nt<NT>(rFcz, row * 8u, v);
                     dacc2 += rv * v;
                 }
                 y = rv;
@@ -639,11 +642,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             else {
                 double az = -s; az -= 0.5 * e1 * e0;
                 const double dn = cheb.c1 * cd + cheb.c2 * (ci * (cr - az));
-                bufStoreF64nt(rCd, row * 8u, dn);
+                bufStoreF64nt<NT>(rCd, row * 8u, dn);
                 y = e0 + dn;
                 dacc += cr * y;                                                  // r.z of the updated z
             }
-            if (MODE == 3) bufStoreF64nt(rFr, row * 8u, y); else bufStoreF64nt(rOut, row * 8u, y);
+            if (MODE == 3) bufStoreF64nt<NT>(rFr, row * 8u, y); else bufStoreF64nt<NT>(rOut, row * 8u, y);
         }
         __syncthreads();    // protects the LDS reuse
         if (!hasNext) break;

@@ -58,6 +58,7 @@ struct Launch {
     // fused residual update (solve(): FusedR): where the S and tile kernels leave their shares of p.Ap (null: not asked for)
     double* sPart = nullptr;
     double* wvPart = nullptr;
+    bool ntSpmv = true;   // cache policy of the pipelined kernels' streams (ps_context::ntLevel >= 1)
     int pipeGrid;   // 0: one-shot kernels; >0: persistent software-pipelined kernels with this many blocks
     int xcdAware;   // pipelined kernels: runs of this many chunks are dealt to the XCDs round robin (ChunkWalk); 0 = plain walk
     void spmvS(int mode, const double* x, double* out) const {
@@ -78,9 +79,10 @@ struct Launch {
             const int nChunks = gridFor(rowsS, BS);
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
-#define PS_LAUNCH_SP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
+#define PS_LAUNCH_SP(MODE_, NV_, F64_, NT_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_, F64_, NT_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
                                                     M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, sched(M, gr.x), nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart)
-#define PS_LAUNCH_SP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_SP(MODE_, NV_, false); else PS_LAUNCH_SP(MODE_, NV_, true); } while (0)
+#define PS_LAUNCH_SP2(MODE_, NV_) do { if (!M.packed) PS_LAUNCH_SP(MODE_, NV_, true, true); else if (ntSpmv) PS_LAUNCH_SP(MODE_, NV_, false, true); \
+                                       else PS_LAUNCH_SP(MODE_, NV_, false, false); } while (0)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP2(0, 1); else PS_LAUNCH_SP2(1, 1); }
             else { if (mode == 0) PS_LAUNCH_SP2(0, 2); else PS_LAUNCH_SP2(1, 2); }
 #undef PS_LAUNCH_SP2
@@ -152,12 +154,13 @@ struct Launch {
             const int nChunks = gridFor(rowsSt, BS);
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
-#define PS_LAUNCH_TP(MODE_, NV_, F64_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
+#define PS_LAUNCH_TP(MODE_, NV_, F64_, NT_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_, NT_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
                                                     M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr)
-#define PS_LAUNCH_TP2(MODE_, NV_) do { if (M.packed) PS_LAUNCH_TP(MODE_, NV_, false); else PS_LAUNCH_TP(MODE_, NV_, true); } while (0)
+#define PS_LAUNCH_TP2(MODE_, NV_) do { if (!M.packed) PS_LAUNCH_TP(MODE_, NV_, true, true); else if (ntSpmv) PS_LAUNCH_TP(MODE_, NV_, false, true); \
+                                       else PS_LAUNCH_TP(MODE_, NV_, false, false); } while (0)
             if (mode == 3) {
                 if (!M.packed) throw Error("internal: fused residual update on the fp64 stream");
-                if (M.nv == 1) PS_LAUNCH_TP(3, 1, false); else PS_LAUNCH_TP(3, 2, false);
+                if (M.nv == 1) PS_LAUNCH_TP2(3, 1); else PS_LAUNCH_TP2(3, 2);
                 return;
             }
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_TP2(0, 1); else if (mode == 1) PS_LAUNCH_TP2(1, 1); else PS_LAUNCH_TP2(2, 1); }
@@ -207,9 +210,11 @@ Launch mk(ps_context* c, const int* done) {
     static int xa = -1;
     if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 16; }   // chunks per XCD run (rounded down to a power of two); 0: plain walk
     L.xcdAware = xa > 0 ? xa : 0;
+    L.ntSpmv = c->ntLevel() >= 1;
     return L;
 }
-constexpr int64_t FUSED_STEP_MIN_ROWS = 10000000;   // see solve()
+constexpr int64_t FUSED_STEP_MIN_ROWS = 12000000;   // see solve()
+constexpr int64_t NT_LEVEL1_MIN_ROWS = 4000000, NT_LEVEL2_MIN_ROWS = 10000000;   // see ps_context::ntLevel
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
 }  // namespace
 
@@ -265,6 +270,18 @@ void ps_context::constructPreconditioner() {
 // last iterate, then max(8.4, 1.25 * estimate) — same procedure as the oracle (ps_oracle_solve.cpp:estimateLambdaMax).
 // The stencil part of A is a sum of rank-one face terms with <= 8 entries, so its lambda_max(D^-1 A) <= 8 by Cauchy-Schwarz;
 // the measurement covers the tile part.  10 applies at setup (~1 % of a 256^3 step).
+// Cache policy by system size (PS_NT_LEVEL = 0 / 1 / 2 forces): 2 = non-temporal streams in the SpMV kernels and the vector
+// kernels (a 45 M-row iteration moves 6.7 GB: nothing survives to the next kernel, and keeping the once-per-launch streams out of
+// the way of the gathers is worth 7 % of a step), 1 = in the SpMV kernels only, 0 = default policy everywhere (the working set of
+// an iteration, ~150 B per row, fits the 256 MB memory-side cache or nearly: let it serve the next kernel).  Measured us per
+// iteration at level 0 / 1 / 2 (cavity): 64^3 (0.8 M rows) 58.6 / 60.6 / 61.2; 96^3 (2.6 M) 97.9 / 104.8 / 103.4; 128^3 (5.9 M) 194.0 /
+// 187.4 / 191.8; 160^3 (11.4 M) 341.7 / 337.7 / 336.0; 192^3 (19.4 M) 558 / 535 / 530; 224^3 (30.6 M) 858 / 838 / 810.
+int ps_context::ntLevel() const {
+    static const int env = getenv("PS_NT_LEVEL") ? atoi(getenv("PS_NT_LEVEL")) : -1;
+    if (env >= 0) return env;
+    return nSystem < NT_LEVEL1_MIN_ROWS ? 0 : (nSystem < NT_LEVEL2_MIN_ROWS ? 1 : 2);
+}
+
 double ps_context::chebTheta() const { return 0.5 * (chebLmax + chebLmax / 30.); }   // centre of the interval [lmax/30, lmax]
 
 void ps_context::estimateLambdaMax() {
@@ -383,7 +400,8 @@ int ps_context::solve() {
     // A p is neither written nor read back (16 B per row less) and the step is four launches (FusedR, ps_kernels_spmv.hpp).
     // Every St workgroup sums the partials of three producers in its prologue (up to 4096 + regions + 1024 + 1024 values, from
     // L2): a fixed ~15 us per iteration, against 16 B per row saved.  Measured us per iteration, fused / five-kernel: 64^3
-    // (0.8 M rows) 71 / 63, 128^3 (5.9 M) 206 / 197, 256^3 (45 M) 1147 / 1248 -> on from 10 M rows.  (Folding the partials 64 to
+    // (0.8 M rows) 71 / 63, 128^3 (5.9 M) 199 / 189, 160^3 (11.4 M) 339 / 336, 192^3 (19.4 M) 536 / 576, 256^3 (45 M) 1147 / 1248
+    // -> on from 12 M rows.  (Folding the partials 64 to
     // 1 in the producers with a ticket per group costs more than it saves: one device-scope atomic per workgroup, +30 us per
     // iteration with write-through stores and no fence, +650 us with __threadfence(), which flushes the XCD's L2.)
     // PS_FUSED_R = 0 / 1 forces it off / on (on only where the kernels exist).
@@ -406,9 +424,9 @@ int ps_context::solve() {
         const int cnt0 = chebyshevApply(r.p, zvec, dvec, rzPart, nullptr);
         HIP_CHECK(hipMemcpyAsync(pvec.p, zvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(BS), 0, stream, rzPart, cnt0, dotPartials.p);
-        hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, 1, tol, maxit);
+        hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, 1, tol, maxit, ntLevel() >= 2 ? 1 : 0);
     } else
-    hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, tol, maxit);
+    hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, vb, tol, maxit, ntLevel() >= 2 ? 1 : 0);
     // the first direction's share of p.Ap on the diagonal
     if (fused) hipLaunchKernelGGL(k_uinv_pp, dim3(vb), dim3(BS), 0, stream, (const double*)pvec.p, ucode, (const double*)uDict.p, (const double*)uInv.p, n, fU);
     CGScalars h{};
@@ -645,6 +663,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         scratch.alloc(1);
         CGScalars h{};
         h.tol2 = -1.;                                  // the stop test never fires
+        h.vecNT = c->ntLevel() >= 2 ? 1 : 0;
         if (base == "cg_update_xp" || base == "cg_update_xp_u") h.rsold2[0] = 1.;   // beta = 0 / 1 ; (cg_update_r, spmv_St_r: alpha = 0 / p.Ap with p.Ap = +-1024 below)
         HIP_CHECK(hipMemcpyAsync(scratch.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
         ps::DevBuf<double>& ones = c->benchOnes;       // input partials of the fused scalar prologues

@@ -509,11 +509,13 @@ def test_exported_system_import_errors(gpu, tmp_path):
                                  {"PS_PIPE_GRID": "0"}, {"PS_XCD": "0"}, {"PS_SCHED": "1", "PS_IL_SUPER": "2"},
                                  {"PS_IL_ORIGIN": "8", "PS_IL_SUPER": "2,2,1"}, {"PS_NO_DIAG_CODES": "1"}, {"PS_TILE_SPLIT": "1"},
                                  {"PS_BLK": "1"}, {"PS_SCHED": "3"}, {"PS_FUSED_R": "1"},
-                                 {"PS_FUSED_R": "1", "PS_TILE_SPLIT": "1"}, {"PS_FUSED_R": "1", "PS_NO_DIAG_CODES": "1"}])
+                                 {"PS_FUSED_R": "1", "PS_TILE_SPLIT": "1"}, {"PS_FUSED_R": "1", "PS_NO_DIAG_CODES": "1"},
+                                 {"PS_NT_LEVEL": "1"}, {"PS_NT_LEVEL": "2"}, {"PS_FUSED_R": "1", "PS_NT_LEVEL": "2"}])
 def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     """The SpMV has four storage formats chosen at setup — compressed stream with int8 value codes (3 B/nnz) or with fp64
     values (10 B/nnz: values that are not code * scale), both on the pipelined kernels; int8-coded CSR and fp64 CSR on the
-    one-shot kernels — plus A/B switches read once per process (numbering lattice, chunk schedule, walk).  Run the
+    one-shot kernels — plus switches read once per process (numbering lattice, chunk schedule, walk; the four-kernel PCG step
+    and the cache-policy level, which default by system size: this grid runs five kernels at level 0).  Run the
     alternatives in a child process: same iteration count, same velocities to rounding (the formats reproduce the same
     fp64 products; only summation orders of the dot products differ)."""
     import os
@@ -523,7 +525,7 @@ def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     p.tolerance = 1e-8
     p.maxSolverIterations = 20000
     assert gpu.step(sc, p) == abi.SUCCESS
-    assert int(gpu.array("fusedStep")[0]) == 0    # small system: five-kernel PCG step (the four-kernel one runs from 10 M rows, or PS_FUSED_R=1)
+    assert int(gpu.array("fusedStep")[0]) == 0    # small system: five-kernel PCG step (the four-kernel one runs from 12 M rows, or PS_FUSED_R=1)
     out = str(tmp_path / "alt.npz")
     code = (
         "import sys, numpy as np\n"
