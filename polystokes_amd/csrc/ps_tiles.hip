@@ -243,8 +243,10 @@ constexpr int MPAD = 32;
 
 template <int MODE>
 __global__ void __launch_bounds__(BS) k_region_outer_mfma(TileArgs A, double* __restrict__ partial) {
-    __shared__ double sa[FBATCH][MPAD];
-    __shared__ double sb[FBATCH][MPAD];
+    // rows padded to 33 doubles: with 32 every lane of a wave stores its row's entry n into the SAME bank pair (row stride 256 B =
+    // all 64 banks) — a 32-way conflict on each of the 32 stores per face, which was most of this kernel's time
+    __shared__ double sa[FBATCH][MPAD + 1];
+    __shared__ double sb[FBATCH][MPAD + 1];
     const int item = blockIdx.x;
     const int r = A.itemRegion[item], axis = A.itemAxis[item], start = A.itemStart[item];
     const int bx0 = A.bbox[r * 6 + 0], by0 = A.bbox[r * 6 + 1], bz0 = A.bbox[r * 6 + 2];
