@@ -169,8 +169,9 @@ def main():
         dist.init_process_group(backend="gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    if args.transport == "tcp":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: ranks share the GPUs there are
+    # fewer GPUs than ranks (a rehearsal on a small box): ranks share the GPUs there are — RCCL refuses duplicate devices, so
+    # such a run ends up on the host-staged transport (explicitly with --transport tcp, or through the fallback below)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
 
     strong = args.scaling == "strong"
@@ -202,9 +203,11 @@ def main():
     if args.maxit > 0:
         p.maxSolverIterations = args.maxit   # the BiCGStab fallback then runs too: use for kernel profiling only
     solver.upload(sc, p)           # host -> HBM, outside the timed region
+    transport_used = None
     if world > 1:
         solver.set_slab(slab)
-        if args.transport == "tcp":
+
+        def tcp_init():
             port = torch.zeros(1, dtype=torch.int64)
             if rank == 0:
                 import socket
@@ -213,12 +216,46 @@ def main():
                     port[0] = 20000 + so.getsockname()[1] % 20000
             dist.broadcast(port, 0)
             solver.comm_init_tcp(rank, world, "127.0.0.1", int(port.item()))
+
+        def all_ok(ok):                          # every rank learns whether EVERY rank succeeded (gloo, CPU)
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+
+        if args.transport == "tcp":
+            tcp_init()
+            transport_used = "tcp (host-staged rehearsal)"
         else:
+            # RCCL, with a way out that still produces a line: if librccl cannot be loaded, the communicator cannot be built or its
+            # self-test (all-reduce + grouped send/recv) fails on ANY rank, ALL ranks switch to the host-staged transport and the
+            # line says so — slower, but the multi-GPU solve is measured instead of lost.  Each step is agreed on over gloo before
+            # the next collective call, so no rank waits inside RCCL for a rank that has already given up.
+            why = ""
             uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                uid.copy_(torch.tensor(list(polystokes_amd.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            solver.comm_init(bytes(uid.tolist()), rank, world)
+            try:
+                mine = polystokes_amd.comm_unique_id()       # loads librccl on every rank; only rank 0's id is used
+                if rank == 0:
+                    uid.copy_(torch.tensor(list(mine), dtype=torch.uint8))
+                ok = True
+            except Exception as e:                           # noqa: BLE001
+                ok, why = False, "load: %s" % e
+            if all_ok(ok):
+                dist.broadcast(uid, 0)
+                try:
+                    solver.comm_init(bytes(uid.tolist()), rank, world)
+                    solver.comm_selftest()
+                    ok = True
+                except Exception as e:                       # noqa: BLE001
+                    ok, why = False, "init/self-test: %s" % e
+                ok = all_ok(ok)
+            else:
+                ok = False
+            if ok:
+                transport_used = "rccl"
+            else:
+                sys.stderr.write("[bench rank %d] RCCL transport unavailable (%s): falling back to the host-staged transport\n" % (rank, why or "another rank failed"))
+                tcp_init()
+                transport_used = "tcp (FALLBACK: RCCL unavailable%s)" % ((": " + why[:160]) if why else " on another rank")
 
     def barrier():
         torch.cuda.synchronize()
@@ -300,7 +337,7 @@ def main():
         "other_kernels": {k: v for k, v in kern.items() if k != dom},
     }
 
-    link = "RCCL halo exchange + all-reduce" if args.transport == "rccl" else "host-staged TCP transport (REHEARSAL: ranks share GPUs, not a performance number)"
+    link = "RCCL halo exchange + all-reduce" if transport_used == "rccl" else "host-staged TCP transport (%s; not the RCCL number)" % transport_used
     par = "1 GPU" if world == 1 else ("%d z-slabs of one %d^3 scene (strong), %s" % (world, n, link) if strong
                                        else "%d z-slabs, one %d-layer slab per GPU (weak), %s" % (world, n, link))
     workload = {"cavity": "synthetic lid-driven cavity", "coil": "synthetic coiling column (honey_coil stand-in)", "spheres": "pool with 8 moving solid spheres (armadillos stand-in)"}[scene_name]
@@ -316,6 +353,8 @@ def main():
         "stage_ms": {abi.STAGE_NAMES[i]: float(st.stage_ms[i]) for i in range(len(abi.STAGE_NAMES))},
         "roofline": roofline,
     }
+    if transport_used:
+        out["transport"] = transport_used
     if world == 1:
         # the boundary as the Houdini shim uses it: host fp32 fields in, velocity / valid fields out (polystokes_step)
         t0 = time.perf_counter()

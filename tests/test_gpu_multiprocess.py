@@ -101,3 +101,29 @@ def test_multiprocess_list_mismatch_fails_every_rank(tmp_path):
     res = _run_ranks("cavity_w2_failrank", 2, tmp_path)
     assert [int(r["rc"]) for r in res] == [-1, -1], [str(r["err"]) for r in res]
     assert all("exchange lists" in str(r["err"]) for r in res), [str(r["err"]) for r in res]
+
+
+def test_bench_two_ranks_produces_one_line_whatever_the_transport(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: spawns one process per rank, rendezvous over gloo, and prints ONE JSON
+    line.  With two GPUs the ranks talk over RCCL; on a one-GPU box RCCL refuses the duplicate device, every rank agrees on that
+    (gloo) before any further collective, and all of them switch to the host-staged transport — the line says which."""
+    import json
+    import polystokes_amd
+    try:                                   # a second device?  (probed through the library: no torch import in this process)
+        polystokes_amd.Solver(1).close()
+        two_gpus = True
+    except polystokes_amd.PolyStokesError:
+        two_gpus = False
+    env = dict(os.environ, MASTER_PORT=str(_free_port_base(1)))
+    pr = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--res", "32", "--steps", "1", "--warmup", "1",
+                         "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, env=env)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [l for l in pr.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["unit"] == "ms/step" and d["value"] > 0 and d["cg_iterations"] > 0
+    assert d["config"]["grid"] == [32, 32, 64] and d["scaling"] == "weak"
+    if two_gpus:
+        assert d["transport"] == "rccl"
+    else:
+        assert d["transport"].startswith("tcp (FALLBACK")
