@@ -243,7 +243,8 @@ int32_t ps_set_slab(ps_context* ctx, const ps_slab* slab);            /* after p
  * whose setup fails makes every rank return PS_FAILED instead of leaving its neighbours waiting. */
 int32_t ps_comm_unique_id(void* id128);
 int32_t ps_comm_init_rccl(ps_context* ctx, const void* id128, int32_t rank, int32_t world);
-int32_t ps_comm_selftest(ps_context* ctx);   /* all-reduce + grouped send/recv on the communicator */
+int32_t ps_comm_selftest(ps_context* ctx);   /* collective: all-reduce, grouped send/recv to self, and (slab set, world > 1) one ring
+                                              * step with the real neighbours and a check of the all-reduced sums */
 /* Host-staged transport instead of RCCL (pack -> D2H -> TCP -> H2D -> unpack; scalar all-reduce through rank 0):
  * one process per rank, several ranks may share one GPU (RCCL refuses duplicate devices) — the route by which the
  * real multi-process path runs on a single-GPU box, and the fallback where librccl is missing.  Rank r listens on

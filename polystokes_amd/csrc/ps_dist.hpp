@@ -710,6 +710,21 @@ int32_t ps_comm_selftest(ps_context* c) {
         HIP_CHECK(hipStreamSynchronize(c->stream));
         for (int i = 0; i < 4; ++i) if (b[i] != v[i]) throw Error("send/recv self-test mismatch");
         if (a[3] != v[3]) throw Error("all-reduce touched elements beyond count");
+        // with a slab set: one ring step between REAL neighbours (send up, receive from below), the pattern of Dist::transport
+        const int world = c->slab.world, rank = c->slab.rank;
+        if (c->slabEnabled && world > 1) {
+            if (a[0] != world * v[0] || a[1] != world * v[1] || a[2] != world * v[2]) throw Error("all-reduce self-test: wrong sum over the ranks");
+            const double mine[4] = {(double)rank, 100. + rank, -1. - rank, 0.5 * rank};
+            HIP_CHECK(hipMemcpyAsync(c->sendLo.p, mine, 32, hipMemcpyHostToDevice, c->stream));
+            const int up = (rank + 1) % world, down = (rank + world - 1) % world;
+            ncclCheck(L.GroupStart(), "ncclGroupStart");
+            ncclCheck(L.Send(c->sendLo.p, 4, NCCL_DOUBLE, up, c->rcclComm, c->stream), "ncclSend");
+            ncclCheck(L.Recv(c->recvLo.p, 4, NCCL_DOUBLE, down, c->rcclComm, c->stream), "ncclRecv");
+            ncclCheck(L.GroupEnd(), "ncclGroupEnd");
+            HIP_CHECK(hipMemcpyAsync(b, c->recvLo.p, 32, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (b[0] != (double)down || b[1] != 100. + down || b[2] != -1. - down || b[3] != 0.5 * down) throw Error("neighbour send/recv self-test mismatch");
+        }
         return PS_SUCCESS;   // a[0..2] = world * v (checked by the caller, who knows the world size)
     } PS_CATCH_ALL(c)
 }
