@@ -2,6 +2,8 @@
 
 Bit-exact for every integer / index / label / weight array; stated fp64 tolerances elsewhere.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -601,6 +603,21 @@ def test_four_kernel_step_matches_and_is_reproducible(gpu, tmp_path, precond, de
     assert int(alt["outcomes"]) == 1
     assert abs(float(alt["it"]) - gpu.stats.solveData[1]) <= 1
     assert np.linalg.norm(alt["x"] - x_ref) <= 1e-6 * np.linalg.norm(x_ref)
+
+
+@pytest.mark.skipif(os.environ.get("PS_TEST_CHILD") == "1", reason="this IS the child run")
+def test_oracle_parity_with_the_large_system_switches_forced(tmp_path):
+    """The four-kernel PCG step and the non-temporal cache policies switch on by system size (12 M / 4 M / 10 M rows), far above
+    what the oracle can check.  Run the oracle-parity tests of the solve (all fixed scenes: free surfaces, no tiles, ragged grids,
+    layer variants; Jacobi; BiCGStab fallback; Chebyshev) once more in a child pytest with both forced on."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PS_FUSED_R="1", PS_NT_LEVEL="2", PS_TEST_CHILD="1")
+    pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                         "-k", "solve_matches or jacobi_pcg or bicgstab or chebyshev or rhs_and_operator or zero_rhs"],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    assert pr.returncode == 0, pr.stdout[-4000:]
+    assert " passed" in pr.stdout and "failed" not in pr.stdout, pr.stdout[-2000:]
 
 
 def test_bad_parameters_are_refused(gpu):
