@@ -327,9 +327,11 @@ def main():
         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
         "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_ms": ms,
-        "algorithmic_bytes_definition": ("stored format: 3*nnz (16-bit windowed column + int8 value code) + 1*rows (row length) + 72 B per 256-row chunk "
+        "algorithmic_bytes_definition": ("stored format: 3*nnz (16-bit windowed column + int8 value code) + 1*rows (row length) + 80 B per chunk "
                                          "+ 8*cols (t once) + 8*rows (p) + 1*rows (coded uInv) + %s") % ("16*rows (r read + written) + 4*rows (fp32 Jacobi diagonal); A p is not stored" if fused else "8*rows (y)") if (coded and c16) else
                                         "CSR: (12 | 10 | 5)*nnz + 4*(rows+1) + 8*rows (y) + 8*cols (x once) + 16*rows (fused epilogue)",
+        "stream_runs": (lambda r: {"S_distinct_entries": int(r[0]), "S_entries": int(r[1]), "St_distinct_entries": int(r[2]), "St_entries": int(r[3]),
+                                   "note": "chunks with byte-identical (col16, code, row length) runs share one run, so most of the matrix stream is served from cache: algorithmic bytes still count every entry once per launch (the loads are issued), the HBM bytes are in `traffic`"})(solver.array("streamRuns")),
         "value_format": ("16-bit windowed col + int8 value code (3 B/nnz, lossless)" if c16 else "int32 col + int8 value code (5 B/nnz, lossless)") if coded
                         else ("16-bit windowed col + fp64 value (10 B/nnz)" if c16 else "int32 col + fp64 value (12 B/nnz)"),
         "csr_equivalent": {"bytes_per_launch": csr, "GBps": csr_gbps, "frac_of_peak_if_it_moved_them": csr_gbps / HBM_PEAK_GBS,

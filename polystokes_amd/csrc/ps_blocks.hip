@@ -420,11 +420,11 @@ BlockArgs makeArgs(ps_context* c) {
 }
 
 // Compressed SpMV stream, step 1: entries per chunk rounded up to a multiple of 4 (scanned into the chunk starts)
-__global__ void k_chunk_len4(const int32_t* __restrict__ ptr, int rows, int nChunks, int32_t* __restrict__ len4, int32_t* __restrict__ maxLen) {
+__global__ void k_chunk_len4(const int32_t* __restrict__ ptr, const int2* __restrict__ chunkRows, int nChunks, int32_t* __restrict__ len4, int32_t* __restrict__ maxLen) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch > nChunks) return;
     int n = 0;
-    if (ch < nChunks) { n = ptr[min(ch * BS + BS, rows)] - ptr[ch * BS]; atomicMax(maxLen, n); }
+    if (ch < nChunks) { const int2 cr = chunkRows[ch]; n = ptr[cr.x + cr.y] - ptr[cr.x]; atomicMax(maxLen, n); }
     len4[ch] = (n + 3) & ~3;
 }
 // step 2, one block per chunk: 16-bit windowed columns.  Greedy cover of the chunk's column set by windows
@@ -433,17 +433,18 @@ __global__ void k_chunk_len4(const int32_t* __restrict__ ptr, int rows, int nChu
 // handful of short runs (own voxels, the j/k neighbours, the 6 neighbouring blocks, skin rows of adjacent tiles), so 16
 // windows are plenty.  Also copies the value codes to the aligned layout and writes the row-length bytes.
 __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const int8_t* __restrict__ code,
-                                                    int rows, const int32_t* __restrict__ start4, uint16_t* __restrict__ col16,
-                                                    int8_t* __restrict__ code4, int32_t* __restrict__ winBase, int2* __restrict__ chunkRange,
+                                                    const int2* __restrict__ chunkRows, const int32_t* __restrict__ start4, uint16_t* __restrict__ col16,
+                                                    int8_t* __restrict__ code4, int32_t* __restrict__ winBase, int4* __restrict__ chunkInfo,
                                                     uint8_t* __restrict__ len8, int32_t* __restrict__ fail) {
     __shared__ int red[BS / 64];
     __shared__ int bmin;
     const int chunk = blockIdx.x;
-    const int r0 = chunk * BS;
-    const int p0 = ptr[r0], p1 = ptr[min(r0 + BS, rows)];
+    const int2 cr = chunkRows[chunk];
+    const int r0 = cr.x;
+    const int p0 = ptr[r0], p1 = ptr[r0 + cr.y];
     const int q0 = start4[chunk], q1 = start4[chunk + 1];          // q1 - q0 = (p1 - p0) rounded up to 4
-    if (threadIdx.x == 0) chunkRange[chunk] = make_int2(q0, q0 + (p1 - p0));
-    if (r0 + (int)threadIdx.x < rows) len8[r0 + threadIdx.x] = (uint8_t)(ptr[r0 + threadIdx.x + 1] - ptr[r0 + threadIdx.x]);
+    if (threadIdx.x == 0) chunkInfo[chunk] = make_int4(q0, q0 + (p1 - p0), cr.x, cr.y);
+    if ((int)threadIdx.x < cr.y) len8[r0 + threadIdx.x] = (uint8_t)(ptr[r0 + threadIdx.x + 1] - ptr[r0 + threadIdx.x]);
     constexpr int SL = 8;                               // <= 8 entries per row: <= 2048 entries per chunk
     if (p1 - p0 > SL * BS) { if (threadIdx.x == 0) *fail = 1; return; }
     int c[SL];
@@ -480,11 +481,73 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
     for (int u = 0; u < SL; ++u) left |= open[u];
     if (left) *fail = 1;
 }
-// the fp64 values of a matrix in the aligned chunk layout of its compressed stream (padding entries 0)
-__global__ void __launch_bounds__(BS) k_val4_build(const int32_t* __restrict__ ptr, const double* __restrict__ val, int rows,
-                                                   const int2* __restrict__ chunkRange, double* __restrict__ val4) {
+// ---- shared runs (DevCSR::chunkInfo) -----------------------------------------------------------------------------------
+// A chunk's payload = its aligned run of (col16, code4) entries and the length bytes of its rows.  Equivalent lattice blocks
+// (same pattern of active cells, same neighbourhood) produce byte-identical payloads — columns are window-relative, the window
+// bases stay per chunk — so every chunk whose payload equals an earlier chunk's is pointed at that chunk's run: the kernels then
+// stream one copy of each distinct run and find it in cache.  (1) a 64-bit hash per payload, (2) a device hash table keeps the
+// smallest chunk index per hash, (3) every other chunk compares its bytes with that representative's and, if equal, takes its run.
+constexpr unsigned long long HASH_EMPTY = 0xffffffffffffffffull;
+__device__ inline unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+__global__ void __launch_bounds__(64) k_chunk_hash(const int4* __restrict__ chunkInfo, const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4,
+                                                   const uint8_t* __restrict__ len8, unsigned long long* __restrict__ hash) {
     const int chunk = blockIdx.x;
-    const int p0 = ptr[chunk * BS], n = chunkRange[chunk].y - chunkRange[chunk].x, q0 = chunkRange[chunk].x;
+    const int4 ci = chunkInfo[chunk];
+    const int n4 = (ci.y - ci.x + 3) & ~3;
+    unsigned long long h = 0;
+    for (int i = threadIdx.x; i < n4; i += 64)                      // position-keyed terms: the sum does not depend on the order
+        h += mix64(((unsigned long long)i << 32) | ((unsigned long long)col16[ci.x + i] << 8) | (uint8_t)code4[ci.x + i]);
+    for (int i = threadIdx.x; i < ci.w; i += 64) h += mix64(0x4000000000000000ull | ((unsigned long long)i << 32) | len8[ci.z + i]);
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o, 64);
+    if (threadIdx.x == 0) {
+        h = mix64(h ^ (((unsigned long long)(unsigned)n4 << 32) | (unsigned)ci.w));
+        hash[chunk] = h == HASH_EMPTY ? 0ull : h;
+    }
+}
+__global__ void k_chunk_rep_insert(const unsigned long long* __restrict__ hash, int nChunks, unsigned long long* __restrict__ keys, int32_t* __restrict__ vals, unsigned mask) {
+    const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= nChunks) return;
+    const unsigned long long h = hash[chunk];
+    unsigned slot = (unsigned)(h >> 17) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe, slot = (slot + 1) & mask) {
+        unsigned long long cur = keys[slot];
+        if (cur == HASH_EMPTY) { cur = atomicCAS(&keys[slot], HASH_EMPTY, h); if (cur == HASH_EMPTY) cur = h; }
+        if (cur == h) { atomicMin(&vals[slot], chunk); return; }
+    }
+}
+// one workgroup per chunk: look the representative up, compare the payloads, redirect the run
+__global__ void __launch_bounds__(64) k_chunk_share(const unsigned long long* __restrict__ hash, const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                    unsigned mask, int4* __restrict__ chunkInfo, const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4,
+                                                    const uint8_t* __restrict__ len8, unsigned long long* __restrict__ uniqueLen) {
+    const int chunk = blockIdx.x;
+    const unsigned long long h = hash[chunk];
+    unsigned slot = (unsigned)(h >> 17) & mask;
+    while (keys[slot] != h) slot = (slot + 1) & mask;                // present: inserted by k_chunk_rep_insert
+    const int rep = vals[slot];
+    const int4 ci = chunkInfo[chunk];
+    const int n4 = (ci.y - ci.x + 3) & ~3;
+    bool same = rep != chunk;
+    if (same) {
+        const int4 cr = chunkInfo[rep];                              // a representative's entry is never rewritten (it is its own)
+        same = (cr.y - cr.x) == (ci.y - ci.x) && cr.w == ci.w;
+        if (same) {
+            for (int i = threadIdx.x; i < n4; i += 64) same = same && col16[ci.x + i] == col16[cr.x + i] && code4[ci.x + i] == code4[cr.x + i];
+            for (int i = threadIdx.x; i < ci.w; i += 64) same = same && len8[ci.z + i] == len8[cr.z + i];
+        }
+        same = __all(same) != 0;
+        if (same && threadIdx.x == 0) { chunkInfo[chunk].x = cr.x; chunkInfo[chunk].y = cr.y; }
+    }
+    if (!same && threadIdx.x == 0) atomicAdd(uniqueLen, (unsigned long long)n4);
+}
+// the fp64 values of a matrix in the aligned chunk layout of its compressed stream (padding entries 0)
+__global__ void __launch_bounds__(BS) k_val4_build(const int32_t* __restrict__ ptr, const double* __restrict__ val,
+                                                   const int4* __restrict__ chunkInfo, double* __restrict__ val4) {
+    const int chunk = blockIdx.x;
+    const int4 ci = chunkInfo[chunk];
+    const int p0 = ptr[ci.z], n = ci.y - ci.x, q0 = ci.x;
     const int n4 = (n + 3) & ~3;
     for (int i = threadIdx.x; i < n4; i += BS) val4[q0 + i] = i < n ? val[p0 + i] : 0.;
 }
@@ -492,22 +555,47 @@ __global__ void __launch_bounds__(BS) k_val4_build(const int32_t* __restrict__ p
 void ps_context::buildVal4(ps::DevCSR& M) {
     if (!M.col16ok || M.val4.p) return;
     M.val4.alloc((size_t)M.streamLen + 8);
-    hipLaunchKernelGGL(k_val4_build, dim3((unsigned)gridFor(M.rows, BS)), dim3(BS), 0, stream, M.ptr.p, M.val.p, (int)M.rows, M.chunkRange.p, M.val4.p);
+    hipLaunchKernelGGL(k_val4_build, dim3((unsigned)M.nChunks), dim3(BS), 0, stream, M.ptr.p, M.val.p, M.chunkInfo.p, M.val4.p);
 }
 // Compressed SpMV stream (DevCSR::col16 ...); decided per matrix.  With coded values it is 3 B per entry; when the values are
 // not code * scale (user-supplied weights, PS_FORCE_FP64_VALUES=1) the same windowed 16-bit columns go with the fp64 values
 // (10 B per entry, DevCSR::val4) and the same pipelined kernels run.  PS_COL32=1 keeps the one-shot CSR kernels.
-void ps_context::buildCol16(ps::DevCSR& M, int slot) {
+void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>& cuts) {
     M.col16ok = false;
+    M.nChunks = 0;
     M.val4.free();
     const char* e = getenv("PS_COL32");
     if (M.rows == 0 || M.nnz == 0 || (e && atoi(e) != 0)) return;
-    const int nChunks = gridFor(M.rows, BS);
+    // Chunk table.  `cuts` (ascending row indices, first 0, last M.rows; may be empty) are where the numbering's lattice blocks
+    // and the tiles' skin-row ranges begin.  A range of >= CHUNK_ALIGN_MIN rows starts its own chunk — equivalent blocks then
+    // cut their rows into chunks the same way and produce identical runs (dedupChunks) — shorter ranges (thin layers at a
+    // free surface) are packed with their neighbours so that the chunk count stays close to rows / 256.
+    std::vector<int2> rowsOf;
+    {
+        constexpr int CHUNK_ALIGN_MIN = 512;
+        static const bool plain = getenv("PS_CHUNK_PLAIN") && atoi(getenv("PS_CHUNK_PLAIN")) != 0;   // A/B: uniform 256-row chunks
+        bool ok = !plain && cuts.size() >= 2 && cuts.front() == 0 && (int64_t)cuts.back() == M.rows;
+        for (size_t i = 1; ok && i < cuts.size(); ++i) ok = cuts[i] >= cuts[i - 1];
+        auto emit = [&](int64_t lo, int64_t hi) { for (int64_t r = lo; r < hi; r += BS) rowsOf.push_back(make_int2((int)r, (int)std::min<int64_t>(BS, hi - r))); };
+        if (!ok) emit(0, M.rows);
+        else {
+            int64_t runLo = 0;
+            for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+                const int64_t lo = cuts[i], hi = cuts[i + 1];
+                if (hi - lo >= CHUNK_ALIGN_MIN) { emit(runLo, lo); emit(lo, hi); runLo = hi; }
+            }
+            emit(runLo, M.rows);
+        }
+    }
+    const int nChunks = (int)rowsOf.size();
+    DevBuf<int2> chunkRows;
+    chunkRows.alloc((size_t)nChunks);
+    HIP_CHECK(hipMemcpyAsync(chunkRows.p, rowsOf.data(), (size_t)nChunks * sizeof(int2), hipMemcpyHostToDevice, stream));
     DevBuf<int32_t> start4;
     start4.alloc((size_t)nChunks + 1);
     HIP_CHECK(hipMemsetAsync(counters.p + 25, 0, sizeof(int32_t), stream));
-    hipLaunchKernelGGL(k_chunk_len4, dim3(gridFor(nChunks + 1, BS)), dim3(BS), 0, stream, M.ptr.p, (int)M.rows, nChunks, start4.p, counters.p + 25);
-    const int64_t total4 = exclusiveScanI32(start4.p, nChunks + 1);
+    hipLaunchKernelGGL(k_chunk_len4, dim3(gridFor(nChunks + 1, BS)), dim3(BS), 0, stream, M.ptr.p, (const int2*)chunkRows.p, nChunks, start4.p, counters.p + 25);
+    const int64_t total4 = exclusiveScanI32(start4.p, nChunks + 1);   // (synchronises: rowsOf may go out of scope after this)
     if (total4 < 0) return;                                           // would overflow 32 bits: keep the CSR kernels
     const int maxLen = readCounter(25);
     M.nv = std::max(1, (maxLen + 4 * BS - 1) / (4 * BS));
@@ -515,15 +603,37 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot) {
     // the kernels address everything through 32-bit buffer descriptors: every array they touch must stay below 4 GiB
     if ((uint64_t)std::max(M.rows, M.cols) * 8 >= 0xffffffffull || (uint64_t)total4 * 2 >= 0xffffffffull) return;
     M.streamLen = total4;
+    M.uniqueLen = total4;
+    M.nChunks = nChunks;
     M.col16.alloc((size_t)total4 + 8); M.code4.alloc((size_t)total4 + 8);
-    M.winBase.alloc((size_t)nChunks * 16); M.chunkRange.alloc((size_t)nChunks); M.len8.alloc((size_t)M.rows);
+    M.winBase.alloc((size_t)nChunks * 16); M.chunkInfo.alloc((size_t)nChunks); M.len8.alloc((size_t)M.rows);
     HIP_CHECK(hipMemsetAsync(counters.p + slot, 0, sizeof(int32_t), stream));
-    hipLaunchKernelGGL(k_col16_build, dim3((unsigned)nChunks), dim3(BS), 0, stream, M.ptr.p, M.col.p, M.code.p, (int)M.rows, start4.p, M.col16.p,
-                       M.code4.p, M.winBase.p, M.chunkRange.p, M.len8.p, counters.p + slot);
+    hipLaunchKernelGGL(k_col16_build, dim3((unsigned)nChunks), dim3(BS), 0, stream, M.ptr.p, M.col.p, M.code.p, (const int2*)chunkRows.p, start4.p, M.col16.p,
+                       M.code4.p, M.winBase.p, M.chunkInfo.p, M.len8.p, counters.p + slot);
     M.col16ok = readCounter(slot) == 0;
     if (M.col16ok && !M.packed) buildVal4(M);
-    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] compressed stream: rows %lld nnz %lld, fullest chunk %d (nv %d), ok %d\n",
-                                           (long long)M.rows, (long long)M.nnz, maxLen, M.nv, (int)M.col16ok);
+    static const bool noShare = getenv("PS_NO_SHARED_RUNS") && atoi(getenv("PS_NO_SHARED_RUNS")) != 0;
+    if (M.col16ok && M.packed && shareRuns && !noShare && nChunks > 1) {          // coded values only: the fp64 values of equal codes need not be equal bits
+        unsigned cap = 1024;
+        while (cap < 4u * (unsigned)nChunks) cap <<= 1;
+        DevBuf<unsigned long long> hash, keys, uniq;
+        DevBuf<int32_t> vals;
+        hash.alloc((size_t)nChunks); keys.alloc(cap); vals.alloc(cap); uniq.alloc(1);
+        HIP_CHECK(hipMemsetAsync(keys.p, 0xff, (size_t)cap * 8, stream));
+        HIP_CHECK(hipMemsetAsync(vals.p, 0x7f, (size_t)cap * 4, stream));
+        HIP_CHECK(hipMemsetAsync(uniq.p, 0, 8, stream));
+        hipLaunchKernelGGL(k_chunk_hash, dim3((unsigned)nChunks), dim3(64), 0, stream, (const int4*)M.chunkInfo.p, (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p,
+                           (const uint8_t*)M.len8.p, hash.p);
+        hipLaunchKernelGGL(k_chunk_rep_insert, dim3(gridFor(nChunks, BS)), dim3(BS), 0, stream, (const unsigned long long*)hash.p, nChunks, keys.p, vals.p, cap - 1);
+        hipLaunchKernelGGL(k_chunk_share, dim3((unsigned)nChunks), dim3(64), 0, stream, (const unsigned long long*)hash.p, (const unsigned long long*)keys.p,
+                           (const int32_t*)vals.p, cap - 1, M.chunkInfo.p, (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p, (const uint8_t*)M.len8.p, uniq.p);
+        unsigned long long u = 0;
+        HIP_CHECK(hipMemcpyAsync(&u, uniq.p, 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        M.uniqueLen = (int64_t)u;
+    }
+    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] compressed stream: rows %lld nnz %lld, %d chunks, fullest %d (nv %d), ok %d, distinct runs hold %lld of %lld entries\n",
+                                           (long long)M.rows, (long long)M.nnz, nChunks, maxLen, M.nv, (int)M.col16ok, (long long)M.uniqueLen, (long long)M.streamLen);
 }
 
 // ---- value-set coding of the diagonals (ps_context.hpp: uCode / mcCode) ----------------------------------------------
@@ -608,187 +718,19 @@ void ps_context::buildDiagonalCodes() {
     if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] diagonal value sets: uInv %s, McInv %s\n", uCoded ? "coded (<= 256 values)" : "fp64", mcCoded ? "coded" : "fp64");
 }
 
-// Chunk -> XCD schedule of the persistent SpMV kernels (ChunkWalk): built on the host from the block starts of the internal
-// numbering.  A 256-row chunk belongs to the super-block of its first row; the skin-row chunks of S go with the super-block
-// holding the min corner of their region's box.  Super-blocks (non-empty ones, in sequence order) are dealt to the 8 XCDs
-// round robin, so the chip as a whole still sweeps a compact window of memory.
-// OFF by default (PS_SCHED=1 enables it): measured at 256^3 it removes only 5-12 % of the L2 fills and no time
-// (profiles/r02_spmv_locality.md) — on this chip two workgroups share a fill only when they run on the same or the adjacent CU
-// (the PS_SCHED_DUP probe below: chunks walked twice by workgroups <= 16 apart cost +25 % fills, >= 32 apart +100 %), and
-// a line survives in the 4 MiB L2 for about one chunk time.  Kept for the probes and for scenes with other geometry.
-void ps_context::buildChunkSchedule(ps::DevCSR& M, bool faceRows) {
-    M.schedOk = false;
-    const char* e = getenv("PS_SCHED");
-    const int mode = e ? atoi(e) : 0;
-    if (!M.col16ok || mode == 0 || ilBlocks == 0) return;
-    const int nChunks = gridFor(M.rows, BS);
-    if (nChunks < 64) return;
-    if (mode == 3) {
-        // "sweep" walk (A/B): every XCD owns one contiguous eighth of the chunks, and inside it every group of 16 workgroups (the
-        // domain in which fills are shared) sweeps its own contiguous sub-span: at iteration it the group works on 16 consecutive
-        // chunks, at it + 1 on the next 16 — the neighbours in k of one iteration are the rows of the next
-        const char* pgE = getenv("PS_PIPE_GRID");
-        const int grid = std::min(nChunks, pgE ? atoi(pgE) : 4096) & ~7;
-        if (grid < 128) return;
-        const int per = grid / 8, groups = per / 16;
-        if (groups < 1 || per % 16) return;
-        std::vector<int32_t> list;
-        int lo = 0;
-        for (int x = 0; x < 8; ++x) {
-            M.schedOff[x] = (int)list.size();
-            const int hi = (int)((int64_t)nChunks * (x + 1) / 8);
-            const int cnt = hi - lo;
-            const int span = (cnt + groups - 1) / groups;            // chunks per group
-            const int iters = (span + 15) / 16;
-            for (int it = 0; it < iters; ++it)
-                for (int l = 0; l < per; ++l) {
-                    const int g = l / 16, j = l % 16;
-                    const int c = g * span + it * 16 + j;
-                    list.push_back((it * 16 + j < span && c < cnt) ? lo + c : 0x7fffffff);   // holes: the kernels skip chunk ids >= nChunks
-                }
-            lo = hi;
-        }
-        M.schedOff[8] = (int)list.size();
-        M.sched.alloc(list.size());
-        HIP_CHECK(hipMemcpyAsync(M.sched.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        M.schedOk = true;
-        return;
+// the compressed streams of S and St.  share = false (bench.py's "_fp64" kernels: the fp64-value stream as a system with arbitrary
+// weights would have it) keeps every chunk on its own run.
+void ps_context::buildStreams(bool share) {
+    // where chunks should start: the lattice blocks of the numbering (active rows; DOFs), then every tile's skin rows
+    std::vector<int32_t> cutsS, cutsT;
+    if (!blockStartRow.empty() && (int64_t)blockStartRow.back() == nActiveVs) {
+        cutsS = blockStartRow;
+        for (size_t r = 1; r < regionRowPtrHost.size(); ++r) cutsS.push_back((int32_t)(nActiveVs + regionRowPtrHost[r]));
     }
-    const std::vector<int32_t>& bs = faceRows ? blockStartRow : blockStartSys;
-    const int sbv = ilSuper[0] * ilSuper[1] * ilSuper[2];
-    const int nSB = ilBlocks / sbv;
-    const int64_t nActive = faceRows ? nActiveVs : M.rows;
-    std::vector<int32_t> sbOf((size_t)nChunks);
-    {   // active part: walk the block starts
-        size_t b = 0;
-        for (int ch = 0; ch < nChunks; ++ch) {
-            const int64_t r0 = (int64_t)ch * BS;
-            if (r0 >= nActive) break;
-            while (b + 1 < bs.size() - 1 && bs[b + 1] <= r0) ++b;
-            sbOf[(size_t)ch] = (int32_t)(b / (size_t)sbv);
-        }
-    }
-    if (faceRows && nReducedRows > 0) {
-        const int LBx = (g.nx + 1 + ilOrigin[0] + 15) / 16, LBy = (g.ny + 1 + ilOrigin[1] + 15) / 16;
-        const int NSx = (LBx + ilSuper[0] - 1) / ilSuper[0], NSy = (LBy + ilSuper[1] - 1) / ilSuper[1];
-        size_t r = 0;
-        for (int ch = (int)((nActive + BS - 1) / BS); ch < nChunks; ++ch) {
-            const int64_t rr = (int64_t)ch * BS - nActive;
-            while (r + 1 < regionRowPtrHost.size() - 1 && regionRowPtrHost[r + 1] <= rr) ++r;
-            const int bx = (hbbox[r * 6 + 0] + ilOrigin[0]) / 16, by = (hbbox[r * 6 + 1] + ilOrigin[1]) / 16, bz = (hbbox[r * 6 + 2] + ilOrigin[2]) / 16;
-            const int sb = ((bz / ilSuper[2]) * NSy + by / ilSuper[1]) * NSx + bx / ilSuper[0];
-            sbOf[(size_t)ch] = std::min(sb, nSB - 1);
-        }
-    }
-    // counting sort of the chunks by super-block (stable: active chunks first, then the skin chunks, ascending)
-    std::vector<int32_t> cnt((size_t)nSB + 1, 0);
-    {   // PS_SCHED_ONLY=1|2 (traffic attribution runs): only the active / only the skin chunks of S are walked
-        const char* eo = getenv("PS_SCHED_ONLY");
-        const int only = (eo && faceRows) ? atoi(eo) : 0;
-        const int firstSkin = (int)((nActive + BS - 1) / BS);
-        if (only) for (int ch = 0; ch < nChunks; ++ch) if ((only == 1) != (ch < firstSkin)) sbOf[(size_t)ch] = -1;
-    }
-    for (int ch = 0; ch < nChunks; ++ch) if (sbOf[(size_t)ch] >= 0) cnt[(size_t)sbOf[(size_t)ch] + 1]++;
-    std::vector<int32_t> xcdOf((size_t)nSB, 0);
-    int next = 0;
-    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int sb = 0; sb < nSB; ++sb)
-        if (cnt[(size_t)sb + 1] > 0) {
-            int x = next & 7;
-            if (mode == 2) { x = 0; for (int q = 1; q < 8; ++q) if (load[q] < load[x]) x = q; }   // least loaded (A/B)
-            xcdOf[(size_t)sb] = x; load[x] += cnt[(size_t)sb + 1]; ++next;
-        }
-    int64_t mx = 0;
-    for (int q = 0; q < 8; ++q) mx = std::max(mx, load[q]);
-    if (mx * 8 > (int64_t)nChunks * 5 / 4 + 8 * 64) return;   // a lopsided deal (few, uneven super-blocks): keep the computed walk
-    for (int sb = 0; sb < nSB; ++sb) cnt[(size_t)sb + 1] += cnt[(size_t)sb];
-    std::vector<int32_t> bySb((size_t)nChunks);
-    {
-        std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
-        for (int ch = 0; ch < nChunks; ++ch) if (sbOf[(size_t)ch] >= 0) bySb[(size_t)pos[(size_t)sbOf[(size_t)ch]]++] = ch;
-    }
-    std::vector<int32_t> list((size_t)nChunks);
-    int o = 0;
-    for (int x = 0; x < 8; ++x) {
-        M.schedOff[x] = o;
-        for (int sb = 0; sb < nSB; ++sb)
-            if (xcdOf[(size_t)sb] == x)
-                for (int32_t q = cnt[(size_t)sb]; q < cnt[(size_t)sb + 1]; ++q) list[(size_t)o++] = bySb[(size_t)q];
-    }
-    M.schedOff[8] = o;
-    if (const char* ed = getenv("PS_SCHED_DUP")) {   // L2 retention probe: every group of d list entries is walked twice in a row (S only)
-        const int d = atoi(ed);
-        if (d > 0 && faceRows) {
-            std::vector<int32_t> l2;
-            int off2[9];
-            for (int x = 0; x < 8; ++x) {
-                off2[x] = (int)l2.size();
-                for (int g0 = M.schedOff[x]; g0 < M.schedOff[x + 1]; g0 += d)
-                    for (int rep = 0; rep < 2; ++rep)
-                        for (int q = g0; q < std::min(M.schedOff[x + 1], g0 + d); ++q) l2.push_back(list[(size_t)q]);
-            }
-            off2[8] = (int)l2.size();
-            list.swap(l2);
-            for (int x = 0; x < 9; ++x) M.schedOff[x] = off2[x];
-        }
-    }
-    M.sched.alloc(list.size());
-    HIP_CHECK(hipMemcpyAsync(M.sched.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    M.schedOk = true;
-    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] chunk schedule (%s): %d chunks, %d super-blocks, fullest XCD %lld\n",
-                                           faceRows ? "S" : "St", nChunks, nSB, (long long)mx);
-}
-
-// Units of the block-resident S kernel (k_spmv_S_blk): one per non-empty lattice block — the 256-row chunks whose first row lies
-// in the block, then the skin-row chunks of the regions whose box starts in it — with the block's contiguous DOF range as the
-// window the workgroup keeps in LDS (capped: a denser block than the window holds is still correct, its tail is gathered).
-void ps_context::buildBlockUnits(ps::DevCSR& M) {
-    M.nUnits = 0;
-    const char* e = getenv("PS_BLK");
-    if (!(e && atoi(e) != 0) || !M.col16ok || !M.packed || ilBlocks == 0 || slabEnabled) return;
-    if (ilSuper[0] * ilSuper[1] * ilSuper[2] != 1) return;
-    constexpr int WCAP = 11776;
-    const int nChunks = gridFor(M.rows, BS);
-    const int nB = ilBlocks;
-    std::vector<std::vector<int32_t>> per((size_t)nB);
-    {
-        size_t b = 0;
-        const int firstSkin = (int)((nActiveVs + BS - 1) / BS);
-        for (int ch = 0; ch < firstSkin && ch < nChunks; ++ch) {
-            const int64_t r0 = (int64_t)ch * BS;
-            while (b + 1 < blockStartRow.size() - 1 && blockStartRow[b + 1] <= r0) ++b;
-            per[b].push_back(ch);
-        }
-        if (nReducedRows > 0) {
-            const int LBx = (g.nx + 1 + ilOrigin[0] + 15) / 16, LBy = (g.ny + 1 + ilOrigin[1] + 15) / 16;
-            size_t r = 0;
-            for (int ch = firstSkin; ch < nChunks; ++ch) {
-                const int64_t rr = (int64_t)ch * BS - nActiveVs;
-                while (r + 1 < regionRowPtrHost.size() - 1 && regionRowPtrHost[r + 1] <= rr) ++r;
-                const int bx = (hbbox[r * 6 + 0] + ilOrigin[0]) / 16, by = (hbbox[r * 6 + 1] + ilOrigin[1]) / 16, bz = (hbbox[r * 6 + 2] + ilOrigin[2]) / 16;
-                per[(size_t)std::min((bz * LBy + by) * LBx + bx, nB - 1)].push_back(ch);
-            }
-        }
-    }
-    std::vector<int32_t> chunks;
-    std::vector<int4> units;
-    chunks.reserve((size_t)nChunks);
-    for (int b = 0; b < nB; ++b) {
-        if (per[(size_t)b].empty()) continue;
-        int4 u;
-        u.x = (int)chunks.size(); u.y = (int)per[(size_t)b].size();
-        u.z = blockStartSys[(size_t)b]; u.w = std::min(WCAP, blockStartSys[(size_t)b + 1] - blockStartSys[(size_t)b]);
-        units.push_back(u);
-        chunks.insert(chunks.end(), per[(size_t)b].begin(), per[(size_t)b].end());
-    }
-    if (units.empty()) return;
-    M.unitChunks.alloc(chunks.size()); M.units.alloc(units.size());
-    HIP_CHECK(hipMemcpyAsync(M.unitChunks.p, chunks.data(), chunks.size() * 4, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(M.units.p, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    M.nUnits = (int)units.size();
+    if (!blockStartSys.empty() && (int64_t)blockStartSys.back() == nSystem) cutsT = blockStartSys;
+    shareRuns = share;
+    buildCol16(S, 22, cutsS);
+    buildCol16(St, 23, cutsT);
 }
 
 // ConstructMatrixBlocks.cpp:9-292
@@ -918,11 +860,7 @@ void ps_context::constructMatrixBlocks() {
         const int32_t flag = S.packed ? 1 : 0;
         HIP_CHECK(hipMemcpyAsync(counters.p + 21, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        buildCol16(S, 22);
-        buildCol16(St, 23);
-        buildChunkSchedule(S, true);
-        buildChunkSchedule(St, false);
-        buildBlockUnits(S);
+        buildStreams(true);
         buildDiagonalCodes();
         const int32_t c16 = (S.col16ok ? 1 : 0) | (St.col16ok ? 2 : 0);
         HIP_CHECK(hipMemcpyAsync(counters.p + 24, &c16, sizeof(c16), hipMemcpyHostToDevice, stream));

@@ -281,6 +281,11 @@ void ps_context::registerArrays() {
     // 1: the last PCG solve ran the four-kernel step (residual update inside the St kernel, ps_solve.hip)
     HIP_CHECK(hipMemcpyAsync(counters.p + 28, &fusedStepHost, sizeof(int32_t), hipMemcpyHostToDevice, stream));
     reg("fusedStep", counters.p + 28, 1, 4);
+    // entries of the distinct runs of the compressed streams / all entries: S, then St (equal without sharing; 0 without a stream)
+    streamRunsHost[0] = S.col16ok ? (int32_t)S.uniqueLen : 0; streamRunsHost[1] = S.col16ok ? (int32_t)S.streamLen : 0;
+    streamRunsHost[2] = St.col16ok ? (int32_t)St.uniqueLen : 0; streamRunsHost[3] = St.col16ok ? (int32_t)St.streamLen : 0;
+    HIP_CHECK(hipMemcpyAsync(counters.p + 29, streamRunsHost, 4 * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    reg("streamRuns", counters.p + 29, 4, 4);
     reg("sysPerm", permSys.p, nSystem, 4);
     reg("rowPerm", permRow.p, nActiveVs, 4);
     reg("S.ptr", S.ptr.p, S.rows + 1, 4); reg("S.col", S.col.p, S.nnz, 4); reg("S.val", S.val.p, S.nnz, 8);
@@ -630,6 +635,10 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
         // over a real solve matches the in-sequence figure.
         const bool seq = k.compare(0, 4, "seq:") == 0;
         if (seq) k = k.substr(4);
+        // "_fp64": the streams as a system with arbitrary weights has them — no shared runs (equal codes there, not equal values)
+        const bool unshared = k.size() > 5 && k.compare(k.size() - 5, 5, "_fp64") == 0 && c->S.col16ok && c->St.col16ok && c->S.packed;
+        struct Reshare { ps_context* c; bool on; ~Reshare() { if (on) { try { c->buildStreams(true); } catch (...) {} } } } reshare{c, unshared};
+        if (unshared) c->buildStreams(false);
         std::vector<std::string> pred;
         if (seq) {
             if (k == "spmv_St" || k == "spmv_St_r") pred = {"spmv_S", "tiles"};
@@ -679,12 +688,15 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             auto perNnz = [&](const ps::DevCSR& M) { return csr ? 12. : (M.col16ok ? ((M.packed && !fp64) ? 3. : 10.) : (M.packed ? 5. : 12.)); };
             auto c16 = [&](const ps::DevCSR& M) { return !csr && M.col16ok; };
             const double perNnzS = perNnz(c->S), perNnzT = perNnz(c->St);
-            const double winS = c16(c->S) ? 0.25 * (double)c->nRows : 0., winT = c16(c->St) ? 0.25 * (double)c->nSystem : 0.;   // 64 B of window bases per 256-row chunk
+            // every entry of the matrix counts once per launch: the kernel loads all of them; how many of those loads are served from
+            // cache because chunks share their runs (DevCSR::uniqueLen, array "streamRuns") shows in the measured HBM traffic
+            const double entS = nnz, entT = nnz;
+            const double winS = c16(c->S) ? 80. * (double)c->S.nChunks : 0., winT = c16(c->St) ? 80. * (double)c->St.nChunks : 0.;   // 64 B of window bases + 16 B of ranges per chunk
             const double ptrS = c16(c->S) ? 1. : 4., ptrT = c16(c->St) ? 1. : 4.;   // row length byte | row pointer
             // the fused diagonals: fp64 array, or a 1-byte value-set code per row on the pipelined kernels (ps_context.hpp: uCode / mcCode)
             const double dMc = (c16(c->S) && c->mcCoded) ? 1. : 8., dU = (c16(c->St) && c->uCoded) ? 1. : 8.;
-            const double bS = winS + perNnzS * nnz + ptrS * (rowsS + 1) + 8. * rowsS + 8. * rowsT + dMc * (double)c->nActiveVs;
-            const double bT = winT + perNnzT * nnz + ptrT * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + dU * rowsT;
+            const double bS = winS + perNnzS * entS + ptrS * (rowsS + 1) + 8. * rowsS + 8. * rowsT + dMc * (double)c->nActiveVs;
+            const double bT = winT + perNnzT * entT + ptrT * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + dU * rowsT;
             if (kb == "spmv_S") *algorithmic_bytes = bS;
             else if (kb == "spmv_St") *algorithmic_bytes = bT;
             // fused residual update: r read and written in place of the A p store, + the fp32 Jacobi diagonal

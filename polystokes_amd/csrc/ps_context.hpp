@@ -17,26 +17,22 @@ struct DevCSR {
     // The fill kernels verify code*scale == val bit for bit; if any entry fails, the SpMV streams `val` instead.
     DevBuf<int8_t> code;
     bool packed = false;
-    // Compressed stream of the persistent SpMV kernels (only with `packed`, and only if EVERY chunk fits: col16ok).
-    // Per 256-row chunk: a 4-entry-aligned run [chunkRange.x, chunkRange.y) of (col16, code4) entries in CSR order;
-    // col = winBase[chunk*16 + (c16 >> 12)] + (c16 & 4095) (up to 16 windows of 4096 columns per chunk);
-    // len8 = entries per row.  nv = ceil(fullest chunk / 1024) = 4-entry groups per lane.
+    // Compressed stream of the persistent SpMV kernels (with `packed`, or with val4; only if EVERY chunk fits: col16ok).
+    // A chunk = up to 256 consecutive rows [chunkInfo.z, chunkInfo.z + chunkInfo.w) and a 4-entry-aligned run [chunkInfo.x,
+    // chunkInfo.y) of (col16, code4) entries in CSR order; col = winBase[chunk*16 + (c16 >> 12)] + (c16 & 4095) (up to 16 windows
+    // of 4096 columns per chunk); len8 = entries per row.  nv = ceil(fullest chunk / 1024) = 4-entry groups per lane.
+    // Chunks start at the boundaries of the numbering's lattice blocks (and of the tiles' skin-row ranges): equivalent blocks then
+    // produce byte-identical runs, and a chunk whose run equals an earlier chunk's points at THAT run (ps_blocks.hip:
+    // dedupChunks) — a periodic tile structure streams one copy of each distinct run, from cache.
     DevBuf<uint16_t> col16;
     DevBuf<int8_t> code4;
     DevBuf<double> val4;         // the fp64 values in the same aligned chunk layout (only when the values are not coded)
     DevBuf<int32_t> winBase;
-    DevBuf<int2> chunkRange;
+    DevBuf<int4> chunkInfo;      // (run begin, run end, first row, row count)
     DevBuf<uint8_t> len8;
+    int nChunks = 0;
+    int64_t uniqueLen = 0;       // entries of the runs some chunk actually points at (== streamLen without sharing)
     bool col16ok = false;
-    // Scheduled walk of the persistent kernels: the chunks of one super-block of the numbering lattice (and, for S, the skin
-    // rows of its tiles) go to ONE XCD, back to back, so the x / t lines they share are filled into one L2 once.
-    // Block-resident walk (k_spmv_S_blk): units = lattice blocks, each with its chunk list and the DOF window it keeps in LDS
-    DevBuf<int32_t> unitChunks;  // chunk ids, unit after unit
-    DevBuf<int4> units;          // (chunkBegin, chunkCount, winLo, winLen)
-    int nUnits = 0;
-    DevBuf<int32_t> sched;       // 8 lists, concatenated
-    int schedOff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool schedOk = false;
     int nv = 2;
     int64_t streamLen = 0;       // entries of col16 / code4 (multiple of 4)
 };
@@ -144,6 +140,7 @@ struct ps_context {
     bool uCoded = false, mcCoded = false;
     int32_t diagFlagsHost = 0;
     int32_t fusedStepHost = 0;
+    int32_t streamRunsHost[4] = {0, 0, 0, 0};
     void buildDiagonalCodes();
     ps::DevBuf<float> dinvF;   // the Jacobi diagonal as the PCG kernels read it (fp32 storage, see constructPreconditioner)
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
@@ -214,10 +211,10 @@ struct ps_context {
     void computeReducedViscosityMatricesInteriorOnly();
     void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
     void constructMatrixBlocks();                         // ps_blocks.hip
-    void buildCol16(ps::DevCSR& M, int counterSlot);      // ps_blocks.hip
+    void buildCol16(ps::DevCSR& M, int counterSlot, const std::vector<int32_t>& cuts);   // ps_blocks.hip; cuts: row indices where a chunk should start
+    void buildStreams(bool share);                        // both compressed streams (ps_blocks.hip)
+    bool shareRuns = true;
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
-    void buildChunkSchedule(ps::DevCSR& M, bool faceRows);
-    void buildBlockUnits(ps::DevCSR& M);
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();

@@ -190,16 +190,13 @@ struct FusedR {
     // above is that of the Jacobi diagonal)
     const double* dinv64; double invTheta; double* cd; double* cz;
 };
-struct ChunkSched { const int32_t* list; int off[9]; };   // per-XCD chunk lists (ps_context::buildChunkSchedule); list == null: computed walk
+// Walk of a persistent workgroup over the chunk ids: runs of G = 1 << sh consecutive chunks are dealt to the 8 XCDs round robin
+// (workgroup b runs on XCD b & 7), inside an XCD to its workgroups in order; sh < 0: plain grid-stride walk
 struct ChunkWalk {
-    int sh, x, l, per;   // G = 1 << sh chunks per run; sh < 0: plain walk
-    const int32_t* list; // scheduled walk: this XCD's chunks list[lo .. lo + n), dealt to its workgroups round robin
-    int lo, n;
-    __device__ ChunkWalk(int g, const ChunkSched& s)
-        : sh(g > 0 ? 31 - __builtin_clz((unsigned)g) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3), list(s.list),
-          lo(s.list ? s.off[blockIdx.x & 7] : 0), n(s.list ? s.off[(blockIdx.x & 7) + 1] - s.off[blockIdx.x & 7] : 0) {}
+    int sh, x, l, per;
+    __device__ explicit ChunkWalk(int g)
+        : sh(g > 0 ? 31 - __builtin_clz((unsigned)g) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3) {}
     __device__ int at(int it) const {
-        if (list) { const int q = l + it * per; return q < n ? list[lo + q] : 0x7fffffff; }
         if (sh < 0) return blockIdx.x + it * gridDim.x;
         const int q = l + it * per;
         return ((((q >> sh) << 3) + x) << sh) + (q & ((1 << sh) - 1));
@@ -236,9 +233,11 @@ __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, d
 #ifndef PS_EPI_AUX
 #define PS_EPI_AUX 2       // the per-row streams of the epilogues (row length, x, uInv / codes): read once per launch -> nt (St -3 %)
 #endif
-// NT (template parameter of the pipelined kernels): the non-temporal policies above, or default policy everywhere.  Chosen per
-// system size (ps_context::ntLevel): streams that are touched once per launch should not sweep the caches of a 45 M-row system,
-// but a system that fits in the 256 MB memory-side cache (or nearly) is served from it between kernels if they are allowed to stay.
+// POL (template parameter of the pipelined kernels), bit 0: the non-temporal policies above for the result stores and the per-row
+// epilogue streams; bit 1: for the matrix stream (col16 / code4 / val4).  Chosen per system (Launch::policy): streams that are
+// touched once per launch should not sweep the caches of a 45 M-row system, but a system that fits in the 256 MB memory-side
+// cache (or nearly) is served from it between kernels if they are allowed to stay; and a matrix stream whose runs are SHARED
+// between chunks (DevCSR::uniqueLen) is read again and again — it must stay cached (non-temporal it is 11 % slower than unshared).
 template <bool NT> __device__ inline double bufLoadF64epi(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, NT ? PS_EPI_AUX : 0));
 }
@@ -336,19 +335,21 @@ __device__ inline double rowSum(const double* prod, int ea, int len) {
     for (int k = 0; k < ML; ++k) s = k < len ? s + v[k] : s;
     return s;
 }
+constexpr unsigned ROW_NONE = 0x1fffffffu;   // row index of an idle lane: beyond any array (rows * 8 < 4 GiB), positive as an int
 // Both kernels: gathers of the current chunk, prefetch of the next, products to LDS (entry e of the chunk at
 // prod[(e & 3) * PL + (e >> 2)]: conflict-free writes), row offsets from the length bytes (wave scans + 4 wave totals).
-template <int MODE, int NV, bool F64, bool NT>
+template <int MODE, int NV, bool F64, int POL>
 __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, const double* __restrict__ val4, int streamLen,
-                                                    const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
+                                                    const int32_t* __restrict__ winBase, const int4* __restrict__ chunkInfo,
                                                     const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
                                                     int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
-                                                    const int* __restrict__ done, ChunkSched sched, int nChunks, int xcdAware,
+                                                    const int* __restrict__ done, int nChunks, int xcdAware,
                                                     const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict, double* __restrict__ stPart) {
     // stPart (MODE 0, may be null): per workgroup, the sum over its ACTIVE rows of s_f t_f = dt McInv_f s_f^2 — the active-face
     // share of x . A x, so that the residual update can run inside the St kernel (ps_solve.hip: fused step)
     if (done && *done) return;
     constexpr int PL = BS * NV;
+    constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;   // stores + per-row epilogue streams | the matrix stream
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
     __shared__ double dict[MODE == 0 ? 256 : 1];      // value-set coded McInv (ps_context.hpp: mcCode): first read after the loop's first barrier
@@ -357,20 +358,20 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, F64 ? 0 : (size_t)streamLen),
                                  rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
                                  rMcc = bufRsrc(mcCode, mcCode ? (size_t)nA : 0), rOut = bufRsrc(out, (size_t)rows * 8);
-    const ChunkWalk W(xcdAware, sched);
+    const ChunkWalk W(xcdAware);
     int it = 0;
     int chunk = W.at(0);
     if (chunk >= nChunks) { if (MODE == 0 && stPart && threadIdx.x == 0) stPart[blockIdx.x] = 0.; return; }
     double stAcc = 0.;
-    int2 pr = chunkRange[chunk];
+    int4 pr = chunkInfo[chunk];
     Stream4<NV, F64> cur, nxt;
-    loadStream4<NV, F64, NT>(rCol, rCode, val4, pr.x, pr.y, cur);
+    loadStream4<NV, F64, SNT>(rCol, rCode, val4, pr.x, pr.y, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = W.at(1);
-    int2 npr = {0, 0};
-    if (nchunk < nChunks) npr = chunkRange[nchunk];
+    int4 npr = {0, 0, 0, 0};
+    if (nchunk < nChunks) npr = chunkInfo[nchunk];
     while (true) {
-        const unsigned row = (unsigned)chunk * BS + threadIdx.x;
+        const unsigned row = (int)threadIdx.x < pr.w ? (unsigned)pr.z + threadIdx.x : ROW_NONE;   // lanes past the chunk's rows: every access out of range
         const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, NT ? PS_EPI_AUX : 0);   // 0 past the last row
         double sc = 1.;
         int mcc = 0;
@@ -386,15 +387,15 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
             for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
         }
         Vals4<F64 ? NV : 0> cv;
-        if constexpr (F64) loadVals4<NV, NT>(val4, pr.x, pr.y, cv);
+        if constexpr (F64) loadVals4<NV, SNT>(val4, pr.x, pr.y, cv);
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream4<NV, F64, NT>(rCol, rCode, val4, npr.x, npr.y, nxt);
+            loadStream4<NV, F64, SNT>(rCol, rCode, val4, npr.x, npr.y, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = W.at(it + 2);
-        int2 nnpr = {0, 0};
-        if (nn < nChunks) nnpr = chunkRange[nn];
+        int4 nnpr = {0, 0, 0, 0};
+        if (nn < nChunks) nnpr = chunkInfo[nn];
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
             if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
@@ -424,111 +425,17 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
         if (threadIdx.x == 0) stPart[blockIdx.x] = bs;
     }
 }
-// ---- block-resident variant of S: x of a lattice block lives in LDS ------------------------------------------------------
-// A 1024-thread workgroup owns one UNIT at a time — the chunks of one 16^3 lattice block (its active rows and the skin rows of its
-// tiles, ps_context::buildBlockUnits) — and first copies the block's contiguous DOF range x[winLo, winLo + winLen) into LDS with
-// coalesced loads.  The four 256-thread groups then each process chunks of the unit exactly like k_spmv_S_pipe, except that a
-// gather whose column falls inside the window reads LDS; the others (neighbour blocks) go to memory as before.  The window is a
-// cache, not an assumption: any column outside it is simply fetched, so results are those of the pipelined kernel bit for bit.
-struct BlkUnit { int chunkBegin, chunkCount, winLo, winLen; };
-constexpr int BLK_T = 1024, BLK_G = BLK_T / BS;
-constexpr int BLK_WCAP = 11776;                      // doubles of x per unit (92 KB; + 64 KB of product slots + tables < 160 KB)
-template <int MODE, int NV>
-__global__ void __launch_bounds__(BLK_T) k_spmv_S_blk(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, int streamLen,
-                                                      const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
-                                                      const uint8_t* __restrict__ len8, double scale, const double* __restrict__ x, int cols, int rows,
-                                                      int nA, double dt, const double* __restrict__ McInv, double* __restrict__ out,
-                                                      const int* __restrict__ done, const BlkUnit* __restrict__ units, int nUnits,
-                                                      const int32_t* __restrict__ unitChunks, const uint8_t* __restrict__ mcCode,
-                                                      const double* __restrict__ mcDict) {
-    if (done && *done) return;
-    constexpr int PL = BS * NV;
-    __shared__ double xw[BLK_WCAP];
-    __shared__ double prodAll[BLK_G][4 * PL];
-    __shared__ __align__(16) int wtotAll[BLK_G][BS / 64];
-    __shared__ double dict[MODE == 0 ? 256 : 1];
-    const int g = threadIdx.x >> 8, t = threadIdx.x & 255;
-    double* prod = prodAll[g];
-    int* wtot = wtotAll[g];
-    if (MODE == 0 && mcCode && threadIdx.x < 256) dict[threadIdx.x] = mcDict[threadIdx.x];
-    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(col16, (size_t)streamLen * 2), rCode = bufRsrc(code4, (size_t)streamLen),
-                                 rLen = bufRsrc(len8, (size_t)rows), rX = bufRsrc(x, (size_t)cols * 8), rMc = bufRsrc(McInv, (size_t)nA * 8),
-                                 rMcc = bufRsrc(mcCode, mcCode ? (size_t)nA : 0), rOut = bufRsrc(out, (size_t)rows * 8);
-    for (int u = blockIdx.x; u < nUnits; u += gridDim.x) {
-        const BlkUnit U = units[u];
-        // this group's first chunk and its stream: requested before the window copy so that the two latencies overlap
-        int ci = g;
-        int chunk = ci < U.chunkCount ? unitChunks[U.chunkBegin + ci] : -1;
-        int2 pr = {0, 0};
-        if (chunk >= 0) pr = chunkRange[chunk];
-        Stream4<NV, false> cur, nxt;
-        loadStream4<NV, false, true>(rCol, rCode, nullptr, pr.x, pr.y, cur, (unsigned)t);
-        int myBase = chunk >= 0 ? winBase[chunk * 16 + (t & 15)] : 0, nBase = 0;
-        for (int i = threadIdx.x; i < U.winLen; i += BLK_T) xw[i] = x[U.winLo + i];
-        __syncthreads();
-        const int rounds = (U.chunkCount + BLK_G - 1) / BLK_G;
-        for (int q = 0; q < rounds; ++q) {
-            const unsigned row = chunk >= 0 ? (unsigned)chunk * BS + t : 0xffffffffu;
-            const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, 0);   // 0 past the last row / for an idle group
-            double sc = 1.;
-            int mcc = 0;
-            if (MODE == 0) {
-                if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, 0);
-                else { const double m = bufLoadF64(rMc, row * 8u); sc = row < (unsigned)nA ? dt * m : 1.; }
-            }
-            double xv[4 * NV];
-            unsigned rel[4 * NV];
-#pragma unroll
-            for (int w = 0; w < NV; ++w) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned c = streamCol(cur.c[w], j, myBase);
-                    rel[4 * w + j] = c - (unsigned)U.winLo;
-                    const bool inWin = rel[4 * w + j] < (unsigned)U.winLen;
-                    xv[4 * w + j] = bufGatherF64(rX, inWin ? 0xffffffffu : c * 8u);       // out of range: 0, no memory access
-                }
-            }
-            // next chunk of this group
-            const int nci = ci + BLK_G;
-            const int nchunk = nci < U.chunkCount ? unitChunks[U.chunkBegin + nci] : -1;
-            int2 npr = {0, 0};
-            if (nchunk >= 0) { npr = chunkRange[nchunk]; nBase = winBase[nchunk * 16 + (t & 15)]; }
-            loadStream4<NV, false, true>(rCol, rCode, nullptr, npr.x, npr.y, nxt, (unsigned)t);
-#pragma unroll
-            for (int w = 0; w < NV; ++w) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned r = rel[4 * w + j];
-                    const double xx = r < (unsigned)U.winLen ? xw[r] : xv[4 * w + j];
-                    prod[j * PL + t + w * BS] = streamVal(cur.v[w], j, scale) * xx;
-                }
-            }
-            const int incl = waveInclusiveScan(len);
-            if ((t & 63) == 63) wtot[t >> 6] = incl;
-            __syncthreads();
-            {
-                const int4 wt = *reinterpret_cast<const int4*>(wtot);
-                const int wv = t >> 6;
-                const int ea = incl - len + (wv > 0 ? wt.x : 0) + (wv > 1 ? wt.y : 0) + (wv > 2 ? wt.z : 0);
-                const double s = rowSum<8, PL>(prod, ea, len);
-                if (MODE == 0 && mcCode) sc = row < (unsigned)nA ? dt * dict[mcc] : 1.;
-                bufStoreF64nt<true>(rOut, row * 8u, s * sc);                         // dropped past the last row / for an idle group
-            }
-            __syncthreads();
-            ci = nci; chunk = nchunk; pr = npr; cur = nxt; myBase = nBase;
-        }
-    }
-}
-template <int MODE, int NV, bool F64, bool NT>
+template <int MODE, int NV, bool F64, int POL>
 __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, const double* __restrict__ val4, int streamLen,
-                                                     const int32_t* __restrict__ winBase, const int2* __restrict__ chunkRange,
+                                                     const int32_t* __restrict__ winBase, const int4* __restrict__ chunkInfo,
                                                      const uint8_t* __restrict__ len8, double scale, const double* __restrict__ t, int cols, int rows,
                                                      const double* __restrict__ uInv, const double* __restrict__ xin, const double* __restrict__ add,
                                                      double* __restrict__ out, double* __restrict__ partial, const int* __restrict__ done,
-                                                     ChunkSched sched, int nChunks, int xcdAware, ChebArgs cheb,
+                                                     int nChunks, int xcdAware, ChebArgs cheb,
                                                      const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr) {
     if (done && *done) return;
     constexpr int PL = BS * NV;
+    constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;   // stores + per-row epilogue streams | the matrix stream
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
     __shared__ double dict[MODE != 1 ? 256 : 1];      // value-set coded uInv (ps_context.hpp: uCode)
@@ -562,7 +469,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                  rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0),
                                  rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0), rFcd = bufRsrc(fr.cd, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0),
                                  rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0);
-    const ChunkWalk W(xcdAware, sched);
+    const ChunkWalk W(xcdAware);
     int it = 0;
     int chunk = W.at(0);
     if (chunk >= nChunks) {
@@ -571,15 +478,15 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         return;
     }
     double dacc = 0., dacc2 = 0.;
-    int2 pr = chunkRange[chunk];
+    int4 pr = chunkInfo[chunk];
     Stream4<NV, F64> cur, nxt;
-    loadStream4<NV, F64, NT>(rCol, rCode, val4, pr.x, pr.y, cur);
+    loadStream4<NV, F64, SNT>(rCol, rCode, val4, pr.x, pr.y, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = W.at(1);
-    int2 npr = {0, 0};
-    if (nchunk < nChunks) npr = chunkRange[nchunk];
+    int4 npr = {0, 0, 0, 0};
+    if (nchunk < nChunks) npr = chunkInfo[nchunk];
     while (true) {
-        const unsigned row = (unsigned)chunk * BS + threadIdx.x;
+        const unsigned row = (int)threadIdx.x < pr.w ? (unsigned)pr.z + threadIdx.x : ROW_NONE;   // lanes past the chunk's rows: every access out of range
         const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, NT ? PS_EPI_AUX : 0);   // 0 past the last row
         const double e0 = bufLoadF64epi<NT>(rE0, row * 8u);                                       // x (MODE 0, 2) / the vector added (MODE 1)
         double e1 = 0., cr = 0., ci = 0., cd = 0.;
@@ -600,15 +507,15 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
         }
         Vals4<F64 ? NV : 0> cv;
-        if constexpr (F64) loadVals4<NV, NT>(val4, pr.x, pr.y, cv);
+        if constexpr (F64) loadVals4<NV, SNT>(val4, pr.x, pr.y, cv);
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream4<NV, F64, NT>(rCol, rCode, val4, npr.x, npr.y, nxt);
+            loadStream4<NV, F64, SNT>(rCol, rCode, val4, npr.x, npr.y, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = W.at(it + 2);
-        int2 nnpr = {0, 0};
-        if (nn < nChunks) nnpr = chunkRange[nn];
+        int4 nnpr = {0, 0, 0, 0};
+        if (nn < nChunks) nnpr = chunkInfo[nn];
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
             if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;

@@ -49,40 +49,26 @@ struct Launch {
         else { if (M.packed) PS_LAUNCH_S(1, true); else PS_LAUNCH_S(1, false); }
 #undef PS_LAUNCH_S
     }
-    static ChunkSched sched(const ps::DevCSR& M, unsigned grid) {
-        ChunkSched s;
-        s.list = (M.schedOk && grid >= 8 && grid % 8 == 0) ? M.sched.p : nullptr;
-        for (int q = 0; q < 9; ++q) s.off[q] = M.schedOff[q];
-        return s;
-    }
     // fused residual update (solve(): FusedR): where the S and tile kernels leave their shares of p.Ap (null: not asked for)
     double* sPart = nullptr;
     double* wvPart = nullptr;
     bool ntSpmv = true;   // cache policy of the pipelined kernels' streams (ps_context::ntLevel >= 1)
+    // POL of the pipelined kernels (ps_kernels_spmv.hpp): 0 = default policy; 1 = non-temporal stores and epilogue streams, cached matrix
+    // stream (most runs shared between chunks: read again and again); 3 = the matrix stream non-temporal too (every run read once)
+    int policy(const ps::DevCSR& M) const { return !ntSpmv ? 0 : (2 * M.uniqueLen <= M.streamLen ? 1 : 3); }
     int pipeGrid;   // 0: one-shot kernels; >0: persistent software-pipelined kernels with this many blocks
     int xcdAware;   // pipelined kernels: runs of this many chunks are dealt to the XCDs round robin (ChunkWalk); 0 = plain walk
     void spmvS(int mode, const double* x, double* out) const {
         if (rowsS == 0) return;
         const ps::DevCSR& M = c->S;
-        if (pipeGrid > 0 && M.col16ok && M.packed && M.nUnits > 0) {   // block-resident x (PS_BLK=1)
-            static const int blkGrid = getenv("PS_BLK_GRID") ? atoi(getenv("PS_BLK_GRID")) : 256;
-            const dim3 gr((unsigned)std::min(M.nUnits, blkGrid)), bl(BLK_T);
-#define PS_LAUNCH_SB(MODE_, NV_) hipLaunchKernelGGL((k_spmv_S_blk<MODE_, NV_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, \
-                                                    (const BlkUnit*)M.units.p, M.nUnits, M.unitChunks.p, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p)
-            if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SB(0, 1); else PS_LAUNCH_SB(1, 1); }
-            else { if (mode == 0) PS_LAUNCH_SB(0, 2); else PS_LAUNCH_SB(1, 2); }
-#undef PS_LAUNCH_SB
-            return;
-        }
         if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
-            const int nChunks = gridFor(rowsS, BS);
+            const int nChunks = c->S.nChunks;
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
-#define PS_LAUNCH_SP(MODE_, NV_, F64_, NT_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_, F64_, NT_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, sched(M, gr.x), nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart)
-#define PS_LAUNCH_SP2(MODE_, NV_) do { if (!M.packed) PS_LAUNCH_SP(MODE_, NV_, true, true); else if (ntSpmv) PS_LAUNCH_SP(MODE_, NV_, false, true); \
-                                       else PS_LAUNCH_SP(MODE_, NV_, false, false); } while (0)
+#define PS_LAUNCH_SP(MODE_, NV_, F64_, POL_) hipLaunchKernelGGL((k_spmv_S_pipe<MODE_, NV_, F64_, POL_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
+                                                    M.chunkInfo.p, M.len8.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart)
+#define PS_LAUNCH_SP2(MODE_, NV_) do { const int pol = policy(M); if (!M.packed) PS_LAUNCH_SP(MODE_, NV_, true, 3); else if (pol == 3) PS_LAUNCH_SP(MODE_, NV_, false, 3); \
+                                       else if (pol == 1) PS_LAUNCH_SP(MODE_, NV_, false, 1); else PS_LAUNCH_SP(MODE_, NV_, false, 0); } while (0)
             if (M.nv == 1) { if (mode == 0) PS_LAUNCH_SP2(0, 1); else PS_LAUNCH_SP2(1, 1); }
             else { if (mode == 0) PS_LAUNCH_SP2(0, 2); else PS_LAUNCH_SP2(1, 2); }
 #undef PS_LAUNCH_SP2
@@ -151,13 +137,13 @@ struct Launch {
         FusedR fr{};
         if (fused) fr = *fused;
         if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
-            const int nChunks = gridFor(rowsSt, BS);
+            const int nChunks = c->St.nChunks;
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
-#define PS_LAUNCH_TP(MODE_, NV_, F64_, NT_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_, NT_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
-                                                    M.chunkRange.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, sched(M, gr.x), nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr)
-#define PS_LAUNCH_TP2(MODE_, NV_) do { if (!M.packed) PS_LAUNCH_TP(MODE_, NV_, true, true); else if (ntSpmv) PS_LAUNCH_TP(MODE_, NV_, false, true); \
-                                       else PS_LAUNCH_TP(MODE_, NV_, false, false); } while (0)
+#define PS_LAUNCH_TP(MODE_, NV_, F64_, POL_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_, POL_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
+                                                    M.chunkInfo.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr)
+#define PS_LAUNCH_TP2(MODE_, NV_) do { const int pol = policy(M); if (!M.packed) PS_LAUNCH_TP(MODE_, NV_, true, 3); else if (pol == 3) PS_LAUNCH_TP(MODE_, NV_, false, 3); \
+                                       else if (pol == 1) PS_LAUNCH_TP(MODE_, NV_, false, 1); else PS_LAUNCH_TP(MODE_, NV_, false, 0); } while (0)
             if (mode == 3) {
                 if (!M.packed) throw Error("internal: fused residual update on the fp64 stream");
                 if (M.nv == 1) PS_LAUNCH_TP2(3, 1); else PS_LAUNCH_TP2(3, 2);
@@ -181,20 +167,18 @@ struct Launch {
         if (xcd > 0) { if (g >= 8) g &= ~7; else xcd = 0; }
         return g;
     }
-    // the fused step needs both products on the persistent coded-stream kernels (their per-workgroup partials) and the S kernel
-    // not on the block-resident prototype
+    // the fused step needs both products on the persistent coded-stream kernels (their per-workgroup partials)
     bool fusedOk() const {
-        return stOnPipe() && c->St.packed && pipeGrid > 0 && c->S.col16ok && c->S.packed && c->S.nUnits == 0 && rowsS > 0;
+        return stOnPipe() && c->St.packed && pipeGrid > 0 && c->S.col16ok && c->S.packed && rowsS > 0;
     }
     int sBlocks() const {
-        const int nChunks = gridFor(rowsS, BS);
+        const int nChunks = c->S.nChunks;
         int xcd = xcdAware;
         return pipeBlocks(nChunks, xcd, true);
     }
     int stBlocks() const {   // number of p.Ap partials the St kernel writes: one per block
-        const int nChunks = gridFor(rowsSt, BS);
         int xcd = xcdAware;
-        return stOnPipe() ? pipeBlocks(nChunks, xcd, c->St.packed) : nChunks;
+        return stOnPipe() ? pipeBlocks(c->St.nChunks, xcd, c->St.packed) : gridFor(rowsSt, BS);
     }
 };
 Launch mk(ps_context* c, const int* done) {
