@@ -623,6 +623,23 @@ def test_oracle_parity_with_the_large_system_switches_forced(tmp_path):
     assert " passed" in pr.stdout and "failed" not in pr.stdout, pr.stdout[-2000:]
 
 
+def test_shared_runs_on_a_periodic_scene(gpu, oracle_mod):
+    """Chunks of the compressed stream start at lattice-block / tile boundaries, and chunks with byte-identical runs share one run
+    (array `streamRuns` = distinct / all entries of S, then St).  A 64^3 cavity has 64 tiles in 27 neighbourhood classes: most of
+    the stream must be shared, and the operator must still be the oracle's."""
+    sc, p = scenes.cavity(64)
+    o = oracle_mod.Oracle()
+    o.run(sc, p, solve=False)
+    gpu.upload(sc, p)
+    gpu.setup()
+    r = gpu.array("streamRuns")
+    assert r[1] > 0 and r[3] > 0
+    assert r[0] <= 0.6 * r[1] and r[2] <= 0.6 * r[3], r          # the interior classes repeat
+    x = np.random.RandomState(5).standard_normal(gpu.nP + gpu.nT)
+    yo, yg = o.apply(x), gpu.apply(x)
+    assert np.abs(yo - yg).max() <= 1e-10 * np.abs(yo).max()
+
+
 def test_bad_parameters_are_refused(gpu):
     """A raw ABI caller gets an error (ps_last_error) instead of a division by zero or a non-finite system."""
     sc, p = scenes.cavity(16)
