@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
     const int r0 = cr.x;
     const int p0 = ptr[r0], p1 = ptr[r0 + cr.y];
     const int q0 = start4[chunk], q1 = start4[chunk + 1];          // q1 - q0 = (p1 - p0) rounded up to 4
-    if (threadIdx.x == 0) chunkInfo[chunk] = make_int4(q0, q0 + (p1 - p0), cr.x, cr.y);
+    if (threadIdx.x == 0) chunkInfo[chunk] = make_int4(q0, (p1 - p0) | (cr.y << 16), cr.x, cr.x);   // (run begin, entries | rows << 16, first row, row source)
     if ((int)threadIdx.x < cr.y) len8[r0 + threadIdx.x] = (uint8_t)(ptr[r0 + threadIdx.x + 1] - ptr[r0 + threadIdx.x]);
     constexpr int SL = 8;                               // <= 8 entries per row: <= 2048 entries per chunk
     if (p1 - p0 > SL * BS) { if (threadIdx.x == 0) *fail = 1; return; }
@@ -496,14 +496,14 @@ __global__ void __launch_bounds__(64) k_chunk_hash(const int4* __restrict__ chun
                                                    const uint8_t* __restrict__ len8, unsigned long long* __restrict__ hash) {
     const int chunk = blockIdx.x;
     const int4 ci = chunkInfo[chunk];
-    const int n4 = (ci.y - ci.x + 3) & ~3;
+    const int n4 = ((ci.y & 0xffff) + 3) & ~3, rows = (int)((unsigned)ci.y >> 16);
     unsigned long long h = 0;
     for (int i = threadIdx.x; i < n4; i += 64)                      // position-keyed terms: the sum does not depend on the order
         h += mix64(((unsigned long long)i << 32) | ((unsigned long long)col16[ci.x + i] << 8) | (uint8_t)code4[ci.x + i]);
-    for (int i = threadIdx.x; i < ci.w; i += 64) h += mix64(0x4000000000000000ull | ((unsigned long long)i << 32) | len8[ci.z + i]);
+    for (int i = threadIdx.x; i < rows; i += 64) h += mix64(0x4000000000000000ull | ((unsigned long long)i << 32) | len8[ci.z + i]);
     for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o, 64);
     if (threadIdx.x == 0) {
-        h = mix64(h ^ (((unsigned long long)(unsigned)n4 << 32) | (unsigned)ci.w));
+        h = mix64(h ^ (((unsigned long long)(unsigned)n4 << 32) | (unsigned)rows));
         hash[chunk] = h == HASH_EMPTY ? 0ull : h;
     }
 }
@@ -518,27 +518,36 @@ __global__ void k_chunk_rep_insert(const unsigned long long* __restrict__ hash, 
         if (cur == h) { atomicMin(&vals[slot], chunk); return; }
     }
 }
-// one workgroup per chunk: look the representative up, compare the payloads, redirect the run
+// one workgroup per chunk: look the representative up, compare the payloads, redirect the run and the row-byte source.
+// rowCode (may be null): the value-set codes of the kernel's diagonal (uCode per DOF; mcCode per ACTIVE face row, codeRows of them):
+// read per row like the length bytes, so they have to agree too for the rows that have one.
 __global__ void __launch_bounds__(64) k_chunk_share(const unsigned long long* __restrict__ hash, const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
                                                     unsigned mask, int4* __restrict__ chunkInfo, const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4,
-                                                    const uint8_t* __restrict__ len8, unsigned long long* __restrict__ uniqueLen) {
+                                                    const uint8_t* __restrict__ len8, const uint8_t* __restrict__ rowCode, int codeRows,
+                                                    unsigned long long* __restrict__ uniqueLen) {
     const int chunk = blockIdx.x;
     const unsigned long long h = hash[chunk];
     unsigned slot = (unsigned)(h >> 17) & mask;
     while (keys[slot] != h) slot = (slot + 1) & mask;                // present: inserted by k_chunk_rep_insert
     const int rep = vals[slot];
     const int4 ci = chunkInfo[chunk];
-    const int n4 = (ci.y - ci.x + 3) & ~3;
+    const int n = ci.y & 0xffff, n4 = (n + 3) & ~3, rows = (int)((unsigned)ci.y >> 16);
     bool same = rep != chunk;
     if (same) {
         const int4 cr = chunkInfo[rep];                              // a representative's entry is never rewritten (it is its own)
-        same = (cr.y - cr.x) == (ci.y - ci.x) && cr.w == ci.w;
+        same = cr.y == ci.y;
         if (same) {
             for (int i = threadIdx.x; i < n4; i += 64) same = same && col16[ci.x + i] == col16[cr.x + i] && code4[ci.x + i] == code4[cr.x + i];
-            for (int i = threadIdx.x; i < ci.w; i += 64) same = same && len8[ci.z + i] == len8[cr.z + i];
+            for (int i = threadIdx.x; i < rows; i += 64) {
+                same = same && len8[ci.z + i] == len8[cr.z + i];
+                if (rowCode) {
+                    const bool a = ci.z + i < codeRows, b = cr.z + i < codeRows;
+                    same = same && a == b && (!a || rowCode[ci.z + i] == rowCode[cr.z + i]);
+                }
+            }
         }
         same = __all(same) != 0;
-        if (same && threadIdx.x == 0) { chunkInfo[chunk].x = cr.x; chunkInfo[chunk].y = cr.y; }
+        if (same && threadIdx.x == 0) { chunkInfo[chunk].x = cr.x; chunkInfo[chunk].w = cr.z; }
     }
     if (!same && threadIdx.x == 0) atomicAdd(uniqueLen, (unsigned long long)n4);
 }
@@ -547,7 +556,7 @@ __global__ void __launch_bounds__(BS) k_val4_build(const int32_t* __restrict__ p
                                                    const int4* __restrict__ chunkInfo, double* __restrict__ val4) {
     const int chunk = blockIdx.x;
     const int4 ci = chunkInfo[chunk];
-    const int p0 = ptr[ci.z], n = ci.y - ci.x, q0 = ci.x;
+    const int p0 = ptr[ci.z], n = ci.y & 0xffff, q0 = ci.x;
     const int n4 = (n + 3) & ~3;
     for (int i = threadIdx.x; i < n4; i += BS) val4[q0 + i] = i < n ? val[p0 + i] : 0.;
 }
@@ -560,7 +569,7 @@ void ps_context::buildVal4(ps::DevCSR& M) {
 // Compressed SpMV stream (DevCSR::col16 ...); decided per matrix.  With coded values it is 3 B per entry; when the values are
 // not code * scale (user-supplied weights, PS_FORCE_FP64_VALUES=1) the same windowed 16-bit columns go with the fp64 values
 // (10 B per entry, DevCSR::val4) and the same pipelined kernels run.  PS_COL32=1 keeps the one-shot CSR kernels.
-void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>& cuts) {
+void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>& cuts, const uint8_t* rowCode, int codeRows) {
     M.col16ok = false;
     M.nChunks = 0;
     M.val4.free();
@@ -626,7 +635,7 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
                            (const uint8_t*)M.len8.p, hash.p);
         hipLaunchKernelGGL(k_chunk_rep_insert, dim3(gridFor(nChunks, BS)), dim3(BS), 0, stream, (const unsigned long long*)hash.p, nChunks, keys.p, vals.p, cap - 1);
         hipLaunchKernelGGL(k_chunk_share, dim3((unsigned)nChunks), dim3(64), 0, stream, (const unsigned long long*)hash.p, (const unsigned long long*)keys.p,
-                           (const int32_t*)vals.p, cap - 1, M.chunkInfo.p, (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p, (const uint8_t*)M.len8.p, uniq.p);
+                           (const int32_t*)vals.p, cap - 1, M.chunkInfo.p, (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p, (const uint8_t*)M.len8.p, rowCode, codeRows, uniq.p);
         unsigned long long u = 0;
         HIP_CHECK(hipMemcpyAsync(&u, uniq.p, 8, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -729,8 +738,8 @@ void ps_context::buildStreams(bool share) {
     }
     if (!blockStartSys.empty() && (int64_t)blockStartSys.back() == nSystem) cutsT = blockStartSys;
     shareRuns = share;
-    buildCol16(S, 22, cutsS);
-    buildCol16(St, 23, cutsT);
+    buildCol16(S, 22, cutsS, mcCoded ? mcCode.p : nullptr, (int)nActiveVs);
+    buildCol16(St, 23, cutsT, uCoded ? uCode.p : nullptr, (int)nSystem);
 }
 
 // ConstructMatrixBlocks.cpp:9-292
@@ -860,8 +869,8 @@ void ps_context::constructMatrixBlocks() {
         const int32_t flag = S.packed ? 1 : 0;
         HIP_CHECK(hipMemcpyAsync(counters.p + 21, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
+        buildDiagonalCodes();   // before the streams: chunks that share a run also share their rows' diagonal codes
         buildStreams(true);
-        buildDiagonalCodes();
         const int32_t c16 = (S.col16ok ? 1 : 0) | (St.col16ok ? 2 : 0);
         HIP_CHECK(hipMemcpyAsync(counters.p + 24, &c16, sizeof(c16), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

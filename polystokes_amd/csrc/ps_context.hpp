@@ -28,7 +28,7 @@ struct DevCSR {
     DevBuf<int8_t> code4;
     DevBuf<double> val4;         // the fp64 values in the same aligned chunk layout (only when the values are not coded)
     DevBuf<int32_t> winBase;
-    DevBuf<int4> chunkInfo;      // (run begin, run end, first row, row count)
+    DevBuf<int4> chunkInfo;      // (run begin, entries | rows << 16, first row, first row of the run's owner) — ps_kernels_spmv.hpp:Chunk
     DevBuf<uint8_t> len8;
     int nChunks = 0;
     int64_t uniqueLen = 0;       // entries of the runs some chunk actually points at (== streamLen without sharing)
@@ -211,7 +211,7 @@ struct ps_context {
     void computeReducedViscosityMatricesInteriorOnly();
     void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
     void constructMatrixBlocks();                         // ps_blocks.hip
-    void buildCol16(ps::DevCSR& M, int counterSlot, const std::vector<int32_t>& cuts);   // ps_blocks.hip; cuts: row indices where a chunk should start
+    void buildCol16(ps::DevCSR& M, int counterSlot, const std::vector<int32_t>& cuts, const uint8_t* rowCode, int codeRows);   // ps_blocks.hip; cuts: row indices where a chunk should start
     void buildStreams(bool share);                        // both compressed streams (ps_blocks.hip)
     bool shareRuns = true;
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)

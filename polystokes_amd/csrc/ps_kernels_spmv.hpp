@@ -335,6 +335,10 @@ __device__ inline double rowSum(const double* prod, int ea, int len) {
     for (int k = 0; k < ML; ++k) s = k < len ? s + v[k] : s;
     return s;
 }
+// chunkInfo entry (DevCSR::chunkInfo): x = first entry of the run, y = entries | rows << 16, z = first row, w = first row of the
+// chunk whose run this is (== z unless the run is shared: the per-row BYTE streams — lengths, value-set codes — are read there too)
+struct Chunk { int q0, q1, row0, rows, src; };
+__host__ __device__ inline Chunk decodeChunk(int4 v) { return Chunk{v.x, v.x + (v.y & 0xffff), v.z, (int)((unsigned)v.y >> 16), v.w}; }
 constexpr unsigned ROW_NONE = 0x1fffffffu;   // row index of an idle lane: beyond any array (rows * 8 < 4 GiB), positive as an int
 // Both kernels: gathers of the current chunk, prefetch of the next, products to LDS (entry e of the chunk at
 // prod[(e & 3) * PL + (e >> 2)]: conflict-free writes), row offsets from the length bytes (wave scans + 4 wave totals).
@@ -350,6 +354,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     if (done && *done) return;
     constexpr int PL = BS * NV;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;   // stores + per-row epilogue streams | the matrix stream
+    constexpr bool BNT = NT && SNT;                               // the per-row byte streams go with the runs: cached when runs are shared
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
     __shared__ double dict[MODE == 0 ? 256 : 1];      // value-set coded McInv (ps_context.hpp: mcCode): first read after the loop's first barrier
@@ -363,42 +368,43 @@ __global__ void __launch_bounds__(BS) k_spmv_S_pipe(const uint16_t* __restrict__
     int chunk = W.at(0);
     if (chunk >= nChunks) { if (MODE == 0 && stPart && threadIdx.x == 0) stPart[blockIdx.x] = 0.; return; }
     double stAcc = 0.;
-    int4 pr = chunkInfo[chunk];
+    Chunk pr = decodeChunk(chunkInfo[chunk]);
     Stream4<NV, F64> cur, nxt;
-    loadStream4<NV, F64, SNT>(rCol, rCode, val4, pr.x, pr.y, cur);
+    loadStream4<NV, F64, SNT>(rCol, rCode, val4, pr.q0, pr.q1, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = W.at(1);
-    int4 npr = {0, 0, 0, 0};
-    if (nchunk < nChunks) npr = chunkInfo[nchunk];
+    Chunk npr{0, 0, 0, 0, 0};
+    if (nchunk < nChunks) npr = decodeChunk(chunkInfo[nchunk]);
     while (true) {
-        const unsigned row = (int)threadIdx.x < pr.w ? (unsigned)pr.z + threadIdx.x : ROW_NONE;   // lanes past the chunk's rows: every access out of range
-        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, NT ? PS_EPI_AUX : 0);   // 0 past the last row
+        const bool live = (int)threadIdx.x < pr.rows;                                   // lanes past the chunk's rows: every access out of range
+        const unsigned row = live ? (unsigned)pr.row0 + threadIdx.x : ROW_NONE, srow = live ? (unsigned)pr.src + threadIdx.x : ROW_NONE;
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)srow, 0, BNT ? PS_EPI_AUX : 0);   // 0 past the last row
         double sc = 1.;
         int mcc = 0;
         if (MODE == 0) {
-            if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, NT ? PS_EPI_AUX : 0);
+            if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)srow, 0, BNT ? PS_EPI_AUX : 0);
             else { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
         }
         double xv[4 * NV];
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
-            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
+            if (w > 0 && pr.q0 + 4 * w * BS >= pr.q1) break;                  // block-uniform: this group of the chunk is empty
 #pragma unroll
             for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rX, streamCol(cur.c[w], j, myBase) * 8u);
         }
         Vals4<F64 ? NV : 0> cv;
-        if constexpr (F64) loadVals4<NV, SNT>(val4, pr.x, pr.y, cv);
+        if constexpr (F64) loadVals4<NV, SNT>(val4, pr.q0, pr.q1, cv);
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream4<NV, F64, SNT>(rCol, rCode, val4, npr.x, npr.y, nxt);
+            loadStream4<NV, F64, SNT>(rCol, rCode, val4, npr.q0, npr.q1, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = W.at(it + 2);
-        int4 nnpr = {0, 0, 0, 0};
-        if (nn < nChunks) nnpr = chunkInfo[nn];
+        Chunk nnpr{0, 0, 0, 0, 0};
+        if (nn < nChunks) nnpr = decodeChunk(chunkInfo[nn]);
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
-            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
+            if (w > 0 && pr.q0 + 4 * w * BS >= pr.q1) break;
 #pragma unroll
             for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = prodVal<F64>(cur, cv, w, j, scale) * xv[4 * w + j];
         }
@@ -436,6 +442,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
     if (done && *done) return;
     constexpr int PL = BS * NV;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;   // stores + per-row epilogue streams | the matrix stream
+    constexpr bool BNT = NT && SNT;                               // the per-row byte streams go with the runs: cached when runs are shared
     __shared__ double prod[4 * PL];
     __shared__ __align__(16) int wtot[BS / 64];
     __shared__ double dict[MODE != 1 ? 256 : 1];      // value-set coded uInv (ps_context.hpp: uCode)
@@ -478,20 +485,21 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         return;
     }
     double dacc = 0., dacc2 = 0.;
-    int4 pr = chunkInfo[chunk];
+    Chunk pr = decodeChunk(chunkInfo[chunk]);
     Stream4<NV, F64> cur, nxt;
-    loadStream4<NV, F64, SNT>(rCol, rCode, val4, pr.x, pr.y, cur);
+    loadStream4<NV, F64, SNT>(rCol, rCode, val4, pr.q0, pr.q1, cur);
     int myBase = winBase[chunk * 16 + (threadIdx.x & 15)], nBase = 0;
     int nchunk = W.at(1);
-    int4 npr = {0, 0, 0, 0};
-    if (nchunk < nChunks) npr = chunkInfo[nchunk];
+    Chunk npr{0, 0, 0, 0, 0};
+    if (nchunk < nChunks) npr = decodeChunk(chunkInfo[nchunk]);
     while (true) {
-        const unsigned row = (int)threadIdx.x < pr.w ? (unsigned)pr.z + threadIdx.x : ROW_NONE;   // lanes past the chunk's rows: every access out of range
-        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)row, 0, NT ? PS_EPI_AUX : 0);   // 0 past the last row
+        const bool live = (int)threadIdx.x < pr.rows;                                   // lanes past the chunk's rows: every access out of range
+        const unsigned row = live ? (unsigned)pr.row0 + threadIdx.x : ROW_NONE, srow = live ? (unsigned)pr.src + threadIdx.x : ROW_NONE;
+        const int len = (int)__builtin_amdgcn_raw_buffer_load_b8(rLen, (int)srow, 0, BNT ? PS_EPI_AUX : 0);   // 0 past the last row
         const double e0 = bufLoadF64epi<NT>(rE0, row * 8u);                                       // x (MODE 0, 2) / the vector added (MODE 1)
         double e1 = 0., cr = 0., ci = 0., cd = 0.;
         int uc = 0;
-        if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, NT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
+        if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)srow, 0, BNT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
         if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }
         float fdv = 1.f;
         if (MODE == 3) {
@@ -502,23 +510,23 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         double xv[4 * NV];
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
-            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;                  // block-uniform: this group of the chunk is empty
+            if (w > 0 && pr.q0 + 4 * w * BS >= pr.q1) break;                  // block-uniform: this group of the chunk is empty
 #pragma unroll
             for (int j = 0; j < 4; ++j) xv[4 * w + j] = bufGatherF64(rT, streamCol(cur.c[w], j, myBase) * 8u);
         }
         Vals4<F64 ? NV : 0> cv;
-        if constexpr (F64) loadVals4<NV, SNT>(val4, pr.x, pr.y, cv);
+        if constexpr (F64) loadVals4<NV, SNT>(val4, pr.q0, pr.q1, cv);
         const bool hasNext = nchunk < nChunks;
         if (hasNext) {
-            loadStream4<NV, F64, SNT>(rCol, rCode, val4, npr.x, npr.y, nxt);
+            loadStream4<NV, F64, SNT>(rCol, rCode, val4, npr.q0, npr.q1, nxt);
             nBase = winBase[nchunk * 16 + (threadIdx.x & 15)];
         }
         const int nn = W.at(it + 2);
-        int4 nnpr = {0, 0, 0, 0};
-        if (nn < nChunks) nnpr = chunkInfo[nn];
+        Chunk nnpr{0, 0, 0, 0, 0};
+        if (nn < nChunks) nnpr = decodeChunk(chunkInfo[nn]);
 #pragma unroll
         for (int w = 0; w < NV; ++w) {
-            if (w > 0 && pr.x + 4 * w * BS >= pr.y) break;
+            if (w > 0 && pr.q0 + 4 * w * BS >= pr.q1) break;
 #pragma unroll
             for (int j = 0; j < 4; ++j) prod[j * PL + threadIdx.x + w * BS] = prodVal<F64>(cur, cv, w, j, scale) * xv[4 * w + j];
         }

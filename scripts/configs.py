@@ -18,7 +18,7 @@ if world == 1:
     for rep in range(2):
         t0 = time.time(); rc = s.step_device(); dtm = (time.time() - t0) * 1e3
         print(name, n, "rc", rc, "n", s.nP + s.nT, "iters", int(s.stats.solveData[1]), "step ms %.1f" % dtm,
-              "setup ms %.1f" % sum(s.stats.stage_ms[i] for i in range(8)), "regions", s.nRegions, flush=True)
+              "setup ms %.1f" % sum(s.stats.stage_ms[i] for i in range(8)), "regions", s.nRegions, "stream runs (S distinct/all, St distinct/all)", list(s.array("streamRuns")), flush=True)
 else:
     g = polystokes_amd.Group(world)
     for r in range(world):
