@@ -57,6 +57,7 @@ struct Launch {
     // stream (most runs shared between chunks: read again and again); 3 = the matrix stream non-temporal too (every run read once)
     int policy(const ps::DevCSR& M) const { return !ntSpmv ? 0 : (2 * M.uniqueLen <= M.streamLen ? 1 : 3); }
     int pipeGrid;   // 0: one-shot kernels; >0: persistent software-pipelined kernels with this many blocks
+    int stGrid = 0; // > 0: the St kernel's own cap
     int xcdAware;   // pipelined kernels: runs of this many chunks are dealt to the XCDs round robin (ChunkWalk); 0 = plain walk
     void spmvS(int mode, const double* x, double* out) const {
         if (rowsS == 0) return;
@@ -139,7 +140,7 @@ struct Launch {
         if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
             const int nChunks = c->St.nChunks;
             int xcdAware = this->xcdAware;
-            const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed)), bl(BS);
+            const dim3 gr(pipeBlocks(nChunks, xcdAware, M.packed, stGridFor(mode))), bl(BS);
 #define PS_LAUNCH_TP(MODE_, NV_, F64_, POL_) hipLaunchKernelGGL((k_spmv_St_pipe<MODE_, NV_, F64_, POL_>), gr, bl, 0, c->stream, M.col16.p, M.code4.p, M.val4.p, (int)M.streamLen, M.winBase.p, \
                                                     M.chunkInfo.p, M.len8.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr)
 #define PS_LAUNCH_TP2(MODE_, NV_) do { const int pol = policy(M); if (!M.packed) PS_LAUNCH_TP(MODE_, NV_, true, 3); else if (pol == 3) PS_LAUNCH_TP(MODE_, NV_, false, 3); \
@@ -161,9 +162,9 @@ struct Launch {
     // grid of a persistent kernel; the XCD-grouped walk needs a multiple of 8 blocks (workgroup b runs on XCD b & 7)
     // The fp64-value stream (10 B per entry) runs one chunk per workgroup: measured at 256^3 St 0.54 ms against 0.64 ms
     // persistent (the persistent walk pays when the stream is short and the loop is issue-bound, not when it is 3x heavier).
-    int pipeBlocks(int nChunks, int& xcd, bool packed) const {
+    int pipeBlocks(int nChunks, int& xcd, bool packed, int gridCap = 0) const {
         if (!packed) { xcd = 0; return nChunks; }
-        int g = std::min(nChunks, pipeGrid);
+        int g = std::min(nChunks, gridCap > 0 ? gridCap : pipeGrid);
         if (xcd > 0) { if (g >= 8) g &= ~7; else xcd = 0; }
         return g;
     }
@@ -176,9 +177,14 @@ struct Launch {
         int xcd = xcdAware;
         return pipeBlocks(nChunks, xcd, true);
     }
-    int stBlocks() const {   // number of p.Ap partials the St kernel writes: one per block
+    // Workgroups of the St kernel.  With the residual update in its epilogue (mode 3) it runs best on 6 per CU — measured at 256^3,
+    // rocprof average in a solve: 1280 / 1536 workgroups 415 us, 1792 489, 2048 445, 2560 / 3072 425, 4096 430 (and every workgroup
+    // less is 10 K partial sums less to read in the prologue); S and the other St modes keep 16 per CU (S: 300 us at 4096, 324 at
+    // 1536, 339 at 1024).  PS_PIPE_GRID_ST overrides.
+    int stGridFor(int mode) const { return stGrid > 0 ? stGrid : (mode == 3 && pipeGrid >= 1536 ? 1536 : 0); }
+    int stBlocks(int mode = 0) const {   // number of partials the St kernel writes: one per block
         int xcd = xcdAware;
-        return stOnPipe() ? pipeBlocks(c->St.nChunks, xcd, c->St.packed) : gridFor(rowsSt, BS);
+        return stOnPipe() ? pipeBlocks(c->St.nChunks, xcd, c->St.packed, stGridFor(mode)) : gridFor(rowsSt, BS);
     }
 };
 Launch mk(ps_context* c, const int* done) {
@@ -191,13 +197,15 @@ Launch mk(ps_context* c, const int* done) {
         pg = g ? atoi(g) : 4096;                   // persistent pipelined kernels, 16 blocks per CU, by default
     }
     L.pipeGrid = pg;
+    static const int sg = getenv("PS_PIPE_GRID_ST") ? atoi(getenv("PS_PIPE_GRID_ST")) : 0;
+    L.stGrid = pg > 0 ? sg : 0;
     static int xa = -1;
     if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 16; }   // chunks per XCD run (rounded down to a power of two); 0: plain walk
     L.xcdAware = xa > 0 ? xa : 0;
     L.ntSpmv = c->ntLevel() >= 1;
     return L;
 }
-constexpr int64_t FUSED_STEP_MIN_ROWS = 12000000;   // see solve()
+constexpr int64_t FUSED_STEP_MIN_ROWS = 2000000;   // see solve()
 constexpr int64_t NT_LEVEL1_MIN_ROWS = 4000000, NT_LEVEL2_MIN_ROWS = 10000000;   // see ps_context::ntLevel
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
 }  // namespace
@@ -361,7 +369,7 @@ int ps_context::solve() {
     CGScalars* sc = scal.p;
     const int* done = &sc->done;
     Launch L = mk(this, done);
-    const int stBlocks = L.stBlocks();
+    const int stBlocks = L.stBlocks(0), stBF = L.stBlocks(3);   // workgroups of the St kernel: plain / with the residual update
     double* zvec = nullptr; double* dvec = nullptr; double* rzPart = nullptr;
     if (cheb) {
         tmp1.alloc((size_t)n); tmp2.alloc((size_t)n);
@@ -383,11 +391,11 @@ int ps_context::solve() {
     // + 1/2 sum uInv p^2) is complete before the St kernel starts, so that kernel forms alpha and updates r in its epilogue —
     // A p is neither written nor read back (16 B per row less) and the step is four launches (FusedR, ps_kernels_spmv.hpp).
     // Every St workgroup sums the partials of three producers in its prologue (up to 4096 + regions + 1024 + 1024 values, from
-    // L2): a fixed ~15 us per iteration, against 16 B per row saved.  Measured us per iteration, fused / five-kernel: 64^3
-    // (0.8 M rows) 71 / 63, 128^3 (5.9 M) 199 / 189, 160^3 (11.4 M) 339 / 336, 192^3 (19.4 M) 536 / 576, 256^3 (45 M) 1147 / 1248
-    // -> on from 12 M rows.  (Folding the partials 64 to
-    // 1 in the producers with a ticket per group costs more than it saves: one device-scope atomic per workgroup, +30 us per
-    // iteration with write-through stores and no fence, +650 us with __threadfence(), which flushes the XCD's L2.)
+    // L2): a fixed cost per iteration, against 16 B per row saved.  Measured us per iteration, four / five kernels (St on 1536
+    // workgroups, shared runs): 64^3 (0.8 M rows) 58.8 / 57.3, 96^3 (2.6 M) 93.2 / 95.6, 128^3 (5.9 M) 164.8 / 175.5, 160^3 (11.4 M)
+    // 285.9 / 309.3, 192^3 (19.4 M) 466.7 / 506.5, 256^3 (45 M) 1147 / 1248 (before shared runs) -> on from 2 M rows.  (Folding the
+    // partials 64 to 1 in the producers with a ticket per group costs more than it saves: one device-scope atomic per workgroup,
+    // +30 us per iteration with write-through stores and no fence, +650 us with __threadfence(), which flushes the XCD's L2.)
     // PS_FUSED_R = 0 / 1 forces it off / on (on only where the kernels exist).
     static const int fusedEnv = getenv("PS_FUSED_R") ? atoi(getenv("PS_FUSED_R")) : -1;
     const bool fused = fusedEnv != 0 && (fusedEnv > 0 || n >= FUSED_STEP_MIN_ROWS) && L.fusedOk();
@@ -396,7 +404,7 @@ int ps_context::solve() {
     double *fS = nullptr, *fT = nullptr, *fU = nullptr, *fR = nullptr;
     const uint8_t* ucode = uCoded ? uCode.p : nullptr;
     if (fused) {
-        fusedPart.alloc((size_t)sBlocks + (size_t)regionCount + VGRID + 2 * (size_t)stBlocks + 16);
+        fusedPart.alloc((size_t)sBlocks + (size_t)regionCount + VGRID + 2 * (size_t)stBF + 16);
         fS = fusedPart.p; fT = fS + sBlocks; fU = fT + regionCount; fR = fU + VGRID;
         L.sPart = fS; L.wvPart = fT;
     }
@@ -427,15 +435,15 @@ int ps_context::solve() {
                 L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                 const int c2 = chebyshevApply(r.p, zvec, dvec, rzPart, sc, true);
                 const double* part; int cnt;
-                if (c2 > 0) rzReduce(rzPart, c2, part, cnt); else { part = fR + stBlocks; cnt = stBlocks; }
-                hipLaunchKernelGGL(k_cg_update_xp_z_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBlocks, part, cnt, it, (const double*)zvec,
+                if (c2 > 0) rzReduce(rzPart, c2, part, cnt); else { part = fR + stBF; cnt = stBF; }
+                hipLaunchKernelGGL(k_cg_update_xp_z_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, part, cnt, it, (const double*)zvec,
                                    x.p, pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
                 continue;
             }
             if (fused) {
                 const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, dv, fR, nullptr, 0., nullptr, nullptr};
                 L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
-                hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBlocks, dv ? 1 : 0, it, (const double*)r.p, dv, x.p,
+                hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, dv ? 1 : 0, it, (const double*)r.p, dv, x.p,
                                    pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
                 continue;
             }
