@@ -161,9 +161,10 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 // 8 waves/SIMD.  Here a block loops over row chunks (grid = #CUs x 16) and, while the gathers / LDS reduction of
 // chunk i are in flight, the stream of chunk i+1 is already loading into a second register set and the bounds of
 // chunk i+2 are being fetched.  They read the compressed form of the matrix built by ps_context::buildCol16:
-//   * per 256-row chunk a 4-entry-aligned run of (16-bit windowed column, int8 value code): 3 B per entry, fetched as
-//     one 8-byte + one 4-byte load per lane for 4 consecutive entries,
-//   * 16 window bases and an (begin, end) pair per chunk, one row-length byte per row (prefix-summed in the block)
+//   * per chunk (<= 256 consecutive rows, starting at lattice-block / tile boundaries) a 4-entry-aligned run of (16-bit windowed
+//     column, int8 value code): 3 B per entry, fetched as one 8-byte + one 4-byte load per lane for 4 consecutive entries — chunks
+//     whose runs are byte-identical share ONE run (ps_blocks.hip: k_chunk_share), which then comes from cache,
+//   * 16 window bases and a Chunk record (below) per chunk, one row-length byte per row (prefix-summed in the block)
 // and reproduce the fp64 CSR product bit for bit (same values, same summation order within a row).
 //
 // chunk walk of a persistent block.  Plain: chunk = block + it * grid.  Grouped (G = xcdAware > 0): workgroups b, b+8, ...
