@@ -597,10 +597,10 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
         }
     }
     const int nChunks = (int)rowsOf.size();
-    DevBuf<int2> chunkRows;
+    DevBuf<int2>& chunkRows = scrChunkRows;      // setup scratch kept with the context: a hipMalloc / hipFree pair per build costs more than the kernels
     chunkRows.alloc((size_t)nChunks);
     HIP_CHECK(hipMemcpyAsync(chunkRows.p, rowsOf.data(), (size_t)nChunks * sizeof(int2), hipMemcpyHostToDevice, stream));
-    DevBuf<int32_t> start4;
+    DevBuf<int32_t>& start4 = scrStart4;
     start4.alloc((size_t)nChunks + 1);
     HIP_CHECK(hipMemsetAsync(counters.p + 25, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(k_chunk_len4, dim3(gridFor(nChunks + 1, BS)), dim3(BS), 0, stream, M.ptr.p, (const int2*)chunkRows.p, nChunks, start4.p, counters.p + 25);
@@ -625,8 +625,8 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
     if (M.col16ok && M.packed && shareRuns && !noShare && nChunks > 1) {          // coded values only: the fp64 values of equal codes need not be equal bits
         unsigned cap = 1024;
         while (cap < 4u * (unsigned)nChunks) cap <<= 1;
-        DevBuf<unsigned long long> hash, keys, uniq;
-        DevBuf<int32_t> vals;
+        DevBuf<unsigned long long>& hash = scrHash; DevBuf<unsigned long long>& keys = scrKeys; DevBuf<unsigned long long>& uniq = scrUniq;
+        DevBuf<int32_t>& vals = scrVals;
         hash.alloc((size_t)nChunks); keys.alloc(cap); vals.alloc(cap); uniq.alloc(1);
         HIP_CHECK(hipMemsetAsync(keys.p, 0xff, (size_t)cap * 8, stream));
         HIP_CHECK(hipMemsetAsync(vals.p, 0x7f, (size_t)cap * 4, stream));

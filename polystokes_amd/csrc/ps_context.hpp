@@ -214,6 +214,7 @@ struct ps_context {
     void buildCol16(ps::DevCSR& M, int counterSlot, const std::vector<int32_t>& cuts, const uint8_t* rowCode, int codeRows);   // ps_blocks.hip; cuts: row indices where a chunk should start
     void buildStreams(bool share);                        // both compressed streams (ps_blocks.hip)
     bool shareRuns = true;
+    ps::DevBuf<int2> scrChunkRows; ps::DevBuf<int32_t> scrStart4, scrVals, scrKeep, scrRemap; ps::DevBuf<unsigned long long> scrHash, scrKeys, scrUniq;   // buildCol16 scratch
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
     void assembleSystemPressureStressFactored();          // ps_solve.hip

@@ -896,7 +896,7 @@ void ps_context::constructCenterReducedIndices() {
     if (regionCount > 0) {
         const int64_t R = regionCount;
         bbox.alloc((size_t)R * 6);
-        DevBuf<int32_t> keep, remap;
+        DevBuf<int32_t>& keep = scrKeep; DevBuf<int32_t>& remap = scrRemap;
         keep.alloc((size_t)R);
         remap.alloc((size_t)R);
         hipLaunchKernelGGL(k_bbox_init, dim3(gridFor(R, BS)), bl, 0, stream, bbox.p, R);
@@ -996,7 +996,7 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     hipLaunchKernelGGL(k_il_count, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nbk, counters.p + 8);
     const int nBlocks = (int)(run / per);
-    DevBuf<int32_t> bstart;
+    DevBuf<int32_t>& bstart = scrStart4;      // scratch kept with the context (also the stream build's)
     bstart.alloc((size_t)nBlocks + 1);
     hipLaunchKernelGGL(k_il_assign, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p, o, counters.p + 10, bstart.p);
     const int64_t total = readCounter(8);
