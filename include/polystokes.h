@@ -199,7 +199,11 @@ int32_t ps_apply_preconditioner(ps_context* ctx, const double* r, double* z);
 /* Inspection of solver state by name — the data behind printAllData()'s 43 point clouds
  * (Solver.cpp:1030-1074) and exportComponentMatrices() (Solver.cpp:543-566).
  * ps_query_array returns the element count (or <0 if unknown) and the element size in bytes;
- * ps_read_array copies it to host. */
+ * ps_read_array copies it to host.
+ * Beside the reference's arrays there are a few int32 diagnostics of the device path: "valuesCoded" (1: stencil values are
+ * int8 codes), "columns16" (bit 0 / 1: S / St have the compressed 16-bit-column stream), "diagonalsCoded" (bit 0 / 1: uInv /
+ * McInv are 1-byte value-set codes), "fusedStep" (1: the last PCG solve ran the four-kernel step), "streamRuns" (4 values:
+ * entries of the distinct runs / all entries of the compressed stream of S, then of St). */
 int64_t ps_query_array(ps_context* ctx, const char* name, int32_t* elem_bytes);
 int32_t ps_read_array(ps_context* ctx, const char* name, void* dst, int64_t dst_bytes);
 
