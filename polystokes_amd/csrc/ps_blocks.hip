@@ -493,13 +493,15 @@ __device__ inline unsigned long long mix64(unsigned long long x) {
     return x;
 }
 __global__ void __launch_bounds__(64) k_chunk_hash(const int4* __restrict__ chunkInfo, const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4,
-                                                   const uint8_t* __restrict__ len8, unsigned long long* __restrict__ hash) {
+                                                   const uint8_t* __restrict__ len8, unsigned long long* __restrict__ hash, int weak) {
     const int chunk = blockIdx.x;
     const int4 ci = chunkInfo[chunk];
     const int n4 = ((ci.y & 0xffff) + 3) & ~3, rows = (int)((unsigned)ci.y >> 16);
     unsigned long long h = 0;
+    if (!weak)                                                      // weak (test switch): lengths only — different payloads collide, the byte compare decides
     for (int i = threadIdx.x; i < n4; i += 64)                      // position-keyed terms: the sum does not depend on the order
         h += mix64(((unsigned long long)i << 32) | ((unsigned long long)col16[ci.x + i] << 8) | (uint8_t)code4[ci.x + i]);
+    if (!weak)
     for (int i = threadIdx.x; i < rows; i += 64) h += mix64(0x4000000000000000ull | ((unsigned long long)i << 32) | len8[ci.z + i]);
     for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o, 64);
     if (threadIdx.x == 0) {
@@ -622,6 +624,7 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
     M.col16ok = readCounter(slot) == 0;
     if (M.col16ok && !M.packed) buildVal4(M);
     static const bool noShare = getenv("PS_NO_SHARED_RUNS") && atoi(getenv("PS_NO_SHARED_RUNS")) != 0;
+    static const bool weakHash = getenv("PS_WEAK_CHUNK_HASH") && atoi(getenv("PS_WEAK_CHUNK_HASH")) != 0;   // test: force hash collisions
     if (M.col16ok && M.packed && shareRuns && !noShare && nChunks > 1) {          // coded values only: the fp64 values of equal codes need not be equal bits
         unsigned cap = 1024;
         while (cap < 4u * (unsigned)nChunks) cap <<= 1;
@@ -632,7 +635,7 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
         HIP_CHECK(hipMemsetAsync(vals.p, 0x7f, (size_t)cap * 4, stream));
         HIP_CHECK(hipMemsetAsync(uniq.p, 0, 8, stream));
         hipLaunchKernelGGL(k_chunk_hash, dim3((unsigned)nChunks), dim3(64), 0, stream, (const int4*)M.chunkInfo.p, (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p,
-                           (const uint8_t*)M.len8.p, hash.p);
+                           (const uint8_t*)M.len8.p, hash.p, weakHash ? 1 : 0);
         hipLaunchKernelGGL(k_chunk_rep_insert, dim3(gridFor(nChunks, BS)), dim3(BS), 0, stream, (const unsigned long long*)hash.p, nChunks, keys.p, vals.p, cap - 1);
         hipLaunchKernelGGL(k_chunk_share, dim3((unsigned)nChunks), dim3(64), 0, stream, (const unsigned long long*)hash.p, (const unsigned long long*)keys.p,
                            (const int32_t*)vals.p, cap - 1, M.chunkInfo.p, (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p, (const uint8_t*)M.len8.p, rowCode, codeRows, uniq.p);

@@ -515,7 +515,7 @@ def test_exported_system_import_errors(gpu, tmp_path):
                                  {"PS_FUSED_R": "1"},
                                  {"PS_FUSED_R": "1", "PS_TILE_SPLIT": "1"}, {"PS_FUSED_R": "1", "PS_NO_DIAG_CODES": "1"},
                                  {"PS_NT_LEVEL": "1"}, {"PS_NT_LEVEL": "2"}, {"PS_FUSED_R": "1", "PS_NT_LEVEL": "2"},
-                                 {"PS_NO_SHARED_RUNS": "1"}, {"PS_CHUNK_PLAIN": "1"}, {"PS_CHUNK_PLAIN": "1", "PS_FUSED_R": "1", "PS_NT_LEVEL": "2"}])
+                                 {"PS_NO_SHARED_RUNS": "1"}, {"PS_CHUNK_PLAIN": "1"}, {"PS_WEAK_CHUNK_HASH": "1"}, {"PS_CHUNK_PLAIN": "1", "PS_FUSED_R": "1", "PS_NT_LEVEL": "2"}])
 def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     """The SpMV has four storage formats chosen at setup — compressed stream with int8 value codes (3 B/nnz) or with fp64
     values (10 B/nnz: values that are not code * scale), both on the pipelined kernels; int8-coded CSR and fp64 CSR on the
