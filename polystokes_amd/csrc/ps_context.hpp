@@ -222,7 +222,7 @@ struct ps_context {
     int solve();
     void estimateLambdaMax();
     void applyPreconditionerDevice(const double* r, double* z, double* scratch);   // z = M^-1 r (parity hook, ps_apply_preconditioner)
-    int chebyshevApply(const double* rvec, double* z, double* d, double* rzPartial, const ps::CGScalars* sc, bool firstDone = false);
+    int chebyshevApply(const double* rvec, double* zA, double* zB, double* rzPartial, const ps::CGScalars* sc, bool firstDone = false, double** zOut = nullptr);
     double chebTheta() const;
     int ntLevel() const;
     int solveEigenCG();                                   // Solver.cpp:814-862 on the factored device operator

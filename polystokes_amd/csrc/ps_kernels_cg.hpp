@@ -342,31 +342,31 @@ __global__ void __launch_bounds__(BS) k_sum1(const double* __restrict__ partial,
     if (threadIdx.x == 0) *out = s;
 }
 // ---- Chebyshev-Jacobi polynomial preconditioner (PS_PRE_CHEBYSHEV) -------------------------------------------------
-// first term: d = z = dinv r / theta ; partial of r.z (used when the polynomial has this one term only)
+// first term: z_1 = dinv r / theta ; partial of r.z (used when the polynomial has this one term only)
 __global__ void __launch_bounds__(BS) k_cheb_first(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
-                                                   double invTheta, double* __restrict__ d, double* __restrict__ z, int64_t n, double* __restrict__ partial) {
+                                                   double invTheta, double* __restrict__ z, int64_t n, double* __restrict__ partial) {
     if (sc && sc->done) return;
     double acc = 0.;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = r[i];
         const double v = dinv[i] * rv * invTheta;
-        d[i] = v; z[i] = v;
+        z[i] = v;
         acc += rv * v;
     }
     const double s = blockReduceSum(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
-// a later term, unfused form (the St kernel's MODE 2 epilogue does the same per row): Az given
+// a later term, unfused form (the St kernel's MODE 2 epilogue does the same per row): Az = A z_j given; z_{j+1} -> znext, which may be
+// the z_{j-1} buffer (zprev null: z_{j-1} = 0)
 __global__ void __launch_bounds__(BS) k_cheb_step(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
-                                                  const double* __restrict__ Az, double c1, double c2, double* __restrict__ d, double* __restrict__ z,
-                                                  int64_t n, double* __restrict__ partial) {
+                                                  const double* __restrict__ Az, double c1, double c2, const double* __restrict__ z, const double* zprev,
+                                                  double* znext, int64_t n, double* __restrict__ partial) {
     if (sc && sc->done) return;
     double acc = 0.;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
-        const double rv = r[i];
-        const double dn = c1 * d[i] + c2 * (dinv[i] * (rv - Az[i]));
-        const double zn = z[i] + dn;
-        d[i] = dn; z[i] = zn;
+        const double rv = r[i], zj = z[i];
+        const double zn = zj + (c1 * (zj - (zprev ? zprev[i] : 0.)) + c2 * (dinv[i] * (rv - Az[i])));
+        znext[i] = zn;
         acc += rv * zn;
     }
     const double s = blockReduceSum(acc);

@@ -171,9 +171,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 // run on XCD b & 7 (verified with s_getreg HW_REG_XCC_ID), so runs of G consecutive chunks are dealt to the XCDs round
 // robin — rows that gather the same lines of x (k-plane neighbours, a few chunks apart) then share ONE L2, while
 // the chip as a whole still sweeps one compact window of memory.
-// MODE 2 of the St kernel: one term of the Chebyshev preconditioner fused into the epilogue (ps_context::solve):
-//   Az = (A z)[row];  d[row] = c1 d[row] + c2 dinv[row] (r[row] - Az);  z[row] += d[row];  partial += r[row] z[row]
-struct ChebArgs { const double* r; const double* dinv; double* d; double c1, c2; };
+// MODE 2 of the St kernel: one term of the Chebyshev preconditioner fused into the epilogue (ps_context::chebyshevApply), in its
+// three-term form (no difference vector to keep):  Az = (A z_j)[row];  z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 dinv (r - Az);
+// partial += r z_{j+1}.  z_j is the kernel's x (xin), z_{j-1} is read from zprev (null: zero) and z_{j+1} goes to `out` — the
+// caller passes the z_{j-1} buffer: every row is read and then written by the same thread.
+struct ChebArgs { const double* r; const double* dinv; const double* zprev; double c1, c2; };
 // MODE 3 of the St kernel: the residual update of the PCG step inside the epilogue.  x . A x is known BEFORE the kernel starts,
 // from the factored form:  x.Ax = -( sum_active s_f t_f  +  sum_tiles w.v  +  1/2 sum_j uInv_j x_j^2 )  (partials of the S kernel,
 // of the tile kernel and of k_cg_update_xp) — so every workgroup forms alpha itself and does r -= alpha (A p) on its rows with
@@ -187,9 +189,9 @@ struct FusedR {
     int it;
     double* r; const float* dinvF;        // residual (updated in place), fp32 Jacobi diagonal (null: identity)
     double* rPart;                        // out: partials of r.r at [block], of r.z at [gridDim + block]
-    // Chebyshev preconditioner: the polynomial's first term on the new r, d = z = dinv r / theta (null: not asked for; then r.z
+    // Chebyshev preconditioner: the polynomial's first term on the new r, z_1 = dinv r / theta -> cz (null: not asked for; then r.z
     // above is that of the Jacobi diagonal)
-    const double* dinv64; double invTheta; double* cd; double* cz;
+    const double* dinv64; double invTheta; double* cz;
 };
 // Walk of a persistent workgroup over the chunk ids: runs of G = 1 << sh consecutive chunks are dealt to the 8 XCDs round robin
 // (workgroup b runs on XCD b & 7), inside an XCD to its workgroups in order; sh < 0: plain grid-stride walk
@@ -473,10 +475,9 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                  rE0 = bufRsrc(MODE == 1 ? add : xin, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8),
                                  rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
-                                 rCd = bufRsrc(cheb.d, MODE == 2 ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
+                                 rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
                                  rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0),
-                                 rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0), rFcd = bufRsrc(fr.cd, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0),
-                                 rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cd) ? (size_t)rows * 8 : 0);
+                                 rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0);
     const ChunkWalk W(xcdAware);
     int it = 0;
     int chunk = W.at(0);
@@ -501,12 +502,12 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         double e1 = 0., cr = 0., ci = 0., cd = 0.;
         int uc = 0;
         if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)srow, 0, BNT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
-        if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }
+        if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }   // cd = z_{j-1} (0: no buffer)
         float fdv = 1.f;
         if (MODE == 3) {
             cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, NT ? PS_EPI_AUX : 0));
             if (fr.dinvF) fdv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(row * 4u), 0, NT ? PS_EPI_AUX : 0));
-            if (fr.cd) ci = bufLoadF64epi<NT>(rF64, row * 8u);
+            if (fr.cz) ci = bufLoadF64epi<NT>(rF64, row * 8u);
         }
         double xv[4 * NV];
 #pragma unroll
@@ -548,17 +549,16 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                 const double rv = cr - alpha * y;                                // pcg.h:316
                 dacc += rv * rv;
                 dacc2 += fr.dinvF ? rv * ((double)fdv * rv) : 0.;
-                if (fr.cd) {                                                     // k_cheb_first on this row
+                if (fr.cz) {                                                     // k_cheb_first on this row
                     const double v = ci * rv * fr.invTheta;
-                    bufStoreF64nt<NT>(rFcd, row * 8u, v); bufStoreF64nt<NT>(rFcz, row * 8u, v);
+                    bufStoreF64nt<NT>(rFcz, row * 8u, v);
                     dacc2 += rv * v;
                 }
                 y = rv;
             }
             else {
                 double az = -s; az -= 0.5 * e1 * e0;
-                const double dn = cheb.c1 * cd + cheb.c2 * (ci * (cr - az));
-                bufStoreF64nt<NT>(rCd, row * 8u, dn);
+                const double dn = cheb.c1 * (e0 - cd) + cheb.c2 * (ci * (cr - az));
                 y = e0 + dn;
                 dacc += cr * y;                                                  // r.z of the updated z
             }
@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         if (threadIdx.x == 0) partial[blockIdx.x] = bs;   // gridDim.x partials (Launch::stBlocks)
     }
     if (MODE == 3) {
-        const double b0 = blockReduceSum(dacc), b1 = (fr.dinvF || fr.cd) ? blockReduceSum(dacc2) : 0.;
+        const double b0 = blockReduceSum(dacc), b1 = (fr.dinvF || fr.cz) ? blockReduceSum(dacc2) : 0.;
         if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[gridDim.x + blockIdx.x] = b1; }
     }
 }

@@ -303,12 +303,14 @@ void ps_context::estimateLambdaMax() {
 }
 
 // z = q(D^-1 A) D^-1 r: k terms of the Chebyshev iteration on [lmax/30, lmax] (k-1 operator applies), see include/polystokes.h.
-// Terms 2..k run as S, tiles and the St kernel with the update fused into its epilogue (MODE 2): per term the St kernel reads
-// r, dinv, d besides its own operands and writes d and z in place — no separate vector pass.  rzPartial receives the partials
-// of r.z of the final z (count returned); `sc` (may be null) lets the kernels of a converged solve exit early.
-// firstDone: the caller already holds the first term d = z = dinv r / theta (the St kernel of the four-kernel PCG step forms it
-// on the rows it updates) — with a one-term polynomial nothing is launched and 0 is returned.
-int ps_context::chebyshevApply(const double* rvec, double* z, double* d, double* rzPartial, const ps::CGScalars* sc, bool firstDone) {
+// Three-term form: z_1 = D^-1 r / theta, z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 D^-1 (r - A z_j) — two buffers, zA and zB, taking turns
+// (z_1 in zA, z_2 in zB, z_3 in zA, ...); *zOut is the one holding the final z.  Terms 2..k run as S, tiles and the St kernel with the
+// update fused into its epilogue (MODE 2): per term it reads r, dinv, z_{j-1} besides its own operands and writes z_{j+1} over
+// z_{j-1} — no separate vector pass.  rzPartial receives the partials of r.z of the final z (count returned); `sc` (may be null) lets
+// the kernels of a converged solve exit early.
+// firstDone: the caller already holds z_1 in zA (the St kernel of the four-kernel PCG step forms it on the rows it updates) — with
+// a one-term polynomial nothing is launched and 0 is returned.
+int ps_context::chebyshevApply(const double* rvec, double* zA, double* zB, double* rzPartial, const ps::CGScalars* sc, bool firstDone, double** zOut) {
     const int64_t n = nSystem;
     const int k = P.preconditionerDegree > 0 ? P.preconditionerDegree : 4;
     const double lmax = chebLmax, lmin = lmax / 30.;
@@ -317,25 +319,29 @@ int ps_context::chebyshevApply(const double* rvec, double* z, double* d, double*
     const int vb = dotBlocks(n);
     const int* done = sc ? &sc->done : nullptr;
     Launch L = mk(this, done);
-    if (!firstDone) hipLaunchKernelGGL(k_cheb_first, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, 1. / theta, d, z, n, rzPartial);
+    if (!firstDone) hipLaunchKernelGGL(k_cheb_first, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, 1. / theta, zA, n, rzPartial);
     int count = firstDone ? 0 : vb;
+    double* cur = zA; double* other = zB;    // z_j, and the buffer of z_{j-1} that receives z_{j+1}
     for (int j = 1; j < k; ++j) {
         const double rhoN = 1. / (2. * sigma - rho);
         const double c1 = rhoN * rho, c2 = 2. * rhoN / delta;
-        L.spmvS(0, z, ts.p);
+        const double* zprev = j == 1 ? nullptr : other;            // z_0 = 0
+        L.spmvS(0, cur, ts.p);
         L.tiles(0, ts.p);
         if (L.stOnPipe()) {
-            const ChebArgs ca{rvec, dinv.p, d, c1, c2};
-            L.spmvSt(2, ts.p, z, nullptr, z, rzPartial, &ca);
+            const ChebArgs ca{rvec, dinv.p, zprev, c1, c2};
+            L.spmvSt(2, ts.p, cur, nullptr, other, rzPartial, &ca);
             count = L.stBlocks();
         } else {
             tmp5.alloc((size_t)n);
-            L.spmvSt(0, ts.p, z, nullptr, tmp5.p, dotPartials2.p);
-            hipLaunchKernelGGL(k_cheb_step, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, (const double*)tmp5.p, c1, c2, d, z, n, rzPartial);
+            L.spmvSt(0, ts.p, cur, nullptr, tmp5.p, dotPartials2.p);
+            hipLaunchKernelGGL(k_cheb_step, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, (const double*)tmp5.p, c1, c2, (const double*)cur, zprev, other, n, rzPartial);
             count = vb;
         }
+        std::swap(cur, other);
         rho = rhoN;
     }
+    if (zOut) *zOut = cur;
     return count;
 }
 
@@ -345,7 +351,9 @@ void ps_context::applyPreconditionerDevice(const double* rvec, double* z, double
     const int vb = dotBlocks(n);
     if (P.preconditioner == PS_PRE_CHEBYSHEV) {
         chebPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(n, BS)) + 16);
-        chebyshevApply(rvec, z, scratch, chebPartials.p, nullptr);
+        double* zfin = z;
+        chebyshevApply(rvec, z, scratch, chebPartials.p, nullptr, false, &zfin);
+        if (zfin != z) HIP_CHECK(hipMemcpyAsync(z, zfin, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     } else if (P.preconditioner == PS_PRE_DIAGONAL) {
         hipLaunchKernelGGL(k_mulv, dim3(vb), dim3(BS), 0, stream, z, dinv.p, rvec, n);   // the fp64 diagonal (the PCG kernels read its fp32 copy)
     } else {
@@ -413,8 +421,9 @@ int ps_context::solve() {
     hipLaunchKernelGGL(k_cg_init_f, dim3(vb), dim3(BS), 0, stream, b.p, dv, x.p, r.p, pvec.p, n, dotPartials.p);
     if (cheb) {   // z = M^-1 r, p = z, rsold = r.z
         HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(CGScalars), stream));   // `done` must read 0 inside the polynomial's kernels
-        const int cnt0 = chebyshevApply(r.p, zvec, dvec, rzPart, nullptr);
-        HIP_CHECK(hipMemcpyAsync(pvec.p, zvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        double* z0 = zvec;
+        const int cnt0 = chebyshevApply(r.p, zvec, dvec, rzPart, nullptr, false, &z0);
+        HIP_CHECK(hipMemcpyAsync(pvec.p, z0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(BS), 0, stream, rzPart, cnt0, dotPartials.p);
         hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, 1, tol, maxit, ntLevel() >= 2 ? 1 : 0);
     } else
@@ -431,17 +440,18 @@ int ps_context::solve() {
             L.spmvS(0, pvec.p, ts.p);
             L.tiles(0, ts.p);
             if (fused && cheb) {   // St kernel: r -= alpha A p and the polynomial's first term on the new r; then terms 2..k; then x, p
-                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, nullptr, fR, dinv.p, 1. / chebTheta(), dvec, zvec};
+                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, nullptr, fR, dinv.p, 1. / chebTheta(), zvec};
                 L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
-                const int c2 = chebyshevApply(r.p, zvec, dvec, rzPart, sc, true);
+                double* zfin = zvec;
+                const int c2 = chebyshevApply(r.p, zvec, dvec, rzPart, sc, true, &zfin);
                 const double* part; int cnt;
                 if (c2 > 0) rzReduce(rzPart, c2, part, cnt); else { part = fR + stBF; cnt = stBF; }
-                hipLaunchKernelGGL(k_cg_update_xp_z_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, part, cnt, it, (const double*)zvec,
+                hipLaunchKernelGGL(k_cg_update_xp_z_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, part, cnt, it, (const double*)zfin,
                                    x.p, pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
                 continue;
             }
             if (fused) {
-                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, dv, fR, nullptr, 0., nullptr, nullptr};
+                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, dv, fR, nullptr, 0., nullptr};
                 L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                 hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, dv ? 1 : 0, it, (const double*)r.p, dv, x.p,
                                    pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
@@ -458,8 +468,9 @@ int ps_context::solve() {
                                r.p, n, dotPartialsR.p);
             if (cheb) {
                 const double* part; int cnt;
-                rzReduce(rzPart, chebyshevApply(r.p, zvec, dvec, rzPart, sc), part, cnt);
-                hipLaunchKernelGGL(k_cg_update_xp_z, dim3(vb), dim3(BS), 0, stream, sc, (const double*)dotPartialsR.p, vb, part, cnt, it, (const double*)zvec,
+                double* zfin = zvec;
+                rzReduce(rzPart, chebyshevApply(r.p, zvec, dvec, rzPart, sc, false, &zfin), part, cnt);
+                hipLaunchKernelGGL(k_cg_update_xp_z, dim3(vb), dim3(BS), 0, stream, sc, (const double*)dotPartialsR.p, vb, part, cnt, it, (const double*)zfin,
                                    x.p, pvec.p, n, dotPartials3.p);
             } else
             hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, dotPartialsR.p, vb, dv ? 1 : 0, it, r.p, dv, x.p,
@@ -676,7 +687,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         const uint8_t* ucode = c->uCoded ? c->uCode.p : nullptr;
         if (base == "spmv_St_r") {   // the St kernel of the four-kernel step: r (scratch) -= 0 * A x in the epilogue
             if (!L.fusedOk()) throw Error("no fused step on this system");
-            const FusedR fr{scratch.p, ones.p, VGRID, zeros.p, 0, zeros.p, 0, ones.p, 0, 0, c->tmp5.p, dvf, c->dotPartials.p, nullptr, 0., nullptr, nullptr};
+            const FusedR fr{scratch.p, ones.p, VGRID, zeros.p, 0, zeros.p, 0, ones.p, 0, 0, c->tmp5.p, dvf, c->dotPartials.p, nullptr, 0., nullptr};
             L.spmvSt(3, c->ts.p, x, nullptr, nullptr, nullptr, nullptr, &fr);
         }
         else if (base == "cg_update_xp_u")
