@@ -63,10 +63,11 @@ enum ps_solver_type { PS_PCG_MATRIX_VECTOR_PRODUCTS = 0, PS_EIGEN = 1 };
 /* lib/include/units.h:47-53; DIAGONAL is the empty stub at
  * exec/HDK_PolyStokesSolver_Preconditioners.cpp:37-41 that BASELINE.json asks for (Jacobi-PCG). */
 /* PS_PRE_CHEBYSHEV (extension): z = q(D^-1 A) D^-1 r with q the degree-(k-1) Chebyshev polynomial
- * of the interval [lmax/30, lmax], D = diag(A), k = ps_params.preconditionerDegree (default 4): k-1 operator applies per
+ * of the interval [lmax/PS_CHEB_INTERVAL_RATIO, lmax], D = diag(A), k = ps_params.preconditionerDegree (default 4): k-1 operator applies per
  * CG iteration, the same smoother-as-preconditioner idea as the reference's abandoned GS designs
  * (lib/src/Preconditioner.cpp:30-158) on the live pressure-stress operator.  lmax = max(8.4, 1.25 x the estimate of 10 power iterations at setup). */
 enum ps_preconditioner { PS_PRE_IDENTITY = 1, PS_PRE_DIAGONAL = 5, PS_PRE_CHEBYSHEV = 6 };
+#define PS_CHEB_INTERVAL_RATIO 250.0   /* lmax / lmin of the Chebyshev interval: flat optimum 120..1000 on the 256^3 scenes (30: 5 % slower) */
 /* order in which serialAssignFieldIndices walks a field (Classifier.cpp:1738-1770):
  * 0 = UT_VoxelArray order (16^3 voxel tiles, tile-linear, x-fastest inside), 1 = plain x-fastest. */
 enum ps_index_order { PS_ORDER_VOXEL_TILES = 0, PS_ORDER_LINEAR = 1 };

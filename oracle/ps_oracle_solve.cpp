@@ -169,11 +169,11 @@ void Oracle::estimateLambdaMax() {
     }
     chebLmax = std::max(8.4, 1.25 * lam);
 }
-// k terms of the Chebyshev iteration for D^-1 A z = D^-1 r from z = 0 on [lmax/30, lmax] (k-1 operator applies)
+// k terms of the Chebyshev iteration for D^-1 A z = D^-1 r from z = 0 on [lmax/PS_CHEB_INTERVAL_RATIO, lmax] (k-1 operator applies)
 void Oracle::chebyshev(const std::vector<double>& r, std::vector<double>& z) const {
     const size_t n = r.size();
     const int k = P.preconditionerDegree > 0 ? P.preconditionerDegree : 4;
-    const double lmax = chebLmax, lmin = lmax / 30.;
+    const double lmax = chebLmax, lmin = lmax / PS_CHEB_INTERVAL_RATIO;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho = 1. / sigma;
     std::vector<double> d(n), Az(n);

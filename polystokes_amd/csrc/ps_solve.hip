@@ -274,7 +274,8 @@ int ps_context::ntLevel() const {
     return nSystem < NT_LEVEL1_MIN_ROWS ? 0 : (nSystem < NT_LEVEL2_MIN_ROWS ? 1 : 2);
 }
 
-double ps_context::chebTheta() const { return 0.5 * (chebLmax + chebLmax / 30.); }   // centre of the interval [lmax/30, lmax]
+static double chebRatio() { static const double r = getenv("PS_CHEB_RATIO") ? atof(getenv("PS_CHEB_RATIO")) : PS_CHEB_INTERVAL_RATIO; return r; }   // lmax / lmin (PS_CHEB_RATIO: experiments only — the oracle uses the constant)
+double ps_context::chebTheta() const { return 0.5 * (chebLmax + chebLmax / chebRatio()); }   // centre of the interval [lmax/250, lmax]
 
 void ps_context::estimateLambdaMax() {
     // 10 steps of the power iteration on D^-1 A from the ones vector, Rayleigh quotient of the last step (oracle:
@@ -302,7 +303,7 @@ void ps_context::estimateLambdaMax() {
     chebLmax = std::max(8.4, 1.25 * lam);
 }
 
-// z = q(D^-1 A) D^-1 r: k terms of the Chebyshev iteration on [lmax/30, lmax] (k-1 operator applies), see include/polystokes.h.
+// z = q(D^-1 A) D^-1 r: k terms of the Chebyshev iteration on [lmax/250, lmax] (k-1 operator applies), see include/polystokes.h.
 // Three-term form: z_1 = D^-1 r / theta, z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 D^-1 (r - A z_j) — two buffers, zA and zB, taking turns
 // (z_1 in zA, z_2 in zB, z_3 in zA, ...); *zOut is the one holding the final z.  Terms 2..k run as S, tiles and the St kernel with the
 // update fused into its epilogue (MODE 2): per term it reads r, dinv, z_{j-1} besides its own operands and writes z_{j+1} over
@@ -313,7 +314,7 @@ void ps_context::estimateLambdaMax() {
 int ps_context::chebyshevApply(const double* rvec, double* zA, double* zB, double* rzPartial, const ps::CGScalars* sc, bool firstDone, double** zOut) {
     const int64_t n = nSystem;
     const int k = P.preconditionerDegree > 0 ? P.preconditionerDegree : 4;
-    const double lmax = chebLmax, lmin = lmax / 30.;
+    const double lmax = chebLmax, lmin = lmax / chebRatio();
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho = 1. / sigma;
     const int vb = dotBlocks(n);
