@@ -92,6 +92,30 @@ def test_solution_satisfies_reference_stop_rule(big):
     assert vel[0][N - 1].mean() > 10 * abs(vel[0][0]).mean() and abs(vel[0]).max() <= 1.0
 
 
+def test_large_system_paths_and_chebyshev_at_full_size(big):
+    """What switches on by size ran in the solve above: the four-kernel PCG step, and a compressed stream whose chunks share their
+    runs (256^3 cavity: 4096 tiles in 125 neighbourhood classes -> under 2 % distinct entries).  Then the same system with the
+    Chebyshev preconditioner: the reference's stop rule on the true residual, and at least 3.5x fewer iterations than Jacobi."""
+    sc, p, s = big
+    assert s.solve() == abi.SUCCESS
+    it_jacobi = int(s.stats.solveData[1])
+    assert int(s.array("fusedStep")[0]) == 1
+    r = s.array("streamRuns")
+    assert 0 < r[0] <= 0.02 * r[1] and 0 < r[2] <= 0.02 * r[3], r
+    p2 = type(p).from_buffer_copy(p)
+    p2.preconditioner = abi.PRE_CHEBYSHEV
+    s.upload(sc, p2)
+    s.setup()
+    assert s.solve() == abi.SUCCESS
+    x, b = s.array("solutionVector"), s.array("b")
+    res = b - s.apply(x)
+    rre = min(res @ res, (res @ res) / (x @ x))
+    assert rre < p.tolerance ** 2 * 1.001
+    assert 0 < s.stats.solveData[1] * 3.5 <= it_jacobi, (s.stats.solveData[1], it_jacobi)
+    s.upload(sc, p)      # leave the module's context as the other tests expect it
+    s.setup()
+
+
 def test_config2_coil_128_properties():
     """BASELINE config 2 stand-in at its real size (128^3 coil, tile 16 / pad 2): free surface, solid floor, air."""
     import polystokes_amd
