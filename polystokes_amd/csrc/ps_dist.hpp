@@ -353,29 +353,108 @@ struct Dist {
                                                           : "another rank found its exchange lists in disagreement");
     }
 
-    // everything after the per-rank local setup: finish b and the Jacobi diagonal across the cuts
+    using Vec = DevBuf<double> ps_context::*;
+    // out = A in on the owned DOFs of every rank: halo values of `in` fetched, local products, halo contributions of `out` returned
+    void applyDist(Vec in, Vec out) {
+        exchangeX(in);
+        for (ps_context* c : R) {
+            Launch L = mk(c, nullptr);
+            L.spmvS(0, (c->*in).p, c->ts.p);
+            L.tiles(0, c->ts.p);
+            L.spmvSt(0, c->ts.p, (c->*in).p, nullptr, (c->*out).p, c->dotPartials.p);
+        }
+        exchangeAddY(out);
+    }
+    // lambda_max(D^-1 A) for the Chebyshev interval, as ps_context::estimateLambdaMax but with the distributed operator and the
+    // two sums reduced over the ranks: every rank ends with the same value
+    void estimateLambdaMaxDist() {
+        Vec V = &ps_context::tmp1, W = &ps_context::tmp2;
+        const Vec AV = &ps_context::tmp3;
+        for (ps_context* c : R) {
+            const size_t nl = (size_t)std::max<int64_t>(c->nSystem, 1);
+            c->tmp1.alloc(nl); c->tmp2.alloc(nl); c->tmp3.alloc(nl);
+            c->chebPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(std::max<int64_t>(c->nSystem, 1), BS)) + 16);
+            c->dotPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(std::max<int64_t>(c->nSystem, 1), BS)) + 16);
+            hipLaunchKernelGGL(k_fill_f64, dim3(dotBlocks((int64_t)nl)), dim3(BS), 0, c->stream, c->tmp1.p, 1., (int64_t)nl);
+            HIP_CHECK(hipMemsetAsync(c->tmp2.p, 0, nl * 8, c->stream));
+        }
+        for (int it = 0; it < 10; ++it) {
+            applyDist(V, AV);
+            for (ps_context* c : R) {
+                const int64_t n = c->ownHi - c->ownLo, lo = c->ownLo;
+                const int vb = dotBlocks(std::max<int64_t>(n, 1));
+                hipLaunchKernelGGL(k_power_step, dim3(vb), dim3(BS), 0, c->stream, (const double*)(c->*V).p + lo, (const double*)c->tmp3.p + lo,
+                                   (const double*)c->dinv.p + lo, (c->*W).p + lo, n, c->chebPartials.p);
+            }
+            std::swap(V, W);
+        }
+        for (ps_context* c : R) {
+            const int vb = dotBlocks(std::max<int64_t>(c->ownHi - c->ownLo, 1));
+            hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)nullptr, (const double*)c->chebPartials.p, vb, vb, 2, c->redbuf.p);
+        }
+        allreduce(2);
+        double h[2] = {0., 0.};
+        HIP_CHECK(hipMemcpyAsync(h, R[0]->redbuf.p, sizeof(h), hipMemcpyDeviceToHost, R[0]->stream));
+        syncAll();
+        const double lam = (h[0] > 0. && std::isfinite(h[1] / h[0])) ? h[1] / h[0] : 0.;
+        for (ps_context* c : R) c->chebLmax = std::max(8.4, 1.25 * lam);
+    }
+    // z = q(D^-1 A) D^-1 r on the owned DOFs (ps_context::chebyshevApply with the distributed operator; the update of a term is
+    // its own kernel here: A z is complete only after the halo contributions have come back).  Returns the vector holding z;
+    // the partials of r.z of the final z are in chebPartials (dotBlocks(owned) of them per rank).
+    Vec chebyshevDist(Vec Rv) {
+        ps_context* c0 = R[0];
+        const int k = c0->P.preconditionerDegree > 0 ? c0->P.preconditionerDegree : 4;
+        const double lmax = c0->chebLmax, lmin = lmax / PS_CHEB_INTERVAL_RATIO;
+        const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+        double rho = 1. / sigma;
+        Vec cur = &ps_context::tmp1, other = &ps_context::tmp2;
+        const Vec AZ = &ps_context::tmp5;
+        for (ps_context* c : R) {
+            const int64_t n = c->ownHi - c->ownLo, lo = c->ownLo;
+            hipLaunchKernelGGL(k_cheb_first, dim3(dotBlocks(std::max<int64_t>(n, 1))), dim3(BS), 0, c->stream, (const CGScalars*)c->scal.p, (const double*)(c->*Rv).p + lo,
+                               (const double*)c->dinv.p + lo, 1. / theta, c->tmp1.p + lo, n, c->chebPartials.p);
+        }
+        for (int j = 1; j < k; ++j) {
+            const double rhoN = 1. / (2. * sigma - rho);
+            const double c1 = rhoN * rho, c2 = 2. * rhoN / delta;
+            applyDist(cur, AZ);
+            for (ps_context* c : R) {
+                const int64_t n = c->ownHi - c->ownLo, lo = c->ownLo;
+                hipLaunchKernelGGL(k_cheb_step, dim3(dotBlocks(std::max<int64_t>(n, 1))), dim3(BS), 0, c->stream, (const CGScalars*)c->scal.p, (const double*)(c->*Rv).p + lo,
+                                   (const double*)c->dinv.p + lo, (const double*)c->tmp5.p + lo, c1, c2, (const double*)(c->*cur).p + lo,
+                                   j == 1 ? (const double*)nullptr : (const double*)(c->*other).p + lo, (c->*other).p + lo, n, c->chebPartials.p);
+            }
+            std::swap(cur, other);
+            rho = rhoN;
+        }
+        return cur;
+    }
+
+    // everything after the per-rank local setup: finish b and the Jacobi diagonal across the cuts; the Chebyshev interval
     void finishSetup() {
         for (ps_context* c : R) c->redbuf.alloc(8);
         checkLists();
         exchangeAddY(&ps_context::b);
-        const bool jac = R[0]->P.preconditioner == PS_PRE_DIAGONAL;
-        if (jac) {
+        const bool jac = R[0]->P.preconditioner == PS_PRE_DIAGONAL, cheb = R[0]->P.preconditioner == PS_PRE_CHEBYSHEV;
+        if (jac || cheb) {
             exchangeAddY(&ps_context::dinv);
             for (ps_context* c : R) {
                 const int64_t n = c->ownHi - c->ownLo;
                 if (n > 0) {
                     hipLaunchKernelGGL(k_invert_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, n);
-                    hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);
+                    if (jac) hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);
                 }
             }
         }
+        if (cheb) estimateLambdaMaxDist();
     }
 
     int solve() {
         ps_context* c0 = R[0];
         const int maxit = c0->P.maxSolverIterations;
         const double tol = c0->P.tolerance;
-        const bool jac = c0->P.preconditioner == PS_PRE_DIAGONAL;
+        const bool jac = c0->P.preconditioner == PS_PRE_DIAGONAL, cheb = c0->P.preconditioner == PS_PRE_CHEBYSHEV;
         if (c0->P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { c0->err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
         struct Loc { int64_t n, lo; int vb, stBlocks; const float* dv; CGScalars* sc; Launch L; };
         std::vector<Loc> loc(R.size());
@@ -398,6 +477,23 @@ struct Dist {
             HIP_CHECK(hipMemsetAsync(c->dotPartials3.p, 0, VGRID * sizeof(double), c->stream));
             hipLaunchKernelGGL(k_cg_init_f, dim3(l.vb), dim3(BS), 0, c->stream, c->b.p + l.lo, l.dv, c->x.p + l.lo, c->r.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials.p);
             hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)nullptr, c->dotPartials.p, l.vb, 0, 1, c->redbuf.p);
+        }
+        if (cheb) {   // z = M^-1 r, p = z, rsold = r.z
+            for (ps_context* c : R) {
+                const size_t nl = (size_t)std::max<int64_t>(c->nSystem, 1);
+                c->tmp1.alloc(nl); c->tmp2.alloc(nl); c->tmp5.alloc(nl);
+                c->chebPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor((int64_t)nl, BS)) + 16);
+                HIP_CHECK(hipMemsetAsync(c->scal.p, 0, sizeof(CGScalars), c->stream));   // `done` must read 0 inside the polynomial's kernels
+                HIP_CHECK(hipMemsetAsync(c->tmp1.p, 0, nl * 8, c->stream));
+                HIP_CHECK(hipMemsetAsync(c->tmp2.p, 0, nl * 8, c->stream));
+            }
+            const Vec z0 = chebyshevDist(&ps_context::r);
+            for (size_t q = 0; q < R.size(); ++q) {
+                ps_context* c = R[q];
+                Loc& l = loc[q];
+                if (l.n > 0) HIP_CHECK(hipMemcpyAsync(c->pvec.p + l.lo, (c->*z0).p + l.lo, (size_t)l.n * 8, hipMemcpyDeviceToDevice, c->stream));
+                hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)nullptr, (const double*)c->chebPartials.p, l.vb, 0, 1, c->redbuf.p);
+            }
         }
         allreduce(1);
         for (size_t q = 0; q < R.size(); ++q)
@@ -434,6 +530,22 @@ struct Dist {
                     hipLaunchKernelGGL(k_cg_update_r, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, (const double*)nullptr, 0,
                                        (const double*)nullptr, 0, it, c->Ap.p + l.lo, l.dv, c->r.p + l.lo, l.n, c->dotPartialsR.p);
                     hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, c->dotPartialsR.p, l.vb, l.vb, 2, c->redbuf.p);
+                }
+                if (cheb) {   // z = M^-1 r (k-1 distributed applies), then {r.r, r.z} and x, p with the vector z
+                    const Vec zf = chebyshevDist(&ps_context::r);
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)c->chebPartials.p, l.vb, 0, 1, c->redbuf.p + 1);
+                    }
+                    allreduce(2);
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        hipLaunchKernelGGL(k_cg_update_xp_z, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, 1, (const double*)c->redbuf.p + 1, 1, it,
+                                           (const double*)(c->*zf).p + l.lo, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p);
+                    }
+                    continue;
                 }
                 allreduce(2);
                 for (size_t q = 0; q < R.size(); ++q) {
@@ -566,8 +678,6 @@ struct Dist {
 
 int distStep(Dist& D, ps_stats* stats) {
     const auto w0 = std::chrono::high_resolution_clock::now();
-    for (ps_context* c : D.R)
-        if (c->P.preconditioner == PS_PRE_CHEBYSHEV) throw Error("the Chebyshev preconditioner is a single-domain option (slab decomposition: identity or Jacobi)");
     for (ps_context* c : D.R) c->redbuf.alloc(8);
     // a rank whose local setup throws must tell the others before they enter the first exchange (they would wait for ever)
     std::string failure;

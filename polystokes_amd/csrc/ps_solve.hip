@@ -255,7 +255,7 @@ void ps_context::constructPreconditioner() {
     // cross-rank completion of the diagonal (Dist::finishSetup).
     dinvF.alloc((size_t)nSystem);
     if (!slabEnabled) hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(nSystem)), dim3(BS), 0, stream, dinv.p, dinvF.p, nSystem);
-    if (P.preconditioner == PS_PRE_CHEBYSHEV) estimateLambdaMax();
+    if (P.preconditioner == PS_PRE_CHEBYSHEV && !slabEnabled) estimateLambdaMax();   // with a slab: Dist::finishSetup, across the ranks
 }
 
 // lambda_max(D^-1 A) for the Chebyshev polynomial: 10 power iterations from the all-ones vector, Rayleigh quotient of the

@@ -32,6 +32,8 @@ def make(case):
         return tall_cavity(24, 96, precond=abi.PRE_DIAGONAL)
     if base == "coil_w2":
         return tall_coil(32, 64)
+    if base == "cavity_w2_chebyshev":
+        return tall_cavity(32, 64, precond=abi.PRE_CHEBYSHEV)
     if base == "cavity_w2_bicgstab":
         sc, p = tall_cavity(24, 64)
         p.maxSolverIterations = 12
@@ -40,4 +42,4 @@ def make(case):
     raise KeyError(case)
 
 
-WORLD = {"cavity_w2": 2, "cavity_w3_jacobi": 3, "coil_w2": 2, "cavity_w2_bicgstab": 2}
+WORLD = {"cavity_w2": 2, "cavity_w3_jacobi": 3, "coil_w2": 2, "cavity_w2_bicgstab": 2, "cavity_w2_chebyshev": 2}

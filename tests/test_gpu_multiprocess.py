@@ -56,7 +56,7 @@ def _run_ranks(case, world, tmp_path):
     return [np.load(o) for o in outs]
 
 
-@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w2_bicgstab"])
+@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w2_bicgstab", "cavity_w2_chebyshev"])
 def test_multiprocess_tcp_matches_single_domain(case, tmp_path):
     import polystokes_amd
     world = mp_cases.WORLD[case]

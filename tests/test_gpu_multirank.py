@@ -31,7 +31,8 @@ def _tall_coil(n, nz):
     return sc, p
 
 
-@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w4_tile8", "spheres_w2", "spheres_w4_jacobi"])
+@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w4_tile8", "spheres_w2", "spheres_w4_jacobi",
+                                  "cavity_w3_chebyshev", "coil_w2_chebyshev", "spheres_w4_chebyshev_k2"])
 def test_group_matches_single_domain(case):
     import polystokes_amd
     if case.startswith("spheres"):
@@ -40,10 +41,17 @@ def test_group_matches_single_domain(case):
         world = 2 if case == "spheres_w2" else 4
         if world == 4:
             p.preconditioner = abi.PRE_DIAGONAL
+        if case.endswith("chebyshev_k2"):
+            p.preconditioner, p.preconditionerDegree = abi.PRE_CHEBYSHEV, 2
     elif case == "cavity_w2":
         (sc, p), world = _tall_cavity(32, 64), 2
     elif case == "cavity_w3_jacobi":
         (sc, p), world = _tall_cavity(24, 96, precond=abi.PRE_DIAGONAL), 3
+    elif case == "cavity_w3_chebyshev":        # the polynomial preconditioner across cuts: distributed interval estimate and applies
+        (sc, p), world = _tall_cavity(24, 96, precond=abi.PRE_CHEBYSHEV), 3
+    elif case == "coil_w2_chebyshev":
+        (sc, p), world = _tall_coil(32, 64), 2
+        p.preconditioner = abi.PRE_CHEBYSHEV
     elif case == "coil_w2":
         (sc, p), world = _tall_coil(32, 64), 2
     else:
