@@ -127,3 +127,15 @@ def test_bench_two_ranks_produces_one_line_whatever_the_transport(tmp_path):
         assert d["transport"] == "rccl"
     else:
         assert d["transport"].startswith("tcp (FALLBACK")
+
+
+def test_rccl_communicator_next_to_a_live_torch_context():
+    """bench.py's situation for N > 1: torch imported and its GPU context live, then the library's RCCL communicator.  The library
+    must pick up the librccl torch has already mapped (RTLD_NOLOAD) — two copies in one process abort at exit — and a slab step over
+    the communicator (world 1: the exchange lists are empty, the all-reduces real) must run and exit cleanly."""
+    pr = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "scripts", "rccl_with_torch.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                        text=True, timeout=300)
+    assert pr.returncode == 0, pr.stdout[-3000:]
+    after = [l for l in pr.stdout.splitlines() if l.startswith("rccl mapped after:")]
+    assert after and after[0].count("librccl") == 1, pr.stdout[-2000:]
+    assert " rc 1 " in after[0] and "closed" in pr.stdout
