@@ -57,65 +57,65 @@ __device__ inline int64_t stressDOF(const BlockArgs& A, int64_t idx, int type) {
 
 // The stencil row of one face in the reference's slot order: p(dir0,dir1), tau_c(dir0,dir1),
 // tau_e(edgeAxis asc, dir0,dir1).  ConstructMatrixBlocks.cpp:394-421 (G), :466-491 (Dt centres), :553-579 (Dt edges).
-__device__ inline int faceEntries(const BlockArgs& A, int axis, const int3 f, int32_t* cols, double* vals) {
+// Entries of the row of face f: every candidate has its own slot (pressure of the two cells 0-1, their centre stress 2-3, the edge
+// stresses 4-7), absent ones hold the sentinel column.  Static slots and a sorting network keep the two arrays in registers — with
+// `cols[n++] = ...` and an insertion sort they lived in scratch memory (112 B per thread in k_S_fill).
+constexpr int32_t NO_COL = 0x7fffffff;
+template <int AXIS>
+__device__ inline int faceEntriesT(const BlockArgs& A, const int3 f, int32_t (&cols)[8], double (&vals)[8]) {
     const int3 cd = A.g.dims(0);
-    const int3 fd = A.g.dims(1 + axis);
-    const double wF = (double)A.fw[1 + axis][lin3(fd, f.x, f.y, f.z)];
+    const int3 fd = A.g.dims(1 + AXIS);
+    const double wF = (double)A.fw[1 + AXIS][lin3(fd, f.x, f.y, f.z)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { cols[k] = NO_COL; vals[k] = 0.; }
     int n = 0;
-    // pressure
 #pragma unroll
     for (int dir = 0; dir < 2; ++dir) {
         const double sign = dir == 0 ? -1. : 1.;
         int3 c = f;
-        addc(c, axis, dir - 1);
-        if (comp(c, axis) < 0 || comp(c, axis) >= comp(cd, axis)) continue;
+        addc(c, AXIS, dir - 1);
+        if (comp(c, AXIS) < 0 || comp(c, AXIS) >= comp(cd, AXIS)) continue;
         const int64_t cl = lin3(cd, c.x, c.y, c.z);
+        const double coeff = wF * (double)A.lw[0][cl] * A.invDx;
+        if (coeff <= 0.) continue;
         const int pidx = A.sys[0][cl];   // internal index of this cell's pressure (>= 0 iff the cell is ACTIVE)
-        if (pidx < 0) continue;
-        const double coeff = wF * (double)A.lw[0][cl] * A.invDx;
-        if (coeff <= 0.) continue;
-        cols[n] = pidx; vals[n] = sign * coeff; ++n;
-    }
-    // centre stresses
-#pragma unroll
-    for (int dir = 0; dir < 2; ++dir) {
-        const double sign = dir == 0 ? -1. : 1.;
-        int3 c = f;
-        addc(c, axis, dir - 1);
-        if (comp(c, axis) < 0 || comp(c, axis) >= comp(cd, axis)) continue;
-        const int64_t cl = lin3(cd, c.x, c.y, c.z);
-        if (!isActiveL(A.lab[0][cl])) continue;
-        const double coeff = wF * (double)A.lw[0][cl] * A.invDx;
-        if (coeff <= 0.) continue;
-        cols[n] = A.sys[0][cl] + 1 + axis; vals[n] = -1. * sign * coeff; ++n;
+        if (pidx >= 0) { cols[dir] = pidx; vals[dir] = sign * coeff; ++n; }                                     // pressure
+        if (isActiveL(A.lab[0][cl])) { cols[2 + dir] = A.sys[0][cl] + 1 + AXIS; vals[2 + dir] = -1. * sign * coeff; ++n; }   // centre stress
     }
     // edge stresses
-    for (int ea = 0; ea < 3; ++ea) {
-        if (ea == axis) continue;
+    constexpr int EA0 = AXIS == 0 ? 1 : 0, EA1 = AXIS == 2 ? 1 : 2;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int ea = w == 0 ? EA0 : EA1;
         const int3 ed = A.g.dims(4 + ea);
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
             const double sign = dir == 0 ? -1. : 1.;
             int3 e = f;
-            addc(e, 3 - axis - ea, dir);
+            addc(e, 3 - AXIS - ea, dir);
             const int64_t el = lin3(ed, e.x, e.y, e.z);
             if (!isActiveL(A.lab[4 + ea][el])) continue;
             const double coeff = wF * (double)A.lw[4 + ea][el] * A.invDx;
             if (coeff <= 0.) continue;
-            cols[n] = A.sys[4 + ea][el]; vals[n] = -1. * sign * coeff; ++n;
+            cols[4 + 2 * w + dir] = A.sys[4 + ea][el]; vals[4 + 2 * w + dir] = -1. * sign * coeff; ++n;
         }
     }
     return n;
 }
-
-__device__ inline void sortEntries(int n, int32_t* cols, double* vals) {
-    for (int i = 1; i < n; ++i) {
-        const int32_t c = cols[i];
-        const double v = vals[i];
-        int j = i - 1;
-        while (j >= 0 && cols[j] > c) { cols[j + 1] = cols[j]; vals[j + 1] = vals[j]; --j; }
-        cols[j + 1] = c; vals[j + 1] = v;
-    }
+__device__ inline int faceEntries(const BlockArgs& A, int axis, const int3 f, int32_t (&cols)[8], double (&vals)[8]) {
+    return axis == 0 ? faceEntriesT<0>(A, f, cols, vals) : (axis == 1 ? faceEntriesT<1>(A, f, cols, vals) : faceEntriesT<2>(A, f, cols, vals));
+}
+// ascending by column, sentinels last: Batcher's odd-even merge sort for 8 keys (19 compare-exchanges, all indices static)
+__device__ inline void sortEntries(int32_t (&cols)[8], double (&vals)[8]) {
+#define PS_CSWAP(i, j) { const bool sw = cols[i] > cols[j]; const int32_t ci = cols[i], cj = cols[j]; const double vi = vals[i], vj = vals[j]; \
+                         cols[i] = sw ? cj : ci; cols[j] = sw ? ci : cj; vals[i] = sw ? vj : vi; vals[j] = sw ? vi : vj; }
+    PS_CSWAP(0, 1) PS_CSWAP(2, 3) PS_CSWAP(4, 5) PS_CSWAP(6, 7)
+    PS_CSWAP(0, 2) PS_CSWAP(1, 3) PS_CSWAP(4, 6) PS_CSWAP(5, 7)
+    PS_CSWAP(1, 2) PS_CSWAP(5, 6)
+    PS_CSWAP(0, 4) PS_CSWAP(1, 5) PS_CSWAP(2, 6) PS_CSWAP(3, 7)
+    PS_CSWAP(2, 4) PS_CSWAP(3, 5)
+    PS_CSWAP(1, 2) PS_CSWAP(3, 4) PS_CSWAP(5, 6)
+#undef PS_CSWAP
 }
 
 // reduced faces with >= 1 stencil entry, enumerated per region through its face box (same work items
@@ -212,9 +212,11 @@ __global__ void k_S_fill(BlockArgs A, int axis, const int32_t* __restrict__ ptr,
     int32_t cols[8];
     double vals[8];
     const int n = faceEntries(A, axis, unlin3(d, c), cols, vals);
-    sortEntries(n, cols, vals);
+    sortEntries(cols, vals);
     const int p0 = ptr[row];
-    for (int q = 0; q < n; ++q) { col[p0 + q] = cols[q]; val[p0 + q] = vals[q]; code[p0 + q] = encodeVal(A, vals[q]); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < n) { col[p0 + q] = cols[q]; val[p0 + q] = vals[q]; code[p0 + q] = encodeVal(A, vals[q]); }
     if (row < A.nA) {
         double volume = (double)A.fw[1 + axis][c] * (double)A.lw[1 + axis][c];
         const double lo = 0.1 * 0.1;   // MINWEIGHT * MINWEIGHT, :365
@@ -266,16 +268,22 @@ __device__ inline int cellColumn(const BlockArgs& A, int mode, const int3 c, int
     *rhsOut = rhs;
     return n;
 }
-__device__ inline int edgeColumn(const BlockArgs& A, int ea, const int3 e, int32_t* rows, double* vals, double* rhsOut) {
-    const int3 ed = A.g.dims(4 + ea);
+// entries of column tau_e: static slots (two faces per other axis), sentinel rows for the absent ones (see faceEntriesT)
+template <int EA>
+__device__ inline int edgeColumnT(const BlockArgs& A, const int3 e, int32_t (&rows)[4], double (&vals)[4], double* rhsOut) {
+    const int3 ed = A.g.dims(4 + EA);
     const int64_t el = lin3(ed, e.x, e.y, e.z);
-    const double wLe = (double)A.lw[4 + ea][el];
-    const bool edgeSolidish = A.fw[4 + ea][el] < 1.f;
+    const double wLe = (double)A.lw[4 + EA][el];
+    const bool edgeSolidish = A.fw[4 + EA][el] < 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rows[k] = NO_COL; vals[k] = 0.; }
     int n = 0;
     double rhs = 0.;
-    for (int fa = 0; fa < 3; ++fa) {
-        if (fa == ea) continue;
-        const int third = 3 - fa - ea;
+    constexpr int FA0 = EA == 0 ? 1 : 0, FA1 = EA == 2 ? 1 : 2;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int fa = w == 0 ? FA0 : FA1;
+        const int third = 3 - fa - EA;
         const int3 fd = A.g.dims(1 + fa);
 #pragma unroll
         for (int divDir = 0; divDir < 2; ++divDir) {
@@ -289,7 +297,7 @@ __device__ inline int edgeColumn(const BlockArgs& A, int ea, const int3 e, int32
             const float wFf = A.fw[1 + fa][fl];
             const double coeff = (double)wFf * wLe * A.invDx;
             if (coeff <= 0.) continue;
-            rows[n] = row; vals[n] = -1. * sign * coeff; ++n;
+            rows[2 * w + divDir] = row; vals[2 * w + divDir] = -1. * sign * coeff; ++n;
             if (row < A.nA) {   // :582-599
                 const double sc = sign * coeff;
                 const double svel = (double)A.cvel[fa][fl];
@@ -300,6 +308,15 @@ __device__ inline int edgeColumn(const BlockArgs& A, int ea, const int3 e, int32
     }
     *rhsOut = rhs;
     return n;
+}
+__device__ inline int edgeColumn(const BlockArgs& A, int ea, const int3 e, int32_t (&rows)[4], double (&vals)[4], double* rhsOut) {
+    return ea == 0 ? edgeColumnT<0>(A, e, rows, vals, rhsOut) : (ea == 1 ? edgeColumnT<1>(A, e, rows, vals, rhsOut) : edgeColumnT<2>(A, e, rows, vals, rhsOut));
+}
+__device__ inline void sortRows4(int32_t (&rows)[4], double (&vals)[4]) {   // ascending, sentinels last (5 compare-exchanges)
+#define PS_CSWAP(i, j) { const bool sw = rows[i] > rows[j]; const int32_t ci = rows[i], cj = rows[j]; const double vi = vals[i], vj = vals[j]; \
+                         rows[i] = sw ? cj : ci; rows[j] = sw ? ci : cj; vals[i] = sw ? vj : vi; vals[j] = sw ? vi : vj; }
+    PS_CSWAP(0, 1) PS_CSWAP(2, 3) PS_CSWAP(0, 2) PS_CSWAP(1, 3) PS_CSWAP(1, 2)
+#undef PS_CSWAP
 }
 
 __device__ inline float viscAt(const BlockArgs& A, float px, float py, float pz) {
@@ -388,9 +405,11 @@ __global__ void k_St_edges(BlockArgs A, int ea, int32_t* __restrict__ cnt, const
     const int64_t j = A.sys[4 + ea][c];
     const int64_t t = j;
     if (!FILL) { cnt[j] = n; return; }
-    sortRows(n, rows, vals);
+    sortRows4(rows, vals);
     const int p0 = ptr[j];
-    for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; code[p0 + k] = encodeVal(A, vals[k]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < n) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; code[p0 + k] = encodeVal(A, vals[k]); }
     rhsPT[j] = rhs;
     const double vw = clampd((double)A.fw[4 + ea][c], 0.1, 1.0) * (double)A.lw[4 + ea][c];
     const float ox = ea == 0 ? 0.5f : 0.f, oy = ea == 1 ? 0.5f : 0.f, oz = ea == 2 ? 0.5f : 0.f;
