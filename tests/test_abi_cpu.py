@@ -97,3 +97,21 @@ def test_shim_parameter_table_covers_the_params_struct():
                    "polystokes_step(", "ps_set_interrupt("):
         assert needle in src, needle
     assert '"HDK PolyStokes Solver"' in open(os.path.join(ROOT, "shim", "HDK_PolyStokes_shim.h")).read()
+
+
+def test_documented_environment_switches_exist_in_the_sources():
+    """README's table of PS_* switches against the sources: a switch that is documented must be read somewhere (library, Python
+    harness, oracle loader), and every switch the library reads must be documented."""
+    import glob
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    documented = set(re.findall(r"`(PS_[A-Z0-9_]+)", readme))
+    src = ""
+    for pat in ("polystokes_amd/csrc/*.h*", "polystokes_amd/*.py", "oracle/*.py", "bench.py", "__graft_entry__.py"):
+        for f in glob.glob(os.path.join(ROOT, pat)):
+            src += open(f).read()
+    read_in_lib = set(re.findall(r"getenv\(\"(PS_[A-Z0-9_]+)\"\)", src)) | set(re.findall(r"environ(?:\.get)?[\[(]\"(PS_[A-Z0-9_]+)\"", src))
+    compile_time = {"PS_CHEB_INTERVAL_RATIO"}                      # a header constant, not an environment variable
+    missing_in_src = {d for d in documented if d not in src} - compile_time
+    assert not missing_in_src, "documented but not in the sources: %s" % sorted(missing_in_src)
+    undocumented = read_in_lib - documented
+    assert not undocumented, "read by the sources but not in README.md: %s" % sorted(undocumented)
