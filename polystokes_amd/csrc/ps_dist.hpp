@@ -498,6 +498,44 @@ struct Dist {
         allreduce(1);
         for (size_t q = 0; q < R.size(); ++q)
             hipLaunchKernelGGL(k_dscal0, dim3(1), dim3(1), 0, R[q]->stream, loc[q].sc, R[q]->redbuf.p, tol, maxit, R[q]->ntLevel() >= 2 ? 1 : 0);
+        // Four-kernel step across slabs (ps_solve.hip: solve, FusedR): every rank's share of p.Ap in its factored form is known after
+        // the tile kernel — one all-reduce, then the St kernel updates r on the owned DOFs and hands the halo rows' (A p) to the
+        // neighbours, who subtract alpha times it (k_dist_fixup).  Same rule as the single-domain solve: coded streams on every
+        // rank and >= FUSED_STEP_MIN_ROWS owned rows on the largest (PS_FUSED_R = 0 / 1 forces); decided from values every rank
+        // knows or agrees on, so all ranks take the same branch.
+        static const int fusedEnv = getenv("PS_FUSED_R") ? atoi(getenv("PS_FUSED_R")) : -1;
+        bool fused = !cheb && fusedEnv != 0;
+        for (size_t q = 0; q < R.size(); ++q) fused = fused && loc[q].L.fusedOk() && loc[q].n > 0;
+        {
+            double mine[2] = {fused ? 0. : 1., 0.};
+            for (size_t q = 0; q < R.size(); ++q) mine[1] = std::max(mine[1], (double)loc[q].n);
+            if (useRccl || useTcp) {   // a rank without the coded stream vetoes; the size rule looks at the SUM of the owned rows (identical everywhere)
+                for (ps_context* c : R) HIP_CHECK(hipMemcpyAsync(c->redbuf.p, mine, 16, hipMemcpyHostToDevice, c->stream));
+                allreduce(2);
+                HIP_CHECK(hipMemcpyAsync(mine, R[0]->redbuf.p, 16, hipMemcpyDeviceToHost, R[0]->stream));
+                syncAll();
+                mine[1] /= std::max(1, R[0]->slab.world);   // mean owned rows per rank
+            }
+            fused = fused && mine[0] == 0. && (fusedEnv > 0 || mine[1] >= (double)FUSED_STEP_MIN_ROWS);
+        }
+        struct FBuf { double *fS, *fT, *fU, *fR, *fX; int sBlocks, stBF, gFix; };
+        std::vector<FBuf> fb(R.size());
+        if (fused) {
+            for (size_t q = 0; q < R.size(); ++q) {
+                ps_context* c = R[q];
+                Loc& l = loc[q];
+                FBuf& f = fb[q];
+                f.sBlocks = l.L.sBlocks(); f.stBF = l.L.stBlocks(3);
+                f.gFix = (int)std::min<int64_t>(256, std::max<int64_t>(1, (c->nLowOwn + c->nUpOwn + BS - 1) / BS));
+                c->fusedPart.alloc((size_t)f.sBlocks + (size_t)c->regionCount + VGRID + 2 * (size_t)f.stBF + 2 * (size_t)f.gFix + 16);
+                f.fS = c->fusedPart.p; f.fT = f.fS + f.sBlocks; f.fU = f.fT + c->regionCount; f.fR = f.fU + VGRID; f.fX = f.fR + 2 * f.stBF;
+                l.L.sPart = f.fS; l.L.wvPart = f.fT;
+                c->fusedStepHost = 1;
+                const uint8_t* ucode = c->uCoded ? c->uCode.p + l.lo : nullptr;
+                hipLaunchKernelGGL(k_uinv_pp, dim3(l.vb), dim3(BS), 0, c->stream, (const double*)c->pvec.p + l.lo, ucode, (const double*)c->uDict.p,
+                                   (const double*)c->uInv.p + l.lo, l.n, f.fU);
+            }
+        } else for (ps_context* c : R) c->fusedStepHost = 0;
         CGScalars h{};
         const int batch = 25;
         int it = 0;
@@ -507,6 +545,52 @@ struct Dist {
             const int upto = std::min(maxit, it + batch);
             for (; it < upto; ++it) {
                 exchangeX(&ps_context::pvec);
+                if (fused) {
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        l.L.spmvS(0, c->pvec.p, c->ts.p);
+                        l.L.tiles(0, c->ts.p);
+                        hipLaunchKernelGGL(k_fused_local_sum, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fS, f.sBlocks, (const double*)f.fT,
+                                           (int)c->regionCount, (const double*)f.fU, l.vb, (const double*)c->dotPartials3.p, l.vb, c->redbuf.p);
+                    }
+                    allreduce(2);
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        const FusedR fr{l.sc, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, it, c->r.p, jac ? c->dinvF.p : (const float*)nullptr, f.fR, nullptr, 0., nullptr,
+                                        (const double*)c->redbuf.p, (int)c->ownLo, (int)c->ownHi, c->Ap.p};
+                        l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
+                    }
+                    // the halo rows' share of A p goes to its owners (the packing and transport of exchangeAddY; the owners correct r instead of adding into A p)
+                    for (ps_context* c : R)
+                        if (c->nLowHalo + c->nUpHalo > 0)
+                            hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->sendLo.p,
+                                               c->listUpHalo.p, c->nUpHalo, c->sendUp.p, (const double*)c->Ap.p);
+                    transport(1);
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        hipLaunchKernelGGL(k_dist_fixup, dim3(f.gFix), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const int32_t*)c->listLowOwn.p, c->nLowOwn,
+                                           (const double*)c->recvLo.p, (const int32_t*)c->listUpOwn.p, c->nUpOwn, (const double*)c->recvUp.p, c->r.p,
+                                           jac ? (const float*)c->dinvF.p : (const float*)nullptr, f.fX);
+                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, c->redbuf.p);
+                    }
+                    allreduce(2);
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        const uint8_t* ucode = c->uCoded ? c->uCode.p + l.lo : nullptr;
+                        hipLaunchKernelGGL(k_cg_update_xp_u, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, (const double*)nullptr, 0, jac ? 1 : 0, it,
+                                           (const double*)c->r.p + l.lo, l.dv, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p, ucode, (const double*)c->uDict.p,
+                                           (const double*)c->uInv.p + l.lo, f.fU);
+                    }
+                    continue;
+                }
                 for (size_t q = 0; q < R.size(); ++q) {
                     ps_context* c = R[q];
                     Loc& l = loc[q];

@@ -309,11 +309,11 @@ __global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double
                                                      double* __restrict__ p, int64_t n, double* __restrict__ partial) {
     cgUpdateXp<false>(sc, red, rPartial, rCount, jacobi, it, r, dinv, x, p, n, partial, nullptr, nullptr, nullptr, nullptr);
 }
-__global__ void __launch_bounds__(BS) k_cg_update_xp_u(CGScalars* sc, const double* __restrict__ rPartial, int rCount, int jacobi,
+__global__ void __launch_bounds__(BS) k_cg_update_xp_u(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
                                                        int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
                                                        double* __restrict__ p, int64_t n, double* __restrict__ partial,
                                                        const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
-    cgUpdateXp<true>(sc, nullptr, rPartial, rCount, jacobi, it, r, dinv, x, p, n, partial, uCode, uDict, uInv, uPart);
+    cgUpdateXp<true>(sc, red, rPartial, rCount, jacobi, it, r, dinv, x, p, n, partial, uCode, uDict, uInv, uPart);
 }
 // partials of sum_j uInv_j p_j^2 (the first search direction of a fused-step solve)
 __global__ void __launch_bounds__(BS) k_uinv_pp(const double* __restrict__ p, const uint8_t* __restrict__ uCode, const double* __restrict__ uDict,
@@ -328,6 +328,48 @@ __global__ void __launch_bounds__(BS) k_uinv_pp(const double* __restrict__ p, co
     }
     const double s = blockReduceSum(acc);
     if (threadIdx.x == 0) uPart[blockIdx.x] = s;
+}
+
+// ---- four-kernel step across slabs (ps_dist.hpp) ---------------------------------------------------------------------------
+// this rank's share of p.Ap in its factored form and of ||x||^2: out = {sum S + sum T + 1/2 sum U, sum xx}   (one block, fixed order)
+__global__ void __launch_bounds__(BS) k_fused_local_sum(const CGScalars* __restrict__ sc, const double* __restrict__ sPart, int sCount, const double* __restrict__ tPart, int tCount,
+                                                        const double* __restrict__ uPart, int uCount, const double* __restrict__ xxPart, int xxCount, double* __restrict__ out) {
+    if (sc && sc->done) return;
+    const double a = sumPartials(sPart, sCount); __syncthreads();
+    const double b = sumPartials(tPart, tCount); __syncthreads();
+    const double c = sumPartials(uPart, uCount); __syncthreads();
+    const double d = sumPartials(xxPart, xxCount);
+    if (threadIdx.x == 0) { out[0] = a + b + 0.5 * c; out[1] = d; }
+}
+// The St kernel updated r on the owned DOFs with this rank's rows only.  The DOFs next to a cut also receive the neighbour's share
+// c of (A p)_j (its halo rows): r_j -= alpha c, and the partial sums of r.r / r.z are corrected by the change of r_j^2.
+__global__ void __launch_bounds__(BS) k_dist_fixup(const CGScalars* __restrict__ sc, const int32_t* __restrict__ listA, int64_t nA, const double* __restrict__ bufA,
+                                                   const int32_t* __restrict__ listB, int64_t nB, const double* __restrict__ bufB, double* __restrict__ r,
+                                                   const float* __restrict__ dinv, double* __restrict__ partial) {
+    if (sc->done) return;
+    const double alpha = sc->alpha;
+    double a0 = 0., a1 = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < nA + nB; i += (int64_t)gridDim.x * BS) {
+        const int j = i < nA ? listA[i] : listB[i - nA];
+        const double c = i < nA ? bufA[i] : bufB[i - nA];
+        const double ro = r[j], rn = ro - alpha * c;
+        r[j] = rn;
+        const double d = rn * rn - ro * ro;
+        a0 += d;
+        if (dinv) a1 += (double)dinv[j] * d;
+    }
+    const double s0 = blockReduceSum(a0), s1 = blockReduceSum(a1);
+    if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
+}
+// out = {r.r, r.z} of this rank: the St kernel's partials plus the corrections of k_dist_fixup   (one block)
+__global__ void __launch_bounds__(BS) k_sum_rr(const CGScalars* __restrict__ sc, const double* __restrict__ rPart, int rCount, const double* __restrict__ fixPart, int fixCount,
+                                               double* __restrict__ out) {
+    if (sc->done) return;
+    const double a = sumPartials(rPart, rCount); __syncthreads();
+    const double b = sumPartials(rPart + rCount, rCount); __syncthreads();
+    const double c = sumPartials(fixPart, fixCount); __syncthreads();
+    const double d = sumPartials(fixPart + fixCount, fixCount);
+    if (threadIdx.x == 0) { out[0] = a + c; out[1] = b + d; }
 }
 
 // ---- generic vector helpers (BiCGStab fallback, rare) -----------------------------------------------

@@ -192,6 +192,11 @@ struct FusedR {
     // Chebyshev preconditioner: the polynomial's first term on the new r, z_1 = dinv r / theta -> cz (null: not asked for; then r.z
     // above is that of the Jacobi diagonal)
     const double* dinv64; double invTheta; double* cz;
+    // Slab decomposition (ps_dist.hpp): red = {S + T + 1/2 U summed over the ranks, ||x||^2 over the ranks} replaces the partial
+    // sums above; only rows in [ownLo, ownHi) are this rank's DOFs — the others (halo DOFs) carry contributions to a neighbour's
+    // rows: their y goes to yOut and the owner subtracts alpha times it afterwards (k_dist_fixup).  Single domain: red = null,
+    // [0, rows), yOut = null.
+    const double* red; int ownLo, ownHi; double* yOut;
 };
 // Walk of a persistent workgroup over the chunk ids: runs of G = 1 << sh consecutive chunks are dealt to the 8 XCDs round robin
 // (workgroup b runs on XCD b & 7), inside an XCD to its workgroups in order; sh < 0: plain grid-stride walk
@@ -457,7 +462,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         auto sumArr = [&](const double* a, int cnt) { double acc = 0.; for (int i = threadIdx.x; i < cnt; i += BS) acc += a[i]; return blockSumAll(acc); };
         const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
         if (fr.it > 0) {
-            const double xx = sumArr(fr.xxPart, fr.xxCount);
+            const double xx = fr.red ? fr.red[1] : sumArr(fr.xxPart, fr.xxCount);
             const double rr = sc->rr;
             double rre = rr;                               // pcg.h:319-325
             if (rr / xx < rre) rre = rr / xx;
@@ -465,7 +470,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             if (writer) { sc->xx = xx; sc->rre = rre; if (fire) { sc->done = 1; sc->iter = fr.it - 1; } }
             if (fire) return;                              // same verdict in every workgroup
         }
-        const double pAp = -(sumArr(fr.sPart, fr.sCount) + sumArr(fr.tPart, fr.tCount) + 0.5 * sumArr(fr.uPart, fr.uCount));
+        const double pAp = fr.red ? -fr.red[0] : -(sumArr(fr.sPart, fr.sCount) + sumArr(fr.tPart, fr.tCount) + 0.5 * sumArr(fr.uPart, fr.uCount));
         alpha = sc->rsold2[fr.it & 1] / pAp;               // pcg.h:314
         if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
     }
@@ -477,7 +482,8 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                  rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
                                  rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
                                  rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0),
-                                 rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0);
+                                 rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
+                                 rFy = bufRsrc(fr.yOut, (MODE == 3 && fr.yOut) ? (size_t)rows * 8 : 0);
     const ChunkWalk W(xcdAware);
     int it = 0;
     int chunk = W.at(0);
@@ -546,9 +552,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
             else if (MODE == 1) y = -s + e0;
             else if (MODE == 3) {
                 y = -s; y -= 0.5 * e1 * e0;                                      // (A p)[row], not stored
-                const double rv = cr - alpha * y;                                // pcg.h:316
+                const bool mine = (int)row >= fr.ownLo && (int)row < fr.ownHi;   // (idle lanes: false)
+                if (fr.yOut) bufStoreF64nt<NT>(rFy, (!mine && live) ? row * 8u : 0xfffffff8u, y);   // a neighbour's row: its share of A p
+                const double rv = mine ? cr - alpha * y : 0.;                    // pcg.h:316
                 dacc += rv * rv;
-                dacc2 += fr.dinvF ? rv * ((double)fdv * rv) : 0.;
+                dacc2 += (fr.dinvF && mine) ? rv * ((double)fdv * rv) : 0.;      // (the diagonal of a halo row is not this rank's: may be anything)
                 if (fr.cz) {                                                     // k_cheb_first on this row
                     const double v = ci * rv * fr.invTheta;
                     bufStoreF64nt<NT>(rFcz, row * 8u, v);
@@ -562,7 +570,8 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                 y = e0 + dn;
                 dacc += cr * y;                                                  // r.z of the updated z
             }
-            if (MODE == 3) bufStoreF64nt<NT>(rFr, row * 8u, y); else bufStoreF64nt<NT>(rOut, row * 8u, y);
+            if (MODE == 3) bufStoreF64nt<NT>(rFr, ((int)row >= fr.ownLo && (int)row < fr.ownHi) ? row * 8u : 0xfffffff8u, y);
+            else bufStoreF64nt<NT>(rOut, row * 8u, y);
         }
         __syncthreads();    // protects the LDS reuse
         if (!hasNext) break;

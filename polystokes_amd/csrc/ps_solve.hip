@@ -441,7 +441,7 @@ int ps_context::solve() {
             L.spmvS(0, pvec.p, ts.p);
             L.tiles(0, ts.p);
             if (fused && cheb) {   // St kernel: r -= alpha A p and the polynomial's first term on the new r; then terms 2..k; then x, p
-                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, nullptr, fR, dinv.p, 1. / chebTheta(), zvec};
+                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, nullptr, fR, dinv.p, 1. / chebTheta(), zvec, nullptr, 0, (int)n, nullptr};
                 L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                 double* zfin = zvec;
                 const int c2 = chebyshevApply(r.p, zvec, dvec, rzPart, sc, true, &zfin);
@@ -452,9 +452,9 @@ int ps_context::solve() {
                 continue;
             }
             if (fused) {
-                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, dv, fR, nullptr, 0., nullptr};
+                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, dv, fR, nullptr, 0., nullptr, nullptr, 0, (int)n, nullptr};
                 L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
-                hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, dv ? 1 : 0, it, (const double*)r.p, dv, x.p,
+                hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, (const double*)fR, stBF, dv ? 1 : 0, it, (const double*)r.p, dv, x.p,
                                    pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
                 continue;
             }
@@ -688,11 +688,11 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         const uint8_t* ucode = c->uCoded ? c->uCode.p : nullptr;
         if (base == "spmv_St_r") {   // the St kernel of the four-kernel step: r (scratch) -= 0 * A x in the epilogue
             if (!L.fusedOk()) throw Error("no fused step on this system");
-            const FusedR fr{scratch.p, ones.p, VGRID, zeros.p, 0, zeros.p, 0, ones.p, 0, 0, c->tmp5.p, dvf, c->dotPartials.p, nullptr, 0., nullptr};
+            const FusedR fr{scratch.p, ones.p, VGRID, zeros.p, 0, zeros.p, 0, ones.p, 0, 0, c->tmp5.p, dvf, c->dotPartials.p, nullptr, 0., nullptr, nullptr, 0, (int)n, nullptr};
             L.spmvSt(3, c->ts.p, x, nullptr, nullptr, nullptr, nullptr, &fr);
         }
         else if (base == "cg_update_xp_u")
-            hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)zeros.p, VGRID, dvf ? 1 : 0, 0, x, dvf,
+            hipLaunchKernelGGL(k_cg_update_xp_u, dim3(vb), dim3(BS), 0, c->stream, scratch.p, (const double*)nullptr, (const double*)zeros.p, VGRID, dvf ? 1 : 0, 0, x, dvf,
                                c->tmp4.p, c->tmp5.p, n, c->dotPartials.p, ucode, (const double*)c->uDict.p, (const double*)c->uInv.p, c->dotPartials.p + VGRID);
         else if (base == "cg_update_xr")
             hipLaunchKernelGGL(k_cg_update_xr, dim3(vb), dim3(BS), 0, c->stream, scratch.p, x, y, dv, c->tmp4.p, c->tmp5.p, n, c->dotPartials.p);

@@ -44,6 +44,7 @@ def main():
             res["vel%d" % a], res["valid%d" % a] = lv[a], lval[a]
             res["owned%d" % a] = s.array("owned" + "XYZ"[a])
         res["labels"] = s.array("centerLabels")
+        res["fused"] = int(s.array("fusedStep")[0])
     np.savez(out, **res)
     s.close()
 

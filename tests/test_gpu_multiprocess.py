@@ -37,11 +37,11 @@ def _free_port_base(n):
     raise RuntimeError("no free port range")
 
 
-def _run_ranks(case, world, tmp_path):
+def _run_ranks(case, world, tmp_path, env=None):
     base = _free_port_base(world)
     outs = [str(tmp_path / f"{case}.r{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_rank.py"), case, str(world), str(r), str(base), outs[r]],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **(env or {}))) for r in range(world)]
     logs = []
     for pr in procs:
         try:
@@ -56,11 +56,17 @@ def _run_ranks(case, world, tmp_path):
     return [np.load(o) for o in outs]
 
 
-@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w2_bicgstab", "cavity_w2_chebyshev"])
+@pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w2_bicgstab", "cavity_w2_chebyshev",
+                                  "cavity_w2+fused", "cavity_w3_jacobi+fused", "coil_w2+fused", "cavity_w2_bicgstab+fused"])
 def test_multiprocess_tcp_matches_single_domain(case, tmp_path):
+    """"+fused": the four-kernel PCG step across the slabs (default from 2 M owned rows per rank), forced in the rank processes."""
     import polystokes_amd
+    env = {"PS_FUSED_R": "1"} if case.endswith("+fused") else None
+    case = case.replace("+fused", "")
     world = mp_cases.WORLD[case]
-    res = _run_ranks(case, world, tmp_path)          # children first: the parent's own GPU context comes after
+    res = _run_ranks(case, world, tmp_path, env)     # children first: the parent's own GPU context comes after
+    if env:
+        assert all(int(r["fused"]) == 1 for r in res)
     sc, p = mp_cases.make(case)
     single = polystokes_amd.Solver(0)
     rc1 = single.step(sc, p)
