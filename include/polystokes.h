@@ -237,6 +237,8 @@ typedef struct ps_slab {
     int32_t rank, world;
     int32_t zLoOwned, zHiOwned;     /* owned cell layers [zLo, zHi) in LOCAL grid coordinates (multiples of 16) */
     int32_t hasLower, hasUpper;     /* a neighbouring rank exists below / above */
+    int32_t zGlobalOwned;           /* GLOBAL index of the cell layer zLoOwned: tile offsets are formed with global z, so a tile's
+                                     * matrices and fit do not depend on the decomposition */
 } ps_slab;
 int32_t ps_set_slab(ps_context* ctx, const ps_slab* slab);            /* after ps_upload_fields, before setup */
 

@@ -155,7 +155,7 @@ class Solver:
         self._check(self.L.ps_set_interrupt(self.h, C.cast(self._cb, C.c_void_p), None))
 
     def set_slab(self, slab):
-        st = _abi.SlabStruct(slab.rank, slab.world, slab.zLoOwned, slab.zHiOwned, slab.hasLower, slab.hasUpper)
+        st = _abi.SlabStruct(slab.rank, slab.world, slab.zLoOwned, slab.zHiOwned, slab.hasLower, slab.hasUpper, slab.z0)
         self._check(self.L.ps_set_slab(self.h, C.byref(st)))
 
     def comm_selftest(self):

@@ -66,7 +66,7 @@ class Stats(C.Structure):
 
 class SlabStruct(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("zLoOwned", C.c_int32), ("zHiOwned", C.c_int32),
-                ("hasLower", C.c_int32), ("hasUpper", C.c_int32)]
+                ("hasLower", C.c_int32), ("hasUpper", C.c_int32), ("zGlobalOwned", C.c_int32)]
 
 
 def default_params(**kw):

@@ -156,6 +156,7 @@ struct ps_context {
 
     // ---- multi-GPU (slab decomposition; ps_dist.hip) ----
     bool slabEnabled = false;
+    int zOff = 0;               // global z index of the local layer 0 (slab: ps_slab::zGlobalOwned - zLoOwned): face positions use the global k
     ps_slab slab{};
     int64_t ownLo = 0, ownHi = 0;            // owned DOF range in the internal numbering (contiguous: whole 16-layer blocks)
     ps::DevBuf<int32_t> regionOwned;         // R flags

@@ -843,6 +843,7 @@ int32_t ps_set_slab(ps_context* c, const ps_slab* slab) {
         if (!slab->hasUpper && slab->zHiOwned != c->g.nz) throw Error("without an upper neighbour the slab must end at the top layer");
         c->slab = *slab;
         c->slabEnabled = slab->world > 1;
+        c->zOff = c->slabEnabled ? slab->zGlobalOwned - slab->zLoOwned : 0;
         c->isSetup = false;
         return PS_SUCCESS;
     } PS_CATCH_ALL(c)

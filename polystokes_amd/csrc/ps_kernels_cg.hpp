@@ -523,7 +523,7 @@ __global__ void k_lin(double* __restrict__ out, double ca, const double* __restr
 __global__ void __launch_bounds__(128) k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int n, int nP,
                               int nA, double dt, const double* __restrict__ McInv, const double* __restrict__ uInv,
                               const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, const double* __restrict__ COM,
-                              double dx, const double* __restrict__ Binv, double* __restrict__ dinv, int invert) {
+                              double dx, int zoff, const double* __restrict__ Binv, double* __restrict__ dinv, int invert) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     double diag = 0.;
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(128) k_jacobi_diag(const int32_t* __restrict__
         }
         double o[3];
         int axis;
-        rowOffset(rrowFace[rr], COM, r, dx, o, &axis);
+        rowOffset(rrowFace[rr], COM, r, dx, zoff, o, &axis);
         double c[PS_RD];
         basisRow(o[0], o[1], o[2], axis, c);
         for (int m = 0; m < PS_RD; ++m) q[m] += c[m] * v;
@@ -573,7 +573,7 @@ __global__ void k_recover_active(const double* __restrict__ s, const double* __r
 // applySolutionToVelocity, Solver.cpp:937-1028
 __global__ void k_writeback(Grid g, int axis, const int32_t* __restrict__ lab, const int32_t* __restrict__ act, const int32_t* __restrict__ reg,
                             const int32_t* __restrict__ faceRow, const double* __restrict__ ua, const double* __restrict__ creg, const double* __restrict__ COM,
-                            double dx, const float* __restrict__ cvel, const float* __restrict__ velIn, float* __restrict__ velOut, int apply) {
+                            double dx, int zoff, const float* __restrict__ cvel, const float* __restrict__ velIn, float* __restrict__ velOut, int apply) {
     const int3 d = g.dims(1 + axis);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
@@ -585,7 +585,7 @@ __global__ void k_writeback(Grid g, int axis, const int32_t* __restrict__ lab, c
         double v = 0.;
         if (r >= 0) {
             const int3 q = unlin3(d, c);
-            double p[3] = {(double)q.x, (double)q.y, (double)q.z};
+            double p[3] = {(double)q.x, (double)q.y, (double)(q.z + zoff)};
             p[axis] -= 0.5;
             const double ox = p[0] * dx - COM[(int64_t)r * 3 + 0], oy = p[1] * dx - COM[(int64_t)r * 3 + 1], oz = p[2] * dx - COM[(int64_t)r * 3 + 2];
             double C[PS_RD];

@@ -29,6 +29,7 @@ struct TileArgs {
     const float* vel[3];
     const float* visc;
     const double* COM;
+    int zoff;
     const int32_t* bbox;
     const int32_t* itemRegion;
     const int32_t* itemAxis;
@@ -68,7 +69,7 @@ __device__ inline float viscSample(const TileArgs& A, float px, float py, float 
 }
 
 __device__ inline void faceOffset(const TileArgs& A, int axis, int i, int j, int k, int region, double* o) {
-    double p[3] = {(double)i, (double)j, (double)k};
+    double p[3] = {(double)i, (double)j, (double)(k + A.zoff)};   // global k: ps_kernels_tiles.hpp, rowOffset
     p[axis] -= 0.5;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { p[q] *= A.dx; p[q] -= A.COM[(int64_t)region * 3 + q]; }
@@ -334,7 +335,7 @@ __global__ void k_region_sum(const double* __restrict__ partial, const int32_t* 
 }
 
 // Solver.cpp:1274-1324 + :355-371.  Exact integer sums (order independent), COM = sum * (dx / count).
-__global__ void k_com(Grid g, double dx, const int32_t* __restrict__ lab, const int32_t* __restrict__ reg,
+__global__ void k_com(Grid g, double dx, int zoff, const int32_t* __restrict__ lab, const int32_t* __restrict__ reg,
                       const int32_t* __restrict__ bbox, double* __restrict__ COM) {
     const int r = blockIdx.x;
     const int3 d = g.dims(0);
@@ -345,7 +346,7 @@ __global__ void k_com(Grid g, double dx, const int32_t* __restrict__ lab, const 
     for (int64_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
         const int i = bx0 + (int)(pos % ex), j = by0 + (int)((pos / ex) % ey), k = bz0 + (int)(pos / ((int64_t)ex * ey));
         const int64_t c = lin3(d, i, j, k);
-        if (isReducedL(lab[c]) && reg[c] == r) { sx += i; sy += j; sz += k; cnt++; }
+        if (isReducedL(lab[c]) && reg[c] == r) { sx += i; sy += j; sz += k + zoff; cnt++; }
     }
     __shared__ unsigned long long sm[4][BS];
     sm[0][threadIdx.x] = sx; sm[1][threadIdx.x] = sy; sm[2][threadIdx.x] = sz; sm[3][threadIdx.x] = cnt;
@@ -490,6 +491,7 @@ TileArgs makeArgs(ps_context* c) {
     for (int a = 0; a < 3; ++a) A.vel[a] = c->vel[a].p;
     A.visc = c->viscosity.p;
     A.COM = c->COM.p;
+    A.zoff = c->zOff;
     A.bbox = c->bbox.p;
     A.itemRegion = c->fbItemRegion.p; A.itemAxis = c->fbItemAxis.p; A.itemStart = c->fbItemStart.p;
     return A;
@@ -567,7 +569,7 @@ void ps_context::computeCenterOfMasses() {
     HIP_CHECK(hipMemcpyAsync(fbItemStart.p, iS.data(), iS.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(fbRegionItemPtr.p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    hipLaunchKernelGGL(k_com, dim3((unsigned)R), dim3(BS), 0, stream, g, dx, labels[0].p, reducedIdx[0].p, bbox.p, COM.p);
+    hipLaunchKernelGGL(k_com, dim3((unsigned)R), dim3(BS), 0, stream, g, dx, zOff, labels[0].p, reducedIdx[0].p, bbox.p, COM.p);
 }
 
 void ps_context::computeLeastSquaresFits() {
