@@ -27,8 +27,7 @@ for r, sl in enumerate(grp.slabs):
     pairs = sorted(set(zip(own[own >= 0].tolist(), ref[own >= 0].tolist())))
     print("   (local region, global region) pairs on owned cells:", pairs, " mismatched membership:", int(((own >= 0) != (ref >= 0)).sum()))
     for lq, gq in pairs:
-        zoff = (sl.z0 - sl.zLoOwned) * sc.dx
-        print("   region %d->%d  COM local+offset %s  global %s  cells local %d global %d" % (lq, gq, np.round(com[lq] + [0, 0, zoff], 6), np.round(coms[gq], 6), int((rr == lq).sum()), int((rs == gq).sum())))
+        print("   region %d->%d  COM (a slab reports global coordinates) %s  single domain %s  cells local %d global %d" % (lq, gq, np.round(com[lq], 6), np.round(coms[gq], 6), int((rr == lq).sum()), int((rs == gq).sum())))
 s1 = grp.ranks[1]
 for nm in ("reducedMassMatrices", "reducedViscosityMatrices", "Inv_Mr_plus_2JDtuDJ", "reducedRHSVector"):
     try:
