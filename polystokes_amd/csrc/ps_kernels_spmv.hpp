@@ -253,6 +253,9 @@ template <bool NT> __device__ inline void bufStoreF64nt(__amdgpu_buffer_rsrc_t r
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byteOff, 0, NT ? PS_STORE_AUX : 0);
 }
 __device__ inline double bufGatherF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
+#ifdef PS_EXP_GATHER_MASK   // timing experiment only (wrong results): every gather falls into the first PS_EXP_GATHER_MASK + 8 bytes
+    byteOff &= PS_EXP_GATHER_MASK;
+#endif
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, PS_GATHER_AUX));
 }
 // one lane's share of a chunk's stream: NV groups of 4 consecutive entries (non-temporal: read once)
