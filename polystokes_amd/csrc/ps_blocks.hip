@@ -26,6 +26,7 @@ struct BlockArgs {
     const int32_t* act[7];
     const int32_t* reg[7];
     const int32_t* sys[7];     // internal system numbering (sysIdx)
+    const int32_t* sysT[3];    // cell -> txx / tyy / tzz (sysIdxT)
     const int32_t* faceRow[3];
     const float* vel[3];
     const float* cvel[3];
@@ -80,7 +81,7 @@ __device__ inline int faceEntriesT(const BlockArgs& A, const int3 f, int32_t (&c
         if (coeff <= 0.) continue;
         const int pidx = A.sys[0][cl];   // internal index of this cell's pressure (>= 0 iff the cell is ACTIVE)
         if (pidx >= 0) { cols[dir] = pidx; vals[dir] = sign * coeff; ++n; }                                     // pressure
-        if (isActiveL(A.lab[0][cl])) { cols[2 + dir] = A.sys[0][cl] + 1 + AXIS; vals[2 + dir] = -1. * sign * coeff; ++n; }   // centre stress
+        if (isActiveL(A.lab[0][cl])) { cols[2 + dir] = A.sysT[AXIS][cl]; vals[2 + dir] = -1. * sign * coeff; ++n; }   // centre stress
     }
     // edge stresses
     constexpr int EA0 = AXIS == 0 ? 1 : 0, EA1 = AXIS == 2 ? 1 : 2;
@@ -120,14 +121,15 @@ __device__ inline void sortEntries(int32_t (&cols)[8], double (&vals)[8]) {
 
 // reduced faces with >= 1 stencil entry, enumerated per region through its face box (same work items
 // as the dense reductions): count, then ordered assignment of rows nA + k.
-__device__ inline bool skinFace(const BlockArgs& A, int axis, int r, int i, int j, int k) {
+// number of stencil entries of the reduced face (axis, i, j, k) of region r; 0: not a skin face
+__device__ inline int skinFaceLen(const BlockArgs& A, int axis, int r, int i, int j, int k) {
     const int3 fd = A.g.dims(1 + axis);
-    if (oob3(fd, i, j, k)) return false;
+    if (oob3(fd, i, j, k)) return 0;
     const int64_t c = lin3(fd, i, j, k);
-    if (A.reg[1 + axis][c] != r || A.lab[1 + axis][c] != PS_REDUCED) return false;
+    if (A.reg[1 + axis][c] != r || A.lab[1 + axis][c] != PS_REDUCED) return 0;
     int32_t cols[8];
     double vals[8];
-    return faceEntries(A, axis, make_int3(i, j, k), cols, vals) > 0;
+    return faceEntries(A, axis, make_int3(i, j, k), cols, vals);
 }
 __device__ inline int blockScanExcl(int v, int* total) {
     __shared__ int waveSums[BS / 64];
@@ -147,48 +149,126 @@ __device__ inline int blockScanExcl(int v, int* total) {
     *total = tot;
     return base + incl - v;
 }
+// the same for six 10-bit counters packed in 64 bits (each thread contributes 0 or 1 per counter: <= 256 per block)
+__device__ inline unsigned long long blockScanExclPacked(unsigned long long v, unsigned long long* total) {
+    __shared__ unsigned long long waveSums64[BS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned lo = __shfl_up((unsigned)(incl & 0xffffffffull), o, 64), hi = __shfl_up((unsigned)(incl >> 32), o, 64);
+        if (lane >= o) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) waveSums64[w] = incl;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) { if (i < w) base += waveSums64[i]; tot += waveSums64[i]; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+// Skin rows (reduced faces with >= 1 stencil entry) of one work item = <= FB_CHUNK positions of a region's union face box.
+// ASSIGN = false counts them.  ASSIGN = true numbers them nA + (item offset) + ..., ordered by (length class, axis, position
+// x-fastest): first the LONG rows (> 2 entries: the faces normal to the tile's surface, 6 entries), then the SHORT ones (tangential
+// faces that touch the tile's surface with an edge: 1-2 entries), each class axis by axis.  Rows of one class and axis have the
+// same shape: a 64-row unit of the row-per-lane SpMV (DevCSR::ecol) is then padded by almost nothing (in (position, axis) order
+// every unit held a 6-entry row and was padded to 6: half its slots empty), and consecutive rows address consecutive DOFs of one
+// kind.  itemLong[item] = number of long rows (the stream build cuts its chunks there).
+constexpr int SKIN_LONG_MIN = 3;
 template <bool ASSIGN>
 __global__ void __launch_bounds__(BS) k_skin(BlockArgs A, const int32_t* __restrict__ bbox, const int32_t* __restrict__ itemRegion,
                                              const int32_t* __restrict__ itemStart, int32_t* __restrict__ itemCount, int32_t* __restrict__ faceRow0,
                                              int32_t* __restrict__ faceRow1, int32_t* __restrict__ faceRow2, uint32_t* __restrict__ rrowFace,
-                                             int32_t* __restrict__ rrowRegion) {
+                                             int32_t* __restrict__ rrowRegion, int32_t* __restrict__ itemLong) {
+    __shared__ unsigned char codes[ASSIGN ? FB_CHUNK : 1];   // per position: 2 bits per axis (0 none, 1 short, 2 long)
     const int item = blockIdx.x;
     const int r = itemRegion[item], start = itemStart[item];
     if (A.regionOwned && !A.regionOwned[r]) {   // tile of another rank (halo): no rows here
         if (!ASSIGN && threadIdx.x == 0) itemCount[item] = 0;
+        if (ASSIGN && threadIdx.x == 0) itemLong[item] = 0;
         return;
     }
     const int bx0 = bbox[r * 6 + 0], by0 = bbox[r * 6 + 1], bz0 = bbox[r * 6 + 2];
     const int ex = bbox[r * 6 + 3] - bx0 + 2, ey = bbox[r * 6 + 4] - by0 + 2, ez = bbox[r * 6 + 5] - bz0 + 2;   // union of the three face boxes
     const int total = ex * ey * ez;
     const int end = min(start + FB_CHUNK, total);
-    int running = ASSIGN ? itemCount[item] : 0;   // exclusive offset of this item (after scan)
+    // pass 1: classify every position; totals per (class, axis) category — category = (long ? 0 : 3) + axis
+    unsigned long long mine = 0;
     for (int base = start; base < end; base += BS) {
         const int pos = base + threadIdx.x;
-        int fl = 0;                                // bit a: the face of axis a at this position is a skin face
-        int i = 0, j = 0, k = 0;
         if (pos < end) {
-            i = bx0 + pos % ex; j = by0 + (pos / ex) % ey; k = bz0 + pos / (ex * ey);
+            const int i = bx0 + pos % ex, j = by0 + (pos / ex) % ey, k = bz0 + pos / (ex * ey);
+            int code = 0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) if (skinFace(A, a, r, i, j, k)) fl |= 1 << a;
+            for (int a = 0; a < 3; ++a) {
+                const int n = skinFaceLen(A, a, r, i, j, k);
+                if (n > 0) { const bool lg = n >= SKIN_LONG_MIN; code |= (lg ? 2 : 1) << (2 * a); mine += 1ull << (10 * ((lg ? 0 : 3) + a)); }
+            }
+            if (ASSIGN) codes[pos - start] = (unsigned char)code;
         }
-        int tot;
-        const int off = blockScanExcl(__popc(fl), &tot);
-        if (ASSIGN && fl) {
-            int rr = running + off;
+    }
+    // (`mine`: per-thread counts, <= FB_CHUNK / BS = 16 per category)
+    int catBase[6] = {0, 0, 0, 0, 0, 0};
+    if (ASSIGN) {
+        // item totals per category from the batches (each batch total <= 256 per category)
+        int itemTot[6] = {0, 0, 0, 0, 0, 0};
+        for (int base = start; base < end; base += BS) {
+            const int pos = base + threadIdx.x;
+            unsigned long long v = 0;
+            if (pos < end) {
+                const int code = codes[pos - start];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
-                if (fl & (1 << a)) {
+                for (int a = 0; a < 3; ++a) { const int q = (code >> (2 * a)) & 3; if (q) v += 1ull << (10 * ((q == 2 ? 0 : 3) + a)); }
+            }
+            unsigned long long bt;
+            blockScanExclPacked(v, &bt);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) itemTot[c] += (int)((bt >> (10 * c)) & 1023ull);
+        }
+        int run = itemCount[item];                 // exclusive offset of this item (after the scan over the items)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { catBase[c] = run; run += itemTot[c]; }
+        if (threadIdx.x == 0) itemLong[item] = itemTot[0] + itemTot[1] + itemTot[2];
+        // pass 2: number the rows
+        for (int base = start; base < end; base += BS) {
+            const int pos = base + threadIdx.x;
+            unsigned long long v = 0;
+            int code = 0;
+            if (pos < end) {
+                code = codes[pos - start];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { const int q = (code >> (2 * a)) & 3; if (q) v += 1ull << (10 * ((q == 2 ? 0 : 3) + a)); }
+            }
+            unsigned long long bt;
+            const unsigned long long off = blockScanExclPacked(v, &bt);
+            if (code) {
+                const int i = bx0 + pos % ex, j = by0 + (pos / ex) % ey, k = bz0 + pos / (ex * ey);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int q = (code >> (2 * a)) & 3;
+                    if (!q) continue;
+                    const int c = (q == 2 ? 0 : 3) + a;
+                    const int rr = catBase[c] + (int)((off >> (10 * c)) & 1023ull);
                     int32_t* faceRow = a == 0 ? faceRow0 : (a == 1 ? faceRow1 : faceRow2);
                     faceRow[lin3(A.g.dims(1 + a), i, j, k)] = (int32_t)(A.nA + rr);
                     rrowFace[rr] = packFace(i, j, k, a);
                     rrowRegion[rr] = r;
-                    ++rr;
                 }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) catBase[c] += (int)((bt >> (10 * c)) & 1023ull);
         }
-        running += tot;
+    } else {
+        // count only: total number of skin faces of the item
+        int n = 0;
+        unsigned long long m = mine;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { n += (int)(m & 1023ull); m >>= 10; }
+        int totalRows;
+        blockScanExcl(n, &totalRows);
+        if (threadIdx.x == 0) itemCount[item] = totalRows;
     }
-    if (!ASSIGN && threadIdx.x == 0) itemCount[item] = running;
 }
 
 __global__ void k_S_count(BlockArgs A, int axis, int32_t* __restrict__ rowCount) {
@@ -362,7 +442,7 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
     const int3 d = A.g.dims(0);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
-    const int idx = A.sys[0][c];   // internal base: p, txx, tyy, tzz = idx + 0..3
+    const int idx = A.sys[0][c];   // internal index of p; txx, tyy, tzz: sysT
     if (idx < 0) return;
     const int3 q = unlin3(d, c);
     int32_t rows[6];
@@ -379,7 +459,7 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
     for (int mode = 0; mode < 4; ++mode) {
         double rhs;
         const int n = cellColumn(A, mode, q, rows, vals, &rhs);
-        const int64_t j = idx + mode;
+        const int64_t j = mode == 0 ? idx : A.sysT[mode - 1][c];
         if (!FILL) { cnt[j] = n; continue; }
         sortRows(n, rows, vals);
         const int p0 = ptr[j];
@@ -426,7 +506,7 @@ BlockArgs makeArgs(ps_context* c) {
         A.lw[s] = c->liquidW[s].p; A.fw[s] = c->fluidW[s].p;
         A.lab[s] = c->labels[s].p; A.act[s] = c->activeIdx[s].p; A.reg[s] = c->reducedIdx[s].p; A.sys[s] = c->sysIdx[s].p;
     }
-    for (int a = 0; a < 3; ++a) { A.faceRow[a] = c->faceRow[a].p; A.vel[a] = c->vel[a].p; A.cvel[a] = c->cvel[a].p; }
+    for (int a = 0; a < 3; ++a) { A.faceRow[a] = c->faceRow[a].p; A.vel[a] = c->vel[a].p; A.cvel[a] = c->cvel[a].p; A.sysT[a] = c->sysIdxT[a].p; }
     A.visc = c->viscosity.p;
     A.nCenter = c->nCenter; A.nEdge0 = c->nEdge[0]; A.nEdge1 = c->nEdge[1];
     A.nP = c->nPressures; A.nA = c->nActiveVs;
@@ -454,10 +534,11 @@ __global__ void k_chunk_len4(const int32_t* __restrict__ ptr, const int2* __rest
 __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const int8_t* __restrict__ code,
                                                     const int2* __restrict__ chunkRows, const int32_t* __restrict__ start4, uint16_t* __restrict__ col16,
                                                     int8_t* __restrict__ code4, int32_t* __restrict__ winBase, int4* __restrict__ chunkInfo,
-                                                    uint8_t* __restrict__ len8, int32_t* __restrict__ fail) {
+                                                    uint8_t* __restrict__ len8, int32_t* __restrict__ fail, int32_t* __restrict__ chunkRep) {
     __shared__ int red[BS / 64];
     __shared__ int bmin;
     const int chunk = blockIdx.x;
+    if (threadIdx.x == 0) chunkRep[chunk] = chunk;                  // owner of the chunk's run (k_chunk_share redirects)
     const int2 cr = chunkRows[chunk];
     const int r0 = cr.x;
     const int p0 = ptr[r0], p1 = ptr[r0 + cr.y];
@@ -545,7 +626,7 @@ __global__ void k_chunk_rep_insert(const unsigned long long* __restrict__ hash, 
 __global__ void __launch_bounds__(64) k_chunk_share(const unsigned long long* __restrict__ hash, const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
                                                     unsigned mask, int4* __restrict__ chunkInfo, const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4,
                                                     const uint8_t* __restrict__ len8, const uint8_t* __restrict__ rowCode, int codeRows,
-                                                    unsigned long long* __restrict__ uniqueLen) {
+                                                    unsigned long long* __restrict__ uniqueLen, int32_t* __restrict__ chunkRep) {
     const int chunk = blockIdx.x;
     const unsigned long long h = hash[chunk];
     unsigned slot = (unsigned)(h >> 17) & mask;
@@ -568,7 +649,7 @@ __global__ void __launch_bounds__(64) k_chunk_share(const unsigned long long* __
             }
         }
         same = __all(same) != 0;
-        if (same && threadIdx.x == 0) { chunkInfo[chunk].x = cr.x; chunkInfo[chunk].w = cr.z; }
+        if (same && threadIdx.x == 0) { chunkInfo[chunk].x = cr.x; chunkInfo[chunk].w = cr.z; chunkRep[chunk] = rep; }
     }
     if (!same && threadIdx.x == 0) atomicAdd(uniqueLen, (unsigned long long)n4);
 }
@@ -581,7 +662,102 @@ __global__ void __launch_bounds__(BS) k_val4_build(const int32_t* __restrict__ p
     const int n4 = (n + 3) & ~3;
     for (int i = threadIdx.x; i < n4; i += BS) val4[q0 + i] = i < n ? val[p0 + i] : 0.;
 }
+// ---- row-per-lane form of the stream (DevCSR::ecol ...) ---------------------------------------------------------------
+// A re-layout of the windowed stream above (same columns, same window bases, same codes): chunk -> four units of 64 rows, a unit
+// padded to the (even) length W of its longest row, lane-major.  Only chunks that own their run get one (shared chunks point at
+// their owner's: chunkRep), so a periodic tile structure stores a few MB.
+__device__ inline int ellCodeWidth(int W) { return W > 4 ? 8 : (W > 0 ? 4 : 0); }
+constexpr int32_t ELL_NULL_BASE = 0x1ffff000;   // (base + 12-bit offset) * 8 >= 0xffff8000: beyond any vector the kernels address (buildEll checks)
+// plan, one block per chunk: unit widths -> sizes of the chunk's column / code runs (0 for a chunk that shares its owner's)
+__global__ void __launch_bounds__(BS) k_ell_plan(const int4* __restrict__ chunkInfo, const uint8_t* __restrict__ len8, const int32_t* __restrict__ chunkRep,
+                                                 int32_t* __restrict__ colLen, int32_t* __restrict__ codeLen, int32_t* __restrict__ wpack, int32_t* __restrict__ fail) {
+    __shared__ int wmax[BS / 64];
+    const int chunk = blockIdx.x;
+    const int4 ci = chunkInfo[chunk];
+    const int rows = (int)((unsigned)ci.y >> 16);
+    int len = (int)threadIdx.x < rows ? (int)len8[ci.z + threadIdx.x] : 0;
+    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_down(len, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int cl = 0, vl = 0, wp = 0;
+        for (int u = 0; u < BS / 64; ++u) {
+            const int W = (wmax[u] + 1) & ~1;
+            if (W > 8) *fail = 1;
+            cl += 64 * W; vl += 64 * ellCodeWidth(W); wp |= (W & 15) << (4 * u);
+        }
+        const bool own = chunkRep[chunk] == chunk;
+        colLen[chunk] = own ? cl : 0; codeLen[chunk] = own ? vl : 0; wpack[chunk] = wp;
+    }
+}
+// fill, one block per chunk (thread = row): lane l of unit u writes its row's entries; slots past the end of the row hold value
+// code 0 and address window 15 — which the chunk does not use (its base is still 0: windows are assigned in ascending order of
+// their bases) and now gets a base beyond every vector (ELL_NULL_BASE): the gather is out of the buffer's range, returns 0 and
+// costs no cache lookup; a chunk that does use 16 windows repeats the row's last column instead (a hit in the line the previous
+// slot touched; the product is +-0).  Lanes past the chunk's last row repeat the last row (their results are never stored).
+// Every chunk writes its record.
+__global__ void __launch_bounds__(BS) k_ell_fill(const int4* __restrict__ chunkInfo, const uint8_t* __restrict__ len8, const int32_t* __restrict__ chunkRep,
+                                                 const uint16_t* __restrict__ col16, const int8_t* __restrict__ code4, const int32_t* __restrict__ colBegin,
+                                                 const int32_t* __restrict__ codeBegin, const int32_t* __restrict__ wpack, uint16_t* __restrict__ ecol,
+                                                 int8_t* __restrict__ ecode, int4* __restrict__ echunk, int32_t* __restrict__ winBase) {
+    const int chunk = blockIdx.x;
+    const int rep = chunkRep[chunk];
+    const bool nullOk = winBase[chunk * 16 + 15] == 0 || winBase[chunk * 16 + 15] == ELL_NULL_BASE;   // (same verdict for a chunk and the owner of its run: same window codes)
+    __syncthreads();
+    if (nullOk && threadIdx.x == 0) winBase[chunk * 16 + 15] = ELL_NULL_BASE;
+    const int4 ci = chunkInfo[chunk];
+    const int rows = (int)((unsigned)ci.y >> 16);
+    const int wp = wpack[chunk];
+    if (threadIdx.x == 0) echunk[chunk] = make_int4(colBegin[rep], codeBegin[rep], ci.z, rows | (wp << 12));
+    if (rep != chunk) return;                                       // (block-uniform)
+    const int len = (int)len8[ci.z + min((int)threadIdx.x, rows - 1)];   // rows >= 1
+    int total;
+    const int mine = (int)threadIdx.x < rows ? len : 0;
+    const int e0 = blockScanExcl(mine, &total);
+    __shared__ int lastE0;
+    if ((int)threadIdx.x == rows - 1) lastE0 = e0;
+    __syncthreads();
+    const int eb = ci.x + ((int)threadIdx.x < rows ? e0 : lastE0);   // first entry of the row this lane presents
+    const int u = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int W = (wp >> (4 * u)) & 15, CW = ellCodeWidth(W);
+    if (W == 0 || u * 64 >= rows) return;                            // a unit without rows has no run
+    int pre = 0, preC = 0;
+    for (int v = 0; v < u; ++v) { const int w = (wp >> (4 * v)) & 15; pre += w; preC += ellCodeWidth(w); }
+    uint16_t* oc = ecol + (size_t)colBegin[chunk] + (size_t)64 * pre + (size_t)lane * W;
+    int8_t* ov = ecode + (size_t)codeBegin[chunk] + (size_t)64 * preC + (size_t)lane * CW;
+    uint16_t lastc = 0;
+    for (int k = 0; k < W; ++k) {
+        if (k < len) lastc = col16[eb + k];
+        oc[k] = (k < len || !nullOk) ? lastc : (uint16_t)0xf000;
+    }
+    for (int k = 0; k < CW; ++k) ov[k] = k < len ? code4[eb + k] : (int8_t)0;
+}
 }  // namespace
+// Row-per-lane form of M's compressed stream (needs the windowed stream of buildCol16 and coded values)
+void ps_context::buildEll(ps::DevCSR& M) {
+    M.ellok = false;
+    static const bool off = getenv("PS_NO_ELL") && atoi(getenv("PS_NO_ELL")) != 0;   // A/B: keep the 4-entries-per-lane kernels
+    if (off || !M.col16ok || !M.packed || M.nChunks == 0 || (uint64_t)std::max(M.rows, M.cols) * 8 >= 0xffff8000ull) return;
+    const int nChunks = M.nChunks;
+    DevBuf<int32_t>& colBegin = scrEllCol; DevBuf<int32_t>& codeBegin = scrEllCode; DevBuf<int32_t>& wpack = scrEllW;
+    colBegin.alloc((size_t)nChunks + 1); codeBegin.alloc((size_t)nChunks + 1); wpack.alloc((size_t)nChunks);
+    HIP_CHECK(hipMemsetAsync(colBegin.p + nChunks, 0, sizeof(int32_t), stream));
+    HIP_CHECK(hipMemsetAsync(codeBegin.p + nChunks, 0, sizeof(int32_t), stream));
+    HIP_CHECK(hipMemsetAsync(counters.p + 25, 0, sizeof(int32_t), stream));
+    hipLaunchKernelGGL(k_ell_plan, dim3((unsigned)nChunks), dim3(BS), 0, stream, (const int4*)M.chunkInfo.p, (const uint8_t*)M.len8.p, (const int32_t*)M.chunkRep.p,
+                       colBegin.p, codeBegin.p, wpack.p, counters.p + 25);
+    const int64_t totCol = exclusiveScanI32(colBegin.p, nChunks + 1);
+    const int64_t totCode = exclusiveScanI32(codeBegin.p, nChunks + 1);
+    if (totCol < 0 || totCode < 0 || (uint64_t)totCol * 2 >= 0xffffffffull || readCounter(25) != 0) return;   // a row longer than 8 / 32-bit offsets: keep the other kernels
+    M.ellCols = totCol; M.ellCodes = totCode; M.ellUniqueCols = totCol;
+    M.ecol.alloc((size_t)totCol + 64); M.ecode.alloc((size_t)totCode + 64); M.echunk.alloc((size_t)nChunks);
+    hipLaunchKernelGGL(k_ell_fill, dim3((unsigned)nChunks), dim3(BS), 0, stream, (const int4*)M.chunkInfo.p, (const uint8_t*)M.len8.p, (const int32_t*)M.chunkRep.p,
+                       (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p, (const int32_t*)colBegin.p, (const int32_t*)codeBegin.p, (const int32_t*)wpack.p,
+                       M.ecol.p, M.ecode.p, M.echunk.p, M.winBase.p);
+    M.ellok = true;
+    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] row-per-lane stream: %d chunks, %lld column slots and %lld code bytes in the distinct runs (nnz %lld)\n",
+                                           nChunks, (long long)totCol, (long long)totCode, (long long)M.nnz);
+}
 void ps_context::buildVal4(ps::DevCSR& M) {
     if (!M.col16ok || M.val4.p) return;
     M.val4.alloc((size_t)M.streamLen + 8);
@@ -592,6 +768,7 @@ void ps_context::buildVal4(ps::DevCSR& M) {
 // (10 B per entry, DevCSR::val4) and the same pipelined kernels run.  PS_COL32=1 keeps the one-shot CSR kernels.
 void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>& cuts, const uint8_t* rowCode, int codeRows) {
     M.col16ok = false;
+    M.ellok = false;
     M.nChunks = 0;
     M.val4.free();
     const char* e = getenv("PS_COL32");
@@ -636,10 +813,10 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
     M.uniqueLen = total4;
     M.nChunks = nChunks;
     M.col16.alloc((size_t)total4 + 8); M.code4.alloc((size_t)total4 + 8);
-    M.winBase.alloc((size_t)nChunks * 16); M.chunkInfo.alloc((size_t)nChunks); M.len8.alloc((size_t)M.rows);
+    M.winBase.alloc((size_t)nChunks * 16); M.chunkInfo.alloc((size_t)nChunks); M.len8.alloc((size_t)M.rows); M.chunkRep.alloc((size_t)nChunks);
     HIP_CHECK(hipMemsetAsync(counters.p + slot, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(k_col16_build, dim3((unsigned)nChunks), dim3(BS), 0, stream, M.ptr.p, M.col.p, M.code.p, (const int2*)chunkRows.p, start4.p, M.col16.p,
-                       M.code4.p, M.winBase.p, M.chunkInfo.p, M.len8.p, counters.p + slot);
+                       M.code4.p, M.winBase.p, M.chunkInfo.p, M.len8.p, counters.p + slot, M.chunkRep.p);
     M.col16ok = readCounter(slot) == 0;
     if (M.col16ok && !M.packed) buildVal4(M);
     static const bool noShare = getenv("PS_NO_SHARED_RUNS") && atoi(getenv("PS_NO_SHARED_RUNS")) != 0;
@@ -657,7 +834,7 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
                            (const uint8_t*)M.len8.p, hash.p, weakHash ? 1 : 0);
         hipLaunchKernelGGL(k_chunk_rep_insert, dim3(gridFor(nChunks, BS)), dim3(BS), 0, stream, (const unsigned long long*)hash.p, nChunks, keys.p, vals.p, cap - 1);
         hipLaunchKernelGGL(k_chunk_share, dim3((unsigned)nChunks), dim3(64), 0, stream, (const unsigned long long*)hash.p, (const unsigned long long*)keys.p,
-                           (const int32_t*)vals.p, cap - 1, M.chunkInfo.p, (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p, (const uint8_t*)M.len8.p, rowCode, codeRows, uniq.p);
+                           (const int32_t*)vals.p, cap - 1, M.chunkInfo.p, (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p, (const uint8_t*)M.len8.p, rowCode, codeRows, uniq.p, M.chunkRep.p);
         unsigned long long u = 0;
         HIP_CHECK(hipMemcpyAsync(&u, uniq.p, 8, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -756,12 +933,13 @@ void ps_context::buildStreams(bool share) {
     std::vector<int32_t> cutsS, cutsT;
     if (!blockStartRow.empty() && (int64_t)blockStartRow.back() == nActiveVs) {
         cutsS = blockStartRow;
-        for (size_t r = 1; r < regionRowPtrHost.size(); ++r) cutsS.push_back((int32_t)(nActiveVs + regionRowPtrHost[r]));
+        for (size_t r = 1; r < skinCutsHost.size(); ++r) cutsS.push_back((int32_t)(nActiveVs + skinCutsHost[r]));   // (skinCutsHost[0] = 0 = the end of the active rows)
     }
     if (!blockStartSys.empty() && (int64_t)blockStartSys.back() == nSystem) cutsT = blockStartSys;
     shareRuns = share;
     buildCol16(S, 22, cutsS, mcCoded ? mcCode.p : nullptr, (int)nActiveVs);
     buildCol16(St, 23, cutsT, uCoded ? uCode.p : nullptr, (int)nSystem);
+    if (share) { buildEll(S); buildEll(St); } else S.ellok = St.ellok = false;   // (the unshared rebuild is bench.py's fp64-value stream: the 4-entries-per-lane kernels)
 }
 
 // ConstructMatrixBlocks.cpp:9-292
@@ -784,17 +962,26 @@ void ps_context::constructMatrixBlocks() {
     maxRegionRows = 0;
     if (regionCount > 0 && sbItems > 0) {
         hipLaunchKernelGGL(k_skin<false>, dim3((unsigned)sbItems), dim3(BS), 0, stream, A, bbox.p, sbItemRegion.p, sbItemStart.p, sbItemCount.p,
-                           faceRow[0].p, faceRow[1].p, faceRow[2].p, (uint32_t*)nullptr, (int32_t*)nullptr);
+                           faceRow[0].p, faceRow[1].p, faceRow[2].p, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
         HIP_CHECK(hipMemsetAsync(sbItemCount.p + sbItems, 0, sizeof(int32_t), stream));
         nReducedRows = exclusiveScanI32(sbItemCount.p, sbItems + 1);
         rrowFace.alloc((size_t)nReducedRows);
         rrowRegion.alloc((size_t)nReducedRows);
+        sbItemLong.alloc((size_t)sbItems);
         hipLaunchKernelGGL(k_skin<true>, dim3((unsigned)sbItems), dim3(BS), 0, stream, A, bbox.p, sbItemRegion.p, sbItemStart.p, sbItemCount.p,
-                           faceRow[0].p, faceRow[1].p, faceRow[2].p, rrowFace.p, rrowRegion.p);
+                           faceRow[0].p, faceRow[1].p, faceRow[2].p, rrowFace.p, rrowRegion.p, sbItemLong.p);
         // region -> row range, and equal pieces of <= RC_ROWS rows for the three-kernel tile apply (host built)
-        std::vector<int32_t> itemOff((size_t)sbItems + 1);
+        std::vector<int32_t> itemOff((size_t)sbItems + 1), itemLong((size_t)sbItems);
         HIP_CHECK(hipMemcpyAsync(itemOff.data(), sbItemCount.p, itemOff.size() * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(itemLong.data(), sbItemLong.p, itemLong.size() * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
+        // where the stream build may start a chunk inside the skin rows: every item's first row and the end of its long rows
+        skinCutsHost.clear();
+        for (int64_t q = 0; q < sbItems; ++q) {
+            skinCutsHost.push_back(itemOff[(size_t)q]);
+            if (itemLong[(size_t)q] > 0 && itemOff[(size_t)q] + itemLong[(size_t)q] < itemOff[(size_t)q + 1]) skinCutsHost.push_back(itemOff[(size_t)q] + itemLong[(size_t)q]);
+        }
+        skinCutsHost.push_back(itemOff[(size_t)sbItems]);
         std::vector<int32_t> rptr((size_t)regionCount + 1), cR, cS, cE, cptr((size_t)regionCount + 1);
         for (int64_t r = 0; r <= regionCount; ++r) rptr[(size_t)r] = itemOff[(size_t)sbRegionItemPtrHost[(size_t)r]];
         regionRowPtrHost = rptr;
@@ -826,6 +1013,7 @@ void ps_context::constructMatrixBlocks() {
     } else {
         nRChunks = 0;
         regionRowPtrHost.assign(1, 0);
+        skinCutsHost.assign(1, 0);
     }
     nRows = nActiveVs + nReducedRows;
     if (nRows >= 0x7fffffff) throw Error("too many face rows");

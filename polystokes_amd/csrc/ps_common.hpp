@@ -101,6 +101,10 @@ template <class T>
 struct Set7 {
     T* p[7];
 };
+template <class T>
+struct Set8 {
+    T* p[8];
+};
 
 // Slab ownership (multi-GPU): which entities of the local (slab + halo) grid this rank owns.  Cells, X/Y faces and
 // XY edges live IN a cell layer k; Z faces and YZ/XZ edges live ON a plane k (the plane below layer k); the plane on a

@@ -30,11 +30,25 @@ struct DevCSR {
     DevBuf<int32_t> winBase;
     DevBuf<int4> chunkInfo;      // (run begin, entries | rows << 16, first row, first row of the run's owner) — ps_kernels_spmv.hpp:Chunk
     DevBuf<uint8_t> len8;
+    DevBuf<int32_t> chunkRep;    // the chunk whose run a chunk points at (itself unless shared)
     int nChunks = 0;
     int64_t uniqueLen = 0;       // entries of the runs some chunk actually points at (== streamLen without sharing)
     bool col16ok = false;
     int nv = 2;
     int64_t streamLen = 0;       // entries of col16 / code4 (multiple of 4)
+    // Row-per-lane form of the same stream (coded values only; ps_blocks.hip:buildEll, ps_kernels_spmv.hpp:k_spmv_*_ell).  A chunk's
+    // rows are cut into four units of 64 consecutive rows, one per wave; a unit is padded to the width W (even, <= 8) of its longest
+    // row and stored lane-major: lane l of the unit finds its row's W windowed 16-bit columns at ecol[unitBegin + l*W ..] and its W
+    // value codes (padded to 4 or 8 bytes) at ecode[...].  Gather instruction k of a wave then covers entry k of 64 CONSECUTIVE rows:
+    // the lanes of a quad address neighbouring columns, which the CU's L1 pipeline serves per distinct line, not per lane
+    // (profiles/r03_spmv_issue.md).  Each lane keeps its row's sum in a register: no LDS round trip, no row-length scan, no barrier.
+    // echunk: (col begin [u16 units], code begin [bytes], first row, rows | W0 << 12 | W1 << 16 | W2 << 20 | W3 << 24).
+    DevBuf<uint16_t> ecol;
+    DevBuf<int8_t> ecode;
+    DevBuf<int4> echunk;         // (the 16 window bases per chunk are winBase: same greedy cover, same columns)
+    bool ellok = false;
+    int64_t ellCols = 0, ellCodes = 0;     // sizes of ecol (u16 units) / ecode (bytes)
+    int64_t ellUniqueCols = 0;             // u16 units of the runs some chunk actually points at (== ellCols without sharing)
 };
 
 // device-resident CG scalars (no host round trip inside the iteration)
@@ -86,6 +100,8 @@ struct ps_context {
     // gathers stay in L2.  sysIdx[0]: cell -> base (p, txx, tyy, tzz = base+0..3); sysIdx[4..6]: edge -> index.
     // permSys[ref system index] = internal index; permRow[ref active-face index] = internal row.
     ps::DevBuf<int32_t> sysIdx[7];
+    ps::DevBuf<int32_t> sysIdxT[3];          // cell -> internal index of its txx / tyy / tzz (sysIdx[0]: its pressure)
+    int ilPlaneMajor = 0;                    // bit 0: DOFs, bit 1: face rows numbered kind-major inside every k-plane of a lattice block (buildInternalNumbering)
     ps::DevBuf<int32_t> permSys, permRow;
     // lattice of the internal numbering (ps_grid.hip:ILDesc): origin offset of the 16^3 blocks and the super-block shape
     // (blocks of one super-block are consecutive: its DOFs / rows are one XCD's working set in the scheduled SpMV walk)
@@ -114,7 +130,8 @@ struct ps_context {
     // skin-row enumeration: items of <= FB_CHUNK positions of a region's UNION face box (ex+1)(ey+1)(ez+1); a position yields up
     // to three rows (its X, Y, Z face) — rows are ordered (region, position x-fastest, axis), so the faces hanging off one
     // voxel are adjacent rows like the active ones
-    ps::DevBuf<int32_t> sbItemRegion, sbItemStart, sbItemCount;
+    ps::DevBuf<int32_t> sbItemRegion, sbItemStart, sbItemCount, sbItemLong;   // sbItemLong: long (> 2 entries) skin rows of the item, numbered first
+    std::vector<int32_t> skinCutsHost;                           // skin-row offsets where a chunk of S's stream may start (item starts, ends of the long rows)
     std::vector<int32_t> sbRegionItemPtrHost;                    // R+1
     int64_t sbItems = 0;
     int64_t maxRegionRows = 0;                                   // fullest region: decides fused / three-kernel tile apply
@@ -213,9 +230,10 @@ struct ps_context {
     void assembleReducedBlocks();                         // AssembleBlocks.cpp:147-244,356-367
     void constructMatrixBlocks();                         // ps_blocks.hip
     void buildCol16(ps::DevCSR& M, int counterSlot, const std::vector<int32_t>& cuts, const uint8_t* rowCode, int codeRows);   // ps_blocks.hip; cuts: row indices where a chunk should start
+    void buildEll(ps::DevCSR& M);                         // the row-per-lane form of M's compressed stream (ps_blocks.hip)
     void buildStreams(bool share);                        // both compressed streams (ps_blocks.hip)
     bool shareRuns = true;
-    ps::DevBuf<int2> scrChunkRows; ps::DevBuf<int32_t> scrStart4, scrVals, scrKeep, scrRemap; ps::DevBuf<unsigned long long> scrHash, scrKeys, scrUniq;   // buildCol16 scratch
+    ps::DevBuf<int2> scrChunkRows; ps::DevBuf<int32_t> scrStart4, scrVals, scrKeep, scrRemap, scrEllCol, scrEllCode, scrEllW; ps::DevBuf<unsigned long long> scrHash, scrKeys, scrUniq;   // buildCol16 scratch
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
     void assembleSystemPressureStressFactored();          // ps_solve.hip

@@ -646,8 +646,8 @@ __global__ void k_scan_apply(int32_t* __restrict__ a, int64_t n, const int32_t* 
 // block b, x-fastest.  An active voxel takes weight[g] consecutive indices.
 struct ILDesc {
     int ngroups;
-    int sample[4];
-    int weight[4];
+    int sample[8];             // the sample grid a group lives on (the four cell groups p, txx, tyy, tzz share grid 0)
+    int weight[8];
     int LBx, LBy, LBz;
     int SBx, SBy, SBz;         // super-block of SBx x SBy x SBz lattice blocks: consecutive in the sequence (L2 working set of one XCD)
     int NSx, NSy;              // super-blocks per axis (x, y)
@@ -704,7 +704,7 @@ __global__ void k_il_count(ILDesc D, Grid g, Set7<const int32_t> lab, int32_t* _
     blockExclusiveScan(cnt, &tot);
     if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
 }
-__global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int32_t* __restrict__ blockOffs, Set7<int32_t> outs,
+__global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int32_t* __restrict__ blockOffs, Set8<int32_t> outs,
                             int32_t* __restrict__ probeOut, int32_t* __restrict__ blockStart) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int w[SCAN_ITEMS], gr[SCAN_ITEMS];
@@ -721,18 +721,27 @@ __global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int
         if (base + i == D.probe[0]) probeOut[0] = off;
         if (base + i == D.probe[1]) probeOut[1] = off;
         if (base + i < D.total && (base + i) % ((int64_t)4096 * D.ngroups) == 0) blockStart[(base + i) / ((int64_t)4096 * D.ngroups)] = off;
-        if (w[i]) { outs.p[D.sample[gr[i]]][cc[i]] = off; off += w[i]; }
+        if (w[i]) { outs.p[gr[i]][cc[i]] = off; off += w[i]; }
     }
 }
+// are all volume fractions of the array multiples of 1/8 (the 2x2x2 sampler's)?  Then every stencil value is an int8 code times
+// 1 / (64 dx) (ps_blocks.hip: encodeVal) and the SpMVs will run the row-per-lane kernels on the coded stream
+__global__ void k_dyadic_check(const float* __restrict__ w, int64_t n, int32_t* __restrict__ fail) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float q = w[i] * 8.f;
+        bad |= !(q == rintf(q) && q >= 0.f && q <= 8.f);
+    }
+    if (bad) *fail = 1;
+}
 // permSys[reference index] = internal index  (reference layout: Solver.h:586-606)
-__global__ void k_perm_cells(Grid g, const int32_t* __restrict__ act, const int32_t* __restrict__ sys, int64_t nP, int64_t nC,
-                             int32_t* __restrict__ perm) {
+__global__ void k_perm_cells(Grid g, const int32_t* __restrict__ act, const int32_t* __restrict__ sys, const int32_t* __restrict__ sxx,
+                             const int32_t* __restrict__ syy, const int32_t* __restrict__ szz, int64_t nP, int64_t nC, int32_t* __restrict__ perm) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.count(0)) return;
     const int q = act[c];
     if (q < 0) return;
-    const int b = sys[c];
-    perm[q] = b; perm[nP + q] = b + 1; perm[nP + nC + q] = b + 2; perm[nP + 2 * nC + q] = b + 3;
+    perm[q] = sys[c]; perm[nP + q] = sxx[c]; perm[nP + nC + q] = syy[c]; perm[nP + 2 * nC + q] = szz[c];
 }
 __global__ void k_perm_simple(const int32_t* __restrict__ act, const int32_t* __restrict__ internal, int64_t n, int64_t refOffset,
                               int32_t* __restrict__ perm) {
@@ -968,9 +977,9 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     D.ngroups = ngroups;
     D.own = own();
     D.ownFilter = ownFilter ? 1 : 0;
-    { const char* e = getenv("PS_IL"); const int m = e ? atoi(e) : 0; D.planeMajor = ownedRange ? (m & 1) : ((m >> 1) & 1); }   // bit 0: DOFs, bit 1: face rows
+    D.planeMajor = ownedRange ? (ilPlaneMajor & 1) : ((ilPlaneMajor >> 1) & 1);   // bit 0: DOFs, bit 1: face rows
     D.probe[0] = D.probe[1] = -1;
-    for (int q = 0; q < 4; ++q) { D.sample[q] = q < ngroups ? samples[q] : 0; D.weight[q] = q < ngroups ? weights[q] : 0; }
+    for (int q = 0; q < 8; ++q) { D.sample[q] = q < ngroups ? samples[q] : 0; D.weight[q] = q < ngroups ? weights[q] : 0; }
     D.ox = ilOrigin[0]; D.oy = ilOrigin[1]; D.oz = ilOrigin[2];
     D.LBx = (g.nx + 1 + D.ox + 15) / 16; D.LBy = (g.ny + 1 + D.oy + 15) / 16; D.LBz = (g.nz + 1 + D.oz + 15) / 16;
     D.SBx = ilSuper[0]; D.SBy = ilSuper[1]; D.SBz = ilSuper[2];
@@ -990,9 +999,8 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     }
     const int nbk = gridFor(run, SCAN_TILE);
     scanBlock.alloc((size_t)nbk);
-    Set7<int32_t> o;
-    for (int q = 0; q < 7; ++q) o.p[q] = nullptr;
-    for (int q = 0; q < ngroups; ++q) o.p[samples[q]] = outs[q];
+    Set8<int32_t> o;
+    for (int q = 0; q < 8; ++q) o.p[q] = q < ngroups ? outs[q] : nullptr;
     hipLaunchKernelGGL(k_il_count, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nbk, counters.p + 8);
     const int nBlocks = (int)(run / per);
@@ -1029,6 +1037,26 @@ void ps_context::buildInternalNumbering() {
         parse3(getenv("PS_IL_ORIGIN"), o);
         parse3(getenv("PS_IL_SUPER"), sb);
         if (slabEnabled) { o[2] = 0; sb[2] = 1; }   // owned DOFs must stay one contiguous range of whole z-layers of blocks
+        // order inside a lattice block: 0 = voxel by voxel (the kinds of DOF / the three faces hanging off one voxel adjacent), 3 = kind
+        // by kind inside every k-plane of the block (all pressures of the plane, all txx, ... / all X faces, all Y, all Z): what the
+        // row-per-lane SpMV kernels want — the four lanes of a quad then gather four CONSECUTIVE entries of one kind
+        // (profiles/r03_spmv_issue.md).  PS_IL = 0..3 overrides (bit 0: DOFs, bit 1: face rows).
+        // Default: kind-major when the row-per-lane kernels will run — the stencil values must be codable, which the weights decide:
+        // face fluid weights x cell / edge liquid weights, all multiples of 1/8 (checked here, the fill kernels verify every entry);
+        // systems with other weights stream fp64 values through the 4-entries-per-lane kernels, which want the voxel-major order.
+        static const bool noEll = getenv("PS_NO_ELL") && atoi(getenv("PS_NO_ELL")) != 0;
+        static const bool forceF64 = getenv("PS_FORCE_FP64_VALUES") && atoi(getenv("PS_FORCE_FP64_VALUES")) != 0;
+        static const bool col32 = getenv("PS_COL32") && atoi(getenv("PS_COL32")) != 0;
+        static const bool oneShot = getenv("PS_PIPE_GRID") && atoi(getenv("PS_PIPE_GRID")) == 0;
+        int mode = 0;
+        if (!noEll && !forceF64 && !col32 && !oneShot) {
+            HIP_CHECK(hipMemsetAsync(counters.p + 40, 0, sizeof(int32_t), stream));
+            for (int s2 : {1, 2, 3}) hipLaunchKernelGGL(k_dyadic_check, dim3(1024), dim3(BS), 0, stream, (const float*)fluidW[s2].p, g.count(s2), counters.p + 40);
+            for (int s2 : {0, 4, 5, 6}) hipLaunchKernelGGL(k_dyadic_check, dim3(1024), dim3(BS), 0, stream, (const float*)liquidW[s2].p, g.count(s2), counters.p + 40);
+            if (readCounter(40) == 0) mode = 3;
+        }
+        const char* e = getenv("PS_IL");
+        ilPlaneMajor = e ? (atoi(e) & 3) : mode;
         for (int a = 0; a < 3; ++a) { ilOrigin[a] = std::min(15, std::max(0, o[a])); ilSuper[a] = std::min(8, std::max(1, sb[a])); }
     }
     const int64_t nC = nCenter, nPq = nCenter;
@@ -1038,13 +1066,18 @@ void ps_context::buildInternalNumbering() {
         sysIdx[s].alloc((size_t)g.count(s));
         hipLaunchKernelGGL(k_fill_i32, dim3(gridFor(g.count(s), BS)), dim3(BS), 0, stream, sysIdx[s].p, g.count(s), -1);
     }
+    for (int a = 0; a < 3; ++a) {
+        sysIdxT[a].alloc((size_t)g.count(0));
+        hipLaunchKernelGGL(k_fill_i32, dim3(gridFor(g.count(0), BS)), dim3(BS), 0, stream, sysIdxT[a].p, g.count(0), -1);
+    }
     for (int a = 0; a < 3; ++a)
         hipLaunchKernelGGL(k_fill_i32, dim3(gridFor(g.count(1 + a), BS)), dim3(BS), 0, stream, faceRow[a].p, g.count(1 + a), -1);
     {
-        const int samples[4] = {0, 4, 5, 6}, weights[4] = {4, 1, 1, 1};
-        int32_t* outs[4] = {sysIdx[0].p, sysIdx[4].p, sysIdx[5].p, sysIdx[6].p};
+        // seven groups, one per kind of DOF: p, txx, tyy, tzz (all on the cell grid), then the YZ / XZ / XY edge stresses
+        const int samples[7] = {0, 0, 0, 0, 4, 5, 6}, weights[7] = {1, 1, 1, 1, 1, 1, 1};
+        int32_t* outs[7] = {sysIdx[0].p, sysIdxT[0].p, sysIdxT[1].p, sysIdxT[2].p, sysIdx[4].p, sysIdx[5].p, sysIdx[6].p};
         int64_t range[2] = {0, 0};
-        const int64_t tot = interleavedIndexAssignEx(4, samples, weights, outs, false, range);
+        const int64_t tot = interleavedIndexAssignEx(7, samples, weights, outs, false, range);
         if (tot != nSys) throw Error("internal numbering: system DOF count mismatch");
         ownLo = range[0]; ownHi = range[1];
     }
@@ -1058,7 +1091,8 @@ void ps_context::buildInternalNumbering() {
     permSys.alloc((size_t)nSys);
     permRow.alloc((size_t)nAct);
     if (slabEnabled) HIP_CHECK(hipMemsetAsync(permRow.p, 0, (size_t)std::max<int64_t>(nAct, 1) * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(k_perm_cells, dim3(gridFor(g.count(0), BS)), dim3(BS), 0, stream, g, activeIdx[0].p, sysIdx[0].p, nPq, nC, permSys.p);
+    hipLaunchKernelGGL(k_perm_cells, dim3(gridFor(g.count(0), BS)), dim3(BS), 0, stream, g, activeIdx[0].p, sysIdx[0].p, sysIdxT[0].p, sysIdxT[1].p,
+                       sysIdxT[2].p, nPq, nC, permSys.p);
     const int64_t eoff[3] = {nPq + 3 * nC, nPq + 3 * nC + nEdge[0], nPq + 3 * nC + nEdge[0] + nEdge[1]};
     for (int e = 0; e < 3; ++e)
         hipLaunchKernelGGL(k_perm_simple, dim3(gridFor(g.count(4 + e), BS)), dim3(BS), 0, stream, activeIdx[4 + e].p, sysIdx[4 + e].p,
@@ -1074,20 +1108,22 @@ void ps_context::buildHaloLists() {
     nLowHalo = nLowOwn = nUpHalo = nUpOwn = 0;
     if (!slabEnabled) return;
     const int zLo = slab.zLoOwned, zHi = slab.zHiOwned;
-    auto slice = [&](int s, int k, std::vector<int32_t>& out) {
+    auto sliceOf = [&](const int32_t* src, int s, int k, std::vector<int32_t>& out) {
         const int3 d = g.dims(s);
         out.assign((size_t)d.x * d.y, -1);
         if (k < 0 || k >= d.z) return;
-        HIP_CHECK(hipMemcpyAsync(out.data(), sysIdx[s].p + (int64_t)d.x * d.y * k, out.size() * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(out.data(), src + (int64_t)d.x * d.y * k, out.size() * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     };
+    auto slice = [&](int s, int k, std::vector<int32_t>& out) { sliceOf(sysIdx[s].p, s, k, out); };
     // order-sensitive hash of the GLOBAL keys (position in the x-fastest slice, sample grid) of a list: local indices differ
     // between the two ranks of a cut, the keys must not (Dist::checkLists)
     auto mix = [](uint64_t& h, uint64_t key) { h = (h ^ key) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
     auto cellsOf = [&](int k, std::vector<int32_t>& list, uint64_t& h) {
-        std::vector<int32_t> sl;
+        std::vector<int32_t> sl, sx, sy, sz;
         slice(0, k, sl);
-        for (size_t q = 0; q < sl.size(); ++q) { const int32_t b = sl[q]; if (b >= 0) { list.push_back(b); list.push_back(b + 1); list.push_back(b + 2); list.push_back(b + 3); mix(h, (uint64_t)q * 8); } }
+        sliceOf(sysIdxT[0].p, 0, k, sx); sliceOf(sysIdxT[1].p, 0, k, sy); sliceOf(sysIdxT[2].p, 0, k, sz);
+        for (size_t q = 0; q < sl.size(); ++q) { const int32_t b = sl[q]; if (b >= 0) { list.push_back(b); list.push_back(sx[q]); list.push_back(sy[q]); list.push_back(sz[q]); mix(h, (uint64_t)q * 8); } }
     };
     auto edgesOf = [&](int s, int k, std::vector<int32_t>& list, uint64_t& h) {
         std::vector<int32_t> sl;

@@ -201,13 +201,19 @@ struct FusedR {
 // Walk of a persistent workgroup over the chunk ids: runs of G = 1 << sh consecutive chunks are dealt to the 8 XCDs round robin
 // (workgroup b runs on XCD b & 7), inside an XCD to its workgroups in order; sh < 0: plain grid-stride walk
 struct ChunkWalk {
-    int sh, x, l, per;
+    int sh, x, l, per, rs;   // rs: a workgroup takes runs of 1 << rs CONSECUTIVE chunks (bits 16.. of the launch parameter): its waves then find the
+                             // lines the previous chunk gathered in the CU's L1
     __device__ explicit ChunkWalk(int g)
-        : sh(g > 0 ? 31 - __builtin_clz((unsigned)g) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3) {}
+        : sh((g & 0xffff) > 0 ? 31 - __builtin_clz((unsigned)(g & 0xffff)) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3), rs(g >> 16) {}
     __device__ int at(int it) const {
-        if (sh < 0) return blockIdx.x + it * gridDim.x;
-        const int q = l + it * per;
-        return ((((q >> sh) << 3) + x) << sh) + (q & ((1 << sh) - 1));
+        const int j = it >> rs, o = it & ((1 << rs) - 1);
+        int run;
+        if (sh < 0) run = blockIdx.x + j * gridDim.x;
+        else {
+            const int q = l + j * per;
+            run = ((((q >> sh) << 3) + x) << sh) + (q & ((1 << sh) - 1));
+        }
+        return (run << rs) + o;
     }
 };
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -592,3 +598,282 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
     }
 }
 
+
+// ---- row-per-lane kernels on DevCSR::ecol / ecode (ps_blocks.hip:buildEll) ------------------------------------------------
+// Why (profiles/r03_spmv_issue.md): the CU's vector-memory path walks a gather instruction one aligned quad of lanes per cycle and
+// pays one L1 tag lookup per DISTINCT 128-byte line in the quad.  With 4 consecutive stream entries per lane (kernels above) the
+// lanes of a quad hold entries 16 apart — four lines, four cycles: both SpMVs sat at 0.8 lookups per cycle and CU, the L1 pipeline
+// saturated while 86 % of the lookups hit.  Here a lane owns a ROW: instruction k gathers entry k of 64 consecutive rows (the three
+// faces of a voxel, then the next voxel), so the lanes of a quad address the same or neighbouring lines.  The row's sum stays in a
+// register: no products through LDS, no row-length scan, no barrier; the four waves of a workgroup walk the chunk list together but
+// never wait for each other.  Same products, same summation order as the kernels above: bit-identical results.
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+struct EllUnit { int W, colByte, codeByte, row0, rows; };   // wave-uniform
+__device__ inline EllUnit ellUnit(int4 ci, int wv) {
+    const unsigned ws = (unsigned)ci.w >> 12;
+    int pre = 0, preC = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int w = (int)((ws >> (4 * u)) & 15u);
+        if (u < wv) { pre += w; preC += w > 4 ? 8 : (w > 0 ? 4 : 0); }
+    }
+    EllUnit e;
+    e.W = (int)((ws >> (4 * wv)) & 15u);
+    e.colByte = ci.x * 2 + 128 * pre;
+    e.codeByte = ci.y + 64 * preC;
+    e.row0 = ci.z + 64 * wv;
+    e.rows = min(64, max(0, (ci.w & 0xfff) - 64 * wv));
+    if (e.rows == 0) e.W = 0;
+    return e;
+}
+struct EllRegs { unsigned c0, c1, c2, c3, v0, v1; };   // scalars, every one written by every path: arrays written in part went to scratch memory
+template <bool NT>
+__device__ inline EllRegs ellLoad(__amdgpu_buffer_rsrc_t rCol, __amdgpu_buffer_rsrc_t rCode, const EllUnit& e, unsigned lane) {
+    constexpr int AUX = NT ? PS_STREAM_AUX : 0;
+    const int cb = e.colByte + (int)lane * 2 * e.W;
+    EllRegs r{0u, 0u, 0u, 0u, 0u, 0u};
+    if (e.W == 8) {
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rCol, cb, 0, AUX);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rCode, e.codeByte + (int)lane * 8, 0, AUX);
+        r = EllRegs{q.x, q.y, q.z, q.w, v.x, v.y};
+    } else if (e.W == 6) {
+        const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96(rCol, cb, 0, AUX);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rCode, e.codeByte + (int)lane * 8, 0, AUX);
+        r = EllRegs{q.x, q.y, q.z, 0u, v.x, v.y};
+    } else if (e.W == 4) {
+        const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rCol, cb, 0, AUX);
+        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rCode, e.codeByte + (int)lane * 4, 0, AUX);
+        r = EllRegs{q.x, q.y, 0u, 0u, v, 0u};
+    } else if (e.W == 2) {
+        const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(rCol, cb, 0, AUX);
+        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rCode, e.codeByte + (int)lane * 4, 0, AUX);
+        r = EllRegs{q, 0u, 0u, 0u, v, 0u};
+    }
+    return r;
+}
+template <int K> __device__ inline unsigned ellColWord(const EllRegs& r) { return K < 2 ? r.c0 : (K < 4 ? r.c1 : (K < 6 ? r.c2 : r.c3)); }
+// the row's W gathers (all in flight together), and — after the caller has issued its prefetches behind them — the products in
+// entry order (CSR order)
+struct EllX { double x0, x1, x2, x3, x4, x5, x6, x7; };
+template <int W>
+__device__ inline EllX ellGather(const EllRegs& r, int myBase, __amdgpu_buffer_rsrc_t rX) {
+    const unsigned cw[4] = {r.c0, r.c1, r.c2, r.c3};
+    double xv[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const unsigned raw = (cw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+        const unsigned col = (unsigned)__shfl(myBase, (int)(raw >> 12), 16) + (raw & 4095u);
+        xv[k] = bufGatherF64(rX, col * 8u);
+    }
+    return EllX{xv[0], xv[1], xv[2], xv[3], xv[4], xv[5], xv[6], xv[7]};
+}
+__device__ inline EllX ellGatherW(int W, const EllRegs& r, int myBase, __amdgpu_buffer_rsrc_t rX) {
+    if (W == 8) return ellGather<8>(r, myBase, rX);
+    if (W == 6) return ellGather<6>(r, myBase, rX);
+    if (W == 4) return ellGather<4>(r, myBase, rX);
+    if (W == 2) return ellGather<2>(r, myBase, rX);
+    return EllX{0., 0., 0., 0., 0., 0., 0., 0.};
+}
+template <int W>
+__device__ inline double ellSum(const EllRegs& r, const EllX& X, double scale) {
+    const unsigned vw[2] = {r.v0, r.v1};
+    const double xv[8] = {X.x0, X.x1, X.x2, X.x3, X.x4, X.x5, X.x6, X.x7};
+    double s = 0.;
+#pragma unroll
+    for (int k = 0; k < W; ++k) s += streamVal(vw[k >> 2], k & 3, scale) * xv[k];
+    return s;
+}
+__device__ inline double ellSumW(int W, const EllRegs& r, const EllX& X, double scale) {
+    if (W == 8) return ellSum<8>(r, X, scale);
+    if (W == 6) return ellSum<6>(r, X, scale);
+    if (W == 4) return ellSum<4>(r, X, scale);
+    if (W == 2) return ellSum<2>(r, X, scale);
+    return 0.;
+}
+// MODE 0 / 1 as k_spmv_S_pipe
+template <int MODE, int POL>
+__global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
+                                                   const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
+                                                   const double* __restrict__ x, int cols, int rows, int nA, double dt, const double* __restrict__ McInv,
+                                                   double* __restrict__ out, const int* __restrict__ done, int nChunks, int xcdAware,
+                                                   const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict, double* __restrict__ stPart) {
+    if (done && *done) return;
+    constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
+    __shared__ double dict[MODE == 0 ? 256 : 1];
+    if (MODE == 0 && mcCode) dict[threadIdx.x] = mcDict[threadIdx.x];
+    __syncthreads();                                                    // the only barrier before the final reduction
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rX = bufRsrc(x, (size_t)cols * 8),
+                                 rMc = bufRsrc(McInv, (size_t)nA * 8), rMcc = bufRsrc(mcCode, mcCode ? (size_t)nA : 0), rOut = bufRsrc(out, (size_t)rows * 8);
+    const ChunkWalk Wk(xcdAware);
+    const unsigned lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double stAcc = 0.;
+    int it = 0;
+    int chunk = Wk.at(0);
+    if (chunk < nChunks) {
+        EllUnit cu = ellUnit(echunk[chunk], wv);
+        EllRegs cur = ellLoad<SNT>(rCol, rCode, cu, lane), nxt{0u, 0u, 0u, 0u, 0u, 0u};
+        int myBase = winBase[chunk * 16 + (lane & 15)], nBase = 0;
+        int nchunk = Wk.at(1);
+        int4 nci = make_int4(0, 0, 0, 0);
+        if (nchunk < nChunks) nci = echunk[nchunk];
+        while (true) {
+            // (1) this unit's gathers first: their address arithmetic waits on nothing but the window lookups
+            const bool live = (int)lane < cu.rows;
+            const unsigned row = live ? (unsigned)cu.row0 + lane : ROW_NONE;
+            double sc = 1.;
+            int mcc = 0;
+            if (MODE == 0) {
+                if (mcCode) mcc = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)row, 0, NT ? PS_EPI_AUX : 0);
+                else { const double m = bufLoadF64(rMc, row * 8u); sc = (int)row < nA ? dt * m : 1.; }
+            }
+            const EllX X = ellGatherW(cu.W, cur, myBase, rX);
+            // (2) behind them: the next unit's stream and the record of the chunk after it
+            const bool hasNext = nchunk < nChunks;
+            EllUnit nu{0, 0, 0, 0, 0};
+            if (hasNext) {
+                nu = ellUnit(nci, wv);
+                nxt = ellLoad<SNT>(rCol, rCode, nu, lane);
+                nBase = winBase[nchunk * 16 + (lane & 15)];
+            }
+            const int nn = Wk.at(it + 2);
+            int4 nnci = make_int4(0, 0, 0, 0);
+            if (nn < nChunks) nnci = echunk[nn];
+            // (3) products, epilogue
+            const double s = ellSumW(cu.W, cur, X, scale);
+            if (MODE == 0 && mcCode) sc = (int)row < nA ? dt * dict[mcc] : 1.;
+            if (MODE == 0) stAcc += (int)row < nA ? s * (s * sc) : 0.;
+            bufStoreF64nt<NT>(rOut, row * 8u, s * sc);                       // dropped past the chunk's last row (row = ROW_NONE)
+            if (!hasNext) break;
+            chunk = nchunk; cu = nu; cur = nxt; myBase = nBase;
+            nchunk = nn; nci = nnci;
+            ++it;
+        }
+    }
+    if (MODE == 0 && stPart) {
+        const double bs = blockReduceSum(stAcc);
+        if (threadIdx.x == 0) stPart[blockIdx.x] = bs;
+    }
+}
+// MODE 0 .. 3 as k_spmv_St_pipe (same prologue, same per-row epilogue, same thread <-> row assignment: bit-identical partial sums)
+template <int MODE, int POL>
+__global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
+                                                    const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
+                                                    const double* __restrict__ t, int cols, int rows, const double* __restrict__ uInv,
+                                                    const double* __restrict__ xin, const double* __restrict__ add, double* __restrict__ out,
+                                                    double* __restrict__ partial, const int* __restrict__ done, int nChunks, int xcdAware, ChebArgs cheb,
+                                                    const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr) {
+    if (done && *done) return;
+    constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
+    __shared__ double dict[MODE != 1 ? 256 : 1];
+    if (MODE != 1 && uCode) dict[threadIdx.x] = uDict[threadIdx.x];
+    double alpha = 0.;
+    if (MODE == 3) {   // as k_spmv_St_pipe: [stop test of iteration it-1], alpha = rsold / p.Ap — identical in every workgroup
+        CGScalars* sc = fr.sc;
+        auto sumArr = [&](const double* a, int cnt) { double acc = 0.; for (int i = threadIdx.x; i < cnt; i += BS) acc += a[i]; return blockSumAll(acc); };
+        const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+        if (fr.it > 0) {
+            const double xx = fr.red ? fr.red[1] : sumArr(fr.xxPart, fr.xxCount);
+            const double rr = sc->rr;
+            double rre = rr;                               // pcg.h:319-325
+            if (rr / xx < rre) rre = rr / xx;
+            const bool fire = rre < sc->tol2;
+            if (writer) { sc->xx = xx; sc->rre = rre; if (fire) { sc->done = 1; sc->iter = fr.it - 1; } }
+            if (fire) return;                              // same verdict in every workgroup
+        }
+        const double pAp = fr.red ? -fr.red[0] : -(sumArr(fr.sPart, fr.sCount) + sumArr(fr.tPart, fr.tCount) + 0.5 * sumArr(fr.uPart, fr.uCount));
+        alpha = sc->rsold2[fr.it & 1] / pAp;               // pcg.h:314
+        if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
+    }
+    __syncthreads();                                       // dict
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
+                                 rE0 = bufRsrc(MODE == 1 ? add : xin, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
+                                 rOut = bufRsrc(out, (size_t)rows * 8),
+                                 rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
+                                 rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
+                                 rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0),
+                                 rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
+                                 rFy = bufRsrc(fr.yOut, (MODE == 3 && fr.yOut) ? (size_t)rows * 8 : 0);
+    const ChunkWalk Wk(xcdAware);
+    const unsigned lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double dacc = 0., dacc2 = 0.;
+    int it = 0;
+    int chunk = Wk.at(0);
+    if (chunk < nChunks) {
+        EllUnit cu = ellUnit(echunk[chunk], wv);
+        EllRegs cur = ellLoad<SNT>(rCol, rCode, cu, lane), nxt{0u, 0u, 0u, 0u, 0u, 0u};
+        int myBase = winBase[chunk * 16 + (lane & 15)], nBase = 0;
+        int nchunk = Wk.at(1);
+        int4 nci = make_int4(0, 0, 0, 0);
+        if (nchunk < nChunks) nci = echunk[nchunk];
+        while (true) {
+            const bool live = (int)lane < cu.rows;
+            const unsigned row = live ? (unsigned)cu.row0 + lane : ROW_NONE;
+            // (1) the per-row streams of the epilogue and this unit's gathers
+            const double e0 = bufLoadF64epi<NT>(rE0, row * 8u);                                       // x (MODE 0, 2, 3) / the vector added (MODE 1)
+            double e1 = 0., cr = 0., ci = 0., cd = 0.;
+            int uc = 0;
+            if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, NT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
+            if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }   // cd = z_{j-1} (0: no buffer)
+            float fdv = 1.f;
+            if (MODE == 3) {
+                cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, NT ? PS_EPI_AUX : 0));
+                if (fr.dinvF) fdv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(row * 4u), 0, NT ? PS_EPI_AUX : 0));
+                if (fr.cz) ci = bufLoadF64epi<NT>(rF64, row * 8u);
+            }
+            const EllX X = ellGatherW(cu.W, cur, myBase, rT);
+            // (2) behind them: the next unit's stream and the record of the chunk after it
+            const bool hasNext = nchunk < nChunks;
+            EllUnit nu{0, 0, 0, 0, 0};
+            if (hasNext) {
+                nu = ellUnit(nci, wv);
+                nxt = ellLoad<SNT>(rCol, rCode, nu, lane);
+                nBase = winBase[nchunk * 16 + (lane & 15)];
+            }
+            const int nn = Wk.at(it + 2);
+            int4 nnci = make_int4(0, 0, 0, 0);
+            if (nn < nChunks) nnci = echunk[nn];
+            // (3) the row's sum and the fused epilogue
+            const double s = ellSumW(cu.W, cur, X, scale);
+            if (MODE != 1 && uCode) e1 = dict[uc];
+            double y;
+            if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
+            else if (MODE == 1) y = -s + e0;
+            else if (MODE == 3) {
+                y = -s; y -= 0.5 * e1 * e0;                                      // (A p)[row], not stored
+                const bool mine = (int)row >= fr.ownLo && (int)row < fr.ownHi;   // (idle lanes: false)
+                if (fr.yOut) bufStoreF64nt<NT>(rFy, (!mine && live) ? row * 8u : 0xfffffff8u, y);   // a neighbour's row: its share of A p
+                const double rv = mine ? cr - alpha * y : 0.;                    // pcg.h:316
+                dacc += rv * rv;
+                dacc2 += (fr.dinvF && mine) ? rv * ((double)fdv * rv) : 0.;      // (the diagonal of a halo row is not this rank's: may be anything)
+                if (fr.cz) {                                                     // k_cheb_first on this row
+                    const double v = ci * rv * fr.invTheta;
+                    bufStoreF64nt<NT>(rFcz, row * 8u, v);
+                    dacc2 += rv * v;
+                }
+                y = rv;
+            }
+            else {
+                double az = -s; az -= 0.5 * e1 * e0;
+                const double dn = cheb.c1 * (e0 - cd) + cheb.c2 * (ci * (cr - az));
+                y = e0 + dn;
+                dacc += cr * y;                                                  // r.z of the updated z
+            }
+            if (MODE == 3) bufStoreF64nt<NT>(rFr, ((int)row >= fr.ownLo && (int)row < fr.ownHi) ? row * 8u : 0xfffffff8u, y);
+            else bufStoreF64nt<NT>(rOut, row * 8u, y);
+            if (!hasNext) break;
+            chunk = nchunk; cu = nu; cur = nxt; myBase = nBase;
+            nchunk = nn; nci = nnci;
+            ++it;
+        }
+    }
+    if (MODE == 0 || MODE == 2) {
+        const double bs = blockReduceSum(dacc);
+        if (threadIdx.x == 0) partial[blockIdx.x] = bs;   // gridDim.x partials (Launch::stBlocks)
+    }
+    if (MODE == 3) {
+        const double b0 = blockReduceSum(dacc), b1 = (fr.dinvF || fr.cz) ? blockReduceSum(dacc2) : 0.;
+        if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[gridDim.x + blockIdx.x] = b1; }
+    }
+}

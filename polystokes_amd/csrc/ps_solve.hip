@@ -62,6 +62,18 @@ struct Launch {
     void spmvS(int mode, const double* x, double* out) const {
         if (rowsS == 0) return;
         const ps::DevCSR& M = c->S;
+        if (pipeGrid > 0 && M.col16ok && M.packed && M.ellok) {   // row-per-lane kernels on the coded stream (ps_kernels_spmv.hpp: k_spmv_S_ell)
+            const int nChunks = c->S.nChunks;
+            int xcdAware = this->xcdAware;
+            const dim3 gr(pipeBlocks(nChunks, xcdAware, true)), bl(BS);
+#define PS_LAUNCH_SE(MODE_, POL_) hipLaunchKernelGGL((k_spmv_S_ell<MODE_, POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                                     M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart)
+#define PS_LAUNCH_SE2(MODE_) do { const int pol = policy(M); if (pol == 3) PS_LAUNCH_SE(MODE_, 3); else if (pol == 1) PS_LAUNCH_SE(MODE_, 1); else PS_LAUNCH_SE(MODE_, 0); } while (0)
+            if (mode == 0) PS_LAUNCH_SE2(0); else PS_LAUNCH_SE2(1);
+#undef PS_LAUNCH_SE2
+#undef PS_LAUNCH_SE
+            return;
+        }
         if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
             const int nChunks = c->S.nChunks;
             int xcdAware = this->xcdAware;
@@ -137,6 +149,18 @@ struct Launch {
         if (cheb) ca = *cheb;
         FusedR fr{};
         if (fused) fr = *fused;
+        if (pipeGrid > 0 && M.col16ok && M.packed && M.ellok) {   // row-per-lane kernels on the coded stream (k_spmv_St_ell)
+            const int nChunks = c->St.nChunks;
+            int xcdAware = this->xcdAware;
+            const dim3 gr(pipeBlocks(nChunks, xcdAware, true, stGridFor(mode))), bl(BS);
+#define PS_LAUNCH_TE(MODE_, POL_) hipLaunchKernelGGL((k_spmv_St_ell<MODE_, POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                                     M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr)
+#define PS_LAUNCH_TE2(MODE_) do { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TE(MODE_, 3); else if (pol == 1) PS_LAUNCH_TE(MODE_, 1); else PS_LAUNCH_TE(MODE_, 0); } while (0)
+            if (mode == 0) PS_LAUNCH_TE2(0); else if (mode == 1) PS_LAUNCH_TE2(1); else if (mode == 2) PS_LAUNCH_TE2(2); else PS_LAUNCH_TE2(3);
+#undef PS_LAUNCH_TE2
+#undef PS_LAUNCH_TE
+            return;
+        }
         if (pipeGrid > 0 && M.col16ok && (M.packed || M.val4.p)) {
             const int nChunks = c->St.nChunks;
             int xcdAware = this->xcdAware;
@@ -202,6 +226,11 @@ Launch mk(ps_context* c, const int* done) {
     static int xa = -1;
     if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 16; }   // chunks per XCD run (rounded down to a power of two); 0: plain walk
     L.xcdAware = xa > 0 ? xa : 0;
+    // log2 of the consecutive chunks a workgroup takes in a row (ChunkWalk): 2 chunks on the row-per-lane kernels (256^3, same box: S 0.264 ->
+    // 0.257 ms, St with the residual update 0.431 -> 0.408; 4 / 8 / 16 chunks: S 0.282 / 0.274 / 0.273, St 0.412 / 0.412 / 0.428)
+    static const int wr = getenv("PS_WG_RUN") ? atoi(getenv("PS_WG_RUN")) : -1;
+    const int run = wr >= 0 ? wr : ((c->S.ellok && c->St.ellok) ? 1 : 0);
+    if (L.xcdAware > 0) L.xcdAware |= (run & 7) << 16;
     L.ntSpmv = c->ntLevel() >= 1;
     return L;
 }

@@ -1,6 +1,6 @@
 """Per-kernel averages of every counter found under <dir>/p*/ (rocprofv3 counter_collection csv)."""
 import collections, csv, glob, json, sys
-KEYS = {"k_spmv_St_pipe<3": "St_r", "k_cg_update_xp_u(": "upd_xp_u", "k_spmv_St_pipe<0": "St", "k_spmv_S_pipe<0": "S", "k_cg_update_r(": "upd_r", "k_cg_update_xp(": "upd_xp",
+KEYS = {"k_spmv_St_pipe<3": "St_r", "k_cg_update_xp_u(": "upd_xp_u", "k_spmv_St_pipe<0": "St", "k_spmv_S_pipe<0": "S", "k_spmv_S_ell<0": "S_ell", "k_spmv_St_ell<3": "St_r_ell", "k_spmv_St_ell<0": "St_ell", "k_cg_update_r(": "upd_r", "k_cg_update_xp(": "upd_xp",
         "k_tile_gather": "gather", "k_tile_expand": "expand", "k_apply_fused": "fused", "k_tile_apply<0": "tile_apply"}
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for fn in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
