@@ -59,8 +59,9 @@ def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw, sample_res=128):
          single-thread vector updates (BASELINE.md section 2, baseline A);
       B  "fair": one pass per block, every row loop split over all OpenMP threads of this process' CPU share;
       and A on one thread.
-    value = setup (single thread: the restatement is literal) scaled by cell count + B's iteration time scaled by the DOF
-    ratio x the GPU run's iteration count: ms/step at the benchmark size, with the best CPU variant."""
+    value = the SOLVE stage of one step: the best variant's iteration time scaled by the DOF ratio x the GPU run's iteration
+    count (extrapolated from the sample size).  The restatement's single-thread setup is reported apart, not in value: the
+    reference's own setup is multi-threaded (Solver.cpp:154)."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before libgomp starts: spinning workers starve a shared host
     from oracle import ps_oracle
     from polystokes_amd import scenes
@@ -78,18 +79,27 @@ def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw, sample_res=128):
     ms_it_b, used_b = o.time_cg_mt(iters, cores)
     scale_cells = n_gpu_cells / float(ns ** 3)
     dof_ratio = gpu_n / float(n_s)
-    est = lambda ms_it: setup_ms * scale_cells + ms_it * dof_ratio * max(gpu_iters, 1)
+    solve = lambda ms_it: ms_it * dof_ratio * max(gpu_iters, 1)
+    best_it = min(ms_it_b, ms_it_a)
+    setup_step = setup_ms * scale_cells
     return {
-        "value": est(min(ms_it_b, ms_it_a)), "unit": "ms/step", "cores": used_b if ms_it_b <= ms_it_a else used_a, "kind": "port",
+        # value = the SOLVE of one step only (the iteration count of the GPU run x the best measured CPU iteration time, scaled by the
+        # DOF ratio): the reference's setup fans out over UT_ThreadedAlgorithm / TBB (Solver.cpp:154) and "hugs zero" in its own plots,
+        # while the restatement's setup is literal single-thread code — its time is reported apart (setup_ms_per_step, setup_threads)
+        # and is NOT part of value.  Compare value with the GPU line's stage_ms.solve.
+        "value": solve(best_it), "unit": "ms/step (solve stage only)", "cores": used_b if ms_it_b <= ms_it_a else used_a, "kind": "port",
+        "solve_ms_per_step": solve(best_it), "setup_ms_per_step": setup_step, "setup_threads": 1,
+        "extrapolated": "measured at %d^3 (%d DOFs), scaled to the benchmark size: x%.2f in DOFs for the solve, x%.1f in cells for the setup" % (ns, n_s, dof_ratio, scale_cells),
         "cpu_model": _cpu_model(), "nproc": os.cpu_count(), "cpu_share": cores,
         "sample": ("oracle (C++ restatement of ApplyPressureStressMatrix + pcg_external_matrix_A) on the same cavity scene at %d^3 "
-                   "(n = %d DOFs, DRAM-resident): setup %.0f ms (1 thread); per CG iteration over %d iterations: baseline A "
+                   "(n = %d DOFs, DRAM-resident); per CG iteration over %d iterations: baseline A "
                    "(reference-shaped, 3 omp sections, per-call McInv*G) %.1f ms on %d threads and %.1f ms on 1 thread; baseline B "
-                   "(fair CSR passes, OpenMP rows) %.1f ms on %d threads; scaled to the benchmark size by cell count (setup) and by "
-                   "the DOF ratio %.2f x the GPU run's %d iterations (solve)" % (ns, n_s, setup_ms, iters, ms_it_a, used_a, ms_it_1t, ms_it_b, used_b, dof_ratio, gpu_iters)),
+                   "(fair CSR passes, OpenMP rows) %.1f ms on %d threads; value = best of A / B x the DOF ratio %.2f x the GPU run's %d "
+                   "iterations — EXTRAPOLATED from %d^3, not measured at the benchmark size; setup of the restatement (1 thread, not in "
+                   "value): %.0f ms at %d^3" % (ns, n_s, iters, ms_it_a, used_a, ms_it_1t, ms_it_b, used_b, dof_ratio, gpu_iters, ns, setup_ms, ns)),
         "sample_res": ns, "sample_dofs": n_s, "sample_setup_ms": setup_ms, "sample_iterations_timed": iters,
-        "baseline_A_reference_shaped": {"ms_per_cg_iter": ms_it_a, "threads": used_a, "ms_per_cg_iter_1_thread": ms_it_1t, "value_ms_per_step": est(ms_it_a)},
-        "baseline_B_fair_openmp": {"ms_per_cg_iter": ms_it_b, "threads": used_b, "value_ms_per_step": est(ms_it_b)},
+        "baseline_A_reference_shaped": {"ms_per_cg_iter": ms_it_a, "threads": used_a, "ms_per_cg_iter_1_thread": ms_it_1t, "solve_ms_per_step": solve(ms_it_a)},
+        "baseline_B_fair_openmp": {"ms_per_cg_iter": ms_it_b, "threads": used_b, "solve_ms_per_step": solve(ms_it_b)},
     }
 
 
@@ -297,6 +307,8 @@ def main():
     # the coded stream, five (S, tiles, St, r update, x/p update) otherwise — the five-kernel ones stay listed: they are what
     # the distributed, Chebyshev and fallback-stream solves launch
     fused = int(solver.array("fusedStep")[0]) == 1
+    rpl = solver.array("rowPerLane")
+    ell = int(rpl[0]) == 3                                  # both products on the row-per-lane kernels
     names = (["spmv_St_r", "cg_update_xp_u"] if fused else []) + ["spmv_St", "spmv_S", "apply", "tiles", "cg_update_r", "cg_update_xp"]
     if coded and c16:
         names += ["spmv_St_fp64", "spmv_S_fp64"]     # the pipelined kernels on fp64 values (10 B/nnz): the non-dyadic-weights fallback
@@ -323,12 +335,14 @@ def main():
     csr = kern["spmv_St_csr"]["algorithmic_bytes"]
     csr_gbps = csr / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {
-        "bound": "hbm", "kernel": "k_spmv_St_pipe<%d,NV,%s,POL> (NV = 1 or 2 four-entry groups per lane, by the fullest chunk; POL = cache policy of its streams%s)" % (mode, "false" if coded else "true", "; MODE 3: r -= alpha A p in the epilogue" if fused else "") if c16 else "k_spmv_St<0,6,%s>" % ("true" if coded else "false"),
+        "bound": "hbm", "kernel": ("k_spmv_St_ell<%d,POL,FX> (one lane per row on the kind-major numbering; POL = cache policy of its streams%s)" % (mode, "; MODE 3: r -= alpha A p in the epilogue, FX = 1: the plain single-domain step" if fused else "")) if ell else
+                                  ("k_spmv_St_pipe<%d,NV,%s,POL> (NV = 1 or 2 four-entry groups per lane, by the fullest chunk; POL = cache policy of its streams%s)" % (mode, "false" if coded else "true", "; MODE 3: r -= alpha A p in the epilogue" if fused else "") if c16 else "k_spmv_St<0,6,%s>" % ("true" if coded else "false")),
         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
         "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_ms": ms,
-        "algorithmic_bytes_definition": ("stored format: 3*nnz (16-bit windowed column + int8 value code) + 1*rows (row length) + 80 B per chunk "
-                                         "+ 8*cols (t once) + 8*rows (p) + 1*rows (coded uInv) + %s") % ("16*rows (r read + written) + 4*rows (fp32 Jacobi diagonal); A p is not stored" if fused else "8*rows (y)") if (coded and c16) else
+        "numbering": {0: "voxel-major (kinds of DOF / faces of a voxel adjacent)", 3: "kind-major inside every k-plane of a 16^3 lattice block (DOFs and face rows)"}.get(int(rpl[1]), "mixed (%d)" % int(rpl[1])),
+        "algorithmic_bytes_definition": ("stored format: 3*nnz (16-bit windowed column + int8 value code; padded slots of the row-per-lane layout NOT counted) + %s80 B per chunk "
+                                         "+ 8*cols (t once) + 8*rows (p) + 1*rows (coded uInv) + %s") % ("" if ell else "1*rows (row length) + ", "16*rows (r read + written) + 4*rows (fp32 Jacobi diagonal); A p is not stored" if fused else "8*rows (y)") if (coded and c16) else
                                         "CSR: (12 | 10 | 5)*nnz + 4*(rows+1) + 8*rows (y) + 8*cols (x once) + 16*rows (fused epilogue)",
         "stream_runs": (lambda r: {"S_distinct_entries": int(r[0]), "S_entries": int(r[1]), "St_distinct_entries": int(r[2]), "St_entries": int(r[3]),
                                    "note": "chunks with byte-identical (col16, code, row length) runs share one run, so most of the matrix stream is served from cache: algorithmic bytes still count every entry once per launch (the loads are issued), the HBM bytes are in `traffic`"})(solver.array("streamRuns")),
@@ -362,7 +376,7 @@ def main():
         t0 = time.perf_counter()
         solver.step(sc, p)
         out["pcie_inclusive_ms"] = (time.perf_counter() - t0) * 1e3
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.precond != "chebyshev":   # the CPU leg times the reference's own (Jacobi / identity) PCG iteration
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.precond != "chebyshev" and scene_name == "cavity":   # the CPU leg times the reference's own (Jacobi / identity) PCG iteration on the headline scene
         out["cpu_baseline"] = cpu_baseline(n ** 3, nsys, iters, dict(tile=16, pad=2, precond=kw["precond"]), args.cpu_sample_res)
     if rank == 0:
         sys.stdout.flush()

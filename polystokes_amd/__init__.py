@@ -110,7 +110,7 @@ _DT = {(4, "i"): np.int32, (4, "f"): np.float32, (8, "f"): np.float64, (4, "u"):
 def _kind(name):
     if name.endswith(("Labels", "Indices", ".col", ".ptr", "Region", "Perm")) or name.startswith("faceRow"):
         return "i"
-    if name in ("valuesCoded", "columns16", "diagonalsCoded", "fusedStep", "streamRuns"):
+    if name in ("valuesCoded", "columns16", "diagonalsCoded", "fusedStep", "streamRuns", "rowPerLane"):
         return "i"
     if name in ("ownedX", "ownedY", "ownedZ"):
         return "f"

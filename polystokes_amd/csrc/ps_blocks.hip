@@ -736,7 +736,8 @@ __global__ void __launch_bounds__(BS) k_ell_fill(const int4* __restrict__ chunkI
 // Row-per-lane form of M's compressed stream (needs the windowed stream of buildCol16 and coded values)
 void ps_context::buildEll(ps::DevCSR& M) {
     M.ellok = false;
-    static const bool off = getenv("PS_NO_ELL") && atoi(getenv("PS_NO_ELL")) != 0;   // A/B: keep the 4-entries-per-lane kernels
+    static const bool off = (getenv("PS_NO_ELL") && atoi(getenv("PS_NO_ELL")) != 0) ||            // A/B: keep the 4-entries-per-lane kernels
+                            (getenv("PS_PIPE_GRID") && atoi(getenv("PS_PIPE_GRID")) == 0);       // (one-shot CSR kernels asked for)
     if (off || !M.col16ok || !M.packed || M.nChunks == 0 || (uint64_t)std::max(M.rows, M.cols) * 8 >= 0xffff8000ull) return;
     const int nChunks = M.nChunks;
     DevBuf<int32_t>& colBegin = scrEllCol; DevBuf<int32_t>& codeBegin = scrEllCode; DevBuf<int32_t>& wpack = scrEllW;

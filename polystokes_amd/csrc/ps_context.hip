@@ -287,6 +287,10 @@ void ps_context::registerArrays() {
     streamRunsHost[2] = St.col16ok ? (int32_t)St.uniqueLen : 0; streamRunsHost[3] = St.col16ok ? (int32_t)St.streamLen : 0;
     HIP_CHECK(hipMemcpyAsync(counters.p + 29, streamRunsHost, 4 * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     reg("streamRuns", counters.p + 29, 4, 4);
+    // bit 0 / 1: S / St run the row-per-lane kernels (DevCSR::ecol); [1]: the numbering mode (ilPlaneMajor)
+    rowPerLaneHost[0] = ((S.ellok && S.packed) ? 1 : 0) | ((St.ellok && St.packed) ? 2 : 0); rowPerLaneHost[1] = ilPlaneMajor;
+    HIP_CHECK(hipMemcpyAsync(counters.p + 34, rowPerLaneHost, 2 * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    reg("rowPerLane", counters.p + 34, 2, 4);
     reg("sysPerm", permSys.p, nSystem, 4);
     reg("rowPerm", permRow.p, nActiveVs, 4);
     reg("S.ptr", S.ptr.p, S.rows + 1, 4); reg("S.col", S.col.p, S.nnz, 4); reg("S.val", S.val.p, S.nnz, 8);
@@ -693,7 +697,10 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             // cache because chunks share their runs (DevCSR::uniqueLen, array "streamRuns") shows in the measured HBM traffic
             const double entS = nnz, entT = nnz;
             const double winS = c16(c->S) ? 80. * (double)c->S.nChunks : 0., winT = c16(c->St) ? 80. * (double)c->St.nChunks : 0.;   // 64 B of window bases + 16 B of ranges per chunk
-            const double ptrS = c16(c->S) ? 1. : 4., ptrT = c16(c->St) ? 1. : 4.;   // row length byte | row pointer
+            // row length byte | row pointer; the row-per-lane kernels read neither (rows padded to the unit's width: the padded slots are
+            // NOT counted as bytes moved — 3 B per real entry, as above)
+            auto ell = [&](const ps::DevCSR& M) { return c16(M) && M.packed && M.ellok && !fp64; };
+            const double ptrS = c16(c->S) ? (ell(c->S) ? 0. : 1.) : 4., ptrT = c16(c->St) ? (ell(c->St) ? 0. : 1.) : 4.;
             // the fused diagonals: fp64 array, or a 1-byte value-set code per row on the pipelined kernels (ps_context.hpp: uCode / mcCode)
             const double dMc = (c16(c->S) && c->mcCoded) ? 1. : 8., dU = (c16(c->St) && c->uCoded) ? 1. : 8.;
             const double bS = winS + perNnzS * entS + ptrS * (rowsS + 1) + 8. * rowsS + 8. * rowsT + dMc * (double)c->nActiveVs;

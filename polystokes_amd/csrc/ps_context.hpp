@@ -158,6 +158,7 @@ struct ps_context {
     int32_t diagFlagsHost = 0;
     int32_t fusedStepHost = 0;
     int32_t streamRunsHost[4] = {0, 0, 0, 0};
+    int32_t rowPerLaneHost[2] = {0, 0};
     void buildDiagonalCodes();
     ps::DevBuf<float> dinvF;   // the Jacobi diagonal as the PCG kernels read it (fp32 storage, see constructPreconditioner)
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;

@@ -204,7 +204,8 @@ struct ChunkWalk {
     int sh, x, l, per, rs;   // rs: a workgroup takes runs of 1 << rs CONSECUTIVE chunks (bits 16.. of the launch parameter): its waves then find the
                              // lines the previous chunk gathered in the CU's L1
     __device__ explicit ChunkWalk(int g)
-        : sh((g & 0xffff) > 0 ? 31 - __builtin_clz((unsigned)(g & 0xffff)) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3), rs(g >> 16) {}
+        : sh((g & 0xffff) > 0 ? 31 - __builtin_clz((unsigned)(g & 0xffff)) : -1), x(blockIdx.x & 7), l(blockIdx.x >> 3), per(gridDim.x >> 3), rs((g >> 16) & 7),
+          tr(((g >> 20) & 1) != 0 && ((g >> 16) & 7) == 2) {}
     __device__ int at(int it) const {
         const int j = it >> rs, o = it & ((1 << rs) - 1);
         int run;
@@ -215,6 +216,13 @@ struct ChunkWalk {
         }
         return (run << rs) + o;
     }
+    // Transposed runs of four chunks (bit 20 of the launch parameter, with rs == 2; row-per-lane kernels): wave w of the workgroup takes
+    // chunk 4 run + w and walks its four 64-row units one per step, so that at any time the four waves work on the SAME sub-range of four
+    // consecutive chunks — in a kind-major numbering the four chunks are four kinds of DOF (faces of three axes) of the same voxels, and
+    // the waves find each other's lines in the CU's L1
+    bool tr;
+    __device__ int chunkOf(int it, int wv) const { return tr ? ((at(it) & ~3) | wv) : at(it); }
+    __device__ int unitOf(int it, int wv) const { return tr ? (it & 3) : wv; }
 };
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // Every access of the loop body goes through a buffer descriptor (buffer_load/store ... offen): 32-bit byte offsets
@@ -709,12 +717,12 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ 
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double stAcc = 0.;
     int it = 0;
-    int chunk = Wk.at(0);
+    int chunk = Wk.chunkOf(0, wv);
     if (chunk < nChunks) {
-        EllUnit cu = ellUnit(echunk[chunk], wv);
+        EllUnit cu = ellUnit(echunk[chunk], Wk.unitOf(0, wv));
         EllRegs cur = ellLoad<SNT>(rCol, rCode, cu, lane), nxt{0u, 0u, 0u, 0u, 0u, 0u};
         int myBase = winBase[chunk * 16 + (lane & 15)], nBase = 0;
-        int nchunk = Wk.at(1);
+        int nchunk = Wk.chunkOf(1, wv);
         int4 nci = make_int4(0, 0, 0, 0);
         if (nchunk < nChunks) nci = echunk[nchunk];
         while (true) {
@@ -732,11 +740,11 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ 
             const bool hasNext = nchunk < nChunks;
             EllUnit nu{0, 0, 0, 0, 0};
             if (hasNext) {
-                nu = ellUnit(nci, wv);
+                nu = ellUnit(nci, Wk.unitOf(it + 1, wv));
                 nxt = ellLoad<SNT>(rCol, rCode, nu, lane);
                 nBase = winBase[nchunk * 16 + (lane & 15)];
             }
-            const int nn = Wk.at(it + 2);
+            const int nn = Wk.chunkOf(it + 2, wv);
             int4 nnci = make_int4(0, 0, 0, 0);
             if (nn < nChunks) nnci = echunk[nn];
             // (3) products, epilogue
@@ -756,7 +764,10 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ 
     }
 }
 // MODE 0 .. 3 as k_spmv_St_pipe (same prologue, same per-row epilogue, same thread <-> row assignment: bit-identical partial sums)
-template <int MODE, int POL>
+// FX = 1 (MODE 3 only): the plain Jacobi / identity PCG step of a single domain — value-set coded uInv, no Chebyshev first term, no
+// halo rows — as compile-time facts: six buffer descriptors less (the generic MODE 3 needs 100 SGPRs, spills them into VGPR lanes
+// and fits 6 waves per SIMD)
+template <int MODE, int POL, int FX>
 __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                     const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                     const double* __restrict__ t, int cols, int rows, const double* __restrict__ uInv,
@@ -765,8 +776,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
                                                     const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr) {
     if (done && *done) return;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
+    static_assert(FX == 0 || MODE == 3, "FX: MODE 3 only");
+    if (FX) { fr.cz = nullptr; fr.yOut = nullptr; fr.dinv64 = nullptr; uInv = nullptr; }   // (the launch site guarantees uCode != null)
+    const bool coded = FX ? true : uCode != nullptr;
     __shared__ double dict[MODE != 1 ? 256 : 1];
-    if (MODE != 1 && uCode) dict[threadIdx.x] = uDict[threadIdx.x];
+    if (MODE != 1 && coded) dict[threadIdx.x] = uDict[threadIdx.x];
     double alpha = 0.;
     if (MODE == 3) {   // as k_spmv_St_pipe: [stop test of iteration it-1], alpha = rsold / p.Ap — identical in every workgroup
         CGScalars* sc = fr.sc;
@@ -790,7 +804,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
                                  rE0 = bufRsrc(MODE == 1 ? add : xin, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8),
                                  rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
-                                 rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
+                                 rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, coded ? (size_t)rows : 0),
                                  rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0),
                                  rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
                                  rFy = bufRsrc(fr.yOut, (MODE == 3 && fr.yOut) ? (size_t)rows * 8 : 0);
@@ -799,12 +813,12 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double dacc = 0., dacc2 = 0.;
     int it = 0;
-    int chunk = Wk.at(0);
+    int chunk = Wk.chunkOf(0, wv);
     if (chunk < nChunks) {
-        EllUnit cu = ellUnit(echunk[chunk], wv);
+        EllUnit cu = ellUnit(echunk[chunk], Wk.unitOf(0, wv));
         EllRegs cur = ellLoad<SNT>(rCol, rCode, cu, lane), nxt{0u, 0u, 0u, 0u, 0u, 0u};
         int myBase = winBase[chunk * 16 + (lane & 15)], nBase = 0;
-        int nchunk = Wk.at(1);
+        int nchunk = Wk.chunkOf(1, wv);
         int4 nci = make_int4(0, 0, 0, 0);
         if (nchunk < nChunks) nci = echunk[nchunk];
         while (true) {
@@ -814,7 +828,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
             const double e0 = bufLoadF64epi<NT>(rE0, row * 8u);                                       // x (MODE 0, 2, 3) / the vector added (MODE 1)
             double e1 = 0., cr = 0., ci = 0., cd = 0.;
             int uc = 0;
-            if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, NT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
+            if (MODE != 1) { if (coded) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, NT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
             if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }   // cd = z_{j-1} (0: no buffer)
             float fdv = 1.f;
             if (MODE == 3) {
@@ -827,16 +841,16 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
             const bool hasNext = nchunk < nChunks;
             EllUnit nu{0, 0, 0, 0, 0};
             if (hasNext) {
-                nu = ellUnit(nci, wv);
+                nu = ellUnit(nci, Wk.unitOf(it + 1, wv));
                 nxt = ellLoad<SNT>(rCol, rCode, nu, lane);
                 nBase = winBase[nchunk * 16 + (lane & 15)];
             }
-            const int nn = Wk.at(it + 2);
+            const int nn = Wk.chunkOf(it + 2, wv);
             int4 nnci = make_int4(0, 0, 0, 0);
             if (nn < nChunks) nnci = echunk[nn];
             // (3) the row's sum and the fused epilogue
             const double s = ellSumW(cu.W, cur, X, scale);
-            if (MODE != 1 && uCode) e1 = dict[uc];
+            if (MODE != 1 && coded) e1 = dict[uc];
             double y;
             if (MODE == 0) { y = -s; y -= 0.5 * e1 * e0; dacc += e0 * y; }   // p.Ap: running sum over this block's chunks (0 past the last row)
             else if (MODE == 1) y = -s + e0;

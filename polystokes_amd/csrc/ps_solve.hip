@@ -65,7 +65,7 @@ struct Launch {
         if (pipeGrid > 0 && M.col16ok && M.packed && M.ellok) {   // row-per-lane kernels on the coded stream (ps_kernels_spmv.hpp: k_spmv_S_ell)
             const int nChunks = c->S.nChunks;
             int xcdAware = this->xcdAware;
-            const dim3 gr(pipeBlocks(nChunks, xcdAware, true)), bl(BS);
+            const dim3 gr(pipeBlocks(nChunks, xcdAware, true, sCap())), bl(BS);
 #define PS_LAUNCH_SE(MODE_, POL_) hipLaunchKernelGGL((k_spmv_S_ell<MODE_, POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
                                                      M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart)
 #define PS_LAUNCH_SE2(MODE_) do { const int pol = policy(M); if (pol == 3) PS_LAUNCH_SE(MODE_, 3); else if (pol == 1) PS_LAUNCH_SE(MODE_, 1); else PS_LAUNCH_SE(MODE_, 0); } while (0)
@@ -153,11 +153,15 @@ struct Launch {
             const int nChunks = c->St.nChunks;
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, true, stGridFor(mode))), bl(BS);
-#define PS_LAUNCH_TE(MODE_, POL_) hipLaunchKernelGGL((k_spmv_St_ell<MODE_, POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+#define PS_LAUNCH_TE(MODE_, POL_) PS_LAUNCH_TEX(MODE_, POL_, 0)
+#define PS_LAUNCH_TEX(MODE_, POL_, FX_) hipLaunchKernelGGL((k_spmv_St_ell<MODE_, POL_, FX_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
                                                      M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr)
 #define PS_LAUNCH_TE2(MODE_) do { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TE(MODE_, 3); else if (pol == 1) PS_LAUNCH_TE(MODE_, 1); else PS_LAUNCH_TE(MODE_, 0); } while (0)
-            if (mode == 0) PS_LAUNCH_TE2(0); else if (mode == 1) PS_LAUNCH_TE2(1); else if (mode == 2) PS_LAUNCH_TE2(2); else PS_LAUNCH_TE2(3);
+            const bool plain3 = mode == 3 && plain3Hint && c->uCoded && !fr.cz && !fr.yOut;   // (fr.dinvF / fr.red stay run-time: null or not)
+            if (plain3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 1); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 1); else PS_LAUNCH_TEX(3, 0, 1); }
+            else if (mode == 0) PS_LAUNCH_TE2(0); else if (mode == 1) PS_LAUNCH_TE2(1); else if (mode == 2) PS_LAUNCH_TE2(2); else PS_LAUNCH_TE2(3);
 #undef PS_LAUNCH_TE2
+#undef PS_LAUNCH_TEX
 #undef PS_LAUNCH_TE
             return;
         }
@@ -199,13 +203,24 @@ struct Launch {
     int sBlocks() const {
         const int nChunks = c->S.nChunks;
         int xcd = xcdAware;
-        return pipeBlocks(nChunks, xcd, true);
+        return pipeBlocks(nChunks, xcd, true, sCap());
     }
+    // The row-per-lane S kernel has no per-workgroup prologue and balances better on more, shorter workgroups — 256^3, same box:
+    // 4096 workgroups 0.265 ms, 5120 0.260, 6144 0.257, 8192 0.258, 12288 0.250 (each is one more partial sum for every St workgroup to read)
+    int sCap() const { return (c->S.ellok && c->S.packed && c->S.col16ok && pipeGrid == 4096) ? 6144 : 0; }
+    // MODE 3 of the row-per-lane St kernel in its plain form (FX = 1: no Chebyshev first term, no halo rows, coded uInv) fits 7 workgroups per CU
+    bool plain3Hint = false;
     // Workgroups of the St kernel.  With the residual update in its epilogue (mode 3) it runs best on 6 per CU — measured at 256^3,
     // rocprof average in a solve: 1280 / 1536 workgroups 415 us, 1792 489, 2048 445, 2560 / 3072 425, 4096 430 (and every workgroup
     // less is 10 K partial sums less to read in the prologue); S and the other St modes keep 16 per CU (S: 300 us at 4096, 324 at
     // 1536, 339 at 1024).  PS_PIPE_GRID_ST overrides.
-    int stGridFor(int mode) const { return stGrid > 0 ? stGrid : (mode == 3 && pipeGrid >= 1536 ? 1536 : 0); }
+    // Row-per-lane kernel, plain MODE 3: 7 per CU — 1536 workgroups 0.418 ms, 1792 0.403, 2048 0.515 (the eighth does not fit: a second round),
+    // 3584 / 5376 as 1792.
+    int stGridFor(int mode) const {
+        if (stGrid > 0) return stGrid;
+        if (mode != 3 || pipeGrid < 1536) return 0;
+        return (plain3Hint && c->St.ellok && c->St.packed && pipeGrid >= 1792) ? 1792 : 1536;
+    }
     int stBlocks(int mode = 0) const {   // number of partials the St kernel writes: one per block
         int xcd = xcdAware;
         return stOnPipe() ? pipeBlocks(c->St.nChunks, xcd, c->St.packed, stGridFor(mode)) : gridFor(rowsSt, BS);
@@ -231,7 +246,10 @@ Launch mk(ps_context* c, const int* done) {
     static const int wr = getenv("PS_WG_RUN") ? atoi(getenv("PS_WG_RUN")) : -1;
     const int run = wr >= 0 ? wr : ((c->S.ellok && c->St.ellok) ? 1 : 0);
     if (L.xcdAware > 0) L.xcdAware |= (run & 7) << 16;
+    static const int wt = getenv("PS_WG_T") ? atoi(getenv("PS_WG_T")) : 0;   // transposed runs of four chunks (ChunkWalk::chunkOf)
+    if (L.xcdAware > 0 && wt && (run & 7) == 2) L.xcdAware |= 1 << 20;
     L.ntSpmv = c->ntLevel() >= 1;
+    L.plain3Hint = c->uCoded && c->P.preconditioner != PS_PRE_CHEBYSHEV && !c->slabEnabled;
     return L;
 }
 constexpr int64_t FUSED_STEP_MIN_ROWS = 2000000;   // see solve()

@@ -67,3 +67,37 @@ def relerr(a, b):
     d = np.abs(a - b).max() if a.size else 0.0
     s = max(np.abs(b).max() if b.size else 0.0, 1e-300)
     return d / s
+
+
+# ---- the system vector as grid fields (for comparisons between decompositions) -------------------------------------------
+DOF_KINDS = ("p", "txx", "tyy", "tzz", "eYZ", "eXZ", "eXY")
+
+
+def dof_field(solver, kind, x, dtype=np.float32):
+    """One kind of DOF of a system vector x (reference numbering, Solver.h:586-606: pressures, then txx, tyy, tzz by cell, then the
+    YZ / XZ / XY edge stresses) as a dense array over its sample grid, NaN where there is no DOF."""
+    cidx = solver.array("centerActiveIndices")
+    nP = int((cidx >= 0).sum())                    # (a slab rank's own count: its stats object holds the group's)
+    if kind in ("p", "txx", "tyy", "tzz"):
+        idx = cidx
+        off = {"p": 0, "txx": nP, "tyy": 2 * nP, "tzz": 3 * nP}[kind]
+    else:
+        nE = [int((solver.array(s + "ActiveIndices") >= 0).sum()) for s in ("edgeYZ", "edgeXZ")]
+        idx = solver.array({"eYZ": "edgeYZ", "eXZ": "edgeXZ", "eXY": "edgeXY"}[kind] + "ActiveIndices")
+        off = 4 * nP + {"eYZ": 0, "eXZ": nE[0], "eXY": nE[0] + nE[1]}[kind]
+    out = np.full(idx.shape, np.nan, dtype)
+    m = idx >= 0
+    out[m] = x[idx[m].astype(np.int64) + off]
+    return out
+
+
+def merge_dof_field(global_out, local, slab, kind):
+    """Copy the DOFs a rank OWNS (cells and XY edges of its layers; YZ / XZ edges on its planes, the plane on a cut belonging to
+    the rank above: DESIGN.md section 6) from its local field (x-fastest, local layers) into the global one."""
+    nzl = slab.nz_local + (1 if kind in ("eYZ", "eXZ") else 0)
+    loc = local.reshape(nzl, -1)
+    glo = global_out.reshape(global_out.size // loc.shape[1], loc.shape[1])
+    k0, k1 = slab.zLoOwned, slab.zHiOwned
+    if kind in ("eYZ", "eXZ") and not slab.hasUpper:
+        k1 += 1                                   # the top plane of the whole domain
+    glo[slab.g0 + k0:slab.g0 + k1] = loc[k0:k1]

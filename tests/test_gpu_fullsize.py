@@ -171,6 +171,13 @@ def test_config4_and_5_full_size_single_and_slabs(scene, n, worlds):
     assert s.nP + s.nT > (5e7 if scene == "coil" else 2e7) and s.nRegions > 1000
     assert _stop_rule_holds(s, p)
     vel1, valid1 = s.vel, s.valid
+    # the solution vector as seven grid fields (p, txx, tyy, tzz, the three edge stresses): the form in which a slab group's solution
+    # can be compared with it, whatever the ranks' numberings
+    from helpers import DOF_KINDS, dof_field, merge_dof_field
+    x1 = s.array("solutionVector")
+    x1_norm = float(np.linalg.norm(x1))
+    fields1 = {k: dof_field(s, k, x1) for k in DOF_KINDS}
+    del x1
     s.close()
     for world in worlds:
         grp = polystokes_amd.Group(world)
@@ -178,6 +185,19 @@ def test_config4_and_5_full_size_single_and_slabs(scene, n, worlds):
         assert rc2 == abi.SUCCESS
         it2 = int(grp.stats.solveData[1])
         assert abs(it1 - it2) <= max(2, 0.02 * it1), (scene, world, it1, it2)
+        # x of the group (every rank's owned DOFs) against the single domain's: the tolerance the north star states, on x
+        d2 = 0.0
+        for kind in DOF_KINDS:
+            merged = np.full(fields1[kind].shape, np.nan, np.float32)
+            for r, sl in enumerate(grp.slabs):
+                xr = grp.ranks[r].array("solutionVector")
+                merge_dof_field(merged, dof_field(grp.ranks[r], kind, xr), sl, kind)
+                del xr
+            assert np.array_equal(np.isnan(merged), np.isnan(fields1[kind])), (scene, world, kind)   # the same DOFs exist
+            d = np.nan_to_num(merged.astype(np.float64) - fields1[kind])
+            d2 += float((d * d).sum())
+            del merged, d
+        assert np.sqrt(d2) <= 10 * p.tolerance * x1_norm, (scene, world, np.sqrt(d2) / x1_norm)
         for a in range(3):
             assert np.array_equal(grp.valid[a], valid1[a]), (scene, world, a)
             # Velocities are NOT compared here: u = dt McInv (rhs/dt - [G Dt] x) differences 1e5-sized terms (coil: mu = 100,
