@@ -91,6 +91,18 @@ for name, width in (("S", 8), ("St", 6)):
     L = np.where(Mu < 0, -1, Mu >> 4).reshape(-1, 64 * width)
     L.sort(axis=1)
     o["unit_distinct_lines_per_entry"] = int(((L[:, 1:] != L[:, :-1]) & (L[:, 1:] >= 0)).sum() + (L[:, 0] >= 0).sum()) / nnz
+    # distinct lines of an ITEM = R consecutive 256-row chunks (an LDS line cache staged once per item): lines / entry, largest item
+    for R in (1, 2, 4, 8, 16):
+        per = 256 * R
+        padi = (-rows) % per
+        Mi = np.concatenate([M[:rows], np.full((padi, width), -1, np.int64)]) if padi else M[:rows]
+        Li = np.where(Mi < 0, -1, Mi >> 4).reshape(-1, per * width)
+        Li.sort(axis=1)
+        dist = ((Li[:, 1:] != Li[:, :-1]) & (Li[:, 1:] >= 0)).sum(axis=1) + (Li[:, 0] >= 0)
+        o["item%d_lines_per_entry" % R] = float(dist.sum() / nnz)
+        o["item%d_max_lines" % R] = int(dist.max())
+        o["item%d_p99_lines" % R] = int(np.percentile(dist, 99))
+    o["vector_lines_per_entry"] = float((int(col.max()) + 16) // 16 / nnz)
     wmax = (Mu >= 0).sum(axis=1).reshape(-1, 64).max(axis=1)
     o["ell_slots_over_nnz"] = float((((wmax + 1) // 2 * 2) * 64).sum() / nnz)
     out[name] = o
