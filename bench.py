@@ -135,11 +135,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--res", dest="n", type=int, default=0, help="grid resolution per axis (default 256; 512 with --scaling strong)")
-    ap.add_argument("--scene", choices=["cavity", "coil", "spheres"], default=None, help="default: cavity (config 3); coil with --scaling strong (config 4)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+    ap.add_argument("--res", dest="n", type=int, default=int(os.environ.get("PS_BENCH_RES", "0")), help="grid resolution per axis (default 256; 512 with --scaling strong)")
+    ap.add_argument("--scene", choices=["cavity", "coil", "spheres"], default=os.environ.get("PS_BENCH_SCENE") or None, help="default: cavity (config 3); coil with --scaling strong (config 4)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("PS_BENCH_SCALING", "weak"),
                     help="N > 1: weak = the n x n x (n N) cavity, one n-layer slab per GPU (default); strong = one n^3 scene cut into N slabs "
-                         "(BASELINE config 4: --scaling strong --scene coil --res 512; config 5: --scene spheres --res 256)")
+                         "(BASELINE config 4: --scaling strong --scene coil --res 512; config 5: --scene spheres --res 256).  A driver that can only "
+                         "pass --gpus N selects the strong series with the environment: PS_BENCH_SCALING=strong [PS_BENCH_SCENE=coil PS_BENCH_RES=512]")
     ap.add_argument("--precond", choices=["jacobi", "identity", "chebyshev"], default="jacobi",
                     help="jacobi (default: the metric's configuration), identity (the reference's default), chebyshev (this library's polynomial preconditioner, degree 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -371,6 +372,24 @@ def main():
     }
     if transport_used:
         out["transport"] = transport_used
+    if dist is not None:
+        # what explains the scaling curve: every rank's cut traffic, the sampled transport and all-reduce times, the owned rows
+        mine = solver.dist_stats()
+        mine["rank"] = rank
+        allst = [None] * world
+        dist.all_gather_object(allst, mine)
+        if rank == 0:
+            ex = [d["exchange_ms_per_transport"] for d in allst if d["exchange_ms_per_transport"] is not None]
+            ar = [d["allreduce_ms"] for d in allst if d["allreduce_ms"] is not None]
+            out["multi_gpu"] = {
+                "overlap": all(d["overlap"] for d in allst),
+                "halo_bytes_per_iter": {"max_per_rank": max(d["halo_bytes_per_iter"] for d in allst), "sum": sum(d["halo_bytes_per_iter"] for d in allst)},
+                "exchange_ms_per_iter": (2.0 * max(ex)) if ex else None,        # two exchanges per iteration (x layers out, A p contributions back), slowest rank
+                "allreduce_ms_per_iter": (2.0 * max(ar)) if ar else None,       # two scalar all-reduces per iteration, incl. their synchronisation
+                "owned_rows": {"max": max(d["owned_dofs"] for d in allst), "min": min(d["owned_dofs"] for d in allst)},
+                "samples": {"exchange": min(d["exchange_samples"] for d in allst), "allreduce": min(d["allreduce_samples"] for d in allst)},
+                "note": "exchange = one transport timed with events on the rank's comm stream at the end of every 25-iteration batch; it runs UNDER the S / St chunks that need no halo value when overlap is true",
+            }
     if world == 1:
         # the boundary as the Houdini shim uses it: host fp32 fields in, velocity / valid fields out (polystokes_step)
         t0 = time.perf_counter()

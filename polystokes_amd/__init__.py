@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
     "polystokes_step", "ps_apply_operator", "ps_apply_preconditioner", "ps_query_array", "ps_read_array",
     "ps_export_component_matrices", "ps_export_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt", "ps_solve_exported_system",
-    "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest", "ps_comm_init_tcp",
+    "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest", "ps_comm_init_tcp", "ps_dist_stats",
     "ps_group_create", "ps_group_destroy", "ps_group_rank", "ps_group_step",
 ]
 
@@ -93,6 +93,8 @@ def lib():
         L.ps_comm_init_tcp.restype = C.c_int32
         L.ps_comm_selftest.argtypes = [C.c_void_p]
         L.ps_comm_selftest.restype = C.c_int32
+        L.ps_dist_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.ps_dist_stats.restype = C.c_int32
         L.ps_group_create.argtypes = [C.c_int32, C.c_int32]
         L.ps_group_create.restype = C.c_void_p
         L.ps_group_destroy.argtypes = [C.c_void_p]
@@ -160,6 +162,15 @@ class Solver:
 
     def comm_selftest(self):
         self._check(self.L.ps_comm_selftest(self.h))
+
+    def dist_stats(self):
+        """What this rank's last distributed solve did (ps_dist_stats): dict of bytes per iteration over its cuts, owned DOFs,
+        whether the exchanges overlapped, sampled transport / all-reduce times."""
+        v = (C.c_double * 8)()
+        self._check(self.L.ps_dist_stats(self.h, v))
+        return {"halo_bytes_per_iter": v[0], "owned_dofs": v[1], "overlap": bool(v[2]),
+                "exchange_ms_per_transport": (v[3] / v[4]) if v[4] else None, "exchange_samples": int(v[4]),
+                "allreduce_ms": (v[5] / v[6]) if v[6] else None, "allreduce_samples": int(v[6])}
 
     def comm_init(self, uid_bytes, rank, world):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)

@@ -180,6 +180,16 @@ struct ps_context {
     ps::DevBuf<int32_t> listLowHalo, listLowOwn, listUpHalo, listUpOwn;
     int64_t nLowHalo = 0, nLowOwn = 0, nUpHalo = 0, nUpOwn = 0;
     ps::DevBuf<double> sendLo, sendUp, recvLo, recvUp, redbuf;
+    // Overlap of the halo exchanges with the rows that do not need them (ps_dist.hpp: Dist::solve).  Chunk lists of the row-per-lane
+    // kernels: [0] S chunks without a halo column, [1] S chunks with one; [2] St chunks holding halo rows with entries (their A p goes
+    // to the neighbour), [3] St chunks of owned rows only.  St chunks of halo rows without entries are in neither: never launched.
+    ps::DevBuf<int32_t> distList[4];
+    int nDistList[4] = {0, 0, 0, 0};
+    bool distListsOk = false;
+    hipStream_t commStream = nullptr;        // transports run here (= stream for in-process ranks: nothing to overlap on one stream)
+    hipEvent_t distEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // what one distributed solve did (ps_dist_stats): bytes per iteration over the cuts, sampled transport / all-reduce times
+    double distStats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void* rcclComm = nullptr;                // ncclComm_t when one process per GPU
     void* hostComm = nullptr;                // host-staged TCP transport (ps_comm_init_tcp): same algorithm without RCCL
     uint64_t hashLowHalo = 0, hashLowOwn = 0, hashUpHalo = 0, hashUpOwn = 0;   // order-sensitive hashes of the lists' global (i, j, kind) keys

@@ -39,6 +39,27 @@ __global__ void k_unpack2(const int32_t* __restrict__ listA, int64_t nA, const d
     if (i < nA) { if (ADD) v[listA[i]] += bufA[i]; else v[listA[i]] = bufA[i]; }
     else if (i < nA + nB) { if (ADD) v[listB[i - nA]] += bufB[i - nA]; else v[listB[i - nA]] = bufB[i - nA]; }
 }
+// Which chunks of S gather a halo value (a column outside the owned DOF range)?  One wave per chunk.
+__global__ void __launch_bounds__(64) k_chunk_flags_S(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const int4* __restrict__ chunkInfo,
+                                                      int ownLo, int ownHi, int32_t* __restrict__ flag) {
+    const int4 ci = chunkInfo[blockIdx.x];
+    const int p0 = ptr[ci.z], p1 = ptr[ci.z + (int)((unsigned)ci.y >> 16)];
+    bool out = false;
+    for (int e = p0 + (int)threadIdx.x; e < p1; e += 64) { const int c = col[e]; out |= c < ownLo || c >= ownHi; }
+    if (__any(out) && threadIdx.x == 0) flag[blockIdx.x] = 1;
+    else if (threadIdx.x == 0) flag[blockIdx.x] = 0;
+}
+// Chunks of St: 0 = halo rows without entries (nothing to do), 1 = owned rows only, 2 = holds halo rows WITH entries (this rank's
+// share of the neighbour's A p)
+__global__ void k_chunk_flags_St(const int32_t* __restrict__ ptr, const int4* __restrict__ chunkInfo, int nChunks, int ownLo, int ownHi, int32_t* __restrict__ flag) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nChunks) return;
+    const int4 ci = chunkInfo[c];
+    const int r0 = ci.z, r1 = ci.z + (int)((unsigned)ci.y >> 16);
+    const int lo = max(r0, ownLo), hi = min(r1, ownHi);
+    const int all = ptr[r1] - ptr[r0], owned = hi > lo ? ptr[hi] - ptr[lo] : 0;
+    flag[c] = (all - owned) > 0 ? 2 : (hi > lo ? 1 : 0);
+}
 // out[q] = sum of partial[q*stride .. q*stride+count)   (q < nq), one block
 __global__ void __launch_bounds__(BS) k_sumq(const CGScalars* __restrict__ sc, const double* __restrict__ partial, int count, int stride, int nq,
                                              double* __restrict__ out) {
@@ -217,21 +238,40 @@ struct Dist {
     bool useTcp = false;          // one process per rank, host-staged TCP (HostComm)
     HostComm* hc() const { return (HostComm*)R[0]->hostComm; }
 
+    // Streams.  One process per rank (RCCL / TCP): the transports run on the rank's second stream (commStream), ordered against the
+    // solver stream by events, so that the rows that do not need a halo value are computed while it travels.  In-process ranks share one
+    // stream: commStream == stream, the same sequence without anything to overlap.
+    void ensureStreams() {
+        for (ps_context* c : R) {
+            if (!(useRccl || useTcp)) { c->commStream = c->stream; continue; }
+            if (!c->commStream || c->commStream == c->stream) HIP_CHECK(hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
+            for (int e = 0; e < 8; ++e) if (!c->distEv[e]) HIP_CHECK(hipEventCreate(&c->distEv[e]));   // (timing events among them: default flags)
+        }
+    }
+    hipStream_t cs(ps_context* c, bool onComm) const { return (onComm && c->commStream) ? c->commStream : c->stream; }
+    // everything queued on `from` so far happens before what is queued on `to` from now on
+    void order(ps_context* c, int ev, bool mainToComm) {
+        if (!c->commStream || c->commStream == c->stream) return;
+        hipStream_t from = mainToComm ? c->stream : c->commStream, to = mainToComm ? c->commStream : c->stream;
+        HIP_CHECK(hipEventRecord(c->distEv[ev], from));
+        HIP_CHECK(hipStreamWaitEvent(to, c->distEv[ev], 0));
+    }
     // sizes: kind 0 = x exchange (send own layers, receive halo), kind 1 = y exchange (send halo contributions, receive for own)
-    void transport(int kind) {
+    void transport(int kind, bool onComm = false) {
         if (useRccl) {
             ps_context* c = R[0];
+            hipStream_t st = cs(c, onComm);
             Rccl& L = rccl();
             const int64_t sLo = kind == 0 ? c->nLowOwn : c->nLowHalo, sUp = kind == 0 ? c->nUpOwn : c->nUpHalo;
             const int64_t rLo = kind == 0 ? c->nLowHalo : c->nLowOwn, rUp = kind == 0 ? c->nUpHalo : c->nUpOwn;
             ncclCheck(L.GroupStart(), "ncclGroupStart");
             if (c->slab.hasLower) {
-                if (sLo) ncclCheck(L.Send(c->sendLo.p, (size_t)sLo, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, c->stream), "ncclSend");
-                if (rLo) ncclCheck(L.Recv(c->recvLo.p, (size_t)rLo, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, c->stream), "ncclRecv");
+                if (sLo) ncclCheck(L.Send(c->sendLo.p, (size_t)sLo, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, st), "ncclSend");
+                if (rLo) ncclCheck(L.Recv(c->recvLo.p, (size_t)rLo, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, st), "ncclRecv");
             }
             if (c->slab.hasUpper) {
-                if (sUp) ncclCheck(L.Send(c->sendUp.p, (size_t)sUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "ncclSend");
-                if (rUp) ncclCheck(L.Recv(c->recvUp.p, (size_t)rUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, c->stream), "ncclRecv");
+                if (sUp) ncclCheck(L.Send(c->sendUp.p, (size_t)sUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, st), "ncclSend");
+                if (rUp) ncclCheck(L.Recv(c->recvUp.p, (size_t)rUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, st), "ncclRecv");
             }
             ncclCheck(L.GroupEnd(), "ncclGroupEnd");
             return;
@@ -239,16 +279,17 @@ struct Dist {
         if (useTcp) {
             ps_context* c = R[0];
             HostComm& H = *hc();
+            hipStream_t st = cs(c, onComm);
             const size_t sLo = (size_t)(c->slab.hasLower ? (kind == 0 ? c->nLowOwn : c->nLowHalo) : 0), sUp = (size_t)(c->slab.hasUpper ? (kind == 0 ? c->nUpOwn : c->nUpHalo) : 0);
             const size_t rLo = (size_t)(c->slab.hasLower ? (kind == 0 ? c->nLowHalo : c->nLowOwn) : 0), rUp = (size_t)(c->slab.hasUpper ? (kind == 0 ? c->nUpHalo : c->nUpOwn) : 0);
             H.hs0.resize(sLo + 1); H.hs1.resize(sUp + 1); H.hr0.resize(rLo + 1); H.hr1.resize(rUp + 1);
-            if (sLo) HIP_CHECK(hipMemcpyAsync(H.hs0.data(), c->sendLo.p, sLo * 8, hipMemcpyDeviceToHost, c->stream));
-            if (sUp) HIP_CHECK(hipMemcpyAsync(H.hs1.data(), c->sendUp.p, sUp * 8, hipMemcpyDeviceToHost, c->stream));
-            HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (sLo) HIP_CHECK(hipMemcpyAsync(H.hs0.data(), c->sendLo.p, sLo * 8, hipMemcpyDeviceToHost, st));
+            if (sUp) HIP_CHECK(hipMemcpyAsync(H.hs1.data(), c->sendUp.p, sUp * 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
             H.exchange(H.hs0.data(), sLo, H.hr0.data(), rLo, H.hs1.data(), sUp, H.hr1.data(), rUp);
-            if (rLo) HIP_CHECK(hipMemcpyAsync(c->recvLo.p, H.hr0.data(), rLo * 8, hipMemcpyHostToDevice, c->stream));
-            if (rUp) HIP_CHECK(hipMemcpyAsync(c->recvUp.p, H.hr1.data(), rUp * 8, hipMemcpyHostToDevice, c->stream));
-            HIP_CHECK(hipStreamSynchronize(c->stream));   // the host buffers are reused by the next exchange
+            if (rLo) HIP_CHECK(hipMemcpyAsync(c->recvLo.p, H.hr0.data(), rLo * 8, hipMemcpyHostToDevice, st));
+            if (rUp) HIP_CHECK(hipMemcpyAsync(c->recvUp.p, H.hr1.data(), rUp * 8, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));   // the host buffers are reused by the next exchange
             return;
         }
         for (size_t q = 0; q < R.size(); ++q) {   // in-process ranks share one stream: plain device copies
@@ -265,7 +306,9 @@ struct Dist {
             if (c->nLowOwn + c->nUpOwn > 0)
                 hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn, c->sendLo.p,
                                    c->listUpOwn.p, c->nUpOwn, c->sendUp.p, (c->*vec).p);
-        transport(0);
+        for (ps_context* c : R) order(c, 0, true);
+        transport(0, true);
+        for (ps_context* c : R) order(c, 1, false);
         for (ps_context* c : R)
             if (c->nLowHalo + c->nUpHalo > 0)
                 hipLaunchKernelGGL(k_unpack2<false>, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo,
@@ -276,16 +319,20 @@ struct Dist {
             if (c->nLowHalo + c->nUpHalo > 0)
                 hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->sendLo.p,
                                    c->listUpHalo.p, c->nUpHalo, c->sendUp.p, (c->*vec).p);
-        transport(1);
+        for (ps_context* c : R) order(c, 0, true);
+        transport(1, true);
+        for (ps_context* c : R) order(c, 1, false);
         for (ps_context* c : R)   // contributions from below and from above land on disjoint DOFs
             if (c->nLowOwn + c->nUpOwn > 0)
                 hipLaunchKernelGGL(k_unpack2<true>, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn,
                                    c->recvLo.p, c->listUpOwn.p, c->nUpOwn, c->recvUp.p, (c->*vec).p);
     }
     void allreduce(int count) {
-        if (useRccl) {
+        if (useRccl) {   // every RCCL call of the communicator goes to ONE stream (the comm stream once it exists)
             ps_context* c = R[0];
-            ncclCheck(rccl().AllReduce(c->redbuf.p, c->redbuf.p, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->rcclComm, c->stream), "ncclAllReduce");
+            order(c, 6, true);
+            ncclCheck(rccl().AllReduce(c->redbuf.p, c->redbuf.p, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->rcclComm, cs(c, true)), "ncclAllReduce");
+            order(c, 7, false);
             return;
         }
         if (useTcp) {
@@ -339,7 +386,8 @@ struct Dist {
         HIP_CHECK(hipMemcpyAsync(c->sendUp.p, mineUp, 64, hipMemcpyHostToDevice, c->stream));
         const int64_t keep[4] = {c->nLowOwn, c->nLowHalo, c->nUpOwn, c->nUpHalo};
         c->nLowOwn = c->nLowHalo = c->slab.hasLower ? 8 : 0; c->nUpOwn = c->nUpHalo = c->slab.hasUpper ? 8 : 0;   // ship 8 doubles each way through the x-exchange path
-        try { transport(0); } catch (...) { c->nLowOwn = keep[0]; c->nLowHalo = keep[1]; c->nUpOwn = keep[2]; c->nUpHalo = keep[3]; throw; }
+        order(c, 0, true);
+        try { transport(0, true); order(c, 1, false); } catch (...) { c->nLowOwn = keep[0]; c->nLowHalo = keep[1]; c->nUpOwn = keep[2]; c->nUpHalo = keep[3]; throw; }
         c->nLowOwn = keep[0]; c->nLowHalo = keep[1]; c->nUpOwn = keep[2]; c->nUpHalo = keep[3];
         double lo[8] = {0}, up[8] = {0};
         if (c->slab.hasLower) HIP_CHECK(hipMemcpyAsync(lo, c->recvLo.p, 64, hipMemcpyDeviceToHost, c->stream));
@@ -432,9 +480,43 @@ struct Dist {
     }
 
     // everything after the per-rank local setup: finish b and the Jacobi diagonal across the cuts; the Chebyshev interval
+    // Chunk lists of the row-per-lane kernels (ps_context::distList): which chunks can run before the halo values have arrived /
+    // while this rank's contributions to its neighbours travel.  Built from two flag kernels and a host pass per setup.
+    void buildLists() {
+        for (ps_context* c : R) {
+            c->distListsOk = false;
+            for (int q = 0; q < 4; ++q) c->nDistList[q] = 0;
+            Launch L = mk(c, nullptr);
+            static const bool off = getenv("PS_DIST_OVERLAP") && atoi(getenv("PS_DIST_OVERLAP")) == 0;   // A/B: the sequential exchange
+            if (off || !L.listsOk() || c->S.nChunks == 0 || c->St.nChunks == 0) continue;
+            const int nS = c->S.nChunks, nT = c->St.nChunks;
+            DevBuf<int32_t>& flags = c->scrVals;               // setup scratch
+            flags.alloc((size_t)std::max(nS, nT));
+            std::vector<int32_t> h((size_t)std::max(nS, nT)), lists[4];
+            hipLaunchKernelGGL(k_chunk_flags_S, dim3((unsigned)nS), dim3(64), 0, c->stream, (const int32_t*)c->S.ptr.p, (const int32_t*)c->S.col.p, (const int4*)c->S.chunkInfo.p,
+                               (int)c->ownLo, (int)c->ownHi, flags.p);
+            HIP_CHECK(hipMemcpyAsync(h.data(), flags.p, (size_t)nS * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < nS; ++i) lists[h[(size_t)i] ? 1 : 0].push_back(i);
+            hipLaunchKernelGGL(k_chunk_flags_St, dim3(gridFor(nT, BS)), dim3(BS), 0, c->stream, (const int32_t*)c->St.ptr.p, (const int4*)c->St.chunkInfo.p, nT,
+                               (int)c->ownLo, (int)c->ownHi, flags.p);
+            HIP_CHECK(hipMemcpyAsync(h.data(), flags.p, (size_t)nT * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < nT; ++i) { if (h[(size_t)i] == 2) lists[2].push_back(i); else if (h[(size_t)i] == 1) lists[3].push_back(i); }
+            for (int q = 0; q < 4; ++q) {
+                c->nDistList[q] = (int)lists[q].size();
+                c->distList[q].alloc(lists[q].size());
+                if (!lists[q].empty()) HIP_CHECK(hipMemcpyAsync(c->distList[q].p, lists[q].data(), lists[q].size() * 4, hipMemcpyHostToDevice, c->stream));
+            }
+            HIP_CHECK(hipStreamSynchronize(c->stream));        // (the host vectors go out of scope)
+            c->distListsOk = true;
+        }
+    }
     void finishSetup() {
         for (ps_context* c : R) c->redbuf.alloc(8);
+        ensureStreams();
         checkLists();
+        buildLists();
         exchangeAddY(&ps_context::b);
         const bool jac = R[0]->P.preconditioner == PS_PRE_DIAGONAL, cheb = R[0]->P.preconditioner == PS_PRE_CHEBYSHEV;
         if (jac || cheb) {
@@ -518,14 +600,36 @@ struct Dist {
             }
             fused = fused && mine[0] == 0. && (fusedEnv > 0 || mine[1] >= (double)FUSED_STEP_MIN_ROWS);
         }
-        struct FBuf { double *fS, *fT, *fU, *fR, *fX; int sBlocks, stBF, gFix; };
+        struct FBuf { double *fS, *fT, *fU, *fR, *fX; int sBlocks, stBF, gFix, sI, tB; };   // sI / tB: workgroups of the first of the two S / St launches
         std::vector<FBuf> fb(R.size());
+        // the exchanges overlap with the rows that do not need them when every rank has its chunk lists (row-per-lane kernels)
+        bool overlap = fused;
+        for (ps_context* c : R) overlap = overlap && c->distListsOk;
+        if (useRccl || useTcp) {   // all ranks take the same branch (the kernels differ, not the messages — but keep the ranks alike)
+            double mine = overlap ? 0. : 1.;
+            for (ps_context* c : R) HIP_CHECK(hipMemcpyAsync(c->redbuf.p, &mine, 8, hipMemcpyHostToDevice, c->stream));
+            allreduce(1);
+            HIP_CHECK(hipMemcpyAsync(&mine, R[0]->redbuf.p, 8, hipMemcpyDeviceToHost, R[0]->stream));
+            syncAll();
+            overlap = overlap && mine == 0.;
+        }
+        const bool timed = c0->commStream && c0->commStream != c0->stream;
+        for (ps_context* c : R) {
+            for (int q = 0; q < 8; ++q) c->distStats[q] = 0.;
+            c->distStats[0] = 8. * (double)(c->nLowOwn + c->nUpOwn + c->nLowHalo + c->nUpHalo);   // bytes this rank sends per iteration (x layers + A p contributions)
+            c->distStats[1] = (double)(c->ownHi - c->ownLo);                                        // owned DOFs
+            c->distStats[2] = overlap ? 1. : 0.;
+        }
         if (fused) {
             for (size_t q = 0; q < R.size(); ++q) {
                 ps_context* c = R[q];
                 Loc& l = loc[q];
                 FBuf& f = fb[q];
-                f.sBlocks = l.L.sBlocks(); f.stBF = l.L.stBlocks(3);
+                f.sBlocks = l.L.sBlocks(); f.stBF = l.L.stBlocks(3); f.sI = 0; f.tB = 0;
+                if (overlap) {
+                    f.sI = l.L.sBlocksFor(c->nDistList[0]); f.sBlocks = f.sI + l.L.sBlocksFor(c->nDistList[1]);
+                    f.tB = l.L.stBlocksFor(c->nDistList[2], 3); f.stBF = f.tB + l.L.stBlocksFor(c->nDistList[3], 3);
+                }
                 f.gFix = (int)std::min<int64_t>(256, std::max<int64_t>(1, (c->nLowOwn + c->nUpOwn + BS - 1) / BS));
                 c->fusedPart.alloc((size_t)f.sBlocks + (size_t)c->regionCount + VGRID + 2 * (size_t)f.stBF + 2 * (size_t)f.gFix + 16);
                 f.fS = c->fusedPart.p; f.fT = f.fS + f.sBlocks; f.fU = f.fT + c->regionCount; f.fR = f.fU + VGRID; f.fX = f.fR + 2 * f.stBF;
@@ -544,6 +648,79 @@ struct Dist {
         while (it < maxit && !finished) {
             const int upto = std::min(maxit, it + batch);
             for (; it < upto; ++it) {
+                if (fused && overlap) {
+                    // (1) p on the cut layers -> the neighbours [comm stream]; meanwhile the S chunks that gather no halo value
+                    const bool sample = it + 1 == upto;          // time the transports of the batch's last iteration (the host synchronises there anyway)
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        if (c->nLowOwn + c->nUpOwn > 0)
+                            hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn, c->sendLo.p,
+                                               c->listUpOwn.p, c->nUpOwn, c->sendUp.p, (const double*)c->pvec.p);
+                        order(c, 0, true);
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        l.L.sList = c->distList[0].p; l.L.nSList = c->nDistList[0]; l.L.sPart = f.fS;
+                        l.L.spmvS(0, c->pvec.p, c->ts.p);
+                    }
+                    if (sample && timed) HIP_CHECK(hipEventRecord(c0->distEv[2], cs(c0, true)));
+                    transport(0, true);
+                    if (sample && timed) HIP_CHECK(hipEventRecord(c0->distEv[3], cs(c0, true)));
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        if (c->nLowHalo + c->nUpHalo > 0)
+                            hipLaunchKernelGGL(k_unpack2<false>, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, cs(c, true), c->listLowHalo.p, c->nLowHalo,
+                                               c->recvLo.p, c->listUpHalo.p, c->nUpHalo, c->recvUp.p, c->pvec.p);
+                        order(c, 1, false);
+                        // (2) the S chunks next to a cut, the tiles, this rank's share of p.Ap
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        l.L.sList = c->distList[1].p; l.L.nSList = c->nDistList[1]; l.L.sPart = f.fS + f.sI;
+                        l.L.spmvS(0, c->pvec.p, c->ts.p);
+                        l.L.tiles(0, c->ts.p);
+                        hipLaunchKernelGGL(k_fused_local_sum, dim3(1), dim3(1024), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fS, f.sBlocks, (const double*)f.fT,
+                                           (int)c->regionCount, (const double*)f.fU, l.vb, (const double*)c->dotPartials3.p, l.vb, c->redbuf.p);
+                    }
+                    allreduce(2);
+                    // (3) St on the chunks that hold halo rows: their share of the neighbours' A p -> [comm stream]; meanwhile St on the rest
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        FusedR fr{l.sc, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, it, c->r.p, jac ? c->dinvF.p : (const float*)nullptr, f.fR, nullptr, 0., nullptr,
+                                  (const double*)c->redbuf.p, (int)c->ownLo, (int)c->ownHi, c->Ap.p, f.stBF};
+                        l.L.stList = c->distList[2].p; l.L.nStList = c->nDistList[2];
+                        l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
+                        if (c->nLowHalo + c->nUpHalo > 0)
+                            hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->sendLo.p,
+                                               c->listUpHalo.p, c->nUpHalo, c->sendUp.p, (const double*)c->Ap.p);
+                        order(c, 4, true);
+                        fr.rPart = f.fR + f.tB;
+                        l.L.stList = c->distList[3].p; l.L.nStList = c->nDistList[3];
+                        l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
+                    }
+                    transport(1, true);
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        order(c, 5, false);
+                        hipLaunchKernelGGL(k_dist_fixup, dim3(f.gFix), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const int32_t*)c->listLowOwn.p, c->nLowOwn,
+                                           (const double*)c->recvLo.p, (const int32_t*)c->listUpOwn.p, c->nUpOwn, (const double*)c->recvUp.p, c->r.p,
+                                           jac ? (const float*)c->dinvF.p : (const float*)nullptr, f.fX);
+                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, c->redbuf.p);
+                    }
+                    allreduce(2);
+                    for (size_t q = 0; q < R.size(); ++q) {
+                        ps_context* c = R[q];
+                        Loc& l = loc[q];
+                        FBuf& f = fb[q];
+                        const uint8_t* ucode = c->uCoded ? c->uCode.p + l.lo : nullptr;
+                        hipLaunchKernelGGL(k_cg_update_xp_u, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, (const double*)nullptr, 0, jac ? 1 : 0, it,
+                                           (const double*)c->r.p + l.lo, l.dv, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p, ucode, (const double*)c->uDict.p,
+                                           (const double*)c->uInv.p + l.lo, f.fU);
+                    }
+                    continue;
+                }
                 exchangeX(&ps_context::pvec);
                 if (fused) {
                     for (size_t q = 0; q < R.size(); ++q) {
@@ -552,7 +729,7 @@ struct Dist {
                         FBuf& f = fb[q];
                         l.L.spmvS(0, c->pvec.p, c->ts.p);
                         l.L.tiles(0, c->ts.p);
-                        hipLaunchKernelGGL(k_fused_local_sum, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fS, f.sBlocks, (const double*)f.fT,
+                        hipLaunchKernelGGL(k_fused_local_sum, dim3(1), dim3(1024), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fS, f.sBlocks, (const double*)f.fT,
                                            (int)c->regionCount, (const double*)f.fU, l.vb, (const double*)c->dotPartials3.p, l.vb, c->redbuf.p);
                     }
                     allreduce(2);
@@ -647,13 +824,26 @@ struct Dist {
                 hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, R[q]->stream, (const CGScalars*)loc[q].sc, R[q]->dotPartials3.p, loc[q].vb, 0, 1, R[q]->redbuf.p);
                 HIP_CHECK(hipMemcpyAsync(R[q]->redbuf.p + 1, &wantStop, 8, hipMemcpyHostToDevice, R[q]->stream));
             }
+            const auto ar0 = std::chrono::high_resolution_clock::now();
+            if (useRccl || useTcp) syncAll();                    // (so that the clock below sees the collective alone)
+            const auto ar1 = std::chrono::high_resolution_clock::now();
             allreduce(2);
+            if (useRccl || useTcp) {
+                syncAll();
+                c0->distStats[5] += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - ar1).count();
+                c0->distStats[6] += 1.;
+            }
+            (void)ar0;
             for (size_t q = 0; q < R.size(); ++q)
                 hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BS), 0, R[q]->stream, loc[q].sc, (const double*)R[q]->redbuf.p, (const double*)nullptr, 0, it - 1);
             double stopSum = 0.;
             HIP_CHECK(hipMemcpyAsync(&h, loc[0].sc, sizeof(h), hipMemcpyDeviceToHost, c0->stream));
             HIP_CHECK(hipMemcpyAsync(&stopSum, c0->redbuf.p + 1, 8, hipMemcpyDeviceToHost, c0->stream));
             syncAll();
+            if (overlap && timed) {   // the transport of the batch's last x exchange, as the comm stream saw it
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, c0->distEv[2], c0->distEv[3]) == hipSuccess) { c0->distStats[3] += (double)ms; c0->distStats[4] += 1.; }
+            }
             if (h.done) finished = true;
             else if (stopSum > 0. || (wantStop > 0. && !useRccl && !useTcp)) { interrupted = true; break; }
         }
@@ -814,6 +1004,9 @@ int ps_dist_step_single(ps_context* c, ps_stats* stats) {   // one process per r
 void ps_dist_release(ps_context* c) {
     if (c->rcclComm) { try { (void)rccl().CommDestroy(c->rcclComm); } catch (...) {} c->rcclComm = nullptr; }
     if (c->hostComm) { delete (HostComm*)c->hostComm; c->hostComm = nullptr; }
+    if (c->commStream && c->commStream != c->stream) (void)hipStreamDestroy(c->commStream);
+    c->commStream = nullptr;
+    for (int e = 0; e < 8; ++e) if (c->distEv[e]) { (void)hipEventDestroy(c->distEv[e]); c->distEv[e] = nullptr; }
 }
 #define PS_CATCH_ALL(ctx)                                                                    \
     catch (const ps::Error& e) { if (ctx) (ctx)->err = e.msg; return PS_FAILED; }            \
@@ -849,6 +1042,14 @@ int32_t ps_set_slab(ps_context* c, const ps_slab* slab) {
     } PS_CATCH_ALL(c)
 }
 
+// What the last distributed solve of this rank did: [0] bytes it sends per iteration over its cuts, [1] owned DOFs, [2] 1 if the
+// exchanges ran under the rows that do not need them, [3] / [4] summed ms / samples of one x-exchange transport (comm stream events,
+// batch ends), [5] / [6] summed ms / samples of one scalar all-reduce incl. its synchronisation (host clock, batch ends), [7] 0
+int32_t ps_dist_stats(ps_context* c, double* out8) {
+    if (!c || !out8) return PS_FAILED;
+    for (int q = 0; q < 8; ++q) out8[q] = c->distStats[q];
+    return PS_SUCCESS;
+}
 int32_t ps_comm_unique_id(void* id128) {
     if (!id128) return PS_FAILED;
     try { ncclCheck(rccl().GetUniqueId(id128), "ncclGetUniqueId"); return PS_SUCCESS; }

@@ -197,6 +197,9 @@ struct FusedR {
     // rows: their y goes to yOut and the owner subtracts alpha times it afterwards (k_dist_fixup).  Single domain: red = null,
     // [0, rows), yOut = null.
     const double* red; int ownLo, ownHi; double* yOut;
+    // the kernel may run as two launches (rows next to a cut first, the rest under the exchange: ps_dist.hpp): partials of r.r at
+    // rPart[block], of r.z at rPart[rStride + block]; 0 = one launch (stride = its grid)
+    int rStride;
 };
 // Walk of a persistent workgroup over the chunk ids: runs of G = 1 << sh consecutive chunks are dealt to the 8 XCDs round robin
 // (workgroup b runs on XCD b & 7), inside an XCD to its workgroups in order; sh < 0: plain grid-stride walk
@@ -688,12 +691,16 @@ __device__ inline double ellSumW(int W, const EllRegs& r, const EllX& X, double 
     return 0.;
 }
 // MODE 0 / 1 as k_spmv_S_pipe
-template <int MODE, int POL>
+template <int MODE, int POL, bool LIST>
 __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                    const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                    const double* __restrict__ x, int cols, int rows, int nA, double dt, const double* __restrict__ McInv,
                                                    double* __restrict__ out, const int* __restrict__ done, int nChunks, int xcdAware,
-                                                   const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict, double* __restrict__ stPart) {
+                                                   const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict, double* __restrict__ stPart,
+                                                   const int32_t* __restrict__ list) {
+    // LIST: `list` holds the chunks this launch works on, nChunks of them — the slab decomposition runs the chunks that touch no
+    // halo column while the halo values are still in flight, and the others afterwards (ps_dist.hpp).  A template parameter: the
+    // single-domain kernels must not pay registers for it (the plain MODE 3 St kernel sits at the edge of 7 waves per SIMD)
     if (done && *done) return;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
     __shared__ double dict[MODE == 0 ? 256 : 1];
@@ -706,14 +713,15 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ 
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double stAcc = 0.;
     int it = 0;
-    int chunk = Wk.at(0);
+    int chunk = Wk.at(0);                                               // POSITIONS in the walk (< nChunks); the chunk itself is list[position] when there is a list
     if (chunk < nChunks) {
-        EllUnit cu = ellUnit(echunk[chunk], wv);
+        const int id0 = LIST ? list[chunk] : chunk;
+        EllUnit cu = ellUnit(echunk[id0], wv);
         EllRegs cur = ellLoad<SNT>(rCol, rCode, cu, lane), nxt{0u, 0u, 0u, 0u, 0u, 0u};
-        int myBase = winBase[chunk * 16 + (lane & 15)], nBase = 0;
-        int nchunk = Wk.at(1);
+        int myBase = winBase[id0 * 16 + (lane & 15)], nBase = 0;
+        int nchunk = Wk.at(1), nid = 0;
         int4 nci = make_int4(0, 0, 0, 0);
-        if (nchunk < nChunks) nci = echunk[nchunk];
+        if (nchunk < nChunks) { nid = LIST ? list[nchunk] : nchunk; nci = echunk[nid]; }
         while (true) {
             // (1) this unit's gathers first: their address arithmetic waits on nothing but the window lookups
             const bool live = (int)lane < cu.rows;
@@ -731,11 +739,12 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ 
             if (hasNext) {
                 nu = ellUnit(nci, wv);
                 nxt = ellLoad<SNT>(rCol, rCode, nu, lane);
-                nBase = winBase[nchunk * 16 + (lane & 15)];
+                nBase = winBase[nid * 16 + (lane & 15)];
             }
             const int nn = Wk.at(it + 2);
+            int nnid = 0;
             int4 nnci = make_int4(0, 0, 0, 0);
-            if (nn < nChunks) nnci = echunk[nn];
+            if (nn < nChunks) { nnid = LIST ? list[nn] : nn; nnci = echunk[nnid]; }
             // (3) products, epilogue
             const double s = ellSumW(cu.W, cur, X, scale);
             if (MODE == 0 && mcCode) sc = (int)row < nA ? dt * dict[mcc] : 1.;
@@ -743,7 +752,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ 
             bufStoreF64nt<NT>(rOut, row * 8u, s * sc);                       // dropped past the chunk's last row (row = ROW_NONE)
             if (!hasNext) break;
             chunk = nchunk; cu = nu; cur = nxt; myBase = nBase;
-            nchunk = nn; nci = nnci;
+            nchunk = nn; nci = nnci; nid = nnid;
             ++it;
         }
     }
@@ -753,21 +762,23 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ 
     }
 }
 // MODE 0 .. 3 as k_spmv_St_pipe (same prologue, same per-row epilogue, same thread <-> row assignment: bit-identical partial sums)
-// FX = 1 (MODE 3 only): the plain Jacobi / identity PCG step of a single domain — value-set coded uInv, no Chebyshev first term, no
-// halo rows — as compile-time facts: six buffer descriptors less (the generic MODE 3 needs 100 SGPRs, spills them into VGPR lanes
-// and fits 6 waves per SIMD)
-template <int MODE, int POL, int FX>
+// FX (MODE 3 only): facts about the launch as compile-time constants, each worth buffer descriptors and branches (the generic MODE 3
+// needs 100 SGPRs, spills them into VGPR lanes and fits 6 waves per SIMD).  Bit 0: value-set coded uInv and no Chebyshev first term
+// (the Jacobi / identity PCG step); bit 1: a single domain (no halo rows, no all-reduced sums, one launch).
+template <int MODE, int POL, int FX, bool LIST>
 __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                     const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                     const double* __restrict__ t, int cols, int rows, const double* __restrict__ uInv,
                                                     const double* __restrict__ xin, const double* __restrict__ add, double* __restrict__ out,
                                                     double* __restrict__ partial, const int* __restrict__ done, int nChunks, int xcdAware, ChebArgs cheb,
-                                                    const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr) {
+                                                    const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr, const int32_t* __restrict__ list) {
+    // list: as in k_spmv_S_ell
     if (done && *done) return;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
     static_assert(FX == 0 || MODE == 3, "FX: MODE 3 only");
-    if (FX) { fr.cz = nullptr; fr.yOut = nullptr; fr.dinv64 = nullptr; uInv = nullptr; }   // (the launch site guarantees uCode != null)
-    const bool coded = FX ? true : uCode != nullptr;
+    if (FX & 1) { fr.cz = nullptr; fr.dinv64 = nullptr; uInv = nullptr; }                                              // (the launch site guarantees uCode != null)
+    if (FX & 2) { fr.yOut = nullptr; fr.rStride = 0; fr.red = nullptr; fr.ownLo = 0; fr.ownHi = rows; }
+    const bool coded = (FX & 1) ? true : uCode != nullptr;
     __shared__ double dict[MODE != 1 ? 256 : 1];
     if (MODE != 1 && coded) dict[threadIdx.x] = uDict[threadIdx.x];
     double alpha = 0.;
@@ -802,14 +813,15 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double dacc = 0., dacc2 = 0.;
     int it = 0;
-    int chunk = Wk.at(0);
+    int chunk = Wk.at(0);                                               // POSITIONS in the walk (< nChunks); the chunk itself is list[position] when there is a list
     if (chunk < nChunks) {
-        EllUnit cu = ellUnit(echunk[chunk], wv);
+        const int id0 = LIST ? list[chunk] : chunk;
+        EllUnit cu = ellUnit(echunk[id0], wv);
         EllRegs cur = ellLoad<SNT>(rCol, rCode, cu, lane), nxt{0u, 0u, 0u, 0u, 0u, 0u};
-        int myBase = winBase[chunk * 16 + (lane & 15)], nBase = 0;
-        int nchunk = Wk.at(1);
+        int myBase = winBase[id0 * 16 + (lane & 15)], nBase = 0;
+        int nchunk = Wk.at(1), nid = 0;
         int4 nci = make_int4(0, 0, 0, 0);
-        if (nchunk < nChunks) nci = echunk[nchunk];
+        if (nchunk < nChunks) { nid = LIST ? list[nchunk] : nchunk; nci = echunk[nid]; }
         while (true) {
             const bool live = (int)lane < cu.rows;
             const unsigned row = live ? (unsigned)cu.row0 + lane : ROW_NONE;
@@ -832,11 +844,12 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
             if (hasNext) {
                 nu = ellUnit(nci, wv);
                 nxt = ellLoad<SNT>(rCol, rCode, nu, lane);
-                nBase = winBase[nchunk * 16 + (lane & 15)];
+                nBase = winBase[nid * 16 + (lane & 15)];
             }
             const int nn = Wk.at(it + 2);
+            int nnid = 0;
             int4 nnci = make_int4(0, 0, 0, 0);
-            if (nn < nChunks) nnci = echunk[nn];
+            if (nn < nChunks) { nnid = LIST ? list[nn] : nn; nnci = echunk[nnid]; }
             // (3) the row's sum and the fused epilogue
             const double s = ellSumW(cu.W, cur, X, scale);
             if (MODE != 1 && coded) e1 = dict[uc];
@@ -867,7 +880,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
             else bufStoreF64nt<NT>(rOut, row * 8u, y);
             if (!hasNext) break;
             chunk = nchunk; cu = nu; cur = nxt; myBase = nBase;
-            nchunk = nn; nci = nnci;
+            nchunk = nn; nci = nnci; nid = nnid;
             ++it;
         }
     }
@@ -877,6 +890,6 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
     }
     if (MODE == 3) {
         const double b0 = blockReduceSum(dacc), b1 = (fr.dinvF || fr.cz) ? blockReduceSum(dacc2) : 0.;
-        if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[gridDim.x + blockIdx.x] = b1; }
+        if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[(fr.rStride > 0 ? fr.rStride : (int)gridDim.x) + blockIdx.x] = b1; }
     }
 }

@@ -52,6 +52,13 @@ struct Launch {
     // fused residual update (solve(): FusedR): where the S and tile kernels leave their shares of p.Ap (null: not asked for)
     double* sPart = nullptr;
     double* wvPart = nullptr;
+    // chunk lists (row-per-lane kernels only; null: every chunk): ps_dist.hpp launches the chunks next to a cut and the others separately
+    const int32_t* sList = nullptr; int nSList = 0;
+    const int32_t* stList = nullptr; int nStList = 0;
+    bool listsOk() const { return pipeGrid > 0 && c->S.col16ok && c->S.packed && c->S.ellok && c->St.col16ok && c->St.packed && c->St.ellok; }
+    // workgroups of a launch over n chunks of S / St (the partial sums it writes)
+    int sBlocksFor(int n) const { int xcd = xcdAware; return n > 0 ? pipeBlocks(n, xcd, true, sCap()) : 0; }
+    int stBlocksFor(int n, int mode) const { int xcd = xcdAware; return n > 0 ? pipeBlocks(n, xcd, true, stGridFor(mode)) : 0; }
     bool ntSpmv = true;   // cache policy of the pipelined kernels' streams (ps_context::ntLevel >= 1)
     // POL of the pipelined kernels (ps_kernels_spmv.hpp): 0 = default policy; 1 = non-temporal stores and epilogue streams, cached matrix
     // stream (most runs shared between chunks: read again and again); 3 = the matrix stream non-temporal too (every run read once)
@@ -63,14 +70,17 @@ struct Launch {
         if (rowsS == 0) return;
         const ps::DevCSR& M = c->S;
         if (pipeGrid > 0 && M.col16ok && M.packed && M.ellok) {   // row-per-lane kernels on the coded stream (ps_kernels_spmv.hpp: k_spmv_S_ell)
-            const int nChunks = c->S.nChunks;
+            const int nChunks = sList ? nSList : c->S.nChunks;     // (a chunk list: the slab decomposition's interior / boundary launches)
+            if (nChunks == 0) return;
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, true, sCap())), bl(BS);
-#define PS_LAUNCH_SE(MODE_, POL_) hipLaunchKernelGGL((k_spmv_S_ell<MODE_, POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                                     M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart)
+#define PS_LAUNCH_SE(MODE_, POL_) do { if (sList) PS_LAUNCH_SEL(MODE_, POL_, true); else PS_LAUNCH_SEL(MODE_, POL_, false); } while (0)
+#define PS_LAUNCH_SEL(MODE_, POL_, LIST_) hipLaunchKernelGGL((k_spmv_S_ell<MODE_, POL_, LIST_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                                     M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart, sList)
 #define PS_LAUNCH_SE2(MODE_) do { const int pol = policy(M); if (pol == 3) PS_LAUNCH_SE(MODE_, 3); else if (pol == 1) PS_LAUNCH_SE(MODE_, 1); else PS_LAUNCH_SE(MODE_, 0); } while (0)
             if (mode == 0) PS_LAUNCH_SE2(0); else PS_LAUNCH_SE2(1);
 #undef PS_LAUNCH_SE2
+#undef PS_LAUNCH_SEL
 #undef PS_LAUNCH_SE
             return;
         }
@@ -150,17 +160,22 @@ struct Launch {
         FusedR fr{};
         if (fused) fr = *fused;
         if (pipeGrid > 0 && M.col16ok && M.packed && M.ellok) {   // row-per-lane kernels on the coded stream (k_spmv_St_ell)
-            const int nChunks = c->St.nChunks;
+            const int nChunks = stList ? nStList : c->St.nChunks;
+            if (nChunks == 0) return;
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, true, stGridFor(mode))), bl(BS);
 #define PS_LAUNCH_TE(MODE_, POL_) PS_LAUNCH_TEX(MODE_, POL_, 0)
-#define PS_LAUNCH_TEX(MODE_, POL_, FX_) hipLaunchKernelGGL((k_spmv_St_ell<MODE_, POL_, FX_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                                     M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr)
+#define PS_LAUNCH_TEX(MODE_, POL_, FX_) do { if (stList) PS_LAUNCH_TEL(MODE_, POL_, FX_, true); else PS_LAUNCH_TEL(MODE_, POL_, FX_, false); } while (0)
+#define PS_LAUNCH_TEL(MODE_, POL_, FX_, LIST_) hipLaunchKernelGGL((k_spmv_St_ell<MODE_, POL_, FX_, LIST_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                                     M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr, stList)
 #define PS_LAUNCH_TE2(MODE_) do { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TE(MODE_, 3); else if (pol == 1) PS_LAUNCH_TE(MODE_, 1); else PS_LAUNCH_TE(MODE_, 0); } while (0)
-            const bool plain3 = mode == 3 && plain3Hint && c->uCoded && !fr.cz && !fr.yOut;   // (fr.dinvF / fr.red stay run-time: null or not)
-            if (plain3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 1); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 1); else PS_LAUNCH_TEX(3, 0, 1); }
+            // MODE 3 specialisations (k_spmv_St_ell: FX): coded uInv without the Chebyshev term, in a single domain (3) or on a slab rank (1)
+            const bool coded3 = mode == 3 && c->uCoded && !fr.cz, single3 = coded3 && plain3Hint && !fr.yOut && !fr.red && fr.rStride == 0;
+            if (single3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 3); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 3); else PS_LAUNCH_TEX(3, 0, 3); }
+            else if (coded3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 1); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 1); else PS_LAUNCH_TEX(3, 0, 1); }
             else if (mode == 0) PS_LAUNCH_TE2(0); else if (mode == 1) PS_LAUNCH_TE2(1); else if (mode == 2) PS_LAUNCH_TE2(2); else PS_LAUNCH_TE2(3);
 #undef PS_LAUNCH_TE2
+#undef PS_LAUNCH_TEL
 #undef PS_LAUNCH_TEX
 #undef PS_LAUNCH_TE
             return;
