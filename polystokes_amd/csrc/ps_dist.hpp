@@ -244,7 +244,13 @@ struct Dist {
     void ensureStreams() {
         for (ps_context* c : R) {
             if (!(useRccl || useTcp)) { c->commStream = c->stream; continue; }
-            if (!c->commStream || c->commStream == c->stream) HIP_CHECK(hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
+            if (!c->commStream || c->commStream == c->stream) {
+                // highest priority: the transport's kernels must find CUs while the persistent S / St workgroups of the solver stream hold
+                // all of them — they are dispatched as those retire, ahead of the solver stream's own next round
+                int lo = 0, hi = 0;
+                HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIP_CHECK(hipStreamCreateWithPriority(&c->commStream, hipStreamNonBlocking, hi));
+            }
             for (int e = 0; e < 8; ++e) if (!c->distEv[e]) HIP_CHECK(hipEventCreate(&c->distEv[e]));   // (timing events among them: default flags)
         }
     }

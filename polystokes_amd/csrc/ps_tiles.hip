@@ -78,7 +78,9 @@ __device__ inline void faceOffset(const TileArgs& A, int axis, int i, int j, int
 
 // g = sum_i contribution_i * C(adjacent face_i): the row-vector side of the viscosity outer products
 // of one reduced face (Solver.cpp:1538-1683).  Returns false if the face contributes nothing.
-__device__ void viscosityRow(const TileArgs& A, int faceAxis, int i, int j, int k, double* gv) {
+// part: 0 = every term; 1 = the cell terms and the first of the two edge axes, 2 = the second edge axis — the MFMA kernel splits the
+// up to 20 basis rows of a face over its two half-blocks (the sum of the two parts differs from part 0 by rounding only)
+__device__ void viscosityRow(const TileArgs& A, int faceAxis, int i, int j, int k, double* gv, int part = 0) {
 #pragma unroll
     for (int n = 0; n < PS_RD; ++n) gv[n] = 0.;
     const int3 cd = A.g.dims(0);
@@ -86,7 +88,7 @@ __device__ void viscosityRow(const TileArgs& A, int faceAxis, int i, int j, int 
     const double dx2 = A.dx * A.dx;
     double row[PS_RD];
     // cell-centred stresses
-    for (int divDir = 0; divDir < 2; ++divDir) {
+    for (int divDir = 0; divDir < (part == 2 ? 0 : 2); ++divDir) {
         int3 c = make_int3(i, j, k);
         addc(c, faceAxis, divDir - 1);
         if (!isReducedL(labAt(A, 0, cd, c.x, c.y, c.z))) continue;
@@ -108,8 +110,11 @@ __device__ void viscosityRow(const TileArgs& A, int faceAxis, int i, int j, int 
         }
     }
     // edge-centred stresses (pure REDUCED edges only)
+    int nth = 0;
     for (int edgeAxis = 0; edgeAxis < 3; ++edgeAxis) {
         if (edgeAxis == faceAxis) continue;
+        ++nth;                                         // 1: the first edge axis of this face, 2: the second
+        if (part != 0 && part != nth) continue;
         const int3 ed = A.g.dims(4 + edgeAxis);
         for (int divDir = 0; divDir < 2; ++divDir) {
             const double divSign = divDir == 0 ? -1. : 1.;
@@ -282,6 +287,7 @@ __global__ void __launch_bounds__(BS) k_region_outer_mfma(TileArgs A, double* __
         double vec[MPAD];
 #pragma unroll
         for (int n = 0; n < MPAD; ++n) vec[n] = 0.;
+        double gv1[MODE == MODE_VISC ? PS_RD : 1];      // MODE_VISC, first half-block: its share of b_f (cell terms + first edge axis)
         if (use) {
             if (!doB || MODE != MODE_VISC) {
                 double o[3];
@@ -292,14 +298,25 @@ __global__ void __launch_bounds__(BS) k_region_outer_mfma(TileArgs A, double* __
                     for (int n = 0; n < PS_RD; ++n) vec[n] *= A.rho;
                 }
                 if (MODE == MODE_LSQ && doB) vec[PS_RD] = (double)A.vel[axis][lin3(fd, i, j, k)];   // rhs column: sum_f C_f u_f
+                if (MODE == MODE_VISC) viscosityRow(A, axis, i, j, k, gv1, 1);
             } else {
-                viscosityRow(A, axis, i, j, k, vec);
+                viscosityRow(A, axis, i, j, k, vec, 2);
             }
+        } else if (MODE == MODE_VISC) {
+#pragma unroll
+            for (int n = 0; n < PS_RD; ++n) gv1[n] = 0.;
         }
         double* dst = doB ? sb[ft] : sa[ft];
 #pragma unroll
         for (int n = 0; n < MPAD; ++n) dst[n] = vec[n];
         __syncthreads();
+        if (MODE == MODE_VISC) {                         // b_f = the two halves' shares
+            if (!doB) {
+#pragma unroll
+                for (int n = 0; n < PS_RD; ++n) sb[ft][n] += gv1[n];
+            }
+            __syncthreads();
+        }
         // 32 k-steps of 4 faces; lane l: A[m = 16 ti + (l&15)][face 4 ks + (l>>4)], B[face][n = 16 tj + (l&15)]
 #pragma unroll 8
         for (int ks = 0; ks < FBATCH / 4; ++ks) {
