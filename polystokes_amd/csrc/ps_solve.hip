@@ -254,7 +254,7 @@ Launch mk(ps_context* c, const int* done) {
     static const int sg = getenv("PS_PIPE_GRID_ST") ? atoi(getenv("PS_PIPE_GRID_ST")) : 0;
     L.stGrid = pg > 0 ? sg : 0;
     static int xa = -1;
-    if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 16; }   // chunks per XCD run (rounded down to a power of two); 0: plain walk
+    if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 64; }   // chunks per XCD run (rounded down to a power of two); 0: plain walk.  64: same kernel times as 4 / 16 / 256 on the row-per-lane kernels, a fifth less HBM-side traffic than 16 (FETCH_SIZE of S 0.64 / 0.54 / 0.44 / 0.42 M KiB at 4 / 16 / 64 / 256)
     L.xcdAware = xa > 0 ? xa : 0;
     // log2 of the consecutive chunks a workgroup takes in a row (ChunkWalk): 2 chunks on the row-per-lane kernels (256^3, same box: S 0.264 ->
     // 0.257 ms, St with the residual update 0.431 -> 0.408; 4 / 8 / 16 chunks: S 0.282 / 0.274 / 0.273, St 0.412 / 0.412 / 0.428)
