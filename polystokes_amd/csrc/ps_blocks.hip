@@ -31,6 +31,7 @@ struct BlockArgs {
     const float* vel[3];
     const float* cvel[3];
     const float* visc;
+    int viscUniform; float viscValue;   // a constant field: its samples without loads (ps_context::upload)
     int64_t nCenter, nEdge0, nEdge1, nP, nA, faceOff[3];
     Own own;
     const int32_t* regionOwned;   // null: all owned
@@ -400,6 +401,7 @@ __device__ inline void sortRows4(int32_t (&rows)[4], double (&vals)[4]) {   // a
 }
 
 __device__ inline float viscAt(const BlockArgs& A, float px, float py, float pz) {
+    if (A.viscUniform) return A.viscValue;
     const int n[3] = {A.g.nx, A.g.ny, A.g.nz};
     const float p[3] = {px, py, pz};
     int i0[3], i1[3];
@@ -508,6 +510,7 @@ BlockArgs makeArgs(ps_context* c) {
     }
     for (int a = 0; a < 3; ++a) { A.faceRow[a] = c->faceRow[a].p; A.vel[a] = c->vel[a].p; A.cvel[a] = c->cvel[a].p; A.sysT[a] = c->sysIdxT[a].p; }
     A.visc = c->viscosity.p;
+    A.viscUniform = c->viscUniform ? 1 : 0; A.viscValue = c->viscUniformValue;
     A.nCenter = c->nCenter; A.nEdge0 = c->nEdge[0]; A.nEdge1 = c->nEdge[1];
     A.nP = c->nPressures; A.nA = c->nActiveVs;
     A.faceOff[0] = 0; A.faceOff[1] = c->nFace[0]; A.faceOff[2] = c->nFace[0] + c->nFace[1];

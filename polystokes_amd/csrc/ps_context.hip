@@ -76,6 +76,14 @@ void ps_context::upload(const ps_params* p, const ps_fields_in* in) {
     uploadField(surface, in->surface, nc, stream);
     uploadField(collision, in->collision, nc, stream);
     uploadField(viscosity, in->viscosity, nc, stream);
+    {   // a constant viscosity field (the usual case: a scalar parameter) needs no sampling: trilinear interpolation of a constant returns
+        // it bit for bit (a + (b - a) t with a == b), so the setup kernels skip the 8 loads per sample (ps_tiles.hip, ps_blocks.hip)
+        const float v0 = in->viscosity[0];
+        bool same = true;
+        for (int64_t i = 1; i < nc && same; ++i) same = in->viscosity[i] == v0;
+        viscUniform = same && std::isfinite(v0);
+        viscUniformValue = v0;
+    }
     for (int a = 0; a < 3; ++a) {
         uploadField(vel[a], in->vel[a], g.count(1 + a), stream);
         uploadField(cvel[a], in->collisionvel[a], g.count(1 + a), stream);

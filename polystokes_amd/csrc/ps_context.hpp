@@ -86,6 +86,8 @@ struct ps_context {
     double valScale = 0;      // invDx / 64
     bool forceFp64Values = false;   // env PS_FORCE_FP64_VALUES=1: never use the coded values (A/B and fallback testing)
     bool haveInputWeights = false;
+    bool viscUniform = false;       // the viscosity field is one value everywhere (checked at upload): samplers return it without loads
+    float viscUniformValue = 0.f;
     bool uploaded = false, isSetup = false, isSolved = false;
 
     // ---- inputs (fp32 Houdini voxel arrays, HDK_PolyStokes.C:235-246) ----

@@ -28,6 +28,7 @@ struct TileArgs {
     const int32_t* reg[7];
     const float* vel[3];
     const float* visc;
+    int viscUniform; float viscValue;   // a constant field: its samples without loads (bit-identical: ps_context::upload)
     const double* COM;
     int zoff;
     const int32_t* bbox;
@@ -44,6 +45,7 @@ __device__ inline int regAt(const TileArgs& A, int s, const int3 d, int i, int j
 }
 
 __device__ inline float viscSample(const TileArgs& A, float px, float py, float pz) {
+    if (A.viscUniform) return A.viscValue;
     // same restatement of SIM_RawField::getValue as ps_grid.hip::sampleCenterField
     const int n[3] = {A.g.nx, A.g.ny, A.g.nz};
     const float p[3] = {px, py, pz};
@@ -507,6 +509,7 @@ TileArgs makeArgs(ps_context* c) {
     for (int s = 0; s < 7; ++s) { A.lab[s] = c->labels[s].p; A.reg[s] = c->reducedIdx[s].p; }
     for (int a = 0; a < 3; ++a) A.vel[a] = c->vel[a].p;
     A.visc = c->viscosity.p;
+    A.viscUniform = c->viscUniform ? 1 : 0; A.viscValue = c->viscUniformValue;
     A.COM = c->COM.p;
     A.zoff = c->zOff;
     A.bbox = c->bbox.p;
