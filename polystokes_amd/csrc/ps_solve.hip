@@ -306,7 +306,7 @@ void ps_context::constructPreconditioner() {
     if (P.preconditioner != PS_PRE_DIAGONAL && P.preconditioner != PS_PRE_CHEBYSHEV && P.solverType != PS_EIGEN) return;   // Eigen's CG always runs its DiagonalPreconditioner
     dinv.alloc((size_t)nSystem);
     if (nSystem == 0) return;
-    hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 128)), dim3(128), 0, stream, St.ptr.p, St.col.p, St.val.p, (int)nSystem,
+    hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 256)), dim3(256), 0, stream, St.ptr.p, St.col.p, St.val.p, (int)nSystem,
                        (int)nPressures, (int)nActiveVs, dt, McInv.p, uInv.p, rrowFace.p, rrowRegion.p, COM.p, dx, zOff, Binv.p, dinv.p,
                        slabEnabled ? 0 : 1);
     // The PCG kernels read the diagonal in fp32 (4 instead of 8 bytes per DOF in both vector kernels).  Any positive
