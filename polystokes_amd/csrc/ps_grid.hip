@@ -12,10 +12,9 @@ namespace {
 
 constexpr int BS = 256;
 
-__constant__ float kSampleOffset[7][3] = {
-    // Solver.h:193-222, order centre, faceX, faceY, faceZ, edgeYZ, edgeXZ, edgeXY
-    {0.5f, 0.5f, 0.5f}, {0.f, 0.5f, 0.5f}, {0.5f, 0.f, 0.5f}, {0.5f, 0.5f, 0.f},
-    {0.5f, 0.f, 0.f},   {0.f, 0.5f, 0.f},  {0.f, 0.f, 0.5f}};
+// sample offsets inside a voxel (Solver.h:193-222), order centre, faceX, faceY, faceZ, edgeYZ, edgeXZ, edgeXY: 0.5 (true) or 0 per axis
+constexpr bool kSampleOffsetHalf[7][3] = {{true, true, true}, {false, true, true}, {true, false, true}, {true, true, false},
+                                          {true, false, false}, {false, true, false}, {false, false, true}};
 
 // SIM_RawField::getValue(pos) restated: trilinear between voxel centres, streak border, fp32,
 // lerp(a,b,t) = a + (b-a)*t, x then y then z.  The library is built with -ffp-contract=off so the
@@ -48,26 +47,82 @@ __device__ inline float sampleCenterField(const float* __restrict__ f, int nx, i
 
 // computeSDFWeightsSampled(sdf, 2, invert=false, minweight=0): Solver.cpp:292-326 (HDK body out of tree,
 // restated: fraction of the 2x2x2 sub-samples of the voxel box whose SDF value is < 0).
-__global__ void k_sdf_weights(Grid g, int s, const float* __restrict__ sdf, int negate, float* __restrict__ dst) {
-    const int3 d = g.dims(s);
-    const int64_t n = (int64_t)d.x * d.y * d.z;
+// All seven sample grids in one launch.  Along an axis the sub-samples of the voxel index q sit at u = q - 0.75, q - 0.25 or q + 0.25
+// (cell-centre coordinates): the grids centred on that axis use the last two, the grids on a face of it the first two.  So the 56
+// sub-samples of the seven grids at (i, j, k) are 27 distinct points, and their trilinear values share the lerps: 27 along x (two
+// loads each), 27 along y, 27 along z — the SAME operations on the same operands as sampleCenterField above does for each of them
+// (x, then y, then z; the index / clamp arithmetic per axis is that function's), so every value is bit-identical; 54 loads per voxel
+// instead of 448 (the r02 kernels, one launch per grid, were bound by exactly those loads: 14 launches, 2.6 ms at 256^3).
+struct AxisSamples { int i0[3], i1[3]; float t[3]; };
+__device__ inline AxisSamples axisSamples(int q, int n) {
+    AxisSamples A;
+    const float pos[3] = {((float)q + 0.f) + -0.25f, ((float)q + 0.f) + 0.25f, ((float)q + 0.5f) + 0.25f};   // (index + offset) +- 0.25, formed as the oracle forms it
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float u = pos[c] - 0.5f;
+        if (u < 0.f) u = 0.f;
+        if (u > (float)(n - 1)) u = (float)(n - 1);
+        int b = (int)u;
+        if (b >= n - 1) { b = n - 1; A.i0[c] = b; A.i1[c] = b; A.t[c] = 0.f; }
+        else { A.i0[c] = b; A.i1[c] = b + 1; A.t[c] = u - (float)b; }
+    }
+    return A;
+}
+__global__ void __launch_bounds__(BS) k_sdf_weights7(Grid g, const float* __restrict__ sdf, int negate, Set7<float> dst) {
+    const int ex = g.nx + 1, ey = g.ny + 1;
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const int3 q = unlin3(d, c);
-    const float cx = (float)q.x + kSampleOffset[s][0], cy = (float)q.y + kSampleOffset[s][1], cz = (float)q.z + kSampleOffset[s][2];
-    int cnt = 0;
+    if (c >= (int64_t)ex * ey * (g.nz + 1)) return;
+    const int i = (int)(c % ex), j = (int)((c / ex) % ey), k = (int)(c / ((int64_t)ex * ey));
+    const AxisSamples X = axisSamples(i, g.nx), Y = axisSamples(j, g.ny), Z = axisSamples(k, g.nz);
+    auto L = [](float a, float b, float tt) { return a + (b - a) * tt; };
+    // the cell rows / planes the y and z samples touch: at most three distinct ones each (j - 1 .. j + 1 clamped), named by value
+    int jr[3] = {Y.i0[0], Y.i0[2], Y.i1[2]}, kr[3] = {Z.i0[0], Z.i0[2], Z.i1[2]};
+    // (i0[0] = i0[1] <= i0[2] <= i1[2]; i1[0] = i1[1] is i0[2] or — at the upper border — i0[0]; so every index used is among the three)
+    float xl[3][3][3];                                     // [x sample][row][plane]
 #pragma unroll
-    for (int sz = 0; sz < 2; ++sz)
+    for (int pz = 0; pz < 3; ++pz)
 #pragma unroll
-        for (int sy = 0; sy < 2; ++sy)
+        for (int py = 0; py < 3; ++py) {
+            const float* row = sdf + (int64_t)g.nx * (jr[py] + (int64_t)g.ny * kr[pz]);
 #pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-                float v = sampleCenterField(sdf, g.nx, g.ny, g.nz, cx + (sx ? 0.25f : -0.25f), cy + (sy ? 0.25f : -0.25f),
-                                            cz + (sz ? 0.25f : -0.25f));
+            for (int cx = 0; cx < 3; ++cx) xl[cx][py][pz] = L(row[X.i0[cx]], row[X.i1[cx]], X.t[cx]);
+        }
+    auto pick = [](int idx, const int* set) { return idx == set[0] ? 0 : (idx == set[1] ? 1 : 2); };
+    int cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int cz = 0; cz < 3; ++cz) {
+        const int z0 = pick(Z.i0[cz], kr), z1 = pick(Z.i1[cz], kr);
+#pragma unroll
+        for (int cy = 0; cy < 3; ++cy) {
+            const int y0 = pick(Y.i0[cy], jr), y1 = pick(Y.i1[cy], jr);
+#pragma unroll
+            for (int cx = 0; cx < 3; ++cx) {
+                auto sel = [&](int py, int pz) {
+                    const float a0 = pz == 0 ? xl[cx][0][0] : (pz == 1 ? xl[cx][0][1] : xl[cx][0][2]);
+                    const float a1 = pz == 0 ? xl[cx][1][0] : (pz == 1 ? xl[cx][1][1] : xl[cx][1][2]);
+                    const float a2 = pz == 0 ? xl[cx][2][0] : (pz == 1 ? xl[cx][2][1] : xl[cx][2][2]);
+                    return py == 0 ? a0 : (py == 1 ? a1 : a2);
+                };
+                const float c0 = L(sel(y0, z0), sel(y1, z0), Y.t[cy]);
+                const float c1 = L(sel(y0, z1), sel(y1, z1), Y.t[cy]);
+                float v = L(c0, c1, Z.t[cz]);
                 if (negate) v = -v;
-                if (v < 0.f) ++cnt;
+                const int in = v < 0.f ? 1 : 0;
+                // which grids own this sub-sample: per axis, sample index 1 belongs to both kinds, 0 to the grids on a face of the
+                // axis (offset 0), 2 to the grids centred on it (offset 0.5)
+#pragma unroll
+                for (int s = 0; s < 7; ++s) {
+                    const bool hx = kSampleOffsetHalf[s][0], hy = kSampleOffsetHalf[s][1], hz = kSampleOffsetHalf[s][2];
+                    if ((hx ? cx >= 1 : cx <= 1) && (hy ? cy >= 1 : cy <= 1) && (hz ? cz >= 1 : cz <= 1)) cnt[s] += in;
+                }
             }
-    dst[c] = (float)cnt / 8.0f;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int3 d = g.dims(s);
+        if (i < d.x && j < d.y && k < d.z) dst.p[s][lin3(d, i, j, k)] = (float)cnt[s] / 8.0f;
+    }
 }
 
 // Classifier.cpp:56-128
@@ -286,35 +341,51 @@ __global__ void k_classify_edges(Grid g, int e, Set7<const float> lw, Set7<const
 // (SIM_VolumetricConnectedComponentBuilder call site Classifier.cpp:220-229.)  Min-label propagation
 // over traversal-order indices with pointer jumping; converges to the smallest order index of the
 // component whatever the interleaving (labels only decrease).
-__global__ void k_cc_init(Grid g, const int32_t* __restrict__ lab, int32_t* __restrict__ cc) {
+// k_cc_init also folds what a step needs to know about a cell's six links (neighbour in bounds and REDUCED, the face between them
+// with liquid weight > 0) into one byte per cell: a step then reads 5 bytes per cell and the labels it follows, not two label
+// arrays and three weight fields (12 launches at 256^3: 3.1 -> 1.6 ms)
+__global__ void k_cc_init(Grid g, const int32_t* __restrict__ lab, Set7<const float> lw, int32_t* __restrict__ cc, uint8_t* __restrict__ link) {
     const int3 d = g.dims(0);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
     const int3 q = unlin3(d, c);
-    cc[c] = lab[c] == PS_REDUCED ? (int32_t)ijkToOrder(d, g.order, q.x, q.y, q.z) : INT_MAX;
+    const bool red = lab[c] == PS_REDUCED;
+    cc[c] = red ? (int32_t)ijkToOrder(d, g.order, q.x, q.y, q.z) : INT_MAX;
+    int m = 0;
+    if (red) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int3 fd = g.dims(1 + a);
+#pragma unroll
+            for (int dir = 0; dir < 2; ++dir) {
+                int3 nb = q;
+                addc(nb, a, dir ? 1 : -1);
+                if (oob3(d, nb.x, nb.y, nb.z)) continue;
+                int3 f = q;
+                addc(f, a, dir);
+                if (!(lw.p[1 + a][lin3(fd, f.x, f.y, f.z)] > 0.f)) continue;
+                if (lab[lin3(d, nb.x, nb.y, nb.z)] != PS_REDUCED) continue;
+                m |= 1 << (2 * a + dir);
+            }
+        }
+    }
+    link[c] = (uint8_t)m;
 }
-__global__ void k_cc_step(Grid g, const int32_t* __restrict__ lab, Set7<const float> lw, int32_t* cc, int32_t* __restrict__ changed) {
+__global__ void k_cc_step(Grid g, const uint8_t* __restrict__ link, int32_t* cc, int32_t* __restrict__ changed) {
     const int3 d = g.dims(0);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
-    if (lab[c] != PS_REDUCED) return;
-    const int3 q = unlin3(d, c);
+    const int lk = link[c];
     const int mine = cc[c];
+    if (mine == INT_MAX) return;                                      // not a REDUCED cell
     int m = mine;
+    const int64_t stride[3] = {1, d.x, (int64_t)d.x * d.y};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const int3 fd = g.dims(1 + a);
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
-            int3 nb = q;
-            addc(nb, a, dir ? 1 : -1);
-            if (oob3(d, nb.x, nb.y, nb.z)) continue;
-            int3 f = q;
-            addc(f, a, dir);
-            if (!(lw.p[1 + a][lin3(fd, f.x, f.y, f.z)] > 0.f)) continue;
-            const int64_t nc = lin3(d, nb.x, nb.y, nb.z);
-            if (lab[nc] != PS_REDUCED) continue;
-            const int v = cc[nc];
+            if (!((lk >> (2 * a + dir)) & 1)) continue;
+            const int v = cc[c + (dir ? stride[a] : -stride[a])];
             if (v < m) m = v;
         }
     }
@@ -799,12 +870,11 @@ int32_t ps_context::orderedIndexAssign(int s, int mode, DevBuf<int32_t>& out) {
 // Solver.cpp:238-289
 void ps_context::buildIntegrationWeightsAlt() {
     if (haveInputWeights) return;   // uploaded by the shim (HDK's own sampler output)
-    for (int s = 0; s < 7; ++s) {
-        const int64_t n = g.count(s);
-        hipLaunchKernelGGL(k_sdf_weights, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, s, surface.p, 0, liquidW[s].p);
-        hipLaunchKernelGGL(k_sdf_weights, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, s, collision.p,
-                           P.negateCollision ? 1 : 0, fluidW[s].p);
-    }
+    const int64_t n = (int64_t)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+    Set7<float> lw, fw;
+    for (int s = 0; s < 7; ++s) { lw.p[s] = liquidW[s].p; fw.p[s] = fluidW[s].p; }
+    hipLaunchKernelGGL(k_sdf_weights7, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, (const float*)surface.p, 0, lw);
+    hipLaunchKernelGGL(k_sdf_weights7, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, (const float*)collision.p, P.negateCollision ? 1 : 0, fw);
 }
 
 void ps_context::classifyCells() {
@@ -859,11 +929,12 @@ void ps_context::constructCenterReducedIndices() {
     const dim3 gr(gridFor(n, BS)), bl(BS);
     int32_t* cc = cellScratch[0].p;
     // connected components
-    hipLaunchKernelGGL(k_cc_init, gr, bl, 0, stream, g, labels[0].p, cc);
+    uint8_t* link = (uint8_t*)cellScratch[2].p;
+    hipLaunchKernelGGL(k_cc_init, gr, bl, 0, stream, g, labels[0].p, cset(liquidW), cc, link);
     for (int guard = 0; guard < 100000; ++guard) {
         zeroCounters();
         for (int it = 0; it < 4; ++it)
-            hipLaunchKernelGGL(k_cc_step, gr, bl, 0, stream, g, labels[0].p, cset(liquidW), cc, counters.p);
+            hipLaunchKernelGGL(k_cc_step, gr, bl, 0, stream, g, (const uint8_t*)link, cc, counters.p);
         if (!readCounter(0)) break;
     }
     int32_t* rootRank = cellScratch[1].p;
