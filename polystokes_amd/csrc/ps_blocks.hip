@@ -559,6 +559,7 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
         c[u] = open[u] ? col[p0 + i] : 0x7fffffff;
         if (q0 + i < q1) { code4[q0 + i] = open[u] ? code[p0 + i] : (int8_t)0; if (!open[u]) col16[q0 + i] = 0; }   // incl. the padding
     }
+    int used = 16;
     for (int w = 0; w < 16; ++w) {
         int m = 0x7fffffff;
 #pragma unroll
@@ -570,8 +571,8 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
         __syncthreads();
         const int base = bmin;
         __syncthreads();
-        if (threadIdx.x == 0) winBase[(int64_t)chunk * 16 + w] = base == 0x7fffffff ? 0 : base;
-        if (base == 0x7fffffff) continue;               // block-uniform: nothing left, remaining windows get base 0
+        if (base == 0x7fffffff) { used = w; break; }    // block-uniform: nothing left, the remaining windows get base 0
+        if (threadIdx.x == 0) winBase[(int64_t)chunk * 16 + w] = base;
 #pragma unroll
         for (int u = 0; u < SL; ++u)
             if (open[u] && c[u] - base < 4096) {
@@ -579,6 +580,7 @@ __global__ void __launch_bounds__(BS) k_col16_build(const int32_t* __restrict__ 
                 open[u] = false;
             }
     }
+    if (threadIdx.x == 0) for (int w = used; w < 16; ++w) winBase[(int64_t)chunk * 16 + w] = 0;
     bool left = false;
 #pragma unroll
     for (int u = 0; u < SL; ++u) left |= open[u];

@@ -185,6 +185,37 @@ __host__ __device__ inline double basisDot(const double ox, const double oy, con
 }
 
 #endif
+// gv += w * C_AX(o) with the axis a compile-time constant: only the entries the row of that axis has (10 / 10 / 14 of the 26), each the
+// same product and the same sum as  basisRow(...); gv[n] += w * row[n]  forms (the other entries would add w * 0): bit-identical
+// sums, a third of the instructions.  The viscosity blocks are sums of thousands of these with heavy cancellation, and on stiff
+// scenes the velocities at a 1e-8 tolerance follow their last bits — the summation order of the oracle stays.
+template <int AX>
+__host__ __device__ inline void basisAccum(const double ox, const double oy, const double oz, const double w, double* gv) {
+#ifdef PS_AFFINE_REGIONS
+    if (AX == 0) { gv[0] += w * 1.; gv[3] += w * ox; gv[4] += w * oy; gv[5] += w * oz; }
+    else if (AX == 1) { gv[1] += w * 1.; gv[6] += w * ox; gv[7] += w * oy; gv[8] += w * oz; }
+    else { gv[2] += w * 1.; gv[3] += w * (-oz); gv[7] += w * (-oz); gv[9] += w * ox; gv[10] += w * oy; }
+#else
+    const double qx[9] = {ox, oy, oz, ox * ox, ox * oy, ox * oz, oy * oy, oy * oz, oz * oz};
+    if (AX == 0) {
+        gv[0] += w * 1.;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) gv[3 + m] += w * qx[m];
+    } else if (AX == 1) {
+        gv[1] += w * 1.;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) gv[12 + m] += w * qx[m];
+    } else {
+        const double z3 = -oz, z6 = -2. * ox * oz, z7 = -1. * oy * oz, z8 = -0.5 * oz * oz;
+        const double z16 = -1. * ox * oz, z18 = -2. * oy * oz;
+        gv[2] += w * 1.;
+        gv[3] += w * z3; gv[6] += w * z6; gv[7] += w * z7; gv[8] += w * z8;
+        gv[13] += w * z3; gv[16] += w * z16; gv[18] += w * z18; gv[19] += w * z8;
+        gv[21] += w * ox; gv[22] += w * oy; gv[23] += w * qx[3]; gv[24] += w * qx[4]; gv[25] += w * qx[6];
+    }
+#endif
+}
+
 
 // face position packed in 32 bits: 10 bits per coordinate + 2 bits axis (grids up to 1023^3)
 __host__ __device__ inline uint32_t packFace(int i, int j, int k, int axis) {

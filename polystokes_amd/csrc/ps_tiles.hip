@@ -79,56 +79,67 @@ __device__ inline void faceOffset(const TileArgs& A, int axis, int i, int j, int
 }
 
 // g = sum_i contribution_i * C(adjacent face_i): the row-vector side of the viscosity outer products
-// of one reduced face (Solver.cpp:1538-1683).  Returns false if the face contributes nothing.
+// of one reduced face (Solver.cpp:1538-1683).
 // part: 0 = every term; 1 = the cell terms and the first of the two edge axes, 2 = the second edge axis — the MFMA kernel splits the
-// up to 20 basis rows of a face over its two half-blocks (the sum of the two parts differs from part 0 by rounding only)
-__device__ void viscosityRow(const TileArgs& A, int faceAxis, int i, int j, int k, double* gv, int part = 0) {
+// up to 20 basis rows of a face over its two half-blocks (the sum of the two parts differs from part 0 by rounding only).
+// FA (the face's axis) is a template parameter: after unrolling, the axis of every adjacent face is a compile-time constant and its
+// basis row is added entry by entry where it has entries (ps_common.hpp: basisAccum) — the sums and their order are those of
+// basisRow + 26 multiply-adds per adjacent face, a third of the instructions (7.8 -> 5.5 ms of the 256^3 setup).  Folding the rows through the 30
+// moments of the face offsets was measured too (5.3 ms) and rejected: it reorders sums that cancel heavily, and on the stiff spheres the
+// velocities at tol 1e-8 then sit 1.3e-4 from the oracle's instead of 4e-6 (tests/test_gpu_parity.py: the tolerance ladder).
+template <int FA>
+__device__ void viscosityRowT(const TileArgs& A, int i, int j, int k, double* gv, int part) {
 #pragma unroll
     for (int n = 0; n < PS_RD; ++n) gv[n] = 0.;
     const int3 cd = A.g.dims(0);
-    const int3 fd = A.g.dims(1 + faceAxis);
+    const int3 fd = A.g.dims(1 + FA);
     const double dx2 = A.dx * A.dx;
-    double row[PS_RD];
     // cell-centred stresses
-    for (int divDir = 0; divDir < (part == 2 ? 0 : 2); ++divDir) {
-        int3 c = make_int3(i, j, k);
-        addc(c, faceAxis, divDir - 1);
-        if (!isReducedL(labAt(A, 0, cd, c.x, c.y, c.z))) continue;
-        if (comp(c, faceAxis) < 0 || comp(c, faceAxis) >= comp(fd, faceAxis)) continue;
-        const double divSign = divDir == 0 ? -1. : 1.;
-        const double visc = (double)viscSample(A, (float)c.x + 0.5f, (float)c.y + 0.5f, (float)c.z + 0.5f);
-        for (int gradDir = 0; gradDir < 2; ++gradDir) {
-            int3 af = c;
-            addc(af, faceAxis, gradDir);
-            const double gradSign = gradDir == 0 ? -1. : 1.;
-            const double contribution = -1. * divSign * gradSign * visc / dx2;
-            const int adj = regAt(A, 1 + faceAxis, fd, af.x, af.y, af.z);
-            if (adj < 0) continue;
-            double o[3];
-            faceOffset(A, faceAxis, af.x, af.y, af.z, adj, o);
-            basisRow(o[0], o[1], o[2], faceAxis, row);
+    if (part != 2) {
 #pragma unroll
-            for (int n = 0; n < PS_RD; ++n) gv[n] += contribution * row[n];
+        for (int divDir = 0; divDir < 2; ++divDir) {
+            int3 c = make_int3(i, j, k);
+            addc(c, FA, divDir - 1);
+            if (!isReducedL(labAt(A, 0, cd, c.x, c.y, c.z))) continue;
+            if (comp(c, FA) < 0 || comp(c, FA) >= comp(fd, FA)) continue;
+            const double divSign = divDir == 0 ? -1. : 1.;
+            const double visc = (double)viscSample(A, (float)c.x + 0.5f, (float)c.y + 0.5f, (float)c.z + 0.5f);
+#pragma unroll
+            for (int gradDir = 0; gradDir < 2; ++gradDir) {
+                int3 af = c;
+                addc(af, FA, gradDir);
+                const double gradSign = gradDir == 0 ? -1. : 1.;
+                const double contribution = -1. * divSign * gradSign * visc / dx2;
+                const int adj = regAt(A, 1 + FA, fd, af.x, af.y, af.z);
+                if (adj < 0) continue;
+                double o[3];
+                faceOffset(A, FA, af.x, af.y, af.z, adj, o);
+                basisAccum<FA>(o[0], o[1], o[2], contribution, gv);
+            }
         }
     }
     // edge-centred stresses (pure REDUCED edges only)
     int nth = 0;
+#pragma unroll
     for (int edgeAxis = 0; edgeAxis < 3; ++edgeAxis) {
-        if (edgeAxis == faceAxis) continue;
+        if (edgeAxis == FA) continue;
         ++nth;                                         // 1: the first edge axis of this face, 2: the second
         if (part != 0 && part != nth) continue;
         const int3 ed = A.g.dims(4 + edgeAxis);
+#pragma unroll
         for (int divDir = 0; divDir < 2; ++divDir) {
             const double divSign = divDir == 0 ? -1. : 1.;
             int3 e = make_int3(i, j, k);
-            addc(e, 3 - faceAxis - edgeAxis, divDir);
+            addc(e, 3 - FA - edgeAxis, divDir);
             if (labAt(A, 4 + edgeAxis, ed, e.x, e.y, e.z) != PS_REDUCED) continue;
             const float ox = edgeAxis == 0 ? 0.5f : 0.f, oy = edgeAxis == 1 ? 0.5f : 0.f, oz = edgeAxis == 2 ? 0.5f : 0.f;
             const float visc = viscSample(A, (float)e.x + ox, (float)e.y + oy, (float)e.z + oz);
+#pragma unroll
             for (int gradAxis = 0; gradAxis < 3; ++gradAxis) {
                 if (gradAxis == edgeAxis) continue;
                 const int adjFaceAxis = 3 - gradAxis - edgeAxis;
                 const int3 ad = A.g.dims(1 + adjFaceAxis);
+#pragma unroll
                 for (int gradDir = 0; gradDir < 2; ++gradDir) {
                     int3 af = e;
                     addc(af, gradAxis, gradDir - 1);
@@ -138,13 +149,18 @@ __device__ void viscosityRow(const TileArgs& A, int faceAxis, int i, int j, int 
                     if (adj < 0) continue;
                     double o[3];
                     faceOffset(A, adjFaceAxis, af.x, af.y, af.z, adj, o);
-                    basisRow(o[0], o[1], o[2], adjFaceAxis, row);
-#pragma unroll
-                    for (int n = 0; n < PS_RD; ++n) gv[n] += contribution * row[n];
+                    if (adjFaceAxis == 0) basisAccum<0>(o[0], o[1], o[2], contribution, gv);
+                    else if (adjFaceAxis == 1) basisAccum<1>(o[0], o[1], o[2], contribution, gv);
+                    else basisAccum<2>(o[0], o[1], o[2], contribution, gv);
                 }
             }
         }
     }
+}
+__device__ void viscosityRow(const TileArgs& A, int faceAxis, int i, int j, int k, double* gv, int part = 0) {
+    if (faceAxis == 0) viscosityRowT<0>(A, i, j, k, gv, part);
+    else if (faceAxis == 1) viscosityRowT<1>(A, i, j, k, gv, part);
+    else viscosityRowT<2>(A, i, j, k, gv, part);
 }
 
 template <int MODE>
