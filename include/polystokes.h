@@ -241,6 +241,19 @@ typedef struct ps_slab {
                                      * matrices and fit do not depend on the decomposition */
 } ps_slab;
 int32_t ps_set_slab(ps_context* ctx, const ps_slab* slab);            /* after ps_upload_fields, before setup */
+/* The same along all three axes (bricks whose faces lie on tile-size multiples; 8 GPUs as 2 x 2 x 2): the rank's local
+ * grid is its owned box plus one 16-cell halo block on every side that has a neighbour.  rank = c0 + dims[0] * (c1 + dims[1] * c2)
+ * for the brick at (c0, c1, c2); the neighbour below / above along axis a is rank -+ the stride of a.  A plane on a cut belongs to the
+ * rank above it (faces and edges with offset 0 along that axis).  Every rank exchanges with its <= 6 face neighbours only: the
+ * DOFs a row touches across two cuts at once belong to rows of another rank.  ps_set_slab is ps_set_brick with dims = {1, 1, world}. */
+typedef struct ps_brick {
+    int32_t rank, world;
+    int32_t dims[3];                /* ranks per axis */
+    int32_t lo[3], hi[3];           /* owned cells [lo, hi) per axis in LOCAL grid coordinates (multiples of 16 and of the tile size) */
+    int32_t hasLower[3], hasUpper[3];
+    int32_t globalLo[3];            /* GLOBAL index of the cell lo: tile offsets are formed with global indices */
+} ps_brick;
+int32_t ps_set_brick(ps_context* ctx, const ps_brick* brick);         /* after ps_upload_fields, before setup */
 
 /* One process per GPU: RCCL communicator on the solver stream.  Rank 0 calls ps_comm_unique_id and hands the
  * 128 bytes to the other ranks (bench.py broadcasts them over gloo); every rank then calls ps_comm_init_rccl.

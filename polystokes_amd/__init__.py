@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
     "polystokes_step", "ps_apply_operator", "ps_apply_preconditioner", "ps_query_array", "ps_read_array",
     "ps_export_component_matrices", "ps_export_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt", "ps_solve_exported_system",
-    "ps_set_slab", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest", "ps_comm_init_tcp", "ps_dist_stats",
+    "ps_set_slab", "ps_set_brick", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest", "ps_comm_init_tcp", "ps_dist_stats",
     "ps_group_create", "ps_group_destroy", "ps_group_rank", "ps_group_step",
 ]
 
@@ -85,6 +85,8 @@ def lib():
         L.ps_set_interrupt.restype = C.c_int32
         L.ps_set_slab.argtypes = [C.c_void_p, C.POINTER(_abi.SlabStruct)]
         L.ps_set_slab.restype = C.c_int32
+        L.ps_set_brick.argtypes = [C.c_void_p, C.POINTER(_abi.BrickStruct)]
+        L.ps_set_brick.restype = C.c_int32
         L.ps_comm_unique_id.argtypes = [C.c_void_p]
         L.ps_comm_unique_id.restype = C.c_int32
         L.ps_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
@@ -159,6 +161,12 @@ class Solver:
     def set_slab(self, slab):
         st = _abi.SlabStruct(slab.rank, slab.world, slab.zLoOwned, slab.zHiOwned, slab.hasLower, slab.hasUpper, slab.z0)
         self._check(self.L.ps_set_slab(self.h, C.byref(st)))
+
+    def set_brick(self, b):
+        """b: partition.Brick (ps_set_brick: the decomposition along all three axes)."""
+        i3 = C.c_int32 * 3
+        st = _abi.BrickStruct(b.rank, b.world, i3(*b.dims), i3(*b.lo), i3(*b.hi), i3(*b.hasLower), i3(*b.hasUpper), i3(*b.g0))
+        self._check(self.L.ps_set_brick(self.h, C.byref(st)))
 
     def comm_selftest(self):
         self._check(self.L.ps_comm_selftest(self.h))
@@ -324,8 +332,12 @@ class Group:
     """`world` ranks inside one process on one GPU (device copies instead of RCCL): the distributed algorithm
     on a single-GPU box.  Same kernels, exchange lists and reduction order as the one-process-per-GPU path."""
 
-    def __init__(self, world, device=0):
+    def __init__(self, world, device=0, dims=None):
+        """dims = (dx, dy, dz) ranks per axis (bricks, dx * dy * dz == world); None: z-slabs."""
         self.L = lib()
+        if dims is not None and dims[0] * dims[1] * dims[2] != world:
+            raise ValueError("dims must multiply to world")
+        self.dims = tuple(dims) if dims is not None else None
         g = self.L.ps_group_create(device, world)
         if not g:
             raise PolyStokesError(self.L.ps_last_error(None).decode())
@@ -345,6 +357,8 @@ class Group:
     def solve_scene(self, scene, params):
         """Partition `scene` into slabs, run the distributed step, merge the owned faces into global arrays."""
         from . import partition
+        if self.dims is not None:
+            return self._solve_scene_bricks(scene, params)
         slabs = [partition.make_slab(scene.nz, self.world, r, params.tileSize) for r in range(self.world)]
         for r, sl in enumerate(slabs):
             self.ranks[r].upload(partition.local_scene(scene, sl), params)
@@ -360,6 +374,25 @@ class Group:
                 partition.merge_faces(vel[a], lv[a], owned, sl, a)
                 partition.merge_faces(valid[a], lval[a], owned, sl, a)
         self.vel, self.valid, self.slabs = vel, valid, slabs
+        return rc
+
+    def _solve_scene_bricks(self, scene, params):
+        from . import partition
+        bricks = [partition.make_brick((scene.nx, scene.ny, scene.nz), self.dims, r, params.tileSize) for r in range(self.world)]
+        for r, b in enumerate(bricks):
+            self.ranks[r].upload(partition.local_scene_brick(scene, b), params)
+            self.ranks[r].set_brick(b)
+        rc = self.step()
+        sh = _abi.grid_shapes(scene.nx, scene.ny, scene.nz)
+        vel = [np.array(scene.vel[a], copy=True) for a in range(3)]
+        valid = [np.zeros(sh["face" + "XYZ"[a]], np.float32) for a in range(3)]
+        for r, b in enumerate(bricks):
+            lv, lval = self.ranks[r].download()
+            for a in range(3):
+                owned = self.ranks[r].array("owned" + "XYZ"[a])
+                partition.merge_faces_brick(vel[a], lv[a], owned, b, a)
+                partition.merge_faces_brick(valid[a], lval[a], owned, b, a)
+        self.vel, self.valid, self.slabs, self.bricks = vel, valid, bricks, bricks
         return rc
 
     def close(self):

@@ -69,6 +69,11 @@ class SlabStruct(C.Structure):
                 ("hasLower", C.c_int32), ("hasUpper", C.c_int32), ("zGlobalOwned", C.c_int32)]
 
 
+class BrickStruct(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("dims", C.c_int32 * 3), ("lo", C.c_int32 * 3), ("hi", C.c_int32 * 3),
+                ("hasLower", C.c_int32 * 3), ("hasUpper", C.c_int32 * 3), ("globalLo", C.c_int32 * 3)]
+
+
 def default_params(**kw):
     """Defaults of the reference's PRM template (exec/HDK_PolyStokes.C:88-208)."""
     p = Params()

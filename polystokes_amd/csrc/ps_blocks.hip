@@ -456,7 +456,7 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
         const double invVisc = clampd(1. / visc, 0., 1.e10);
         uinvv = invVisc * clampd(vw, 1.e-2, 1.);
         uv = visc * clampd(1. / vw, 0., 1.e2);
-        if (!A.own.layer(q.z)) uinvv = 0.;   // the -1/2 uInv x term belongs to the owner of the DOF
+        if (!A.own.cell(q.x, q.y, q.z)) uinvv = 0.;   // the -1/2 uInv x term belongs to the owner of the DOF
     }
     for (int mode = 0; mode < 4; ++mode) {
         double rhs;
@@ -497,7 +497,7 @@ __global__ void k_St_edges(BlockArgs A, int ea, int32_t* __restrict__ cnt, const
     const float ox = ea == 0 ? 0.5f : 0.f, oy = ea == 1 ? 0.5f : 0.f, oz = ea == 2 ? 0.5f : 0.f;
     const double visc = (double)viscAt(A, (float)q.x + ox, (float)q.y + oy, (float)q.z + oz);
     const double invVisc = clampd(1. / visc, 0., 1e10);
-    uInv[t] = A.own.sample(4 + ea, q.z) ? 2. * invVisc * vw : 0.;
+    uInv[t] = A.own.sample(4 + ea, q.x, q.y, q.z) ? 2. * invVisc * vw : 0.;
     if (uDiag) uDiag[t] = 0.5 * visc * clampd(1. / vw, 0., 1.e2);
 }
 

@@ -106,14 +106,21 @@ struct Set8 {
     T* p[8];
 };
 
-// Slab ownership (multi-GPU): which entities of the local (slab + halo) grid this rank owns.  Cells, X/Y faces and
-// XY edges live IN a cell layer k; Z faces and YZ/XZ edges live ON a plane k (the plane below layer k); the plane on a
-// cut belongs to the rank above it, the top plane of the whole domain to the last rank.
+// Ownership (multi-GPU): which entities of the local (brick + halo) grid this rank owns.  Along an axis a sample grid lives either
+// IN the cell layers (offset 0.5 along that axis: cells; X faces along y and z; ...) or ON the planes between them (offset 0: X faces
+// along x; XY edges along x and y; ...).  A layer q is owned iff lo <= q < hi; the plane q on a cut belongs to the rank above it, the
+// last plane of the whole domain to the last rank.  (A z-slab: lo = 0, hi = n, no upper neighbour along x and y.)
 struct Own {
-    int enabled, zLo, zHi, hasUpper;
-    __host__ __device__ bool layer(int k) const { return !enabled || (k >= zLo && k < zHi); }
-    __host__ __device__ bool plane(int k) const { return !enabled || (k >= zLo && k < zHi) || (k == zHi && !hasUpper); }
-    __host__ __device__ bool sample(int s, int k) const { return (s == 3 || s == 4 || s == 5) ? plane(k) : layer(k); }
+    int enabled, lo[3], hi[3], hasUpper[3];
+    __host__ __device__ bool layerA(int a, int q) const { return q >= lo[a] && q < hi[a]; }
+    __host__ __device__ bool planeA(int a, int q) const { return (q >= lo[a] && q < hi[a]) || (q == hi[a] && !hasUpper[a]); }
+    // on planes: faceX (1): x; faceY (2): y; faceZ (3): z; edgeYZ (4): y, z; edgeXZ (5): x, z; edgeXY (6): x, y
+    __host__ __device__ static bool onPlane(int s, int a) {
+        return a == 0 ? (s == 1 || s == 5 || s == 6) : (a == 1 ? (s == 2 || s == 4 || s == 6) : (s == 3 || s == 4 || s == 5));
+    }
+    __host__ __device__ bool along(int s, int a, int q) const { return onPlane(s, a) ? planeA(a, q) : layerA(a, q); }
+    __host__ __device__ bool sample(int s, int i, int j, int k) const { return !enabled || (along(s, 0, i) && along(s, 1, j) && along(s, 2, k)); }
+    __host__ __device__ bool cell(int i, int j, int k) const { return sample(0, i, j, k); }
 };
 
 #ifdef PS_AFFINE_REGIONS

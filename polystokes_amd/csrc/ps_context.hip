@@ -107,8 +107,9 @@ void ps_context::upload(const ps_params* p, const ps_fields_in* in) {
     HIP_CHECK(hipStreamSynchronize(stream));
     uploaded = true; isSetup = false; isSolved = false;
     arrays.clear();          // the registered device pointers may have been re-allocated above
-    slabEnabled = false;     // a slab describes ONE grid: set it again after every upload (ps_set_slab)
-    zOff = 0;
+    slabEnabled = false;     // a decomposition describes ONE grid: set it again after every upload (ps_set_slab / ps_set_brick)
+    blockMapOwned = -1;
+    gOff[0] = gOff[1] = gOff[2] = 0;
 }
 
 void ps_context::fillDimData(ps_stats* st) const {   // Solver.cpp:578-593
@@ -409,7 +410,7 @@ void ps_context::buildExplicitA(std::vector<int64_t>& aptr, std::vector<int32_t>
             for (int64_t q = first[(size_t)r]; q < first[(size_t)r + 1]; ++q) {
                 int i, j, k, axis;
                 unpackFace(rface[(size_t)q], i, j, k, axis);
-                double pos[3] = {(double)i, (double)j, (double)(k + zOff)};
+                double pos[3] = {(double)(i + gOff[0]), (double)(j + gOff[1]), (double)(k + gOff[2])};
                 pos[axis] -= 0.5;
                 double cf[PS_RD];
                 basisRow(pos[0] * dx - com[(size_t)r * 3], pos[1] * dx - com[(size_t)r * 3 + 1], pos[2] * dx - com[(size_t)r * 3 + 2], axis, cf);
@@ -788,7 +789,7 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
                 int i, j, k, a;
                 unpackFace(rface[(size_t)rr], i, j, k, a);
                 const int reg = rreg[(size_t)rr];
-                double pnt[3] = {(double)i, (double)j, (double)(k + c->zOff)};
+                double pnt[3] = {(double)(i + c->gOff[0]), (double)(j + c->gOff[1]), (double)(k + c->gOff[2])};
                 pnt[a] -= 0.5;
                 double C[PS_RD];
                 basisRow(pnt[0] * c->dx - com[(size_t)reg * 3 + 0], pnt[1] * c->dx - com[(size_t)reg * 3 + 1],

@@ -172,16 +172,22 @@ struct ps_context {
     ps::DevBuf<ps::CGScalars> scal;
 
     // ---- multi-GPU (slab decomposition; ps_dist.hip) ----
-    bool slabEnabled = false;
-    int zOff = 0;               // global z index of the local layer 0 (slab: ps_slab::zGlobalOwned - zLoOwned): face positions use the global k
-    ps_slab slab{};
-    int64_t ownLo = 0, ownHi = 0;            // owned DOF range in the internal numbering (contiguous: whole 16-layer blocks)
+    bool slabEnabled = false;                // a decomposition is set (slab or brick) and world > 1
+    int gOff[3] = {0, 0, 0};    // global index of the local cell (0, 0, 0): face positions use global indices, so a tile's matrices do not depend on the decomposition
+    ps_slab slab{};             // rank / world (and the z-range when ps_set_slab was used)
+    ps_brick brick{};           // the owned box in local coordinates, neighbours, global position (ps_set_slab fills it too)
+    int64_t ownLo = 0, ownHi = 0;            // owned DOF range in the internal numbering (contiguous: the owned lattice blocks come first)
     ps::DevBuf<int32_t> regionOwned;         // R flags
-    // exchange lists (internal system indices, canonical x-fastest order): the neighbour's layer my rows touch
-    // (halo) and my layer the neighbour's rows touch (own), below and above
-    ps::DevBuf<int32_t> listLowHalo, listLowOwn, listUpHalo, listUpOwn;
-    int64_t nLowHalo = 0, nLowOwn = 0, nUpHalo = 0, nUpOwn = 0;
-    ps::DevBuf<double> sendLo, sendUp, recvLo, recvUp, redbuf;
+    ps::DevBuf<int32_t> blockMap;            // sequence position -> lattice block (owned blocks first); empty: lattice order
+    int blockMapOwned = -1, blockMapFor = 0; // owned lattice blocks (-1: the map has to be rebuilt: ps_set_brick), blocks it was built for
+    // exchange lists per axis a (internal system indices, canonical order over the cut's cross-section): the neighbour's layer my
+    // rows touch (halo) and my layer the neighbour's rows touch (own), below and above
+    ps::DevBuf<int32_t> listLowHalo[3], listLowOwn[3], listUpHalo[3], listUpOwn[3];
+    int64_t nLowHalo[3] = {0, 0, 0}, nLowOwn[3] = {0, 0, 0}, nUpHalo[3] = {0, 0, 0}, nUpOwn[3] = {0, 0, 0};
+    ps::DevBuf<double> sendLo[3], sendUp[3], recvLo[3], recvUp[3], redbuf;
+    int nbrLo(int a) const { const int st = a == 0 ? 1 : (a == 1 ? brick.dims[0] : brick.dims[0] * brick.dims[1]); return brick.hasLower[a] ? brick.rank - st : -1; }
+    int nbrUp(int a) const { const int st = a == 0 ? 1 : (a == 1 ? brick.dims[0] : brick.dims[0] * brick.dims[1]); return brick.hasUpper[a] ? brick.rank + st : -1; }
+    int64_t exchangeEntries() const { int64_t n = 0; for (int a = 0; a < 3; ++a) n += nLowOwn[a] + nUpOwn[a] + nLowHalo[a] + nUpHalo[a]; return n; }
     // Overlap of the halo exchanges with the rows that do not need them (ps_dist.hpp: Dist::solve).  Chunk lists of the row-per-lane
     // kernels: [0] S chunks without a halo column, [1] S chunks with one; [2] St chunks holding halo rows with entries (their A p goes
     // to the neighbour), [3] St chunks of owned rows only.  St chunks of halo rows without entries are in neither: never launched.
@@ -194,14 +200,15 @@ struct ps_context {
     double distStats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void* rcclComm = nullptr;                // ncclComm_t when one process per GPU
     void* hostComm = nullptr;                // host-staged TCP transport (ps_comm_init_tcp): same algorithm without RCCL
-    uint64_t hashLowHalo = 0, hashLowOwn = 0, hashUpHalo = 0, hashUpOwn = 0;   // order-sensitive hashes of the lists' global (i, j, kind) keys
+    uint64_t hashLowHalo[3] = {0, 0, 0}, hashLowOwn[3] = {0, 0, 0}, hashUpHalo[3] = {0, 0, 0}, hashUpOwn[3] = {0, 0, 0};   // order-sensitive hashes of the lists' global keys
     ps::DevBuf<ps::CGScalars> benchScal;     // scratch of ps_bench_kernel
     ps::DevBuf<double> benchOnes, benchZeros;
     bool ownsStream = true;
     ps::DevBuf<float> ownedFace[3];          // 1 where this rank is responsible for the output face
     ps::Own own() const {
         ps::Own o;
-        o.enabled = slabEnabled ? 1 : 0; o.zLo = slab.zLoOwned; o.zHi = slab.zHiOwned; o.hasUpper = slab.hasUpper;
+        o.enabled = slabEnabled ? 1 : 0;
+        for (int a = 0; a < 3; ++a) { o.lo[a] = brick.lo[a]; o.hi[a] = brick.hi[a]; o.hasUpper[a] = brick.hasUpper[a]; }
         return o;
     }
     void buildHaloLists();                   // ps_grid.hip
@@ -243,7 +250,7 @@ struct ps_context {
     void buildEll(ps::DevCSR& M);                         // the row-per-lane form of M's compressed stream (ps_blocks.hip)
     void buildStreams(bool share);                        // both compressed streams (ps_blocks.hip)
     bool shareRuns = true;
-    ps::DevBuf<int2> scrChunkRows; ps::DevBuf<int32_t> scrStart4, scrVals, scrKeep, scrRemap, scrEllCol, scrEllCode, scrEllW; ps::DevBuf<unsigned long long> scrHash, scrKeys, scrUniq;   // buildCol16 scratch
+    ps::DevBuf<int2> scrChunkRows; ps::DevBuf<int32_t> scrSlice, scrStart4, scrVals, scrKeep, scrRemap, scrEllCol, scrEllCode, scrEllW; ps::DevBuf<unsigned long long> scrHash, scrKeys, scrUniq;   // buildCol16 scratch
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
     void assembleSystemPressureStressFactored();          // ps_solve.hip

@@ -17,6 +17,7 @@
 #include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
+#include <array>
 #include <cstring>
 #include <cstdio>
 
@@ -38,6 +39,15 @@ __global__ void k_unpack2(const int32_t* __restrict__ listA, int64_t nA, const d
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nA) { if (ADD) v[listA[i]] += bufA[i]; else v[listA[i]] = bufA[i]; }
     else if (i < nA + nB) { if (ADD) v[listB[i - nA]] += bufB[i - nA]; else v[listB[i - nA]] = bufB[i - nA]; }
+}
+// the received contributions whose DOF is not this rank's own (it sits on an earlier axis's upper halo plane: see buildHaloLists) are added
+// to the rank's copy, which the exchange along that earlier axis passes on
+__global__ void k_relay2(const int32_t* __restrict__ listA, int64_t nA, const double* __restrict__ bufA, const int32_t* __restrict__ listB, int64_t nB,
+                         const double* __restrict__ bufB, double* __restrict__ v, int ownHi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nA + nB) return;
+    const int j = i < nA ? listA[i] : listB[i - nA];
+    if (j >= ownHi) v[j] += i < nA ? bufA[i] : bufB[i - nA];
 }
 // Which chunks of S gather a halo value (a column outside the owned DOF range)?  One wave per chunk.
 __global__ void __launch_bounds__(64) k_chunk_flags_S(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const int4* __restrict__ chunkInfo,
@@ -98,12 +108,12 @@ __global__ void k_owned_faces(Grid g, int axis, Own own, const int32_t* __restri
     const int3 d = g.dims(1 + axis);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
-    const int k = (int)(c / ((int64_t)d.x * d.y));
+    const int3 q = unlin3(d, c);
     bool mine;
     const int r = reg[c];
     if (faceRow[c] >= 0) mine = true;
     else if (r >= 0 && regionOwned) mine = regionOwned[r] != 0;
-    else mine = own.sample(1 + axis, k);
+    else mine = own.sample(1 + axis, q.x, q.y, q.z);
     out[c] = mine ? 1.f : 0.f;
 }
 
@@ -146,12 +156,17 @@ Rccl& rccl() {
 // (halo exchange) and, for the scalar all-reduce, to rank 0 (star: rank 0 adds the contributions in rank order).
 struct HostComm {
     int rank = 0, world = 1;
-    int fdListen = -1, fdLo = -1, fdUp = -1, fdRoot = -1;
+    int fdListen = -1, fdRoot = -1;
+    int fdLo[3] = {-1, -1, -1}, fdUp[3] = {-1, -1, -1};   // the neighbour below / above along every axis (connected once the brick is known)
+    int nbrLo[3] = {-1, -1, -1}, nbrUp[3] = {-1, -1, -1};
+    std::string host; int basePort = 0;
     std::vector<int> fdLeaf;            // rank 0: connection of every other rank (index = rank)
-    std::vector<double> hs0, hs1, hr0, hr1;
+    std::vector<std::array<int, 3>> pending;   // accepted connections nobody has asked for yet: (fd, rank, kind)
+    std::vector<double> hs[6], hr[6];
     ~HostComm() {
-        for (int fd : {fdListen, fdLo, fdUp, fdRoot}) if (fd >= 0) ::close(fd);
+        for (int fd : {fdListen, fdRoot, fdLo[0], fdLo[1], fdLo[2], fdUp[0], fdUp[1], fdUp[2]}) if (fd >= 0) ::close(fd);
         for (int fd : fdLeaf) if (fd >= 0) ::close(fd);
+        for (auto& q : pending) ::close(q[0]);
     }
     static void sendAll(int fd, const void* p, size_t n) {
         const char* b = (const char*)p;
@@ -187,8 +202,27 @@ struct HostComm {
         }
         throw Error("TCP transport: cannot connect to port " + std::to_string(port));
     }
-    void init(int r, int w, const char* host, int basePort) {
-        rank = r; world = w;
+    // the connection (from, kind): kind 1 = a rank's link to rank 0 (scalar all-reduce), 10 + a = the upper neighbour along axis a
+    // calling.  Connections arrive in any order: the others wait in `pending` until their turn.
+    int acceptFrom(int from, int kind) {
+        for (size_t q = 0; q < pending.size(); ++q)
+            if (pending[q][1] == from && pending[q][2] == kind) { const int fd = pending[q][0]; pending.erase(pending.begin() + (long)q); return fd; }
+        for (;;) {
+            pollfd pf{fdListen, POLLIN, 0};
+            if (::poll(&pf, 1, 120000) <= 0) throw Error("TCP transport: timed out waiting for the other ranks to connect");
+            const int fd = ::accept(fdListen, nullptr, nullptr);
+            if (fd < 0) throw Error("TCP transport: accept() failed");
+            const int one = 1;
+            ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            int32_t hello[2];
+            recvAll(fd, hello, sizeof(hello));
+            if (hello[0] == from && hello[1] == kind) return fd;
+            if (hello[0] < 0 || hello[0] >= world || pending.size() > 256) { ::close(fd); throw Error("TCP transport: unexpected connection"); }
+            pending.push_back({fd, hello[0], hello[1]});
+        }
+    }
+    void init(int r, int w, const char* h, int port) {
+        rank = r; world = w; host = h; basePort = port;
         fdLeaf.assign((size_t)w, -1);
         fdListen = ::socket(AF_INET, SOCK_STREAM, 0);
         if (fdListen < 0) throw Error("TCP transport: socket() failed");
@@ -196,28 +230,29 @@ struct HostComm {
         ::setsockopt(fdListen, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
         sockaddr_in a{};
         a.sin_family = AF_INET; a.sin_port = htons((uint16_t)(basePort + r)); a.sin_addr.s_addr = htonl(INADDR_ANY);
-        if (::bind(fdListen, (sockaddr*)&a, sizeof(a)) != 0 || ::listen(fdListen, w + 2) != 0)
+        if (::bind(fdListen, (sockaddr*)&a, sizeof(a)) != 0 || ::listen(fdListen, 4 * w + 8) != 0)
             throw Error("TCP transport: cannot listen on port " + std::to_string(basePort + r));
-        if (r > 0) { fdLo = connectTo(host, basePort + r - 1, r, 0); fdRoot = connectTo(host, basePort, r, 1); }
-        int expect = (r + 1 < w ? 1 : 0) + (r == 0 ? w - 1 : 0);
-        while (expect > 0) {
-            pollfd pf{fdListen, POLLIN, 0};
-            if (::poll(&pf, 1, 120000) <= 0) throw Error("TCP transport: timed out waiting for the other ranks to connect");
-            const int fd = ::accept(fdListen, nullptr, nullptr);
-            if (fd < 0) throw Error("TCP transport: accept() failed");
-            ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-            int32_t hello[2];
-            recvAll(fd, hello, sizeof(hello));
-            if (hello[1] == 0 && hello[0] == r + 1 && fdUp < 0) fdUp = fd;
-            else if (hello[1] == 1 && r == 0 && hello[0] > 0 && hello[0] < w && fdLeaf[(size_t)hello[0]] < 0) fdLeaf[(size_t)hello[0]] = fd;
-            else { ::close(fd); throw Error("TCP transport: unexpected connection"); }
-            --expect;
-        }
+        if (r > 0) fdRoot = connectTo(host.c_str(), basePort, r, 1);
+        else for (int q = 1; q < w; ++q) fdLeaf[(size_t)q] = acceptFrom(q, 1);
     }
-    // neighbour exchange, ordered so that the chain cannot deadlock: with the lower neighbour receive first, with the upper send first
-    void exchange(const double* sLo, size_t nsLo, double* rLo, size_t nrLo, const double* sUp, size_t nsUp, double* rUp, size_t nrUp) {
-        if (fdLo >= 0) { if (nrLo) recvAll(fdLo, rLo, nrLo * 8); if (nsLo) sendAll(fdLo, sLo, nsLo * 8); }
-        if (fdUp >= 0) { if (nsUp) sendAll(fdUp, sUp, nsUp * 8); if (nrUp) recvAll(fdUp, rUp, nrUp * 8); }
+    // links to the face neighbours (lo[a] / up[a]: their ranks, -1 = none): a rank connects to its lower neighbours and accepts its upper ones
+    void connectNeighbours(const int* lo, const int* up) {
+        bool same = true;
+        for (int a = 0; a < 3; ++a) same = same && lo[a] == nbrLo[a] && up[a] == nbrUp[a];
+        if (same) return;
+        for (int a = 0; a < 3; ++a) {
+            if (fdLo[a] >= 0) { ::close(fdLo[a]); fdLo[a] = -1; }
+            if (fdUp[a] >= 0) { ::close(fdUp[a]); fdUp[a] = -1; }
+            nbrLo[a] = lo[a]; nbrUp[a] = up[a];
+        }
+        for (int a = 0; a < 3; ++a) if (lo[a] >= 0) fdLo[a] = connectTo(host.c_str(), basePort + lo[a], rank, 10 + a);
+        for (int a = 0; a < 3; ++a) if (up[a] >= 0) fdUp[a] = acceptFrom(up[a], 10 + a);
+    }
+    // neighbour exchange along one axis, ordered so that the chain of ranks along it cannot deadlock: with the lower neighbour receive
+    // first, with the upper send first
+    void exchange(int a, const double* sLo, size_t nsLo, double* rLo, size_t nrLo, const double* sUp, size_t nsUp, double* rUp, size_t nrUp) {
+        if (fdLo[a] >= 0) { if (nrLo) recvAll(fdLo[a], rLo, nrLo * 8); if (nsLo) sendAll(fdLo[a], sLo, nsLo * 8); }
+        if (fdUp[a] >= 0) { if (nsUp) sendAll(fdUp[a], sUp, nsUp * 8); if (nrUp) recvAll(fdUp[a], rUp, nrUp * 8); }
     }
     void allreduceSum(double* v, int count) {
         if (world == 1) return;
@@ -262,22 +297,25 @@ struct Dist {
         HIP_CHECK(hipEventRecord(c->distEv[ev], from));
         HIP_CHECK(hipStreamWaitEvent(to, c->distEv[ev], 0));
     }
-    // sizes: kind 0 = x exchange (send own layers, receive halo), kind 1 = y exchange (send halo contributions, receive for own)
-    void transport(int kind, bool onComm = false) {
+    // sizes: kind 0 = x exchange (send own layers, receive halo), kind 1 = y exchange (send halo contributions, receive for own); every
+    // axis with a neighbour, all of them in ONE group of sends and receives (each face neighbour is its own xGMI link)
+    static int64_t nSendLo(const ps_context* c, int kind, int a) { return c->brick.hasLower[a] ? (kind == 0 ? c->nLowOwn[a] : c->nLowHalo[a]) : 0; }
+    static int64_t nSendUp(const ps_context* c, int kind, int a) { return c->brick.hasUpper[a] ? (kind == 0 ? c->nUpOwn[a] : c->nUpHalo[a]) : 0; }
+    static int64_t nRecvLo(const ps_context* c, int kind, int a) { return c->brick.hasLower[a] ? (kind == 0 ? c->nLowHalo[a] : c->nLowOwn[a]) : 0; }
+    static int64_t nRecvUp(const ps_context* c, int kind, int a) { return c->brick.hasUpper[a] ? (kind == 0 ? c->nUpHalo[a] : c->nUpOwn[a]) : 0; }
+    void transport(int kind, bool onComm = false, int only = -1) {   // only >= 0: that axis alone
         if (useRccl) {
             ps_context* c = R[0];
             hipStream_t st = cs(c, onComm);
             Rccl& L = rccl();
-            const int64_t sLo = kind == 0 ? c->nLowOwn : c->nLowHalo, sUp = kind == 0 ? c->nUpOwn : c->nUpHalo;
-            const int64_t rLo = kind == 0 ? c->nLowHalo : c->nLowOwn, rUp = kind == 0 ? c->nUpHalo : c->nUpOwn;
             ncclCheck(L.GroupStart(), "ncclGroupStart");
-            if (c->slab.hasLower) {
-                if (sLo) ncclCheck(L.Send(c->sendLo.p, (size_t)sLo, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, st), "ncclSend");
-                if (rLo) ncclCheck(L.Recv(c->recvLo.p, (size_t)rLo, NCCL_DOUBLE, c->slab.rank - 1, c->rcclComm, st), "ncclRecv");
-            }
-            if (c->slab.hasUpper) {
-                if (sUp) ncclCheck(L.Send(c->sendUp.p, (size_t)sUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, st), "ncclSend");
-                if (rUp) ncclCheck(L.Recv(c->recvUp.p, (size_t)rUp, NCCL_DOUBLE, c->slab.rank + 1, c->rcclComm, st), "ncclRecv");
+            for (int a = 0; a < 3; ++a) {
+                if (only >= 0 && a != only) continue;
+                const int64_t sLo = nSendLo(c, kind, a), sUp = nSendUp(c, kind, a), rLo = nRecvLo(c, kind, a), rUp = nRecvUp(c, kind, a);
+                if (sLo) ncclCheck(L.Send(c->sendLo[a].p, (size_t)sLo, NCCL_DOUBLE, c->nbrLo(a), c->rcclComm, st), "ncclSend");
+                if (rLo) ncclCheck(L.Recv(c->recvLo[a].p, (size_t)rLo, NCCL_DOUBLE, c->nbrLo(a), c->rcclComm, st), "ncclRecv");
+                if (sUp) ncclCheck(L.Send(c->sendUp[a].p, (size_t)sUp, NCCL_DOUBLE, c->nbrUp(a), c->rcclComm, st), "ncclSend");
+                if (rUp) ncclCheck(L.Recv(c->recvUp[a].p, (size_t)rUp, NCCL_DOUBLE, c->nbrUp(a), c->rcclComm, st), "ncclRecv");
             }
             ncclCheck(L.GroupEnd(), "ncclGroupEnd");
             return;
@@ -286,52 +324,100 @@ struct Dist {
             ps_context* c = R[0];
             HostComm& H = *hc();
             hipStream_t st = cs(c, onComm);
-            const size_t sLo = (size_t)(c->slab.hasLower ? (kind == 0 ? c->nLowOwn : c->nLowHalo) : 0), sUp = (size_t)(c->slab.hasUpper ? (kind == 0 ? c->nUpOwn : c->nUpHalo) : 0);
-            const size_t rLo = (size_t)(c->slab.hasLower ? (kind == 0 ? c->nLowHalo : c->nLowOwn) : 0), rUp = (size_t)(c->slab.hasUpper ? (kind == 0 ? c->nUpHalo : c->nUpOwn) : 0);
-            H.hs0.resize(sLo + 1); H.hs1.resize(sUp + 1); H.hr0.resize(rLo + 1); H.hr1.resize(rUp + 1);
-            if (sLo) HIP_CHECK(hipMemcpyAsync(H.hs0.data(), c->sendLo.p, sLo * 8, hipMemcpyDeviceToHost, st));
-            if (sUp) HIP_CHECK(hipMemcpyAsync(H.hs1.data(), c->sendUp.p, sUp * 8, hipMemcpyDeviceToHost, st));
+            for (int a = 0; a < 3; ++a) {
+                if (only >= 0 && a != only) continue;
+                const size_t sLo = (size_t)nSendLo(c, kind, a), sUp = (size_t)nSendUp(c, kind, a);
+                H.hs[2 * a].resize(sLo + 1); H.hs[2 * a + 1].resize(sUp + 1);
+                H.hr[2 * a].resize((size_t)nRecvLo(c, kind, a) + 1); H.hr[2 * a + 1].resize((size_t)nRecvUp(c, kind, a) + 1);
+                if (sLo) HIP_CHECK(hipMemcpyAsync(H.hs[2 * a].data(), c->sendLo[a].p, sLo * 8, hipMemcpyDeviceToHost, st));
+                if (sUp) HIP_CHECK(hipMemcpyAsync(H.hs[2 * a + 1].data(), c->sendUp[a].p, sUp * 8, hipMemcpyDeviceToHost, st));
+            }
             HIP_CHECK(hipStreamSynchronize(st));
-            H.exchange(H.hs0.data(), sLo, H.hr0.data(), rLo, H.hs1.data(), sUp, H.hr1.data(), rUp);
-            if (rLo) HIP_CHECK(hipMemcpyAsync(c->recvLo.p, H.hr0.data(), rLo * 8, hipMemcpyHostToDevice, st));
-            if (rUp) HIP_CHECK(hipMemcpyAsync(c->recvUp.p, H.hr1.data(), rUp * 8, hipMemcpyHostToDevice, st));
+            for (int a = 0; a < 3; ++a)
+                if (only < 0 || a == only) H.exchange(a, H.hs[2 * a].data(), (size_t)nSendLo(c, kind, a), H.hr[2 * a].data(), (size_t)nRecvLo(c, kind, a), H.hs[2 * a + 1].data(),
+                           (size_t)nSendUp(c, kind, a), H.hr[2 * a + 1].data(), (size_t)nRecvUp(c, kind, a));
+            for (int a = 0; a < 3; ++a) {
+                if (only >= 0 && a != only) continue;
+                const size_t rLo = (size_t)nRecvLo(c, kind, a), rUp = (size_t)nRecvUp(c, kind, a);
+                if (rLo) HIP_CHECK(hipMemcpyAsync(c->recvLo[a].p, H.hr[2 * a].data(), rLo * 8, hipMemcpyHostToDevice, st));
+                if (rUp) HIP_CHECK(hipMemcpyAsync(c->recvUp[a].p, H.hr[2 * a + 1].data(), rUp * 8, hipMemcpyHostToDevice, st));
+            }
             HIP_CHECK(hipStreamSynchronize(st));   // the host buffers are reused by the next exchange
             return;
         }
         for (size_t q = 0; q < R.size(); ++q) {   // in-process ranks share one stream: plain device copies
             ps_context* c = R[q];
-            const int64_t sLo = kind == 0 ? c->nLowOwn : c->nLowHalo, sUp = kind == 0 ? c->nUpOwn : c->nUpHalo;
-            if (c->slab.hasLower && sLo)
-                HIP_CHECK(hipMemcpyAsync(R[q - 1]->recvUp.p, c->sendLo.p, (size_t)sLo * 8, hipMemcpyDeviceToDevice, c->stream));
-            if (c->slab.hasUpper && sUp)
-                HIP_CHECK(hipMemcpyAsync(R[q + 1]->recvLo.p, c->sendUp.p, (size_t)sUp * 8, hipMemcpyDeviceToDevice, c->stream));
+            for (int a = 0; a < 3; ++a) {
+                if (only >= 0 && a != only) continue;
+                const int64_t sLo = nSendLo(c, kind, a), sUp = nSendUp(c, kind, a);
+                if (sLo) HIP_CHECK(hipMemcpyAsync(R[(size_t)c->nbrLo(a)]->recvUp[a].p, c->sendLo[a].p, (size_t)sLo * 8, hipMemcpyDeviceToDevice, c->stream));
+                if (sUp) HIP_CHECK(hipMemcpyAsync(R[(size_t)c->nbrUp(a)]->recvLo[a].p, c->sendUp[a].p, (size_t)sUp * 8, hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+    }
+    // pack / unpack of one rank's lists along axis a (the two cuts of an axis in one launch: their lists are disjoint — a brick is at
+    // least one 16-cell block thick).  own = true: the layers of mine the neighbours' rows touch; false: theirs my rows touch.
+    void pack(ps_context* c, bool own, const double* v, hipStream_t st, int a) {
+        const int64_t nA = own ? c->nLowOwn[a] : c->nLowHalo[a], nB = own ? c->nUpOwn[a] : c->nUpHalo[a];
+        if (nA + nB > 0)
+            hipLaunchKernelGGL(k_pack2, dim3(gridFor(nA + nB, BS)), dim3(BS), 0, st, (own ? c->listLowOwn[a] : c->listLowHalo[a]).p, nA, c->sendLo[a].p,
+                               (own ? c->listUpOwn[a] : c->listUpHalo[a]).p, nB, c->sendUp[a].p, v);
+    }
+    template <bool ADD>
+    void unpack(ps_context* c, bool own, double* v, hipStream_t st, int a) {
+        const int64_t nA = own ? c->nLowOwn[a] : c->nLowHalo[a], nB = own ? c->nUpOwn[a] : c->nUpHalo[a];
+        if (nA + nB > 0)
+            hipLaunchKernelGGL(k_unpack2<ADD>, dim3(gridFor(nA + nB, BS)), dim3(BS), 0, st, (own ? c->listLowOwn[a] : c->listLowHalo[a]).p, nA, c->recvLo[a].p,
+                               (own ? c->listUpOwn[a] : c->listUpHalo[a]).p, nB, c->recvUp[a].p, v);
+    }
+    bool axisUsed(int a) const { for (const ps_context* c : R) if (c->brick.hasLower[a] || c->brick.hasUpper[a]) return true; return false; }
+    // The exchanges run axis after axis, each one forwarding what the previous ones brought (ps_grid.hip: buildHaloLists): values x, y, z;
+    // contributions z, y, x.  With cuts along one axis only (slabs) that is one pack / transport / unpack, as before.
+    // values of the cut layers -> the neighbours' halo copies, on the stream `onComm` selects
+    void valuesOut(DevBuf<double> ps_context::*vec, bool onComm) {
+        for (int a = 0; a < 3; ++a) {
+            if (!axisUsed(a)) continue;
+            for (ps_context* c : R) pack(c, true, (c->*vec).p, cs(c, onComm), a);
+            transport(0, onComm, a);
+            for (ps_context* c : R) unpack<false>(c, false, (c->*vec).p, cs(c, onComm), a);
+        }
+    }
+    // the halo rows' contributions -> their owners.  addOwned: the owners add them into vec (b, the Jacobi diagonal, A p of the plain step);
+    // else only the copies on the way are updated (the owners of the fused step correct r from the receive buffers: fixup)
+    void contributionsBack(DevBuf<double> ps_context::*vec, bool onComm, bool addOwned) {
+        for (int a = 2; a >= 0; --a) {
+            if (!axisUsed(a)) continue;
+            for (ps_context* c : R) pack(c, false, (c->*vec).p, cs(c, onComm), a);
+            transport(1, onComm, a);
+            for (ps_context* c : R) {
+                if (addOwned) unpack<true>(c, true, (c->*vec).p, cs(c, onComm), a);
+                else if (c->nLowOwn[a] + c->nUpOwn[a] > 0)
+                    hipLaunchKernelGGL(k_relay2, dim3(gridFor(c->nLowOwn[a] + c->nUpOwn[a], BS)), dim3(BS), 0, cs(c, onComm), (const int32_t*)c->listLowOwn[a].p, c->nLowOwn[a],
+                                       (const double*)c->recvLo[a].p, (const int32_t*)c->listUpOwn[a].p, c->nUpOwn[a], (const double*)c->recvUp[a].p, (c->*vec).p, (int)c->ownHi);
+            }
+        }
+    }
+    // r_j -= alpha * (the neighbours' share of (A p)_j) on the OWNED DOFs next to a cut, from the receive buffers of every axis (a DOF next
+    // to two cuts is corrected twice, each launch sees the r the previous one left); partials of the changes of r.r / r.z: [axis][2][gFix]
+    void fixup(ps_context* c, const CGScalars* sc, bool jac, double* fX, int gFix) {
+        for (int a = 0; a < 3; ++a) {
+            double* part = fX + (size_t)a * 2 * (size_t)gFix;
+            if (c->nLowOwn[a] + c->nUpOwn[a] > 0)
+                hipLaunchKernelGGL(k_dist_fixup, dim3(gFix), dim3(BS), 0, c->stream, sc, (const int32_t*)c->listLowOwn[a].p, c->nLowOwn[a], (const double*)c->recvLo[a].p,
+                                   (const int32_t*)c->listUpOwn[a].p, c->nUpOwn[a], (const double*)c->recvUp[a].p, c->r.p,
+                                   jac ? (const float*)c->dinvF.p : (const float*)nullptr, part, (int)c->ownHi);
+            else HIP_CHECK(hipMemsetAsync(part, 0, 2 * (size_t)gFix * sizeof(double), c->stream));
         }
     }
     void exchangeX(DevBuf<double> ps_context::*vec) {
-        for (ps_context* c : R)
-            if (c->nLowOwn + c->nUpOwn > 0)
-                hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn, c->sendLo.p,
-                                   c->listUpOwn.p, c->nUpOwn, c->sendUp.p, (c->*vec).p);
         for (ps_context* c : R) order(c, 0, true);
-        transport(0, true);
+        valuesOut(vec, true);
         for (ps_context* c : R) order(c, 1, false);
-        for (ps_context* c : R)
-            if (c->nLowHalo + c->nUpHalo > 0)
-                hipLaunchKernelGGL(k_unpack2<false>, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo,
-                                   c->recvLo.p, c->listUpHalo.p, c->nUpHalo, c->recvUp.p, (c->*vec).p);
     }
     void exchangeAddY(DevBuf<double> ps_context::*vec) {
-        for (ps_context* c : R)
-            if (c->nLowHalo + c->nUpHalo > 0)
-                hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->sendLo.p,
-                                   c->listUpHalo.p, c->nUpHalo, c->sendUp.p, (c->*vec).p);
         for (ps_context* c : R) order(c, 0, true);
-        transport(1, true);
+        contributionsBack(vec, true, true);
         for (ps_context* c : R) order(c, 1, false);
-        for (ps_context* c : R)   // contributions from below and from above land on disjoint DOFs
-            if (c->nLowOwn + c->nUpOwn > 0)
-                hipLaunchKernelGGL(k_unpack2<true>, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn,
-                                   c->recvLo.p, c->listUpOwn.p, c->nUpOwn, c->recvUp.p, (c->*vec).p);
     }
     void allreduce(int count) {
         if (useRccl) {   // every RCCL call of the communicator goes to ONE stream (the comm stream once it exists)
@@ -369,41 +455,50 @@ struct Dist {
         HIP_CHECK(hipStreamSynchronize(R[0]->stream));
         return out;
     }
-    // neighbours must agree on the exchange lists: same lengths AND the same global (i, j, kind) keys in the same order
-    // (ps_context::buildHaloLists hashes them) — equal counts of different DOF sets would otherwise pair the wrong entries.
+    // neighbours must agree on the exchange lists: same lengths AND the same keys (position in the cut's cross-section, kind) in the
+    // same order (ps_context::buildHaloLists hashes them) — equal counts of different DOF sets would otherwise pair the wrong entries.
     void checkLists() {
         auto enc = [](int64_t n, uint64_t h, double* o) { o[0] = (double)n; o[1] = (double)(h & 0xffffffu); o[2] = (double)((h >> 24) & 0xffffffu); o[3] = (double)((h >> 48) & 0xffffu); };
         auto same = [](const double* a, const double* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]; };
         if (!useRccl && !useTcp) {
-            for (size_t q = 0; q + 1 < R.size(); ++q) {
-                const ps_context* lo = R[q]; const ps_context* up = R[q + 1];
-                if (lo->nUpHalo != up->nLowOwn || lo->nUpOwn != up->nLowHalo || lo->hashUpHalo != up->hashLowOwn || lo->hashUpOwn != up->hashLowHalo)
-                    throw Error("slab exchange lists disagree across the cut between ranks " + std::to_string(q) + " and " + std::to_string(q + 1));
-            }
+            for (size_t q = 0; q < R.size(); ++q)
+                for (int a = 0; a < 3; ++a) {
+                    const ps_context* lo = R[q];
+                    if (!lo->brick.hasUpper[a]) continue;
+                    const ps_context* up = R[(size_t)lo->nbrUp(a)];
+                    if (lo->nUpHalo[a] != up->nLowOwn[a] || lo->nUpOwn[a] != up->nLowHalo[a] || lo->hashUpHalo[a] != up->hashLowOwn[a] || lo->hashUpOwn[a] != up->hashLowHalo[a])
+                        throw Error("exchange lists disagree across the cut between ranks " + std::to_string(lo->brick.rank) + " and " + std::to_string(up->brick.rank));
+                }
             return;
         }
         ps_context* c = R[0];
-        double mineLo[8], mineUp[8], wantLo[8], wantUp[8];
-        enc(c->nLowOwn, c->hashLowOwn, mineLo); enc(c->nLowHalo, c->hashLowHalo, mineLo + 4);   // what I send down
-        enc(c->nUpOwn, c->hashUpOwn, mineUp); enc(c->nUpHalo, c->hashUpHalo, mineUp + 4);       // what I send up
-        // the lower rank's (UpHalo, UpOwn) must equal my (LowOwn, LowHalo); the upper rank's (LowHalo, LowOwn) my (UpOwn, UpHalo)
-        std::memcpy(wantLo, mineLo, sizeof(wantLo)); std::memcpy(wantUp, mineUp, sizeof(wantUp));
-        HIP_CHECK(hipMemcpyAsync(c->sendLo.p, mineLo, 64, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(c->sendUp.p, mineUp, 64, hipMemcpyHostToDevice, c->stream));
-        const int64_t keep[4] = {c->nLowOwn, c->nLowHalo, c->nUpOwn, c->nUpHalo};
-        c->nLowOwn = c->nLowHalo = c->slab.hasLower ? 8 : 0; c->nUpOwn = c->nUpHalo = c->slab.hasUpper ? 8 : 0;   // ship 8 doubles each way through the x-exchange path
+        if (useTcp) { int lo[3], up[3]; for (int a = 0; a < 3; ++a) { lo[a] = c->nbrLo(a); up[a] = c->nbrUp(a); } hc()->connectNeighbours(lo, up); }
+        double mineLo[3][8], mineUp[3][8];
+        int64_t keep[3][4];
+        for (int a = 0; a < 3; ++a) {
+            enc(c->nLowOwn[a], c->hashLowOwn[a], mineLo[a]); enc(c->nLowHalo[a], c->hashLowHalo[a], mineLo[a] + 4);   // what I send down
+            enc(c->nUpOwn[a], c->hashUpOwn[a], mineUp[a]); enc(c->nUpHalo[a], c->hashUpHalo[a], mineUp[a] + 4);       // what I send up
+            HIP_CHECK(hipMemcpyAsync(c->sendLo[a].p, mineLo[a], 64, hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipMemcpyAsync(c->sendUp[a].p, mineUp[a], 64, hipMemcpyHostToDevice, c->stream));
+            keep[a][0] = c->nLowOwn[a]; keep[a][1] = c->nLowHalo[a]; keep[a][2] = c->nUpOwn[a]; keep[a][3] = c->nUpHalo[a];
+            c->nLowOwn[a] = c->nLowHalo[a] = c->brick.hasLower[a] ? 8 : 0; c->nUpOwn[a] = c->nUpHalo[a] = c->brick.hasUpper[a] ? 8 : 0;   // ship 8 doubles each way through the x-exchange path
+        }
+        auto restore = [&]() { for (int a = 0; a < 3; ++a) { c->nLowOwn[a] = keep[a][0]; c->nLowHalo[a] = keep[a][1]; c->nUpOwn[a] = keep[a][2]; c->nUpHalo[a] = keep[a][3]; } };
         order(c, 0, true);
-        try { transport(0, true); order(c, 1, false); } catch (...) { c->nLowOwn = keep[0]; c->nLowHalo = keep[1]; c->nUpOwn = keep[2]; c->nUpHalo = keep[3]; throw; }
-        c->nLowOwn = keep[0]; c->nLowHalo = keep[1]; c->nUpOwn = keep[2]; c->nUpHalo = keep[3];
-        double lo[8] = {0}, up[8] = {0};
-        if (c->slab.hasLower) HIP_CHECK(hipMemcpyAsync(lo, c->recvLo.p, 64, hipMemcpyDeviceToHost, c->stream));
-        if (c->slab.hasUpper) HIP_CHECK(hipMemcpyAsync(up, c->recvUp.p, 64, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
+        try { transport(0, true); order(c, 1, false); } catch (...) { restore(); throw; }
+        restore();
+        // the lower rank's (UpHalo, UpOwn) must equal my (LowOwn, LowHalo); the upper rank's (LowHalo, LowOwn) my (UpOwn, UpHalo):
         // received from below: its (UpOwn, UpHalo); from above: its (LowOwn, LowHalo)
         bool bad = false;
-        if (c->slab.hasLower && !(same(lo, wantLo + 4) && same(lo + 4, wantLo))) bad = true;
-        if (c->slab.hasUpper && !(same(up, wantUp + 4) && same(up + 4, wantUp))) bad = true;
-        if (sumFlag(bad ? 1. : 0.) > 0.) throw Error(bad ? "slab exchange lists disagree with a neighbour (labels differ across the cut: halo too thin for the layer sizes?)"
+        for (int a = 0; a < 3; ++a) {
+            double lo[8] = {0}, up[8] = {0};
+            if (c->brick.hasLower[a]) HIP_CHECK(hipMemcpyAsync(lo, c->recvLo[a].p, 64, hipMemcpyDeviceToHost, c->stream));
+            if (c->brick.hasUpper[a]) HIP_CHECK(hipMemcpyAsync(up, c->recvUp[a].p, 64, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->brick.hasLower[a] && !(same(lo, mineLo[a] + 4) && same(lo + 4, mineLo[a]))) bad = true;
+            if (c->brick.hasUpper[a] && !(same(up, mineUp[a] + 4) && same(up + 4, mineUp[a]))) bad = true;
+        }
+        if (sumFlag(bad ? 1. : 0.) > 0.) throw Error(bad ? "exchange lists disagree with a neighbour (labels differ across the cut: halo too thin for the layer sizes?)"
                                                           : "another rank found its exchange lists in disagreement");
     }
 
@@ -622,7 +717,7 @@ struct Dist {
         const bool timed = c0->commStream && c0->commStream != c0->stream;
         for (ps_context* c : R) {
             for (int q = 0; q < 8; ++q) c->distStats[q] = 0.;
-            c->distStats[0] = 8. * (double)(c->nLowOwn + c->nUpOwn + c->nLowHalo + c->nUpHalo);   // bytes this rank sends per iteration (x layers + A p contributions)
+            c->distStats[0] = 8. * (double)c->exchangeEntries();   // bytes this rank sends per iteration (x layers + A p contributions)
             c->distStats[1] = (double)(c->ownHi - c->ownLo);                                        // owned DOFs
             c->distStats[2] = overlap ? 1. : 0.;
         }
@@ -636,8 +731,10 @@ struct Dist {
                     f.sI = l.L.sBlocksFor(c->nDistList[0]); f.sBlocks = f.sI + l.L.sBlocksFor(c->nDistList[1]);
                     f.tB = l.L.stBlocksFor(c->nDistList[2], 3); f.stBF = f.tB + l.L.stBlocksFor(c->nDistList[3], 3);
                 }
-                f.gFix = (int)std::min<int64_t>(256, std::max<int64_t>(1, (c->nLowOwn + c->nUpOwn + BS - 1) / BS));
-                c->fusedPart.alloc((size_t)f.sBlocks + (size_t)c->regionCount + VGRID + 2 * (size_t)f.stBF + 2 * (size_t)f.gFix + 16);
+                int64_t mostOwn = 1;
+                for (int a = 0; a < 3; ++a) mostOwn = std::max(mostOwn, c->nLowOwn[a] + c->nUpOwn[a]);
+                f.gFix = (int)std::min<int64_t>(256, (mostOwn + BS - 1) / BS);   // workgroups of one axis's k_dist_fixup; its partials: [axis][2][gFix]
+                c->fusedPart.alloc((size_t)f.sBlocks + (size_t)c->regionCount + VGRID + 2 * (size_t)f.stBF + 6 * (size_t)f.gFix + 16);
                 f.fS = c->fusedPart.p; f.fT = f.fS + f.sBlocks; f.fU = f.fT + c->regionCount; f.fR = f.fU + VGRID; f.fX = f.fR + 2 * f.stBF;
                 l.L.sPart = f.fS; l.L.wvPart = f.fT;
                 c->fusedStepHost = 1;
@@ -659,9 +756,6 @@ struct Dist {
                     const bool sample = it + 1 == upto;          // time the transports of the batch's last iteration (the host synchronises there anyway)
                     for (size_t q = 0; q < R.size(); ++q) {
                         ps_context* c = R[q];
-                        if (c->nLowOwn + c->nUpOwn > 0)
-                            hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowOwn + c->nUpOwn, BS)), dim3(BS), 0, c->stream, c->listLowOwn.p, c->nLowOwn, c->sendLo.p,
-                                               c->listUpOwn.p, c->nUpOwn, c->sendUp.p, (const double*)c->pvec.p);
                         order(c, 0, true);
                         Loc& l = loc[q];
                         FBuf& f = fb[q];
@@ -669,13 +763,10 @@ struct Dist {
                         l.L.spmvS(0, c->pvec.p, c->ts.p);
                     }
                     if (sample && timed) HIP_CHECK(hipEventRecord(c0->distEv[2], cs(c0, true)));
-                    transport(0, true);
+                    valuesOut(&ps_context::pvec, true);          // pack, transport, unpack — axis after axis — on the comm stream
                     if (sample && timed) HIP_CHECK(hipEventRecord(c0->distEv[3], cs(c0, true)));
                     for (size_t q = 0; q < R.size(); ++q) {
                         ps_context* c = R[q];
-                        if (c->nLowHalo + c->nUpHalo > 0)
-                            hipLaunchKernelGGL(k_unpack2<false>, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, cs(c, true), c->listLowHalo.p, c->nLowHalo,
-                                               c->recvLo.p, c->listUpHalo.p, c->nUpHalo, c->recvUp.p, c->pvec.p);
                         order(c, 1, false);
                         // (2) the S chunks next to a cut, the tiles, this rank's share of p.Ap
                         Loc& l = loc[q];
@@ -696,24 +787,19 @@ struct Dist {
                                   (const double*)c->redbuf.p, (int)c->ownLo, (int)c->ownHi, c->Ap.p, f.stBF};
                         l.L.stList = c->distList[2].p; l.L.nStList = c->nDistList[2];
                         l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
-                        if (c->nLowHalo + c->nUpHalo > 0)
-                            hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->sendLo.p,
-                                               c->listUpHalo.p, c->nUpHalo, c->sendUp.p, (const double*)c->Ap.p);
                         order(c, 4, true);
                         fr.rPart = f.fR + f.tB;
                         l.L.stList = c->distList[3].p; l.L.nStList = c->nDistList[3];
                         l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                     }
-                    transport(1, true);
+                    contributionsBack(&ps_context::Ap, true, false);   // [comm stream] the owners correct r from the receive buffers below
                     for (size_t q = 0; q < R.size(); ++q) {
                         ps_context* c = R[q];
                         Loc& l = loc[q];
                         FBuf& f = fb[q];
                         order(c, 5, false);
-                        hipLaunchKernelGGL(k_dist_fixup, dim3(f.gFix), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const int32_t*)c->listLowOwn.p, c->nLowOwn,
-                                           (const double*)c->recvLo.p, (const int32_t*)c->listUpOwn.p, c->nUpOwn, (const double*)c->recvUp.p, c->r.p,
-                                           jac ? (const float*)c->dinvF.p : (const float*)nullptr, f.fX);
-                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, c->redbuf.p);
+                        fixup(c, l.sc, jac, f.fX, f.gFix);
+                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, 3, c->redbuf.p);
                     }
                     allreduce(2);
                     for (size_t q = 0; q < R.size(); ++q) {
@@ -748,19 +834,13 @@ struct Dist {
                         l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                     }
                     // the halo rows' share of A p goes to its owners (the packing and transport of exchangeAddY; the owners correct r instead of adding into A p)
-                    for (ps_context* c : R)
-                        if (c->nLowHalo + c->nUpHalo > 0)
-                            hipLaunchKernelGGL(k_pack2, dim3(gridFor(c->nLowHalo + c->nUpHalo, BS)), dim3(BS), 0, c->stream, c->listLowHalo.p, c->nLowHalo, c->sendLo.p,
-                                               c->listUpHalo.p, c->nUpHalo, c->sendUp.p, (const double*)c->Ap.p);
-                    transport(1);
+                    contributionsBack(&ps_context::Ap, false, false);
                     for (size_t q = 0; q < R.size(); ++q) {
                         ps_context* c = R[q];
                         Loc& l = loc[q];
                         FBuf& f = fb[q];
-                        hipLaunchKernelGGL(k_dist_fixup, dim3(f.gFix), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const int32_t*)c->listLowOwn.p, c->nLowOwn,
-                                           (const double*)c->recvLo.p, (const int32_t*)c->listUpOwn.p, c->nUpOwn, (const double*)c->recvUp.p, c->r.p,
-                                           jac ? (const float*)c->dinvF.p : (const float*)nullptr, f.fX);
-                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, c->redbuf.p);
+                        fixup(c, l.sc, jac, f.fX, f.gFix);
+                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, 3, c->redbuf.p);
                     }
                     allreduce(2);
                     for (size_t q = 0; q < R.size(); ++q) {
@@ -1020,32 +1100,51 @@ void ps_dist_release(ps_context* c) {
 
 extern "C" {
 
-int32_t ps_set_slab(ps_context* c, const ps_slab* slab) {
-    if (!c || !slab) return PS_FAILED;
+int32_t ps_set_brick(ps_context* c, const ps_brick* bk) {
+    if (!c || !bk) return PS_FAILED;
     try {
         if (!c->uploaded) throw Error("ps_upload_fields first");
+        const int n[3] = {c->g.nx, c->g.ny, c->g.nz};
         const int L = 16;
-        if (slab->zLoOwned % L || slab->zHiOwned % L) {
-            if (!(slab->zHiOwned == c->g.nz && !slab->hasUpper && slab->zLoOwned % L == 0)) throw Error("slab cuts must be multiples of 16");
-        }
-        if (c->P.doReducedRegions && c->P.doTile && (slab->zLoOwned % c->P.tileSize || (slab->hasUpper && slab->zHiOwned % c->P.tileSize)))
-            throw Error("slab cuts must be multiples of the tile size");
-        if (c->P.doReducedRegions && !c->P.doTile && slab->world > 1) throw Error("the slab decomposition needs doTile (tile-local regions)");
-        if (slab->zLoOwned < 0 || slab->zHiOwned > c->g.nz || slab->zLoOwned >= slab->zHiOwned) throw Error("bad slab range");
-        if ((slab->hasLower && slab->zLoOwned < 16) || (slab->hasUpper && c->g.nz - slab->zHiOwned < 16)) throw Error("a halo of at least 16 layers is required next to a cut");
-        // every label inside the owned range must equal the global one: the classification reaches L + S cells, the tile
+        if (bk->world < 1 || bk->dims[0] < 1 || bk->dims[1] < 1 || bk->dims[2] < 1 || bk->dims[0] * bk->dims[1] * bk->dims[2] != bk->world || bk->rank < 0 || bk->rank >= bk->world)
+            throw Error("bad decomposition: world = dims[0] * dims[1] * dims[2] ranks, 0 <= rank < world");
+        const int coord[3] = {bk->rank % bk->dims[0], (bk->rank / bk->dims[0]) % bk->dims[1], bk->rank / (bk->dims[0] * bk->dims[1])};
+        if (c->P.doReducedRegions && !c->P.doTile && bk->world > 1) throw Error("the decomposition needs doTile (tile-local regions)");
+        // every label inside the owned box must equal the global one: the classification reaches L + S cells, the tile
         // relabelling tilePadding more, the trilinear samplers one cell each side — all of it has to lie inside the halo block
-        if (slab->world > 1 && c->P.doReducedRegions &&
+        if (bk->world > 1 && c->P.doReducedRegions &&
             c->P.activeLiquidBoundaryLayerSize + c->P.activeSolidBoundaryLayerSize + c->P.tilePadding + 2 > 16)
-            throw Error("activeLiquidBoundaryLayerSize + activeSolidBoundaryLayerSize + tilePadding + 2 exceeds the 16-layer halo of the slab decomposition");
-        if (!slab->hasLower && slab->zLoOwned != 0) throw Error("without a lower neighbour the slab must start at layer 0");
-        if (!slab->hasUpper && slab->zHiOwned != c->g.nz) throw Error("without an upper neighbour the slab must end at the top layer");
-        c->slab = *slab;
-        c->slabEnabled = slab->world > 1;
-        c->zOff = c->slabEnabled ? slab->zGlobalOwned - slab->zLoOwned : 0;
+            throw Error("activeLiquidBoundaryLayerSize + activeSolidBoundaryLayerSize + tilePadding + 2 exceeds the 16-cell halo of the decomposition");
+        for (int a = 0; a < 3; ++a) {
+            const int lo = bk->lo[a], hi = bk->hi[a];
+            if ((bk->hasLower[a] != 0) != (coord[a] > 0) || (bk->hasUpper[a] != 0) != (coord[a] + 1 < bk->dims[a])) throw Error("the brick's neighbours do not match its position in dims");
+            if (lo % L || hi % L) { if (!(hi == n[a] && !bk->hasUpper[a] && lo % L == 0)) throw Error("cuts must be multiples of 16"); }
+            if (c->P.doReducedRegions && c->P.doTile && (lo % c->P.tileSize || (bk->hasUpper[a] && hi % c->P.tileSize))) throw Error("cuts must be multiples of the tile size");
+            if (lo < 0 || hi > n[a] || lo >= hi) throw Error("bad owned range");
+            if ((bk->hasLower[a] && lo < 16) || (bk->hasUpper[a] && n[a] - hi < 16)) throw Error("a halo of at least 16 cells is required next to a cut");
+            if (!bk->hasLower[a] && lo != 0) throw Error("without a lower neighbour the owned range must start at 0");
+            if (!bk->hasUpper[a] && hi != n[a]) throw Error("without an upper neighbour the owned range must end at the last cell");
+        }
+        c->brick = *bk;
+        c->slab.rank = bk->rank; c->slab.world = bk->world;
+        c->slab.zLoOwned = bk->lo[2]; c->slab.zHiOwned = bk->hi[2]; c->slab.hasLower = bk->hasLower[2]; c->slab.hasUpper = bk->hasUpper[2]; c->slab.zGlobalOwned = bk->globalLo[2];
+        c->slabEnabled = bk->world > 1;
+        for (int a = 0; a < 3; ++a) c->gOff[a] = c->slabEnabled ? bk->globalLo[a] - bk->lo[a] : 0;
+        c->blockMapOwned = -1;
         c->isSetup = false;
         return PS_SUCCESS;
     } PS_CATCH_ALL(c)
+}
+int32_t ps_set_slab(ps_context* c, const ps_slab* slab) {   // z-slabs: the decomposition 1 x 1 x world
+    if (!c || !slab) return PS_FAILED;
+    ps_brick b{};
+    b.rank = slab->rank; b.world = slab->world;
+    b.dims[0] = b.dims[1] = 1; b.dims[2] = slab->world;
+    b.lo[0] = b.lo[1] = 0; b.hi[0] = c->g.nx; b.hi[1] = c->g.ny;
+    b.lo[2] = slab->zLoOwned; b.hi[2] = slab->zHiOwned;
+    b.hasLower[2] = slab->hasLower; b.hasUpper[2] = slab->hasUpper;
+    b.globalLo[2] = slab->zGlobalOwned;
+    return ps_set_brick(c, &b);
 }
 
 // What the last distributed solve of this rank did: [0] bytes it sends per iteration over its cuts, [1] owned DOFs, [2] 1 if the
@@ -1096,19 +1195,19 @@ int32_t ps_comm_selftest(ps_context* c) {
     try {
         if (!c->rcclComm) throw Error("no communicator");
         HIP_CHECK(hipSetDevice(c->device));
-        c->redbuf.alloc(8); c->sendLo.alloc(8); c->recvLo.alloc(8);
+        c->redbuf.alloc(8); c->sendLo[2].alloc(8); c->recvLo[2].alloc(8);
         const double v[4] = {1.5, -2.0, 3.25, 4.0};
         HIP_CHECK(hipMemcpyAsync(c->redbuf.p, v, 32, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(c->sendLo.p, v, 32, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(c->sendLo[2].p, v, 32, hipMemcpyHostToDevice, c->stream));
         Rccl& L = rccl();
         ncclCheck(L.AllReduce(c->redbuf.p, c->redbuf.p, 3, NCCL_DOUBLE, NCCL_SUM, c->rcclComm, c->stream), "ncclAllReduce");
         ncclCheck(L.GroupStart(), "ncclGroupStart");
-        ncclCheck(L.Send(c->sendLo.p, 4, NCCL_DOUBLE, c->slab.rank, c->rcclComm, c->stream), "ncclSend");
-        ncclCheck(L.Recv(c->recvLo.p, 4, NCCL_DOUBLE, c->slab.rank, c->rcclComm, c->stream), "ncclRecv");
+        ncclCheck(L.Send(c->sendLo[2].p, 4, NCCL_DOUBLE, c->slab.rank, c->rcclComm, c->stream), "ncclSend");
+        ncclCheck(L.Recv(c->recvLo[2].p, 4, NCCL_DOUBLE, c->slab.rank, c->rcclComm, c->stream), "ncclRecv");
         ncclCheck(L.GroupEnd(), "ncclGroupEnd");
         double a[4], b[4];
         HIP_CHECK(hipMemcpyAsync(a, c->redbuf.p, 32, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipMemcpyAsync(b, c->recvLo.p, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpyAsync(b, c->recvLo[2].p, 32, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
         for (int i = 0; i < 4; ++i) if (b[i] != v[i]) throw Error("send/recv self-test mismatch");
         if (a[3] != v[3]) throw Error("all-reduce touched elements beyond count");
@@ -1117,13 +1216,13 @@ int32_t ps_comm_selftest(ps_context* c) {
         if (c->slabEnabled && world > 1) {
             if (a[0] != world * v[0] || a[1] != world * v[1] || a[2] != world * v[2]) throw Error("all-reduce self-test: wrong sum over the ranks");
             const double mine[4] = {(double)rank, 100. + rank, -1. - rank, 0.5 * rank};
-            HIP_CHECK(hipMemcpyAsync(c->sendLo.p, mine, 32, hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipMemcpyAsync(c->sendLo[2].p, mine, 32, hipMemcpyHostToDevice, c->stream));
             const int up = (rank + 1) % world, down = (rank + world - 1) % world;
             ncclCheck(L.GroupStart(), "ncclGroupStart");
-            ncclCheck(L.Send(c->sendLo.p, 4, NCCL_DOUBLE, up, c->rcclComm, c->stream), "ncclSend");
-            ncclCheck(L.Recv(c->recvLo.p, 4, NCCL_DOUBLE, down, c->rcclComm, c->stream), "ncclRecv");
+            ncclCheck(L.Send(c->sendLo[2].p, 4, NCCL_DOUBLE, up, c->rcclComm, c->stream), "ncclSend");
+            ncclCheck(L.Recv(c->recvLo[2].p, 4, NCCL_DOUBLE, down, c->rcclComm, c->stream), "ncclRecv");
             ncclCheck(L.GroupEnd(), "ncclGroupEnd");
-            HIP_CHECK(hipMemcpyAsync(b, c->recvLo.p, 32, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipMemcpyAsync(b, c->recvLo[2].p, 32, hipMemcpyDeviceToHost, c->stream));
             HIP_CHECK(hipStreamSynchronize(c->stream));
             if (b[0] != (double)down || b[1] != 100. + down || b[2] != -1. - down || b[3] != 0.5 * down) throw Error("neighbour send/recv self-test mismatch");
         }

@@ -729,15 +729,15 @@ struct ILDesc {
     Own own;
     int ownFilter;             // 1: only owned voxels are numbered (face rows); 0: every active voxel (DOFs)
     int planeMajor;
+    const int32_t* blockMap;   // sequence position -> lattice block (a decomposition numbers its owned blocks first); null: lattice order
     int64_t probe[2];          // virtual positions whose running prefix is reported in counters[10], [11]
 };
 __device__ inline bool ilFlag(const ILDesc& D, const Grid& g, const Set7<const int32_t>& lab, int grp, int64_t c) {
     const int s = D.sample[grp];
     if (!isActiveL(lab.p[s][c])) return false;
     if (D.ownFilter) {
-        const int3 d = g.dims(s);
-        const int k = (int)(c / ((int64_t)d.x * d.y));
-        if (!D.own.sample(s, k)) return false;
+        const int3 q = unlin3(g.dims(s), c);
+        if (!D.own.sample(s, q.x, q.y, q.z)) return false;
     }
     return true;
 }
@@ -746,8 +746,9 @@ __device__ inline bool ilDecode(const ILDesc& D, const Grid& g, int64_t u, int* 
     // position = ((block * 4096 + local voxel) * ngroups + group): the groups of ONE voxel index are adjacent, so the
     // 3 face rows (resp. the 7 DOFs) hanging off a cell are contiguous and a row block re-uses the lines it gathers
     const int64_t per = (int64_t)4096 * D.ngroups;
-    const int b = (int)(u / per);
-    const int rem = (int)(u - (int64_t)b * per);
+    const int bs = (int)(u / per);
+    const int b = D.blockMap ? D.blockMap[bs] : bs;
+    const int rem = (int)(u - (int64_t)bs * per);
     int v, gg;
     if (D.planeMajor) {   // per k-plane of the block: group 0's 256 voxels, then group 1's, ... (type-major inside a plane)
         const int pl = rem / (256 * D.ngroups), r2 = rem - pl * 256 * D.ngroups;
@@ -1061,12 +1062,32 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     D.total = run;
     D.nseg = 0;
     D.segStart = nullptr;
-    if (ownedRange) {   // owned DOFs = whole lattice blocks bz in [zLo/16, hasUpper ? zHi/16 : LBz): a contiguous index range
-        const int b0 = slabEnabled ? slab.zLoOwned / 16 : 0;
-        const int b1 = (slabEnabled && slab.hasUpper) ? slab.zHiOwned / 16 : D.LBz;
-        // (with a slab the lattice has SBz = 1 and oz = 0: z-layers of blocks stay whole and in order)
-        D.probe[0] = (int64_t)b0 * D.NSx * D.NSy * D.SBx * D.SBy * per;
-        D.probe[1] = (int64_t)b1 * D.NSx * D.NSy * D.SBx * D.SBy * per;
+    // A decomposition numbers the lattice blocks this rank owns first (both sequences, in lattice order within each class): the owned
+    // DOFs are then one contiguous index range [0, owned).  A block is owned iff along every axis it lies in [lo / 16, hi / 16) — or
+    // beyond, where there is no upper neighbour (the last plane of the domain).  Cuts are multiples of 16: blocks are never split.
+    D.blockMap = nullptr;
+    if (slabEnabled) {
+        const int nB = D.LBx * D.LBy * D.LBz;
+        if (blockMapFor != nB || blockMapOwned < 0) {
+            std::vector<int32_t> own_, rest;
+            const int LB[3] = {D.LBx, D.LBy, D.LBz};
+            for (int b = 0; b < nB; ++b) {
+                const int bc[3] = {b % LB[0], (b / LB[0]) % LB[1], b / (LB[0] * LB[1])};
+                bool mine = true;
+                for (int a = 0; a < 3; ++a) mine = mine && bc[a] >= brick.lo[a] / 16 && (bc[a] < brick.hi[a] / 16 || !brick.hasUpper[a]);
+                (mine ? own_ : rest).push_back(b);
+            }
+            blockMapOwned = (int)own_.size(); blockMapFor = nB;
+            own_.insert(own_.end(), rest.begin(), rest.end());
+            blockMap.alloc((size_t)nB);
+            HIP_CHECK(hipMemcpyAsync(blockMap.p, own_.data(), (size_t)nB * 4, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        D.blockMap = blockMap.p;
+    }
+    if (ownedRange) {
+        D.probe[0] = 0;
+        D.probe[1] = slabEnabled ? (int64_t)blockMapOwned * per : run;
     }
     const int nbk = gridFor(run, SCAN_TILE);
     scanBlock.alloc((size_t)nbk);
@@ -1163,52 +1184,84 @@ void ps_context::buildInternalNumbering() {
                            g.count(1 + a), foff[a], permRow.p);
 }
 
-// Exchange lists for the slab decomposition, built on the host from one-layer slices of sysIdx.
+// Exchange lists of the decomposition, built on the host from one-layer slices of sysIdx.
+namespace {
+// out[q] = src at the cross-section position q of the layer `layer` along `axis` (the two other axes over [r0, r1), lower axis fastest)
+__global__ void k_slice(const int32_t* __restrict__ src, int3 d, int axis, int layer, int3 r0, int3 r1, int32_t* __restrict__ out) {
+    const int b = axis == 0 ? 1 : 0, c = axis == 2 ? 1 : 2;
+    const int nb = comp(r1, b) - comp(r0, b), nc = comp(r1, c) - comp(r0, c);
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nb * nc) return;
+    int3 p = make_int3(0, 0, 0);
+    addc(p, axis, layer); addc(p, b, comp(r0, b) + q % nb); addc(p, c, comp(r0, c) + q / nb);
+    out[q] = oob3(d, p.x, p.y, p.z) ? -1 : src[lin3(d, p.x, p.y, p.z)];
+}
+}  // namespace
 void ps_context::buildHaloLists() {
-    nLowHalo = nLowOwn = nUpHalo = nUpOwn = 0;
+    for (int a = 0; a < 3; ++a) nLowHalo[a] = nLowOwn[a] = nUpHalo[a] = nUpOwn[a] = 0;
     if (!slabEnabled) return;
-    const int zLo = slab.zLoOwned, zHi = slab.zHiOwned;
-    auto sliceOf = [&](const int32_t* src, int s, int k, std::vector<int32_t>& out) {
+    const Own ow = own();
+    DevBuf<int32_t>& scr = scrSlice;
+    // the slice of sample grid s perpendicular to `axis` at `layer`, over the positions this rank owns along the two other axes (the
+    // neighbour across the cut owns the same cross-section: the bricks of a row share their ranges)
+    auto sliceOf = [&](const int32_t* src, int s, int axis, int layer, std::vector<int32_t>& out) {
         const int3 d = g.dims(s);
-        out.assign((size_t)d.x * d.y, -1);
-        if (k < 0 || k >= d.z) return;
-        HIP_CHECK(hipMemcpyAsync(out.data(), src + (int64_t)d.x * d.y * k, out.size() * 4, hipMemcpyDeviceToHost, stream));
+        int r0[3], r1[3];
+        // Along an axis b EARLIER than the cut's, the plane hi_b is taken even when it is the neighbour's: the exchanges run axis after axis
+        // (x, y, z for values; z, y, x for contributions), so what a rank holds there is the copy it received from / will pass on to its
+        // neighbour along b — that is how an edge on two cuts reaches the rank diagonally below (the skin rows of a tile in the corner of its
+        // brick touch such edges, and a tile's rows belong to the tile's owner whatever plane they lie on).
+        for (int b = 0; b < 3; ++b) { r0[b] = brick.lo[b]; r1[b] = brick.hi[b] + ((Own::onPlane(s, b) && (!brick.hasUpper[b] || b < axis)) ? 1 : 0); }
+        const int b = axis == 0 ? 1 : 0, c = axis == 2 ? 1 : 2;
+        const size_t n = (size_t)(r1[b] - r0[b]) * (size_t)(r1[c] - r0[c]);
+        out.assign(n, -1);
+        if (n == 0 || layer < 0 || layer >= comp(d, axis)) return;
+        scr.alloc(n);
+        hipLaunchKernelGGL(k_slice, dim3(gridFor((int64_t)n, BS)), dim3(BS), 0, stream, src, d, axis, layer, make_int3(r0[0], r0[1], r0[2]),
+                           make_int3(r1[0], r1[1], r1[2]), scr.p);
+        HIP_CHECK(hipMemcpyAsync(out.data(), scr.p, n * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     };
-    auto slice = [&](int s, int k, std::vector<int32_t>& out) { sliceOf(sysIdx[s].p, s, k, out); };
-    // order-sensitive hash of the GLOBAL keys (position in the x-fastest slice, sample grid) of a list: local indices differ
+    // order-sensitive hash of the keys (position in the cross-section, sample grid) of a list: local indices differ
     // between the two ranks of a cut, the keys must not (Dist::checkLists)
     auto mix = [](uint64_t& h, uint64_t key) { h = (h ^ key) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
-    auto cellsOf = [&](int k, std::vector<int32_t>& list, uint64_t& h) {
+    auto cellsOf = [&](int axis, int layer, std::vector<int32_t>& list, uint64_t& h) {
         std::vector<int32_t> sl, sx, sy, sz;
-        slice(0, k, sl);
-        sliceOf(sysIdxT[0].p, 0, k, sx); sliceOf(sysIdxT[1].p, 0, k, sy); sliceOf(sysIdxT[2].p, 0, k, sz);
+        sliceOf(sysIdx[0].p, 0, axis, layer, sl);
+        sliceOf(sysIdxT[0].p, 0, axis, layer, sx); sliceOf(sysIdxT[1].p, 0, axis, layer, sy); sliceOf(sysIdxT[2].p, 0, axis, layer, sz);
         for (size_t q = 0; q < sl.size(); ++q) { const int32_t b = sl[q]; if (b >= 0) { list.push_back(b); list.push_back(sx[q]); list.push_back(sy[q]); list.push_back(sz[q]); mix(h, (uint64_t)q * 8); } }
     };
-    auto edgesOf = [&](int s, int k, std::vector<int32_t>& list, uint64_t& h) {
-        std::vector<int32_t> sl;
-        slice(s, k, sl);
-        for (size_t q = 0; q < sl.size(); ++q) { const int32_t b = sl[q]; if (b >= 0) { list.push_back(b); mix(h, (uint64_t)q * 8 + (uint64_t)s); } }
+    auto edgesOf = [&](int axis, int layer, std::vector<int32_t>& list, uint64_t& h) {   // the two edge grids that live on the planes of `axis`
+        for (int s = 4; s < 7; ++s) {
+            if (!Own::onPlane(s, axis)) continue;
+            std::vector<int32_t> sl;
+            sliceOf(sysIdx[s].p, s, axis, layer, sl);
+            for (size_t q = 0; q < sl.size(); ++q) { const int32_t b = sl[q]; if (b >= 0) { list.push_back(b); mix(h, (uint64_t)q * 8 + (uint64_t)s); } }
+        }
     };
-    std::vector<int32_t> lowHalo, lowOwn, upHalo, upOwn;
-    hashLowHalo = hashLowOwn = hashUpHalo = hashUpOwn = 0;
-    if (slab.hasLower) {
-        cellsOf(zLo - 1, lowHalo, hashLowHalo);                                   // their top layer, touched by my z-faces on plane zLo
-        cellsOf(zLo, lowOwn, hashLowOwn); edgesOf(4, zLo, lowOwn, hashLowOwn); edgesOf(5, zLo, lowOwn, hashLowOwn);   // mine, touched by their rows
-    }
-    if (slab.hasUpper) {
-        cellsOf(zHi, upHalo, hashUpHalo); edgesOf(4, zHi, upHalo, hashUpHalo); edgesOf(5, zHi, upHalo, hashUpHalo);   // theirs, touched by my rows
-        cellsOf(zHi - 1, upOwn, hashUpOwn);                                     // mine, touched by their z-faces on plane zHi
-    }
+    (void)ow;
     auto up = [&](const std::vector<int32_t>& h, DevBuf<int32_t>& d, int64_t& n) {
         n = (int64_t)h.size();
         d.alloc(h.size());
         if (n) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, stream));
     };
-    up(lowHalo, listLowHalo, nLowHalo); up(lowOwn, listLowOwn, nLowOwn); up(upHalo, listUpHalo, nUpHalo); up(upOwn, listUpOwn, nUpOwn);
-    const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo, nLowOwn), std::max(nUpHalo, nUpOwn)) + 8;   // >= 8: Dist::checkLists ships counts + hashes through these buffers
-    sendLo.alloc(mx); sendUp.alloc(mx); recvLo.alloc(mx); recvUp.alloc(mx);
-    HIP_CHECK(hipStreamSynchronize(stream));
+    for (int a = 0; a < 3; ++a) {
+        const int lo = brick.lo[a], hi = brick.hi[a];
+        std::vector<int32_t> lowHalo, lowOwn, upHalo, upOwn;
+        hashLowHalo[a] = hashLowOwn[a] = hashUpHalo[a] = hashUpOwn[a] = 0;
+        if (brick.hasLower[a]) {
+            cellsOf(a, lo - 1, lowHalo, hashLowHalo[a]);                                   // their last layer, touched by my faces on the plane lo
+            cellsOf(a, lo, lowOwn, hashLowOwn[a]); edgesOf(a, lo, lowOwn, hashLowOwn[a]);   // mine, touched by their rows
+        }
+        if (brick.hasUpper[a]) {
+            cellsOf(a, hi, upHalo, hashUpHalo[a]); edgesOf(a, hi, upHalo, hashUpHalo[a]);   // theirs, touched by my rows
+            cellsOf(a, hi - 1, upOwn, hashUpOwn[a]);                                      // mine, touched by their faces on the plane hi
+        }
+        up(lowHalo, listLowHalo[a], nLowHalo[a]); up(lowOwn, listLowOwn[a], nLowOwn[a]); up(upHalo, listUpHalo[a], nUpHalo[a]); up(upOwn, listUpOwn[a], nUpOwn[a]);
+        const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo[a], nLowOwn[a]), std::max(nUpHalo[a], nUpOwn[a])) + 8;   // >= 8: Dist::checkLists ships counts + hashes through these buffers
+        sendLo[a].alloc(mx); sendUp[a].alloc(mx); recvLo[a].alloc(mx); recvUp[a].alloc(mx);
+        HIP_CHECK(hipStreamSynchronize(stream));                                           // (the host vectors go out of scope)
+    }
 }
 
 void ps_context::buildValidFaces() {

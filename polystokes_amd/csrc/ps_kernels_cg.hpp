@@ -357,12 +357,13 @@ __global__ void __launch_bounds__(1024) k_fused_local_sum(const CGScalars* __res
 // c of (A p)_j (its halo rows): r_j -= alpha c, and the partial sums of r.r / r.z are corrected by the change of r_j^2.
 __global__ void __launch_bounds__(BS) k_dist_fixup(const CGScalars* __restrict__ sc, const int32_t* __restrict__ listA, int64_t nA, const double* __restrict__ bufA,
                                                    const int32_t* __restrict__ listB, int64_t nB, const double* __restrict__ bufB, double* __restrict__ r,
-                                                   const float* __restrict__ dinv, double* __restrict__ partial) {
+                                                   const float* __restrict__ dinv, double* __restrict__ partial, int ownHi) {
     if (sc->done) return;
     const double alpha = sc->alpha;
     double a0 = 0., a1 = 0.;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < nA + nB; i += (int64_t)gridDim.x * BS) {
         const int j = i < nA ? listA[i] : listB[i - nA];
+        if (j >= ownHi) continue;                        // a copy on its way to another rank (Dist::contributionsBack), not a DOF of this one
         const double c = i < nA ? bufA[i] : bufB[i - nA];
         const double ro = r[j], rn = ro - alpha * c;
         r[j] = rn;
@@ -373,14 +374,18 @@ __global__ void __launch_bounds__(BS) k_dist_fixup(const CGScalars* __restrict__
     const double s0 = blockReduceSum(a0), s1 = blockReduceSum(a1);
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
 }
-// out = {r.r, r.z} of this rank: the St kernel's partials plus the corrections of k_dist_fixup   (one block)
+// out = {r.r, r.z} of this rank: the St kernel's partials plus the corrections of the k_dist_fixup launches (fixSets of them, each
+// [2][fixCount])   (one block)
 __global__ void __launch_bounds__(BS) k_sum_rr(const CGScalars* __restrict__ sc, const double* __restrict__ rPart, int rCount, const double* __restrict__ fixPart, int fixCount,
-                                               double* __restrict__ out) {
+                                               int fixSets, double* __restrict__ out) {
     if (sc->done) return;
     const double a = sumPartials(rPart, rCount); __syncthreads();
     const double b = sumPartials(rPart + rCount, rCount); __syncthreads();
-    const double c = sumPartials(fixPart, fixCount); __syncthreads();
-    const double d = sumPartials(fixPart + fixCount, fixCount);
+    double c = 0., d = 0.;
+    for (int q = 0; q < fixSets; ++q) {
+        c += sumPartials(fixPart + (size_t)q * 2 * fixCount, fixCount); __syncthreads();
+        d += sumPartials(fixPart + (size_t)q * 2 * fixCount + fixCount, fixCount); __syncthreads();
+    }
     if (threadIdx.x == 0) { out[0] = a + c; out[1] = b + d; }
 }
 
@@ -541,7 +546,7 @@ __global__ void k_lin(double* __restrict__ out, double ca, const double* __restr
 __global__ void __launch_bounds__(256) k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int n, int nP,
                               int nA, double dt, const double* __restrict__ McInv, const double* __restrict__ uInv,
                               const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, const double* __restrict__ COM,
-                              double dx, int zoff, const double* __restrict__ Binv, double* __restrict__ dinv, int invert) {
+                              double dx, int3 off, const double* __restrict__ Binv, double* __restrict__ dinv, int invert) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = j < n;
     double diag = 0.;
@@ -562,7 +567,7 @@ __global__ void __launch_bounds__(256) k_jacobi_diag(const int32_t* __restrict__
             cur = r;
             double o[3];
             int axis;
-            rowOffset(rrowFace[rr], COM, r, dx, zoff, o, &axis);
+            rowOffset(rrowFace[rr], COM, r, dx, off, o, &axis);
             double c[PS_RD];
             basisRow(o[0], o[1], o[2], axis, c);
 #pragma unroll
@@ -602,7 +607,7 @@ __global__ void k_recover_active(const double* __restrict__ s, const double* __r
 // applySolutionToVelocity, Solver.cpp:937-1028
 __global__ void k_writeback(Grid g, int axis, const int32_t* __restrict__ lab, const int32_t* __restrict__ act, const int32_t* __restrict__ reg,
                             const int32_t* __restrict__ faceRow, const double* __restrict__ ua, const double* __restrict__ creg, const double* __restrict__ COM,
-                            double dx, int zoff, const float* __restrict__ cvel, const float* __restrict__ velIn, float* __restrict__ velOut, int apply) {
+                            double dx, int3 off, const float* __restrict__ cvel, const float* __restrict__ velIn, float* __restrict__ velOut, int apply) {
     const int3 d = g.dims(1 + axis);
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)d.x * d.y * d.z) return;
@@ -614,7 +619,7 @@ __global__ void k_writeback(Grid g, int axis, const int32_t* __restrict__ lab, c
         double v = 0.;
         if (r >= 0) {
             const int3 q = unlin3(d, c);
-            double p[3] = {(double)q.x, (double)q.y, (double)(q.z + zoff)};
+            double p[3] = {(double)(q.x + off.x), (double)(q.y + off.y), (double)(q.z + off.z)};
             p[axis] -= 0.5;
             const double ox = p[0] * dx - COM[(int64_t)r * 3 + 0], oy = p[1] * dx - COM[(int64_t)r * 3 + 1], oz = p[2] * dx - COM[(int64_t)r * 3 + 2];
             double C[PS_RD];

@@ -3,12 +3,12 @@
 #pragma once
 
 // ---- per-tile reduced apply -------------------------------------------------------------------------
-// zoff (everywhere a face position is formed): global z index of the local layer 0 — a slab forms offsets with the global k, the same
-// arithmetic as the single domain, so that a tile's matrices do not depend on the decomposition (0 without a slab)
-__device__ inline void rowOffset(uint32_t packed, const double* __restrict__ COM, int region, double dx, int zoff, double* o, int* axis) {
+// off (everywhere a face position is formed): global index of the local cell (0, 0, 0) — a rank of a decomposition forms offsets with
+// global indices, the same arithmetic as the single domain, so that a tile's matrices do not depend on the decomposition (0 without one)
+__device__ inline void rowOffset(uint32_t packed, const double* __restrict__ COM, int region, double dx, int3 off, double* o, int* axis) {
     int i, j, k, a;
     unpackFace(packed, i, j, k, a);
-    double p[3] = {(double)i, (double)j, (double)(k + zoff)};
+    double p[3] = {(double)(i + off.x), (double)(j + off.y), (double)(k + off.z)};
     p[a] -= 0.5;
     o[0] = p[0] * dx - COM[(int64_t)region * 3 + 0];
     o[1] = p[1] * dx - COM[(int64_t)region * 3 + 1];
@@ -22,12 +22,12 @@ __device__ inline void rowOffset(uint32_t packed, const double* __restrict__ COM
 //   stream instead of 26 axis-dependent ones), mapped to the 26 entries once per region (momentsToW), and
 //   t_f = C_f . v      is the 10-term dot of mu(o_f) with the per-axis coefficient vector V_a of v (vToAxisCoeffs).
 // Rows of the three axes are interleaved (region, position, axis): the axis is a per-lane select, no divergence.
-__device__ inline void faceMonomials(uint32_t f, double dx, int zoff, double cx, double cy, double cz, double* mu, int* axis) {
+__device__ inline void faceMonomials(uint32_t f, double dx, int3 off, double cx, double cy, double cz, double* mu, int* axis) {
     int i, j, k, a;
     unpackFace(f, i, j, k, a);
-    const double ox = ((double)i - (a == 0 ? 0.5 : 0.)) * dx - cx;
-    const double oy = ((double)j - (a == 1 ? 0.5 : 0.)) * dx - cy;
-    const double oz = ((double)(k + zoff) - (a == 2 ? 0.5 : 0.)) * dx - cz;
+    const double ox = ((double)(i + off.x) - (a == 0 ? 0.5 : 0.)) * dx - cx;
+    const double oy = ((double)(j + off.y) - (a == 1 ? 0.5 : 0.)) * dx - cy;
+    const double oz = ((double)(k + off.z) - (a == 2 ? 0.5 : 0.)) * dx - cz;
     mu[0] = 1.; mu[1] = ox; mu[2] = oy; mu[3] = oz; mu[4] = ox * ox; mu[5] = ox * oy; mu[6] = ox * oz; mu[7] = oy * oy; mu[8] = oy * oz; mu[9] = oz * oz;
     *axis = a;
 }
@@ -106,7 +106,7 @@ __device__ inline double vToAxisCoeff(const double* v, int q) {
 // one lane's share of the moments over the rows rr = first, first + stride, ... < end
 constexpr int TILE_FACE_CACHE = 16;   // packed faces a lane keeps in registers between the gather and the expand of k_tile_apply
 template <bool CACHE, int U>
-__device__ inline void tileAccumulate(int first, int stride, int end, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx, int zoff,
+__device__ inline void tileAccumulate(int first, int stride, int end, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx, int3 off,
                                       double cx, double cy, double cz, double* __restrict__ M, uint32_t* __restrict__ fcache) {
     // U (face, s) pairs are requested together: independent loads in flight, then the arithmetic
     int it = 0;
@@ -132,7 +132,7 @@ __device__ inline void tileAccumulate(int first, int stride, int end, const uint
         for (int u = 0; u < U; ++u) {
             double mu[10];
             int axis;
-            faceMonomials(f[u], dx, zoff, cx, cy, cz, mu, &axis);
+            faceMonomials(f[u], dx, off, cx, cy, cz, mu, &axis);
             const double s0 = axis == 0 ? s[u] : 0., s1 = axis == 1 ? s[u] : 0., s2 = axis == 2 ? s[u] : 0.;
 #pragma unroll
             for (int m = 0; m < 10; ++m) { M[m] += mu[m] * s0; M[10 + m] += mu[m] * s1; M[20 + m] += mu[m] * s2; }
@@ -143,7 +143,7 @@ __device__ inline void tileAccumulate(int first, int stride, int end, const uint
 // region.  One wavefront per chunk, lane-strided rows, wave-shuffle reduction of the 30 moments; lane n < 26 stores entry n of w.
 __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ chunkRegion, const int32_t* __restrict__ chunkStart,
                                                     const int32_t* __restrict__ chunkEnd, const uint32_t* __restrict__ rrowFace,
-                                                    const double* __restrict__ COM, double dx, int zoff, const double* __restrict__ sred,
+                                                    const double* __restrict__ COM, double dx, int3 off, const double* __restrict__ sred,
                                                     double* __restrict__ wpart, const int* __restrict__ done) {
     if (done && *done) return;
     __shared__ double Ms[30];
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ 
     double M[30];
 #pragma unroll
     for (int n = 0; n < 30; ++n) M[n] = 0.;
-    tileAccumulate<false, 4>(chunkStart[ch] + (int)threadIdx.x, 64, chunkEnd[ch], rrowFace, sred, dx, zoff, COM[(int64_t)r * 3], COM[(int64_t)r * 3 + 1], COM[(int64_t)r * 3 + 2], M, nullptr);
+    tileAccumulate<false, 4>(chunkStart[ch] + (int)threadIdx.x, 64, chunkEnd[ch], rrowFace, sred, dx, off, COM[(int64_t)r * 3], COM[(int64_t)r * 3 + 1], COM[(int64_t)r * 3 + 2], M, nullptr);
 #pragma unroll
     for (int n = 0; n < 30; ++n) {
         const double v = waveSumToLane63(M[n]);
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ 
 //   MODE 2: v = invDt BInv rhsR, t = J v, no gather      (right-hand side, AssembleSystem.cpp:448-452)
 template <int MODE, int TB>
 __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ regionRowPtr, const uint32_t* __restrict__ rrowFace,
-                                                   const double* __restrict__ COM, double dx, int zoff, const double* __restrict__ Binv,
+                                                   const double* __restrict__ COM, double dx, int3 off, const double* __restrict__ Binv,
                                                    const double* __restrict__ rhsR, double invDt, double* __restrict__ sred,
                                                    double* __restrict__ vreg, const int* __restrict__ done, double* __restrict__ wvPart) {
     if (done && *done) return;
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
         double M[30];
 #pragma unroll
         for (int n = 0; n < 30; ++n) M[n] = 0.;
-        tileAccumulate<MODE == 0, U>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, zoff, cx, cy, cz, M, fcache);
+        tileAccumulate<MODE == 0, U>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, off, cx, cy, cz, M, fcache);
 #pragma unroll
         for (int n = 0; n < 30; ++n) {
             const double v = waveSumToLane63(M[n]);
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
             if (base + u * TB >= r1) break;
             double mu[10];
             int axis;
-            faceMonomials(f[u], dx, zoff, cx, cy, cz, mu, &axis);
+            faceMonomials(f[u], dx, off, cx, cy, cz, mu, &axis);
             const double* V = Vs + 10 * axis;                        // LDS broadcast-ish reads (3 distinct rows per wave)
             double t = 0.;
 #pragma unroll
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) k_tile_solve(const int32_t* __restrict__ r
 // (scalar loads), each thread expands RC_ROWS/256 rows.
 __global__ void __launch_bounds__(BS) k_tile_expand(const int32_t* __restrict__ chunkRegion, const int32_t* __restrict__ chunkStart,
                                                     const int32_t* __restrict__ chunkEnd, const uint32_t* __restrict__ rrowFace,
-                                                    const double* __restrict__ COM, double dx, int zoff, const double* __restrict__ vreg,
+                                                    const double* __restrict__ COM, double dx, int3 off, const double* __restrict__ vreg,
                                                     double* __restrict__ tred, const int* __restrict__ done) {
     if (done && *done) return;
     const int ch = blockIdx.x;
@@ -320,9 +320,9 @@ __global__ void __launch_bounds__(BS) k_tile_expand(const int32_t* __restrict__ 
         if (rr < e) {
             int i, j, k, axis;
             unpackFace(fq[q], i, j, k, axis);
-            const double ox = ((double)i - (axis == 0 ? 0.5 : 0.)) * dx - cx;
-            const double oy = ((double)j - (axis == 1 ? 0.5 : 0.)) * dx - cy;
-            const double oz = ((double)(k + zoff) - (axis == 2 ? 0.5 : 0.)) * dx - cz;
+            const double ox = ((double)(i + off.x) - (axis == 0 ? 0.5 : 0.)) * dx - cx;
+            const double oy = ((double)(j + off.y) - (axis == 1 ? 0.5 : 0.)) * dx - cy;
+            const double oz = ((double)(k + off.z) - (axis == 2 ? 0.5 : 0.)) * dx - cz;
             tred[rr] = basisDot(ox, oy, oz, axis, v);
         }
     }

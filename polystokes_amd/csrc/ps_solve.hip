@@ -106,7 +106,7 @@ struct Launch {
         const dim3 gr((unsigned)c->regionCount);
         static const bool noFuse = getenv("PS_TILE_SPLIT") && atoi(getenv("PS_TILE_SPLIT")) != 0;   // A/B: force the three-kernel form
         if (c->maxRegionRows <= TILE_FUSED_MAX_ROWS && !noFuse) {   // one workgroup per region: gather, 26x26 block, expand
-#define PS_TILE_APPLY(MODE_, TB_) hipLaunchKernelGGL((k_tile_apply<MODE_, TB_>), gr, dim3(TB_), 0, c->stream, c->regionRowPtr.p, c->rrowFace.p, c->COM.p, c->dx, c->zOff, c->Binv.p, \
+#define PS_TILE_APPLY(MODE_, TB_) hipLaunchKernelGGL((k_tile_apply<MODE_, TB_>), gr, dim3(TB_), 0, c->stream, c->regionRowPtr.p, c->rrowFace.p, c->COM.p, c->dx, make_int3(c->gOff[0], c->gOff[1], c->gOff[2]), c->Binv.p, \
                                                 c->rhsR.p, c->invDt, sred, c->vreg.p, done, wvPart)
             // threads per region: enough threads in flight chip-wide (~256 K) without starving a region of work.  Measured
             // at 256^3 (4096 tiles of 3204 rows): 0.080 ms with 64 threads, 0.087 / 0.106 / 0.166 with 128 / 256 / 512; at 32^3
@@ -127,7 +127,7 @@ struct Launch {
         }
         if (mode != 2 && c->nRChunks > 0)
             hipLaunchKernelGGL(k_tile_gather, dim3((unsigned)c->nRChunks), dim3(64), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
-                               c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, c->zOff, sred, c->wreg.p, done);
+                               c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, make_int3(c->gOff[0], c->gOff[1], c->gOff[2]), sred, c->wreg.p, done);
         const dim3 bl(64);
         if (mode == 0)
             hipLaunchKernelGGL(k_tile_solve<0>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done, wvPart);
@@ -137,7 +137,7 @@ struct Launch {
             hipLaunchKernelGGL(k_tile_solve<2>, gr, bl, 0, c->stream, c->regionChunkPtr.p, c->wreg.p, c->Binv.p, c->rhsR.p, c->invDt, c->vreg.p, done, (double*)nullptr);
         if (mode != 1 && c->nRChunks > 0)
             hipLaunchKernelGGL(k_tile_expand, dim3((unsigned)c->nRChunks), dim3(BS), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
-                               c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, c->zOff, c->vreg.p, sred, done);
+                               c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, make_int3(c->gOff[0], c->gOff[1], c->gOff[2]), c->vreg.p, sred, done);
     }
     void spmvSt_(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
         const dim3 gr(gridFor(rowsSt, BS)), bl(BS);
@@ -307,7 +307,7 @@ void ps_context::constructPreconditioner() {
     dinv.alloc((size_t)nSystem);
     if (nSystem == 0) return;
     hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 256)), dim3(256), 0, stream, St.ptr.p, St.col.p, St.val.p, (int)nSystem,
-                       (int)nPressures, (int)nActiveVs, dt, McInv.p, uInv.p, rrowFace.p, rrowRegion.p, COM.p, dx, zOff, Binv.p, dinv.p,
+                       (int)nPressures, (int)nActiveVs, dt, McInv.p, uInv.p, rrowFace.p, rrowRegion.p, COM.p, dx, make_int3(gOff[0], gOff[1], gOff[2]), Binv.p, dinv.p,
                        slabEnabled ? 0 : 1);
     // The PCG kernels read the diagonal in fp32 (4 instead of 8 bytes per DOF in both vector kernels).  Any positive
     // diagonal is a valid preconditioner; the Jacobi option itself is an extension (the reference's is a stub,
@@ -609,7 +609,7 @@ void ps_context::constructGuessVectors() {
     if (nActiveVs > 0) HIP_CHECK(hipMemcpyAsync(ts.p, oldVs.p, (size_t)nActiveVs * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (regionCount > 0 && nRChunks > 0)
         hipLaunchKernelGGL(k_tile_expand, dim3((unsigned)nRChunks), dim3(BS), 0, stream, rchunkRegion.p, rchunkStart.p, rchunkEnd.p, rrowFace.p,
-                           COM.p, dx, zOff, cfit.p, ts.p + nActiveVs, (const int*)nullptr);
+                           COM.p, dx, make_int3(gOff[0], gOff[1], gOff[2]), cfit.p, ts.p + nActiveVs, (const int*)nullptr);
     Launch L = mk(this, nullptr);
     L.spmvSt(1, ts.p, nullptr, x.p, guess.p, nullptr);   // x is zero here (assemble): guess = -S^T t
     hipLaunchKernelGGL(k_guess_finish, dim3(dotBlocks(n)), dim3(BS), 0, stream, guess.p, uInv.p, permSys.p, nPressures, n);
@@ -696,7 +696,7 @@ void ps_context::applySolutionToVelocity() {
     for (int a = 0; a < 3; ++a) {
         const int64_t n = g.count(1 + a);
         hipLaunchKernelGGL(k_writeback, dim3(gridFor(n, BS)), dim3(BS), 0, stream, g, a, labels[1 + a].p, activeIdx[1 + a].p, reducedIdx[1 + a].p,
-                           faceRow[a].p, recovered.p, recovered.p + nActiveVs, COM.p, dx, zOff, cvel[a].p, vel[a].p, velOut[a].p, 1);
+                           faceRow[a].p, recovered.p, recovered.p + nActiveVs, COM.p, dx, make_int3(gOff[0], gOff[1], gOff[2]), cvel[a].p, vel[a].p, velOut[a].p, 1);
     }
 }
 

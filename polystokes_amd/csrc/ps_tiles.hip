@@ -30,7 +30,7 @@ struct TileArgs {
     const float* visc;
     int viscUniform; float viscValue;   // a constant field: its samples without loads (bit-identical: ps_context::upload)
     const double* COM;
-    int zoff;
+    int3 off;                       // global index of the local cell (0, 0, 0) (ps_kernels_tiles.hpp: rowOffset)
     const int32_t* bbox;
     const int32_t* itemRegion;
     const int32_t* itemAxis;
@@ -71,7 +71,7 @@ __device__ inline float viscSample(const TileArgs& A, float px, float py, float 
 }
 
 __device__ inline void faceOffset(const TileArgs& A, int axis, int i, int j, int k, int region, double* o) {
-    double p[3] = {(double)i, (double)j, (double)(k + A.zoff)};   // global k: ps_kernels_tiles.hpp, rowOffset
+    double p[3] = {(double)(i + A.off.x), (double)(j + A.off.y), (double)(k + A.off.z)};   // global indices: ps_kernels_tiles.hpp, rowOffset
     p[axis] -= 0.5;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { p[q] *= A.dx; p[q] -= A.COM[(int64_t)region * 3 + q]; }
@@ -370,7 +370,7 @@ __global__ void k_region_sum(const double* __restrict__ partial, const int32_t* 
 }
 
 // Solver.cpp:1274-1324 + :355-371.  Exact integer sums (order independent), COM = sum * (dx / count).
-__global__ void k_com(Grid g, double dx, int zoff, const int32_t* __restrict__ lab, const int32_t* __restrict__ reg,
+__global__ void k_com(Grid g, double dx, int3 off, const int32_t* __restrict__ lab, const int32_t* __restrict__ reg,
                       const int32_t* __restrict__ bbox, double* __restrict__ COM) {
     const int r = blockIdx.x;
     const int3 d = g.dims(0);
@@ -381,7 +381,7 @@ __global__ void k_com(Grid g, double dx, int zoff, const int32_t* __restrict__ l
     for (int64_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
         const int i = bx0 + (int)(pos % ex), j = by0 + (int)((pos / ex) % ey), k = bz0 + (int)(pos / ((int64_t)ex * ey));
         const int64_t c = lin3(d, i, j, k);
-        if (isReducedL(lab[c]) && reg[c] == r) { sx += i; sy += j; sz += k + zoff; cnt++; }
+        if (isReducedL(lab[c]) && reg[c] == r) { sx += i + off.x; sy += j + off.y; sz += k + off.z; cnt++; }
     }
     __shared__ unsigned long long sm[4][BS];
     sm[0][threadIdx.x] = sx; sm[1][threadIdx.x] = sy; sm[2][threadIdx.x] = sz; sm[3][threadIdx.x] = cnt;
@@ -527,7 +527,7 @@ TileArgs makeArgs(ps_context* c) {
     A.visc = c->viscosity.p;
     A.viscUniform = c->viscUniform ? 1 : 0; A.viscValue = c->viscUniformValue;
     A.COM = c->COM.p;
-    A.zoff = c->zOff;
+    A.off = make_int3(c->gOff[0], c->gOff[1], c->gOff[2]);
     A.bbox = c->bbox.p;
     A.itemRegion = c->fbItemRegion.p; A.itemAxis = c->fbItemAxis.p; A.itemStart = c->fbItemStart.p;
     return A;
@@ -555,13 +555,16 @@ void ps_context::computeCenterOfMasses() {
     rhsR.alloc((size_t)R * PS_RD);
     regionScratch.alloc((size_t)R * OUTW);
     if (R == 0) { fbItems = 0; return; }
-    if (slabEnabled) {   // a tile is owned iff all of its cells are in my layers; cuts are tile aligned
+    if (slabEnabled) {   // a tile is owned iff all of its cells are in my box; cuts are tile aligned
         std::vector<int32_t> ro((size_t)R, 1);
         for (int64_t r = 0; r < R; ++r) {
-            const int zmin = hbbox[(size_t)r * 6 + 2], zmax = hbbox[(size_t)r * 6 + 5];
-            const bool inside = zmin >= slab.zLoOwned && zmax < slab.zHiOwned;
-            const bool outside = zmax < slab.zLoOwned || zmin >= slab.zHiOwned;
-            if (!inside && !outside) throw Error("a reduced region straddles a slab cut (cuts must be tile aligned; doTile required)");
+            bool inside = true, outside = false;
+            for (int a = 0; a < 3; ++a) {
+                const int mn = hbbox[(size_t)r * 6 + a], mx = hbbox[(size_t)r * 6 + 3 + a];
+                inside = inside && mn >= brick.lo[a] && mx < brick.hi[a];
+                outside = outside || mx < brick.lo[a] || mn >= brick.hi[a];
+            }
+            if (!inside && !outside) throw Error("a reduced region straddles a cut of the decomposition (cuts must be tile aligned; doTile required)");
             ro[(size_t)r] = inside ? 1 : 0;
         }
         regionOwned.alloc((size_t)R);
@@ -605,7 +608,7 @@ void ps_context::computeCenterOfMasses() {
     HIP_CHECK(hipMemcpyAsync(fbItemStart.p, iS.data(), iS.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(fbRegionItemPtr.p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    hipLaunchKernelGGL(k_com, dim3((unsigned)R), dim3(BS), 0, stream, g, dx, zOff, labels[0].p, reducedIdx[0].p, bbox.p, COM.p);
+    hipLaunchKernelGGL(k_com, dim3((unsigned)R), dim3(BS), 0, stream, g, dx, make_int3(gOff[0], gOff[1], gOff[2]), labels[0].p, reducedIdx[0].p, bbox.p, COM.p);
 }
 
 void ps_context::computeLeastSquaresFits() {

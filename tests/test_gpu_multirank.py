@@ -76,6 +76,45 @@ def test_group_matches_single_domain(case):
     single.close()
 
 
+@pytest.mark.parametrize("case", ["cavity64_2x2x2", "cavity64_2x1x2_jacobi", "cavity_1x2x1", "spheres64_2x2x2_jacobi", "coil64_2x2x1", "cavity48_tile8_3x2x2_chebyshev"])
+def test_bricks_match_single_domain(case):
+    """The decomposition along all three axes (bricks; ps_set_brick): in-process ranks on one GPU against the single domain —
+    labels of every owned cell, valid faces, iteration count, velocities; a tile's matrices do not depend on the decomposition."""
+    import polystokes_amd
+    if case == "cavity64_2x2x2":
+        (sc, p), dims = scenes.cavity(64, tile=16), (2, 2, 2)
+    elif case == "cavity64_2x1x2_jacobi":
+        (sc, p), dims = scenes.cavity(64, tile=16, precond=abi.PRE_DIAGONAL), (2, 1, 2)
+    elif case == "cavity_1x2x1":
+        (sc, p), dims = _tall_cavity(32, 32), (1, 2, 1)
+    elif case == "spheres64_2x2x2_jacobi":
+        (sc, p), dims = scenes.spheres(64), (2, 2, 2)
+        p.preconditioner = abi.PRE_DIAGONAL
+    elif case == "coil64_2x2x1":
+        (sc, p), dims = scenes.coil(64), (2, 2, 1)
+    else:
+        (sc, p), dims = scenes.cavity(48, tile=8, precond=abi.PRE_CHEBYSHEV), (3, 2, 2)
+    world = dims[0] * dims[1] * dims[2]
+    single = polystokes_amd.Solver(0)
+    rc1 = single.step(sc, p)
+    grp = polystokes_amd.Group(world, dims=dims)
+    rc2 = grp.solve_scene(sc, p)
+    assert rc1 == rc2 == abi.SUCCESS
+    it1, it2 = single.stats.solveData[1], grp.stats.solveData[1]
+    assert abs(it1 - it2) <= max(2, 0.02 * it1), (it1, it2)
+    lab = single.array("centerLabels").reshape(sc.nz, sc.ny, sc.nx)
+    for r, b in enumerate(grp.bricks):
+        ll = grp.ranks[r].array("centerLabels").reshape(b.n_local[2], b.n_local[1], b.n_local[0])
+        own = ll[b.lo[2]:b.hi[2], b.lo[1]:b.hi[1], b.lo[0]:b.hi[0]]
+        assert np.array_equal(own, lab[b.g0[2]:b.g1[2], b.g0[1]:b.g1[1], b.g0[0]:b.g1[0]]), (case, r)
+    for a in range(3):
+        assert np.array_equal(grp.valid[a], single.valid[a]), case
+        scale = max(np.abs(single.vel[a]).max(), 1e-30)
+        assert np.abs(grp.vel[a] - single.vel[a]).max() <= 20 * p.tolerance * scale, case
+    grp.close()
+    single.close()
+
+
 def test_rccl_entry_points_world1():
     """dlopen'ed RCCL on the solver stream: communicator init, all-reduce, grouped send/recv (to self)."""
     import polystokes_amd
