@@ -145,6 +145,8 @@ def main():
                     help="jacobi (default: the metric's configuration), identity (the reference's default), chebyshev (this library's polynomial preconditioner, degree 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-res", type=int, default=128)
+    ap.add_argument("--bricks", default=os.environ.get("PS_BENCH_BRICKS", ""), help="N > 1: DXxDYxDZ ranks per axis (e.g. 2x2x2) instead of N z-slabs; "
+                    "weak: every GPU owns n^3 cells of the (n DX) x (n DY) x (n DZ) cavity; strong: one n^3 scene cut into bricks")
     ap.add_argument("--transport", choices=["rccl", "tcp"], default="rccl",
                     help="N > 1: rccl = one GPU per rank over RCCL/xGMI (the measured configuration); tcp = host-staged sockets, all ranks "
                          "may share GPU 0 — a REHEARSAL of the multi-process path on a single-GPU box, not a performance number")
@@ -192,6 +194,11 @@ def main():
     kw = dict(tile=16, pad=2, precond=pre)
     solver = polystokes_amd.Solver(local_rank)
     slab = None
+    dims = None
+    if args.bricks and world > 1:
+        dims = tuple(int(v) for v in args.bricks.lower().split("x"))
+        if len(dims) != 3 or dims[0] * dims[1] * dims[2] != world:
+            raise SystemExit("bench.py: --bricks %s does not multiply to %d ranks" % (args.bricks, world))
     if world == 1:
         if scene_name == "cavity":
             sc, p = scenes.cavity(n, **kw)
@@ -199,6 +206,12 @@ def main():
             sc, p = getattr(scenes, scene_name)(n, tile=16, pad=2)
             p.preconditioner = pre
         grid = [n, n, n]
+    elif dims is not None:
+        # bricks (ps_set_brick): the decomposition along all three axes, every rank generating its own box (+ halo blocks)
+        if not strong and scene_name != "cavity":
+            raise SystemExit("weak scaling is defined for the cavity scene; use --scaling strong for %s" % scene_name)
+        sc, p, slab = scenes.scene_brick(scene_name, n, dims, rank, weak=not strong, **kw)
+        grid = [n, n, n] if strong else [n * dims[0], n * dims[1], n * dims[2]]
     elif strong:
         # strong scaling: ONE n^3 scene cut into `world` z-slabs at multiples of 16 (tile-aligned); every rank generates
         # only its own layers (+ one halo block per interior side)
@@ -216,7 +229,10 @@ def main():
     solver.upload(sc, p)           # host -> HBM, outside the timed region
     transport_used = None
     if world > 1:
-        solver.set_slab(slab)
+        if dims is not None:
+            solver.set_brick(slab)
+        else:
+            solver.set_slab(slab)
 
         def tcp_init():
             port = torch.zeros(1, dtype=torch.int64)
@@ -355,8 +371,14 @@ def main():
     }
 
     link = "RCCL halo exchange + all-reduce" if transport_used == "rccl" else "host-staged TCP transport (%s; not the RCCL number)" % transport_used
-    par = "1 GPU" if world == 1 else ("%d z-slabs of one %d^3 scene (strong), %s" % (world, n, link) if strong
-                                       else "%d z-slabs, one %d-layer slab per GPU (weak), %s" % (world, n, link))
+    if world == 1:
+        par = "1 GPU"
+    elif dims is not None:
+        par = ("%dx%dx%d bricks of one %d^3 scene (strong), %s" % (dims + (n, link)) if strong
+               else "%dx%dx%d bricks, %d^3 owned cells per GPU (weak), %s" % (dims + (n, link)))
+    else:
+        par = ("%d z-slabs of one %d^3 scene (strong), %s" % (world, n, link) if strong
+               else "%d z-slabs, one %d-layer slab per GPU (weak), %s" % (world, n, link))
     workload = {"cavity": "synthetic lid-driven cavity", "coil": "synthetic coiling column (honey_coil stand-in)", "spheres": "pool with 8 moving solid spheres (armadillos stand-in)"}[scene_name]
     out = {
         "metric": "Stokes-solve wall ms/step (assembly+PCG) on 256^3 grid; CG iters/sec",

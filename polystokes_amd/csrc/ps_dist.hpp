@@ -1,9 +1,10 @@
-// Multi-GPU: distributed PCG over z-slabs (RCCL or in-process ranks) and its C ABI.
+// Multi-GPU: distributed PCG over bricks / z-slabs (RCCL, host-staged TCP or in-process ranks) and its C ABI.
 // Part of the single translation unit ps_solve.hip (included there, inside its anonymous namespace where noted).
 #pragma once
 
 // =====================================================================================================
-// Multi-GPU: distributed PCG over z-slabs.  Not in the reference (single process).
+// Multi-GPU: distributed PCG over a brick decomposition — z-slabs are its 1 x 1 x N case.  Not in the reference
+// (single process).
 // The same kernels as above run on every rank over its local rows / owned DOF range; what is added is
 //   * pack / unpack of the one-layer exchange lists,
 //   * a transport (RCCL send/recv + all-reduce on the solver stream, or device copies between ranks that
@@ -25,8 +26,8 @@ struct PsNcclUid { char internal[128]; };   // layout of ncclUniqueId
 
 namespace {
 
-// both cut planes of a rank in one launch: entries [0, nA) use list A / buffer A, entries [nA, nA + nB) list B / buffer B.
-// (A DOF lies next to at most one cut — slabs are at least one 16-layer block thick — so the two lists are disjoint.)
+// both cut planes of ONE axis in one launch: entries [0, nA) use list A / buffer A, entries [nA, nA + nB) list B / buffer B.
+// (Along an axis a DOF lies next to at most one cut — a brick is at least one 16-cell block thick — so the two lists are disjoint.)
 __global__ void k_pack2(const int32_t* __restrict__ listA, int64_t nA, double* __restrict__ bufA, const int32_t* __restrict__ listB, int64_t nB,
                         double* __restrict__ bufB, const double* __restrict__ v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

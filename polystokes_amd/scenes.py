@@ -158,3 +158,31 @@ def cavity_slab(n, world, rank, tile=16, pad=2, precond=1):
         velx[top, :, :] = 1.0
     sc = Scene(n, n, nzl, dx, dt, 1.0, [velx, 0.0, 0.0], np.float32(-1.0), np.float32(1.0), 1.0, name=f"cavity{n}x{world}.r{rank}")
     return sc, default_params(tileSize=tile, tilePadding=pad, preconditioner=precond), sl
+
+
+def scene_brick(name, n, dims, rank, tile=16, pad=2, precond=1, weak=False):
+    """Rank-local piece (brick + halo) for a dims[0] x dims[1] x dims[2] decomposition (ps_set_brick).  weak = False: the n^3 scene `name`
+    cut into bricks (strong scaling); weak = True (cavity only): every rank owns n^3 cells of the (n dims[0]) x (n dims[1]) x (n dims[2])
+    cavity with the lid on the global top plane and cells of size 1 / n.  Returns (local Scene, params, Brick)."""
+    from . import partition
+    G = (n * dims[0], n * dims[1], n * dims[2]) if weak else (n, n, n)
+    b = partition.make_brick(G, dims, rank, tile)
+    nx, ny, nz = b.n_local
+    if name == "cavity":
+        dx, dt = 1.0 / n, 1.0e-2
+        velx = np.zeros((nz, ny, nx + 1), dtype=np.float32)
+        top = G[2] - 1 - b.origin[2]          # local index of the global lid layer
+        if 0 <= top < nz:
+            velx[top, :, :] = 1.0
+        sc = Scene(nx, ny, nz, dx, dt, 1.0, [velx, 0.0, 0.0], np.float32(-1.0), np.float32(1.0), 1.0, name=f"cavity{G[0]}x{G[1]}x{G[2]}.b{rank}")
+        return sc, default_params(tileSize=tile, tilePadding=pad, preconditioner=precond), b
+    if weak:
+        raise ValueError("weak scaling is defined for the cavity scene")
+    fn = {"coil": coil, "spheres": spheres}[name]
+    full, p = fn(n, tile, pad, zrange=(b.origin[2], nz))      # the rank's z-layers of the global scene, then its x / y range
+    p.preconditioner = precond
+    zb = partition.Brick.__new__(partition.Brick)
+    zb.__dict__.update(b.__dict__)
+    zb.origin = [b.origin[0], b.origin[1], 0]
+    return partition.local_scene_brick(full, zb), p, b
+

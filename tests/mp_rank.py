@@ -20,15 +20,23 @@ def main():
     from polystokes_amd import partition
     import mp_cases
     sc, p = mp_cases.make(case)
-    sl = partition.make_slab(sc.nz, world, rank, p.tileSize)
+    dims = mp_cases.DIMS.get(case.replace("_interrupt", "").replace("_failrank", ""))
     s = polystokes_amd.Solver(device)
-    loc = partition.local_scene(sc, sl)
+    if dims is not None:
+        sl = partition.make_brick((sc.nx, sc.ny, sc.nz), dims, rank, p.tileSize)
+        loc = partition.local_scene_brick(sc, sl)
+    else:
+        sl = partition.make_slab(sc.nz, world, rank, p.tileSize)
+        loc = partition.local_scene(sc, sl)
     if case.endswith("_failrank") and rank == 1:
         # this rank sees air in a patch of its own first layers: its labels on the cut differ from what rank 0 computes
         # from its halo copy, so the exchange lists disagree (same tile structure, other DOF sets)
         loc.surface[sl.zLoOwned:sl.zLoOwned + 3, 5:12, 5:12] = 1.0
     s.upload(loc, p)
-    s.set_slab(sl)
+    if dims is not None:
+        s.set_brick(sl)
+    else:
+        s.set_slab(sl)
     s.comm_init_tcp(rank, world, "127.0.0.1", port)
     if case.endswith("_interrupt") and rank == world - 1:
         s.set_interrupt(lambda: True)     # ONE rank asks to stop: every rank must return PS_INCOMPLETE at the same batch

@@ -57,7 +57,8 @@ def _run_ranks(case, world, tmp_path, env=None):
 
 
 @pytest.mark.parametrize("case", ["cavity_w2", "cavity_w3_jacobi", "coil_w2", "cavity_w2_bicgstab", "cavity_w2_chebyshev",
-                                  "cavity_w2+fused", "cavity_w3_jacobi+fused", "coil_w2+fused", "cavity_w2_bicgstab+fused"])
+                                  "cavity_w2+fused", "cavity_w3_jacobi+fused", "coil_w2+fused", "cavity_w2_bicgstab+fused",
+                                  "cavity64_b2x2x1", "cavity_b2x1x2+fused"])
 def test_multiprocess_tcp_matches_single_domain(case, tmp_path):
     """"+fused": the four-kernel PCG step across the slabs (default from 2 M owned rows per rank), forced in the rank processes."""
     import polystokes_amd
@@ -78,7 +79,17 @@ def test_multiprocess_tcp_matches_single_domain(case, tmp_path):
     sh = abi.grid_shapes(sc.nx, sc.ny, sc.nz)
     vel = [np.array(sc.vel[a], copy=True) for a in range(3)]
     valid = [np.zeros(sh["face" + "XYZ"[a]], np.float32) for a in range(3)]
+    dims = mp_cases.DIMS.get(case)
     for r in range(world):
+        if dims is not None:            # bricks (ps_set_brick): the same checks on the owned box
+            b = partition.make_brick((sc.nx, sc.ny, sc.nz), dims, r, p.tileSize)
+            ll = res[r]["labels"].reshape(b.n_local[2], b.n_local[1], b.n_local[0])
+            assert np.array_equal(ll[b.lo[2]:b.hi[2], b.lo[1]:b.hi[1], b.lo[0]:b.hi[0]], lab[b.g0[2]:b.g1[2], b.g0[1]:b.g1[1], b.g0[0]:b.g1[0]]), (case, r)
+            for a in range(3):
+                shp = (b.n_local[2] + (a == 2), b.n_local[1] + (a == 1), b.n_local[0] + (a == 0))
+                partition.merge_faces_brick(vel[a], res[r]["vel%d" % a].reshape(shp), res[r]["owned%d" % a], b, a)
+                partition.merge_faces_brick(valid[a], res[r]["valid%d" % a].reshape(shp), res[r]["owned%d" % a], b, a)
+            continue
         sl = partition.make_slab(sc.nz, world, r, p.tileSize)
         ll = res[r]["labels"].reshape(sl.nz_local, sc.ny, sc.nx)
         assert np.array_equal(ll[sl.zLoOwned:sl.zHiOwned], lab[sl.z0:sl.z1]), (case, r)
@@ -133,6 +144,30 @@ def test_bench_two_ranks_produces_one_line_whatever_the_transport(tmp_path):
         assert d["transport"] == "rccl"
     else:
         assert d["transport"].startswith("tcp (FALLBACK")
+
+
+def test_bench_four_ranks_as_bricks(tmp_path):
+    """`bench.py --gpus 4 --bricks 2x2x1`: the decomposition along x and y (ps_set_brick), weak scaling = 32^3 owned cells per rank of the
+    64 x 64 x 32 cavity; on a one-GPU box over the host-staged transport."""
+    import json
+    env = dict(os.environ, MASTER_PORT=str(_free_port_base(1)))
+    pr = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "4", "--bricks", "2x2x1", "--res", "32", "--steps", "1",
+                         "--warmup", "1", "--no-cpu-baseline", "--transport", "tcp"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, env=env)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [l for l in pr.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["value"] > 0 and d["cg_iterations"] > 0
+    assert d["config"]["grid"] == [64, 64, 32] and "2x2x1 bricks" in d["config"]["parallelism"]
+    # the same system as one rank solves it: the iteration count of the 64 x 64 x 32 cavity
+    import polystokes_amd
+    from polystokes_amd import scenes, partition
+    sc = abi.Scene(64, 64, 32, 1.0 / 32, 1.0e-2, 1.0, [np.pad(np.zeros((31, 64, 65), np.float32), ((0, 1), (0, 0), (0, 0)), constant_values=1.0), 0.0, 0.0], -1.0, 1.0, 1.0)
+    _, p = scenes.cavity(32, tile=16, pad=2, precond=abi.PRE_DIAGONAL)
+    single = polystokes_amd.Solver(0)
+    assert single.step(sc, p) == abi.SUCCESS
+    assert abs(single.stats.solveData[1] - d["cg_iterations"]) <= max(2, 0.02 * single.stats.solveData[1])
+    single.close()
 
 
 def test_rccl_communicator_next_to_a_live_torch_context():
