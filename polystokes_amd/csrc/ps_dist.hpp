@@ -399,7 +399,8 @@ struct Dist {
         }
     }
     // r_j -= alpha * (the neighbours' share of (A p)_j) on the OWNED DOFs next to a cut, from the receive buffers of every axis (a DOF next
-    // to two cuts is corrected twice, each launch sees the r the previous one left); partials of the changes of r.r / r.z: [axis][2][gFix]
+    // to two cuts is corrected twice, each launch sees the r the previous one left); partials of the changes of r.r / r.z: [axis][2][gFix] (zeroed once per solve: an axis
+    // without lists leaves its part alone)
     void fixup(ps_context* c, const CGScalars* sc, bool jac, double* fX, int gFix) {
         for (int a = 0; a < 3; ++a) {
             double* part = fX + (size_t)a * 2 * (size_t)gFix;
@@ -407,7 +408,6 @@ struct Dist {
                 hipLaunchKernelGGL(k_dist_fixup, dim3(gFix), dim3(BS), 0, c->stream, sc, (const int32_t*)c->listLowOwn[a].p, c->nLowOwn[a], (const double*)c->recvLo[a].p,
                                    (const int32_t*)c->listUpOwn[a].p, c->nUpOwn[a], (const double*)c->recvUp[a].p, c->r.p,
                                    jac ? (const float*)c->dinvF.p : (const float*)nullptr, part, (int)c->ownHi);
-            else HIP_CHECK(hipMemsetAsync(part, 0, 2 * (size_t)gFix * sizeof(double), c->stream));
         }
     }
     void exchangeX(DevBuf<double> ps_context::*vec) {
@@ -737,6 +737,7 @@ struct Dist {
                 f.gFix = (int)std::min<int64_t>(256, (mostOwn + BS - 1) / BS);   // workgroups of one axis's k_dist_fixup; its partials: [axis][2][gFix]
                 c->fusedPart.alloc((size_t)f.sBlocks + (size_t)c->regionCount + VGRID + 2 * (size_t)f.stBF + 6 * (size_t)f.gFix + 16);
                 f.fS = c->fusedPart.p; f.fT = f.fS + f.sBlocks; f.fU = f.fT + c->regionCount; f.fR = f.fU + VGRID; f.fX = f.fR + 2 * f.stBF;
+                HIP_CHECK(hipMemsetAsync(f.fX, 0, 6 * (size_t)f.gFix * sizeof(double), c->stream));
                 l.L.sPart = f.fS; l.L.wvPart = f.fT;
                 c->fusedStepHost = 1;
                 const uint8_t* ucode = c->uCoded ? c->uCode.p + l.lo : nullptr;

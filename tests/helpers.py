@@ -101,3 +101,18 @@ def merge_dof_field(global_out, local, slab, kind):
     if kind in ("eYZ", "eXZ") and not slab.hasUpper:
         k1 += 1                                   # the top plane of the whole domain
     glo[slab.g0 + k0:slab.g0 + k1] = loc[k0:k1]
+
+
+def merge_dof_field_brick(global_out, local, b, kind, global_n):
+    """The same for a brick (partition.Brick): along every axis a kind lives in the cell layers or on the planes (plane-type axes per
+    kind below), owned range [lo, hi) plus the last plane of the domain where there is no upper neighbour.  global_n = (nx, ny, nz)."""
+    planes = {"p": (), "txx": (), "tyy": (), "tzz": (), "eYZ": (1, 2), "eXZ": (0, 2), "eXY": (0, 1)}[kind]
+    lshape = tuple(b.n_local[a] + (1 if a in planes else 0) for a in (2, 1, 0))
+    gshape = tuple(global_n[a] + (1 if a in planes else 0) for a in (2, 1, 0))
+    loc, glo = local.reshape(lshape), global_out.reshape(gshape)
+    sl_l, sl_g = [], []
+    for a in (2, 1, 0):
+        k0, k1 = b.lo[a], b.hi[a] + (1 if (a in planes and not b.hasUpper[a]) else 0)
+        sl_l.append(slice(k0, k1)); sl_g.append(slice(b.origin[a] + k0, b.origin[a] + k1))
+    glo[tuple(sl_g)] = loc[tuple(sl_l)]
+

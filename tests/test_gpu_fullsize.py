@@ -154,11 +154,12 @@ def _stop_rule_holds(s, p):
     return min(r @ r, (r @ r) / (xs @ xs)) < p.tolerance ** 2 * 1.001
 
 
-@pytest.mark.parametrize("scene,n,worlds", [("coil", 512, (2, 4)), ("spheres", 256, (4,))])
+@pytest.mark.parametrize("scene,n,worlds", [("coil", 512, (2, 4)), ("spheres", 256, (4, (2, 2, 2)))])
 def test_config4_and_5_full_size_single_and_slabs(scene, n, worlds):
     """BASELINE config 4 (coiling column 512^3, 78 M DOFs) and config 5 stand-in (8 moving solid spheres, 256^3, mu = 1e4) at
     their stated sizes: the single-domain step satisfies the reference's stop rule on the operator it solved; the same scene cut
-    into 2 / 4 z-slabs (the distributed algorithm, in-process ranks on this one GPU) takes the same number of iterations, marks the
+    into 2 / 4 z-slabs — and, config 5, into 2 x 2 x 2 bricks: its 8-rank decomposition — (the distributed algorithm,
+    in-process ranks on this one GPU) takes the same number of iterations, marks the
     same faces valid and — where the scene is not of the AMP kind — returns the same velocities.
     The 8-rank run of these configs needs an 8-GPU node (bench.py --gpus 8 --scaling strong --scene coil --res 512)."""
     import polystokes_amd
@@ -173,14 +174,15 @@ def test_config4_and_5_full_size_single_and_slabs(scene, n, worlds):
     vel1, valid1 = s.vel, s.valid
     # the solution vector as seven grid fields (p, txx, tyy, tzz, the three edge stresses): the form in which a slab group's solution
     # can be compared with it, whatever the ranks' numberings
-    from helpers import DOF_KINDS, dof_field, merge_dof_field
+    from helpers import DOF_KINDS, dof_field, merge_dof_field, merge_dof_field_brick
     x1 = s.array("solutionVector")
     x1_norm = float(np.linalg.norm(x1))
     fields1 = {k: dof_field(s, k, x1) for k in DOF_KINDS}
     del x1
     s.close()
     for world in worlds:
-        grp = polystokes_amd.Group(world)
+        dims = world if isinstance(world, tuple) else None
+        grp = polystokes_amd.Group(world, dims=dims) if dims is None else polystokes_amd.Group(dims[0] * dims[1] * dims[2], dims=dims)
         rc2 = grp.solve_scene(sc, p)
         assert rc2 == abi.SUCCESS
         it2 = int(grp.stats.solveData[1])
@@ -191,7 +193,10 @@ def test_config4_and_5_full_size_single_and_slabs(scene, n, worlds):
             merged = np.full(fields1[kind].shape, np.nan, np.float32)
             for r, sl in enumerate(grp.slabs):
                 xr = grp.ranks[r].array("solutionVector")
-                merge_dof_field(merged, dof_field(grp.ranks[r], kind, xr), sl, kind)
+                if dims is None:
+                    merge_dof_field(merged, dof_field(grp.ranks[r], kind, xr), sl, kind)
+                else:
+                    merge_dof_field_brick(merged, dof_field(grp.ranks[r], kind, xr), sl, kind, (sc.nx, sc.ny, sc.nz))
                 del xr
             assert np.array_equal(np.isnan(merged), np.isnan(fields1[kind])), (scene, world, kind)   # the same DOFs exist
             d = np.nan_to_num(merged.astype(np.float64) - fields1[kind])
