@@ -154,7 +154,7 @@ def _stop_rule_holds(s, p):
     return min(r @ r, (r @ r) / (xs @ xs)) < p.tolerance ** 2 * 1.001
 
 
-@pytest.mark.parametrize("scene,n,worlds", [("coil", 512, (2, 4)), ("spheres", 256, (4, (2, 2, 2)))])
+@pytest.mark.parametrize("scene,n,worlds", [("coil", 512, (2, 4, (2, 2, 2))), ("spheres", 256, (4, (2, 2, 2)))])
 def test_config4_and_5_full_size_single_and_slabs(scene, n, worlds):
     """BASELINE config 4 (coiling column 512^3, 78 M DOFs) and config 5 stand-in (8 moving solid spheres, 256^3, mu = 1e4) at
     their stated sizes: the single-domain step satisfies the reference's stop rule on the operator it solved; the same scene cut
