@@ -49,8 +49,8 @@ def add(name, launches, nbytes, flops, model):
     K[name] = (launches, float(nbytes), float(flops), model)
 
 
-add("k_sdf_weights", 14, 4 * N + 4 * (N + 3 * F + 3 * E) / 7.0, 0, "SDF once (4 N) + one weight per sample point (4 B; mean of the 7 sample grids)")
-add("k_cc_step", 12, N * (4 + 4 + 12 + 4), 0, "labels, region ids in / out, three face liquid weights: 24 B per cell")
+add("k_sdf_weights7", 2, 4 * N + 4 * (N + 3 * F + 3 * E), 0, "SDF once (4 N) + one weight per sample point of all seven grids (4 B each)")
+add("k_cc_step", 12, N * (1 + 4 + 4), 0, "link byte, component label in / out: 9 B per cell")
 add("k_S_count", 3, F * 36 + rowsS / 3.0 * 4, 0, "faceRow, face weight, 2 cells x (lw, sys) and 2 x 2 edges x (lab, lw) amortised: 36 B per face; one count per row")
 add("k_S_fill", 3, F * 52 + nnz / 3.0 * 13 + rowsS / 3.0 * 28, 0, "inputs 52 B per face (faceRow, fw, vel, cells: lw lab sys sysT, edges: lab lw sys); per entry col 4 + val 8 + code 1; per row McInv, rhs, old u, ptr")
 add("k_St_cells<true>", 1, N * 52 + float(lenT.sum()) * 13 * (4.0 * nP / max(nsys, 1)) + 4 * nP * 20, 0, "per cell 52 B of inputs; 13 B per entry of the four cell rows; rhs, uInv, ptr per row")
