@@ -117,6 +117,20 @@ def test_bricks_match_single_domain(case):
     single.close()
 
 
+@pytest.mark.skipif(__import__("os").environ.get("PS_TEST_CHILD") == "1", reason="this IS the child run")
+def test_bricks_and_slabs_with_the_four_kernel_step_forced():
+    """The four-kernel PCG step across the cuts (the St kernel corrects r on owned rows, the halo rows' A p travels back axis after axis,
+    k_relay2 / k_dist_fixup) switches on from 2 M owned rows per rank: force it (PS_FUSED_R=1) through the brick and slab cases in a child."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PS_FUSED_R="1", PS_TEST_CHILD="1")
+    pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                         "-k", "test_bricks_match_single_domain or test_group_matches_single_domain"],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    assert pr.returncode == 0, pr.stdout[-3000:]
+
+
 def test_rccl_entry_points_world1():
     """dlopen'ed RCCL on the solver stream: communicator init, all-reduce, grouped send/recv (to self)."""
     import polystokes_amd
