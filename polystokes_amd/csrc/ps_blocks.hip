@@ -297,7 +297,7 @@ __global__ void k_S_fill(BlockArgs A, int axis, const int32_t* __restrict__ ptr,
     const int p0 = ptr[row];
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-        if (q < n) { col[p0 + q] = cols[q]; val[p0 + q] = vals[q]; code[p0 + q] = encodeVal(A, vals[q]); }
+        if (q < n) { col[p0 + q] = cols[q]; if (val) val[p0 + q] = vals[q]; code[p0 + q] = encodeVal(A, vals[q]); }
     if (row < A.nA) {
         double volume = (double)A.fw[1 + axis][c] * (double)A.lw[1 + axis][c];
         const double lo = 0.1 * 0.1;   // MINWEIGHT * MINWEIGHT, :365
@@ -465,7 +465,7 @@ __global__ void k_St_cells(BlockArgs A, int32_t* __restrict__ cnt, const int32_t
         if (!FILL) { cnt[j] = n; continue; }
         sortRows(n, rows, vals);
         const int p0 = ptr[j];
-        for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; code[p0 + k] = encodeVal(A, vals[k]); }
+        for (int k = 0; k < n; ++k) { col[p0 + k] = rows[k]; if (val) val[p0 + k] = vals[k]; code[p0 + k] = encodeVal(A, vals[k]); }
         rhsPT[j] = rhs;
         uInv[j] = mode > 0 ? uinvv : 0.;      // full-length diagonal, zero on pressure rows
         if (uDiag) uDiag[j] = mode > 0 ? uv : 0.;
@@ -491,7 +491,7 @@ __global__ void k_St_edges(BlockArgs A, int ea, int32_t* __restrict__ cnt, const
     const int p0 = ptr[j];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (k < n) { col[p0 + k] = rows[k]; val[p0 + k] = vals[k]; code[p0 + k] = encodeVal(A, vals[k]); }
+        if (k < n) { col[p0 + k] = rows[k]; if (val) val[p0 + k] = vals[k]; code[p0 + k] = encodeVal(A, vals[k]); }
     rhsPT[j] = rhs;
     const double vw = clampd((double)A.fw[4 + ea][c], 0.1, 1.0) * (double)A.lw[4 + ea][c];
     const float ox = ea == 0 ? 0.5f : 0.f, oy = ea == 1 ? 0.5f : 0.f, oz = ea == 2 ? 0.5f : 0.f;
@@ -764,8 +764,21 @@ void ps_context::buildEll(ps::DevCSR& M) {
     if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] row-per-lane stream: %d chunks, %lld column slots and %lld code bytes in the distinct runs (nnz %lld)\n",
                                            nChunks, (long long)totCol, (long long)totCode, (long long)M.nnz);
 }
+namespace {
+__global__ void k_decode_values(const int8_t* __restrict__ code, double scale, int64_t n, double* __restrict__ val) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) val[i] = (double)code[i] * scale;
+}
+}  // namespace
+// the fp64 values of a block whose codes hold them exactly (constructMatrixBlocks does not store them then): exports, benchmarks
+void ps_context::ensureValues(ps::DevCSR& M) {
+    if (M.val.p || M.nnz == 0) return;
+    if (!M.packed || !M.code.p) throw Error("internal: a block without values and without codes");
+    M.val.alloc((size_t)M.nnz);
+    hipLaunchKernelGGL(k_decode_values, dim3(2048), dim3(BS), 0, stream, (const int8_t*)M.code.p, valScale, M.nnz, M.val.p);
+}
 void ps_context::buildVal4(ps::DevCSR& M) {
     if (!M.col16ok || M.val4.p) return;
+    ensureValues(M);
     M.val4.alloc((size_t)M.streamLen + 8);
     hipLaunchKernelGGL(k_val4_build, dim3((unsigned)M.nChunks), dim3(BS), 0, stream, M.ptr.p, M.val.p, M.chunkInfo.p, M.val4.p);
 }
@@ -1047,16 +1060,40 @@ void ps_context::constructMatrixBlocks() {
         if (tot < 0) throw Error("nnz(S) overflows 32-bit row pointers");
         S.nnz = tot;
     }
-    S.col.alloc((size_t)S.nnz); S.val.alloc((size_t)S.nnz); S.code.alloc((size_t)S.nnz);
-    for (int a = 0; a < 3; ++a) {
-        const int64_t n = g.count(1 + a);
-        hipLaunchKernelGGL(k_S_fill, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, S.ptr.p, S.col.p, S.val.p, S.code.p, McInv.p, rhsA.p,
-                           wantExport ? Mc.p : (double*)nullptr, oldVs.p);
+    // The fp64 values are not stored while the codes hold them exactly (every entry is checked as it is coded: counters[20]): nothing on the
+    // solve path reads them then, exports and the fp64-stream benchmarks decode them on demand (ensureValues) — 2 x 8 B per entry less to write
+    // in setup and to keep (2.5 GB at 256^3).  They are written when the codes are refused (PS_FORCE_FP64_VALUES=1) or turn out not to fit:
+    // the fill kernels then run once more with the value arrays.
+    {
+        const char* e = getenv("PS_FORCE_FP64_VALUES");
+        forceFp64Values = e && atoi(e) != 0;
     }
+    auto fillS = [&](bool withValues) {
+        if (withValues) S.val.alloc((size_t)S.nnz); else S.val.free();
+        for (int a = 0; a < 3; ++a) {
+            const int64_t n = g.count(1 + a);
+            hipLaunchKernelGGL(k_S_fill, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, a, S.ptr.p, S.col.p, withValues ? S.val.p : (double*)nullptr, S.code.p, McInv.p, rhsA.p,
+                               wantExport ? Mc.p : (double*)nullptr, oldVs.p);
+        }
+    };
+    S.col.alloc((size_t)S.nnz); S.code.alloc((size_t)S.nnz);
+    fillS(forceFp64Values);
     // St
     St.rows = nSystem; St.cols = nRows;
     St.ptr.alloc((size_t)nSystem + 1);
     HIP_CHECK(hipMemsetAsync(St.ptr.p, 0, ((size_t)nSystem + 1) * sizeof(int32_t), stream));
+    auto fillSt = [&](bool withValues) {
+        if (withValues) St.val.alloc((size_t)St.nnz); else St.val.free();
+        double* v = withValues ? St.val.p : (double*)nullptr;
+        const int64_t n = g.count(0);
+        hipLaunchKernelGGL(k_St_cells<true>, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, (int32_t*)nullptr, St.ptr.p, St.col.p, v, St.code.p,
+                           rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
+        for (int e = 0; e < 3; ++e) {
+            const int64_t ne = g.count(4 + e);
+            hipLaunchKernelGGL(k_St_edges<true>, dim3(gridFor(ne, BS)), dim3(BS), 0, stream, A, e, (int32_t*)nullptr, St.ptr.p, St.col.p,
+                               v, St.code.p, rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
+        }
+    };
     {
         const int64_t n = g.count(0);
         hipLaunchKernelGGL(k_St_cells<false>, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, St.ptr.p, (const int32_t*)nullptr,
@@ -1068,19 +1105,12 @@ void ps_context::constructMatrixBlocks() {
         }
         St.nnz = exclusiveScanI32(St.ptr.p, nSystem + 1);
         if (St.nnz != S.nnz) throw Error("internal: nnz(S^T) != nnz(S)");
-        St.col.alloc((size_t)St.nnz); St.val.alloc((size_t)St.nnz); St.code.alloc((size_t)St.nnz);
-        hipLaunchKernelGGL(k_St_cells<true>, dim3(gridFor(n, BS)), dim3(BS), 0, stream, A, (int32_t*)nullptr, St.ptr.p, St.col.p, St.val.p, St.code.p,
-                           rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
-        for (int e = 0; e < 3; ++e) {
-            const int64_t ne = g.count(4 + e);
-            hipLaunchKernelGGL(k_St_edges<true>, dim3(gridFor(ne, BS)), dim3(BS), 0, stream, A, e, (int32_t*)nullptr, St.ptr.p, St.col.p,
-                               St.val.p, St.code.p, rhsPT.p, uInv.p, wantExport ? uDiag.p : (double*)nullptr);
-        }
+        St.col.alloc((size_t)St.nnz); St.code.alloc((size_t)St.nnz);
+        fillSt(forceFp64Values);
     }
     {
-        const char* e = getenv("PS_FORCE_FP64_VALUES");
-        forceFp64Values = e && atoi(e) != 0;
         const bool ok = readCounter(20) == 0;
+        if (!ok && !forceFp64Values) { fillS(true); fillSt(true); }   // some value is not code * scale: the kernels will stream the values
         S.packed = St.packed = ok && !forceFp64Values;
         const int32_t flag = S.packed ? 1 : 0;
         HIP_CHECK(hipMemcpyAsync(counters.p + 21, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));

@@ -368,6 +368,7 @@ void ps_context::buildExplicitA(std::vector<int64_t>& aptr, std::vector<int32_t>
     const int64_t n = nSystem, nA = nActiveVs, nP = nPressures;
     auto sp = fetch(this, S.ptr.p, nRows + 1);
     auto sc = fetch(this, S.col.p, S.nnz);
+    ensureValues(S);
     auto sv = fetch(this, S.val.p, S.nnz);
     auto mc = fetch(this, McInv.p, nA);
     auto ui = fetch(this, uInv.p, n);
@@ -615,6 +616,11 @@ int64_t ps_query_array(ps_context* c, const char* name, int32_t* elem_bytes) {
 int32_t ps_read_array(ps_context* c, const char* name, void* dst, int64_t dst_bytes) {
     if (!c || !name) return PS_FAILED;
     PS_TRY(c, {
+        if (c->isSetup && (std::strcmp(name, "S.val") == 0 || std::strcmp(name, "St.val") == 0)) {   // decoded on demand (ps_context::ensureValues)
+            ps::DevCSR& M = name[1] == '.' ? c->S : c->St;
+            c->ensureValues(M);
+            c->arrays[name].dptr = M.val.p;
+        }
         auto it = c->arrays.find(name);
         if (it == c->arrays.end()) throw Error(std::string("unknown array ") + name);
         const int64_t need = it->second.count * it->second.elem;
@@ -752,6 +758,7 @@ int32_t ps_export_component_matrices(ps_context* c, const char* prefix) {
         const int64_t nA = c->nActiveVs, nP = c->nPressures, nT = c->nStresses, R = c->regionCount;
         auto sp = fetch(c, c->S.ptr.p, c->S.rows + 1);
         auto sc = fetch(c, c->S.col.p, c->S.nnz);
+        c->ensureValues(c->S);
         auto sv = fetch(c, c->S.val.p, c->S.nnz);
         auto rface = fetch(c, c->rrowFace.p, c->nReducedRows);
         auto rreg = fetch(c, c->rrowRegion.p, c->nReducedRows);

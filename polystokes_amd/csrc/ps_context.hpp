@@ -251,6 +251,7 @@ struct ps_context {
     void buildStreams(bool share);                        // both compressed streams (ps_blocks.hip)
     bool shareRuns = true;
     ps::DevBuf<int2> scrChunkRows; ps::DevBuf<int32_t> scrSlice, scrStart4, scrVals, scrKeep, scrRemap, scrEllCol, scrEllCode, scrEllW; ps::DevBuf<unsigned long long> scrHash, scrKeys, scrUniq;   // buildCol16 scratch
+    void ensureValues(ps::DevCSR& M);                    // decode the fp64 values of a coded block on demand (ps_blocks.hip)
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
     void assembleSystemPressureStressFactored();          // ps_solve.hip

@@ -543,7 +543,8 @@ __global__ void k_lin(double* __restrict__ out, double ca, const double* __restr
 // bound is 1e-9): 351 fused multiply-adds per form instead of 676 multiplies, 676 adds and 676 vector loads of one address each
 // (the vector-memory path takes 16 cycles per wave for such a load: the r02 kernel took 6.3 ms of the 256^3 setup, this one 3.8;
 // fetching a row's entries up front and folding them through the 3 x 10 moments was tried: 220 VGPRs, 6.2 ms).
-__global__ void __launch_bounds__(256) k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int n, int nP,
+__global__ void __launch_bounds__(256) k_jacobi_diag(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                              const int8_t* __restrict__ code, double valScale, int n, int nP,
                               int nA, double dt, const double* __restrict__ McInv, const double* __restrict__ uInv,
                               const uint32_t* __restrict__ rrowFace, const int32_t* __restrict__ rrowRegion, const double* __restrict__ COM,
                               double dx, int3 off, const double* __restrict__ Binv, double* __restrict__ dinv, int invert) {
@@ -559,7 +560,7 @@ __global__ void __launch_bounds__(256) k_jacobi_diag(const int32_t* __restrict__
         int cur = -1;
         while (p < pe) {
             const int f = col[p];
-            const double v = val[p];
+            const double v = val ? val[p] : (double)code[p] * valScale;   // (coded blocks keep no fp64 values: the same bits)
             if (f < nA) { diag += -dt * McInv[f] * v * v; ++p; continue; }
             const int rr = f - nA;
             const int r = rrowRegion[rr];

@@ -306,7 +306,7 @@ void ps_context::constructPreconditioner() {
     if (P.preconditioner != PS_PRE_DIAGONAL && P.preconditioner != PS_PRE_CHEBYSHEV && P.solverType != PS_EIGEN) return;   // Eigen's CG always runs its DiagonalPreconditioner
     dinv.alloc((size_t)nSystem);
     if (nSystem == 0) return;
-    hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 256)), dim3(256), 0, stream, St.ptr.p, St.col.p, St.val.p, (int)nSystem,
+    hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 256)), dim3(256), 0, stream, St.ptr.p, St.col.p, (const double*)St.val.p, (const int8_t*)St.code.p, valScale, (int)nSystem,
                        (int)nPressures, (int)nActiveVs, dt, McInv.p, uInv.p, rrowFace.p, rrowRegion.p, COM.p, dx, make_int3(gOff[0], gOff[1], gOff[2]), Binv.p, dinv.p,
                        slabEnabled ? 0 : 1);
     // The PCG kernels read the diagonal in fp32 (4 instead of 8 bytes per DOF in both vector kernels).  Any positive
@@ -716,7 +716,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         c->buildVal4(c->S); c->buildVal4(c->St);
         c->S.packed = false; c->St.packed = false;
     }
-    if (csr) { c->S.packed = c->St.packed = false; c->S.col16ok = c->St.col16ok = false; }
+    if (csr) { c->ensureValues(c->S); c->ensureValues(c->St); c->S.packed = c->St.packed = false; c->S.col16ok = c->St.col16ok = false; }
     if (base == "spmv_S") L.spmvS(0, x, c->ts.p);
     else if (base == "spmv_St") L.spmvSt(0, c->ts.p, x, nullptr, y, c->dotPartials.p);
     else if (base == "apply") c->applyOperator(x, y, c->dotPartials.p);
