@@ -624,9 +624,19 @@ __device__ inline int blockExclusiveScan(int v, int* total) {
     return base + incl - v;
 }
 
-// flag of traversal position t for the ordered index assignment
-__device__ inline int orderedFlag(const Grid& g, const int3 d, int mode, const int32_t* __restrict__ src, int64_t t, int64_t* linOut) {
-    const int3 q = orderToIjk(d, g.order, t);
+// the voxel after q in the traversal order (its position is t): the x-neighbour, the next row / plane of the 16^3 tile, or — leaving the
+// tile — a full decode.  (One full decode per position, six 64-bit divisions each, was most of the 1.9 ms of these kernels at 256^3.)
+__device__ inline void orderAdvance(const int3 d, int order, int64_t t, int3& q) {
+    if (order == PS_ORDER_LINEAR) { if (++q.x == d.x) { q.x = 0; if (++q.y == d.y) { q.y = 0; ++q.z; } } return; }
+    const int T = 16;
+    const int x0 = (q.x / T) * T, y0 = (q.y / T) * T;
+    if (q.x + 1 < min(d.x, x0 + T)) { ++q.x; return; }
+    if (q.y + 1 < min(d.y, y0 + T)) { q.x = x0; ++q.y; return; }
+    if (q.z + 1 < min(d.z, (q.z / T) * T + T)) { q.x = x0; q.y = y0; ++q.z; return; }
+    q = orderToIjk(d, order, t);
+}
+// flag of the traversal position t (voxel q) for the ordered index assignment
+__device__ inline int orderedFlag(const int3 d, int mode, const int32_t* __restrict__ src, int64_t t, const int3 q, int64_t* linOut) {
     const int64_t c = lin3(d, q.x, q.y, q.z);
     *linOut = c;
     if (mode == 0) return isActiveL(src[c]) ? 1 : 0;   // serialAssignFieldIndices, Classifier.cpp:1764
@@ -637,10 +647,14 @@ __global__ void k_ordered_count(Grid g, int s, int mode, const int32_t* __restri
     const int64_t n = (int64_t)d.x * d.y * d.z;
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int cnt = 0;
+    int3 q = base < n ? orderToIjk(d, g.order, base) : make_int3(0, 0, 0);
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         const int64_t t = base + i;
         int64_t c;
-        if (t < n) cnt += orderedFlag(g, d, mode, src, t, &c);
+        if (t < n) {
+            if (i) orderAdvance(d, g.order, t, q);
+            cnt += orderedFlag(d, mode, src, t, q, &c);
+        }
     }
     int tot;
     blockExclusiveScan(cnt, &tot);
@@ -654,11 +668,15 @@ __global__ void k_ordered_assign(Grid g, int s, int mode, const int32_t* __restr
     int fl[SCAN_ITEMS];
     int64_t cc[SCAN_ITEMS];
     int cnt = 0;
+    int3 q = base < n ? orderToIjk(d, g.order, base) : make_int3(0, 0, 0);
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         const int64_t t = base + i;
         fl[i] = 0;
         cc[i] = 0;
-        if (t < n) fl[i] = orderedFlag(g, d, mode, src, t, &cc[i]);
+        if (t < n) {
+            if (i) orderAdvance(d, g.order, t, q);
+            fl[i] = orderedFlag(d, mode, src, t, q, &cc[i]);
+        }
         cnt += fl[i];
     }
     int tot;
@@ -765,12 +783,41 @@ __device__ inline bool ilDecode(const ILDesc& D, const Grid& g, int64_t u, int* 
     *lin = lin3(d, i, j, k);
     return true;
 }
+// The SCAN_ITEMS = 8 consecutive positions a thread takes, decoded once (kind-major order only): they are eight x-neighbours of one kind
+// in one row of a lattice block — group, linear index of the first, how many of them lie inside the grid.  (One decode per position was
+// a third of the numbering's 2.6 ms at 256^3: 64-bit divisions.)
+__device__ inline void ilDecode8(const ILDesc& D, const Grid& g, int64_t base, int* grp, int64_t* lin0, int* nIn) {
+    *nIn = 0; *grp = 0; *lin0 = 0;
+    if (base >= D.total) return;
+    const unsigned per = 4096u * (unsigned)D.ngroups;
+    const int bs = (int)(base / per);
+    const unsigned rem = (unsigned)(base - (int64_t)bs * per);
+    const int b = D.blockMap ? D.blockMap[bs] : bs;
+    const unsigned pl = rem / (256u * (unsigned)D.ngroups), r2 = rem - pl * 256u * (unsigned)D.ngroups;
+    const int gg = (int)(r2 >> 8), v = (int)((pl << 8) | (r2 & 255u));
+    const int sbv = D.SBx * D.SBy * D.SBz;
+    const int sb = b / sbv, wi = b - sb * sbv;
+    const int bx = (sb % D.NSx) * D.SBx + wi % D.SBx, by = ((sb / D.NSx) % D.NSy) * D.SBy + (wi / D.SBx) % D.SBy,
+              bz = (sb / (D.NSx * D.NSy)) * D.SBz + wi / (D.SBx * D.SBy);
+    const int i = 16 * bx + (v & 15) - D.ox, j = 16 * by + ((v >> 4) & 15) - D.oy, k = 16 * bz + (v >> 8) - D.oz;
+    const int3 d = g.dims(D.sample[gg]);
+    *grp = gg;
+    if (i < 0 || j < 0 || k < 0 || j >= d.y || k >= d.z || i >= d.x) return;   // (i >= 0 and a multiple of 8 here: the origin offsets are 0)
+    *lin0 = lin3(d, i, j, k);
+    *nIn = min(SCAN_ITEMS, d.x - i);
+}
 __global__ void k_il_count(ILDesc D, Grid g, Set7<const int32_t> lab, int32_t* __restrict__ blockSums) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int cnt = 0;
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int grp; int64_t c;
-        if (ilDecode(D, g, base + i, &grp, &c) && ilFlag(D, g, lab, grp, c)) cnt += D.weight[grp];
+    if (D.planeMajor) {
+        int grp, nIn; int64_t lin0;
+        ilDecode8(D, g, base, &grp, &lin0, &nIn);
+        for (int i = 0; i < nIn; ++i) if (ilFlag(D, g, lab, grp, lin0 + i)) cnt += D.weight[grp];
+    } else {
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            int grp; int64_t c;
+            if (ilDecode(D, g, base + i, &grp, &c) && ilFlag(D, g, lab, grp, c)) cnt += D.weight[grp];
+        }
     }
     int tot;
     blockExclusiveScan(cnt, &tot);
@@ -782,19 +829,29 @@ __global__ void k_il_assign(ILDesc D, Grid g, Set7<const int32_t> lab, const int
     int w[SCAN_ITEMS], gr[SCAN_ITEMS];
     int64_t cc[SCAN_ITEMS];
     int cnt = 0;
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        w[i] = 0; gr[i] = 0; cc[i] = 0;
-        if (ilDecode(D, g, base + i, &gr[i], &cc[i]) && ilFlag(D, g, lab, gr[i], cc[i])) w[i] = D.weight[gr[i]];
-        cnt += w[i];
+    if (D.planeMajor) {
+        int grp, nIn; int64_t lin0;
+        ilDecode8(D, g, base, &grp, &lin0, &nIn);
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            gr[i] = grp; cc[i] = lin0 + i;
+            w[i] = (i < nIn && ilFlag(D, g, lab, grp, lin0 + i)) ? D.weight[grp] : 0;
+            cnt += w[i];
+        }
+    } else {
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            w[i] = 0; gr[i] = 0; cc[i] = 0;
+            if (ilDecode(D, g, base + i, &gr[i], &cc[i]) && ilFlag(D, g, lab, gr[i], cc[i])) w[i] = D.weight[gr[i]];
+            cnt += w[i];
+        }
     }
     int tot;
     int off = blockExclusiveScan(cnt, &tot) + blockOffs[blockIdx.x];
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        if (base + i == D.probe[0]) probeOut[0] = off;
-        if (base + i == D.probe[1]) probeOut[1] = off;
-        if (base + i < D.total && (base + i) % ((int64_t)4096 * D.ngroups) == 0) blockStart[(base + i) / ((int64_t)4096 * D.ngroups)] = off;
+    // (block starts and the probes are multiples of 4096 ngroups, a thread's first position is a multiple of 8: only that one can be either)
+    if (base == D.probe[0]) probeOut[0] = off;
+    if (base == D.probe[1]) probeOut[1] = off;
+    if (base < D.total && base % ((int64_t)4096 * D.ngroups) == 0) blockStart[base / ((int64_t)4096 * D.ngroups)] = off;
+    for (int i = 0; i < SCAN_ITEMS; ++i)
         if (w[i]) { outs.p[gr[i]][cc[i]] = off; off += w[i]; }
-    }
 }
 // are all volume fractions of the array multiples of 1/8 (the 2x2x2 sampler's)?  Then every stencil value is an int8 code times
 // 1 / (64 dx) (ps_blocks.hip: encodeVal) and the SpMVs will run the row-per-lane kernels on the coded stream
