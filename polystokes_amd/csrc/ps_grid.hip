@@ -1257,7 +1257,6 @@ __global__ void k_slice(const int32_t* __restrict__ src, int3 d, int axis, int l
 void ps_context::buildHaloLists() {
     for (int a = 0; a < 3; ++a) nLowHalo[a] = nLowOwn[a] = nUpHalo[a] = nUpOwn[a] = 0;
     if (!slabEnabled) return;
-    const Own ow = own();
     DevBuf<int32_t>& scr = scrSlice;
     // the slice of sample grid s perpendicular to `axis` at `layer`, over the positions this rank owns along the two other axes (the
     // neighbour across the cut owns the same cross-section: the bricks of a row share their ranges)
@@ -1296,7 +1295,6 @@ void ps_context::buildHaloLists() {
             for (size_t q = 0; q < sl.size(); ++q) { const int32_t b = sl[q]; if (b >= 0) { list.push_back(b); mix(h, (uint64_t)q * 8 + (uint64_t)s); } }
         }
     };
-    (void)ow;
     auto up = [&](const std::vector<int32_t>& h, DevBuf<int32_t>& d, int64_t& n) {
         n = (int64_t)h.size();
         d.alloc(h.size());
