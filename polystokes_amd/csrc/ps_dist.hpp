@@ -791,8 +791,9 @@ struct Dist {
                         l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                         order(c, 4, true);
                         fr.rPart = f.fR + f.tB;
-                        l.L.stList = c->distList[3].p; l.L.nStList = c->nDistList[3];
+                        l.L.stList = c->distList[3].p; l.L.nStList = c->nDistList[3]; l.L.stOwnedOnly = true;
                         l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
+                        l.L.stOwnedOnly = false;
                     }
                     contributionsBack(&ps_context::Ap, true, false);   // [comm stream] the owners correct r from the receive buffers below
                     for (size_t q = 0; q < R.size(); ++q) {

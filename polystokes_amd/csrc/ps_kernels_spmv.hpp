@@ -764,7 +764,8 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell(const uint16_t* __restrict__ 
 // MODE 0 .. 3 as k_spmv_St_pipe (same prologue, same per-row epilogue, same thread <-> row assignment: bit-identical partial sums)
 // FX (MODE 3 only): facts about the launch as compile-time constants, each worth buffer descriptors and branches (the generic MODE 3
 // needs 100 SGPRs, spills them into VGPR lanes and fits 6 waves per SIMD).  Bit 0: value-set coded uInv and no Chebyshev first term
-// (the Jacobi / identity PCG step); bit 1: a single domain (no halo rows, no all-reduced sums, one launch).
+// (the Jacobi / identity PCG step); bit 1: a single domain (no halo rows, no all-reduced sums, one launch); bit 2: a rank's launch over
+// chunks of owned rows only (ps_dist.hpp: the St launch that runs under the exchange — most of a rank's rows).
 template <int MODE, int POL, int FX, bool LIST>
 __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                     const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
@@ -778,6 +779,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
     static_assert(FX == 0 || MODE == 3, "FX: MODE 3 only");
     if (FX & 1) { fr.cz = nullptr; fr.dinv64 = nullptr; uInv = nullptr; }                                              // (the launch site guarantees uCode != null)
     if (FX & 2) { fr.yOut = nullptr; fr.rStride = 0; fr.red = nullptr; fr.ownLo = 0; fr.ownHi = rows; }
+    if (FX & 4) { fr.yOut = nullptr; fr.ownLo = 0; fr.ownHi = rows; }   // a rank of a decomposition, chunks of OWNED rows only (the launch under the exchange): no halo row to hand on
     const bool coded = (FX & 1) ? true : uCode != nullptr;
     __shared__ double dict[MODE != 1 ? 256 : 1];
     if (MODE != 1 && coded) dict[threadIdx.x] = uDict[threadIdx.x];

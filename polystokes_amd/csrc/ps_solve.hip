@@ -55,6 +55,7 @@ struct Launch {
     // chunk lists (row-per-lane kernels only; null: every chunk): ps_dist.hpp launches the chunks next to a cut and the others separately
     const int32_t* sList = nullptr; int nSList = 0;
     const int32_t* stList = nullptr; int nStList = 0;
+    bool stOwnedOnly = false;        // the St chunk list holds owned rows only (the decomposition's launch under the exchange): FX bit 2
     bool listsOk() const { return pipeGrid > 0 && c->S.col16ok && c->S.packed && c->S.ellok && c->St.col16ok && c->St.packed && c->St.ellok; }
     // workgroups of a launch over n chunks of S / St (the partial sums it writes)
     int sBlocksFor(int n) const { int xcd = xcdAware; return n > 0 ? pipeBlocks(n, xcd, true, sCap()) : 0; }
@@ -172,6 +173,7 @@ struct Launch {
             // MODE 3 specialisations (k_spmv_St_ell: FX): coded uInv without the Chebyshev term, in a single domain (3) or on a slab rank (1)
             const bool coded3 = mode == 3 && c->uCoded && !fr.cz, single3 = coded3 && plain3Hint && !fr.yOut && !fr.red && fr.rStride == 0;
             if (single3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 3); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 3); else PS_LAUNCH_TEX(3, 0, 3); }
+            else if (coded3 && stOwnedOnly && stList) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEL(3, 3, 5, true); else if (pol == 1) PS_LAUNCH_TEL(3, 1, 5, true); else PS_LAUNCH_TEL(3, 0, 5, true); }
             else if (coded3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 1); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 1); else PS_LAUNCH_TEX(3, 0, 1); }
             else if (mode == 0) PS_LAUNCH_TE2(0); else if (mode == 1) PS_LAUNCH_TE2(1); else if (mode == 2) PS_LAUNCH_TE2(2); else PS_LAUNCH_TE2(3);
 #undef PS_LAUNCH_TE2
