@@ -227,7 +227,7 @@ bool HDK_PolyStokes::solveGasSubclass(SIM_Engine& engine, SIM_Object* obj, SIM_T
         surfaceField->getField()->getVoxelRes(rx, ry, rz);
         in.nx = rx; in.ny = ry; in.nz = rz;
     }
-    in.dx = (float)dx; in.dt = (float)dt; in.density = constantLiquidDensity;
+    in.dx = dx; in.dt = dt; in.density = constantLiquidDensity;   // fpreal (double) like HDK_PolyStokes.C:319-320
     const UT_Vector3 orig = velocityField->getOrig();
     in.orig[0] = orig.x(); in.orig[1] = orig.y(); in.orig[2] = orig.z();
     for (int a = 0; a < 3; ++a) { in.vel[a] = vel[a].data(); in.collisionvel[a] = cvel[a].data(); }
