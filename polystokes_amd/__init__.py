@@ -108,11 +108,11 @@ def lib():
     return _lib
 
 
-_DT = {(4, "i"): np.int32, (4, "f"): np.float32, (8, "f"): np.float64, (4, "u"): np.uint32}
+_DT = {(1, "i"): np.int8, (4, "i"): np.int32, (4, "f"): np.float32, (8, "f"): np.float64, (4, "u"): np.uint32}
 
 
 def _kind(name):
-    if name.endswith(("Labels", "Indices", ".col", ".ptr", "Region", "Perm")) or name.startswith("faceRow"):
+    if name.endswith(("Labels", "Indices", ".col", ".ptr", "Region", "Perm", ".chunkInfo", ".chunkRep", ".code")) or name.startswith("faceRow"):
         return "i"
     if name in ("valuesCoded", "columns16", "diagonalsCoded", "fusedStep", "streamRuns", "rowPerLane"):
         return "i"

@@ -237,11 +237,21 @@ struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
     void alloc(size_t count) {
-        if (count <= n && p) return;
+        if (count <= n && p) { poison(); return; }
         free();
         if (count == 0) count = 1;
         HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
         n = count;
+        poison();
+    }
+    // PS_DEBUG_POISON=1 (tests only): whatever alloc() hands out — a fresh block or the buffer a previous step left — is filled with
+    // 0xff bytes (NaN / -1) first, so that a kernel consuming words nobody wrote this step shows up in the results
+    void poison() {
+        static const bool on = getenv("PS_DEBUG_POISON") && atoi(getenv("PS_DEBUG_POISON")) != 0;
+        if (!on || !p) return;
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemset((void*)p, 0xff, n * sizeof(T)));
+        HIP_CHECK(hipDeviceSynchronize());
     }
     void free() {
         if (p) (void)hipFree(p);

@@ -217,7 +217,11 @@ int ps_context::solveStage(ps_stats* stats) {
     }
     T.mark(1);
     buildValidFaces();
-    const bool apply = P.doSolve && result != PS_UNSUPPORTED_SOLVER && result != PS_INCOMPLETE && (result == PS_SUCCESS || P.keepNonConvergedResults);
+    // HDK_PolyStokes.C:566-583: recovery and write-back run when the solve succeeded OR keepNonConvergedResults is set — also with
+    // doSolve off (result INCOMPLETE; the solution vector then still holds the zeros of assemble(), AssembleSystem.cpp:469, and the
+    // velocities come out as u = McInv rhs_a on active faces, the smoothed fit on reduced ones).  "Unsupported Solver." returns
+    // before any of it (:530-535); an interrupted solve (this library's extension) leaves the field alone.
+    const bool apply = result != PS_UNSUPPORTED_SOLVER && !(P.doSolve && interrupted) && (result == PS_SUCCESS || P.keepNonConvergedResults);
     if (apply) {
         recoverVelocityFromPressureStress();
         T.mark(2);
@@ -304,6 +308,12 @@ void ps_context::registerArrays() {
     reg("rowPerm", permRow.p, nActiveVs, 4);
     reg("S.ptr", S.ptr.p, S.rows + 1, 4); reg("S.col", S.col.p, S.nnz, 4); reg("S.val", S.val.p, S.nnz, 8);
     reg("St.ptr", St.ptr.p, St.rows + 1, 4); reg("St.col", St.col.p, St.nnz, 4); reg("St.val", St.val.p, St.nnz, 8);
+    // the chunk tables of the compressed streams (4 int32 per chunk: run begin, entries | rows << 16, first row, run owner's first row),
+    // the coded values and the chunk each chunk shares its run with: for the layout studies of scripts/
+    if (S.col16ok) { reg("S.chunkInfo", S.chunkInfo.p, (int64_t)S.nChunks * 4, 4); reg("S.chunkRep", S.chunkRep.p, S.nChunks, 4); }
+    if (St.col16ok) { reg("St.chunkInfo", St.chunkInfo.p, (int64_t)St.nChunks * 4, 4); reg("St.chunkRep", St.chunkRep.p, St.nChunks, 4); }
+    if (S.packed) reg("S.code", S.code.p, S.nnz, 1);
+    if (St.packed) reg("St.code", St.code.p, St.nnz, 1);
     reg("reducedRowFace", rrowFace.p, nReducedRows, 4);
     reg("reducedRowRegion", rrowRegion.p, nReducedRows, 4);
     static const char* ax[3] = {"X", "Y", "Z"};

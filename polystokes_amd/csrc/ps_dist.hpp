@@ -60,8 +60,9 @@ __global__ void __launch_bounds__(64) k_chunk_flags_S(const int32_t* __restrict_
     if (__any(out) && threadIdx.x == 0) flag[blockIdx.x] = 1;
     else if (threadIdx.x == 0) flag[blockIdx.x] = 0;
 }
-// Chunks of St: 0 = halo rows without entries (nothing to do), 1 = owned rows only, 2 = holds halo rows WITH entries (this rank's
-// share of the neighbour's A p)
+// Chunks of St: 0 = halo rows without entries (nothing to do), 1 = owned rows ONLY (every row of the chunk inside [ownLo, ownHi): the
+// launch compiled for that treats all of its rows as owned), 2 = holds halo rows — with entries (this rank's share of the neighbour's
+// A p), or empty ones next to owned rows (a chunk that straddles ownHi: short lattice-block ranges are packed with their neighbours)
 __global__ void k_chunk_flags_St(const int32_t* __restrict__ ptr, const int4* __restrict__ chunkInfo, int nChunks, int ownLo, int ownHi, int32_t* __restrict__ flag) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nChunks) return;
@@ -69,7 +70,21 @@ __global__ void k_chunk_flags_St(const int32_t* __restrict__ ptr, const int4* __
     const int r0 = ci.z, r1 = ci.z + (int)((unsigned)ci.y >> 16);
     const int lo = max(r0, ownLo), hi = min(r1, ownHi);
     const int all = ptr[r1] - ptr[r0], owned = hi > lo ? ptr[hi] - ptr[lo] : 0;
-    flag[c] = (all - owned) > 0 ? 2 : (hi > lo ? 1 : 0);
+    const bool inside = r0 >= ownLo && r1 <= ownHi;
+    flag[c] = (all - owned) > 0 ? 2 : (hi > lo ? (inside ? 1 : 2) : 0);
+}
+// A halo row that RECEIVES relayed contributions (k_relay2: v[j] += ... for j >= ownHi) must be rewritten by the St launch of every
+// iteration, else the sums of earlier iterations stay in it: its chunk goes to the list whose launch stores the halo rows' y
+__global__ void k_chunk_flags_relay(const int32_t* __restrict__ listA, int64_t nA, const int32_t* __restrict__ listB, int64_t nB, int ownHi,
+                                    const int4* __restrict__ chunkInfo, int nChunks, int32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nA + nB) return;
+    const int j = i < nA ? listA[i] : listB[i - nA];
+    if (j < ownHi) return;
+    int lo = 0, hi = nChunks - 1;                         // the last chunk whose first row is <= j (chunks are consecutive row ranges)
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chunkInfo[mid].z <= j) lo = mid; else hi = mid - 1; }
+    const int4 ci = chunkInfo[lo];
+    if (j >= ci.z && j < ci.z + (int)((unsigned)ci.y >> 16)) flag[lo] = 2;
 }
 // out[q] = sum of partial[q*stride .. q*stride+count)   (q < nq), one block
 __global__ void __launch_bounds__(BS) k_sumq(const CGScalars* __restrict__ sc, const double* __restrict__ partial, int count, int stride, int nq,
@@ -602,6 +617,10 @@ struct Dist {
             for (int i = 0; i < nS; ++i) lists[h[(size_t)i] ? 1 : 0].push_back(i);
             hipLaunchKernelGGL(k_chunk_flags_St, dim3(gridFor(nT, BS)), dim3(BS), 0, c->stream, (const int32_t*)c->St.ptr.p, (const int4*)c->St.chunkInfo.p, nT,
                                (int)c->ownLo, (int)c->ownHi, flags.p);
+            for (int a = 0; a < 3; ++a)
+                if (c->nLowOwn[a] + c->nUpOwn[a] > 0)
+                    hipLaunchKernelGGL(k_chunk_flags_relay, dim3(gridFor(c->nLowOwn[a] + c->nUpOwn[a], BS)), dim3(BS), 0, c->stream, (const int32_t*)c->listLowOwn[a].p, c->nLowOwn[a],
+                                       (const int32_t*)c->listUpOwn[a].p, c->nUpOwn[a], (int)c->ownHi, (const int4*)c->St.chunkInfo.p, nT, flags.p);
             HIP_CHECK(hipMemcpyAsync(h.data(), flags.p, (size_t)nT * 4, hipMemcpyDeviceToHost, c->stream));
             HIP_CHECK(hipStreamSynchronize(c->stream));
             for (int i = 0; i < nT; ++i) { if (h[(size_t)i] == 2) lists[2].push_back(i); else if (h[(size_t)i] == 1) lists[3].push_back(i); }
@@ -625,6 +644,7 @@ struct Dist {
             exchangeAddY(&ps_context::dinv);
             for (ps_context* c : R) {
                 const int64_t n = c->ownHi - c->ownLo;
+                if (jac) HIP_CHECK(hipMemsetAsync(c->dinvF.p, 0, (size_t)std::max<int64_t>(c->nSystem, 1) * sizeof(float), c->stream));   // (halo rows: never read as a diagonal)
                 if (n > 0) {
                     hipLaunchKernelGGL(k_invert_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, n);
                     if (jac) hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);
@@ -659,6 +679,16 @@ struct Dist {
             Loc& l = loc[q];
             HIP_CHECK(hipMemsetAsync(c->pvec.p, 0, (size_t)std::max<int64_t>(c->nSystem, 1) * 8, c->stream));
             HIP_CHECK(hipMemsetAsync(c->dotPartials3.p, 0, VGRID * sizeof(double), c->stream));
+            // halo rows: A p there is this rank's share of a neighbour's row (or nothing: rows no launch of the overlapped step
+            // touches are still packed by contributionsBack), r is never this rank's — neither may hold what an earlier step left
+            if (c->nSystem > c->ownHi) {
+                HIP_CHECK(hipMemsetAsync(c->Ap.p + c->ownHi, 0, (size_t)(c->nSystem - c->ownHi) * 8, c->stream));
+                HIP_CHECK(hipMemsetAsync(c->r.p + c->ownHi, 0, (size_t)(c->nSystem - c->ownHi) * 8, c->stream));
+            }
+            if (c->ownLo > 0) {
+                HIP_CHECK(hipMemsetAsync(c->Ap.p, 0, (size_t)c->ownLo * 8, c->stream));
+                HIP_CHECK(hipMemsetAsync(c->r.p, 0, (size_t)c->ownLo * 8, c->stream));
+            }
             hipLaunchKernelGGL(k_cg_init_f, dim3(l.vb), dim3(BS), 0, c->stream, c->b.p + l.lo, l.dv, c->x.p + l.lo, c->r.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials.p);
             hipLaunchKernelGGL(k_sumq, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)nullptr, c->dotPartials.p, l.vb, 0, 1, c->redbuf.p);
         }
@@ -1059,7 +1089,8 @@ int distStep(Dist& D, ps_stats* stats) {
     if (c0->P.doSolve) result = D.solve();
     D.syncAll();
     const auto w2 = std::chrono::high_resolution_clock::now();
-    const bool apply = c0->P.doSolve && result != PS_UNSUPPORTED_SOLVER && result != PS_INCOMPLETE && (result == PS_SUCCESS || c0->P.keepNonConvergedResults);
+    // (as ps_context::solveStage: HDK_PolyStokes.C:566-583 — also with doSolve off, then from the zero solution vector)
+    const bool apply = result != PS_UNSUPPORTED_SOLVER && !(c0->P.doSolve && c0->interrupted) && (result == PS_SUCCESS || c0->P.keepNonConvergedResults);
     D.recoverAndWriteBack(apply);
     for (ps_context* c : D.R) {
         c->lastStats.solveData[0] = c->solveError;

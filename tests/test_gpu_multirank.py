@@ -194,3 +194,76 @@ def test_group_bicgstab_fallback_matches_single_domain():
             assert np.abs(grp.vel[a] - single.vel[a]).max() <= 20 * p.tolerance * scale
     grp.close()
     single.close()
+
+
+def _compare_with_single(single, grp, sc, p, tag):
+    rc1 = single.step(sc, p)
+    rc2 = grp.solve_scene(sc, p)
+    assert rc1 == rc2 == abi.SUCCESS, tag
+    it1, it2 = single.stats.solveData[1], grp.stats.solveData[1]
+    assert abs(it1 - it2) <= max(2, 0.02 * it1), (tag, it1, it2)
+    for a in range(3):
+        assert np.array_equal(grp.valid[a], single.valid[a]), tag
+        scale = max(np.abs(single.vel[a]).max(), 1e-30)
+        assert np.isfinite(grp.vel[a]).all(), tag
+        assert np.abs(grp.vel[a] - single.vel[a]).max() <= 20 * p.tolerance * scale, tag
+
+
+@pytest.mark.skipif(__import__("os").environ.get("PS_TEST_REUSE_CHILD") != "1", reason="runs in the child of the test below")
+@pytest.mark.parametrize("dims", [None, (2, 2, 1), (2, 1, 2)])
+def test_reused_group_child(dims):
+    """One Group (and one single-domain context) stepped through scenes with DIFFERENT free surfaces — so a different DOF numbering,
+    different halo rows and chunk lists in buffers the previous step sized and filled (halo rows of A p that no launch of
+    the overlapped four-kernel step writes were packed for the neighbours all the same)."""
+    import polystokes_amd
+    world = 2 if dims is None else dims[0] * dims[1] * dims[2]
+    single = polystokes_amd.Solver(0)
+    grp = polystokes_amd.Group(world, dims=dims)
+    seq = [scenes.spheres(64), scenes.coil(64), _tall_coil(32, 64) if dims is None else scenes.cavity(64, tile=16), scenes.spheres(64)]
+    for i, (sc, p) in enumerate(seq):
+        p.preconditioner = abi.PRE_DIAGONAL if i % 2 == 0 else abi.PRE_IDENTITY
+        _compare_with_single(single, grp, sc, p, (dims, i, sc.name))
+    grp.close()
+    single.close()
+
+
+@pytest.mark.skipif(__import__("os").environ.get("PS_TEST_CHILD") == "1", reason="this IS the child run")
+@pytest.mark.parametrize("poison", ["0", "1"])
+def test_group_reused_across_scenes_with_the_four_kernel_step(poison):
+    """ADVICE r03 (high / medium / low): contexts reused across uploads with another numbering, the overlapped four-kernel step forced;
+    with PS_DEBUG_POISON=1 every buffer alloc() hands out is filled with NaN / -1 first, so a word nobody wrote this step shows."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PS_FUSED_R="1", PS_TEST_CHILD="1", PS_TEST_REUSE_CHILD="1", PS_DEBUG_POISON=poison)
+    pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                         "-k", "test_reused_group_child"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    assert pr.returncode == 0, pr.stdout[-3000:]
+
+
+@pytest.mark.parametrize("mode", ["dosolve_off_keep", "dosolve_off_drop", "noconverge_keep", "noconverge_drop"])
+def test_group_parameter_paths_match_single_domain(mode):
+    """doSolve = 0 and keepNonConvergedResults = 0 across a cut (HDK_PolyStokes.C:513,566,590-605; ps_dist.hpp:distStep): result code,
+    valid faces and the velocity field of a 2-rank group against the single domain."""
+    import polystokes_amd
+    sc, p = scenes.spheres(32, tile=8)
+    if mode.startswith("dosolve_off"):
+        p.doSolve = 0
+    else:
+        p.maxSolverIterations = 4
+    p.keepNonConvergedResults = 1 if mode.endswith("keep") else 0
+    single = polystokes_amd.Solver(0)
+    rc1 = single.step(sc, p)
+    grp = polystokes_amd.Group(2)
+    rc2 = grp.solve_scene(sc, p)
+    assert rc1 == rc2 == (abi.INCOMPLETE if p.doSolve == 0 else abi.NOCONVERGE)
+    for a in range(3):
+        assert np.array_equal(grp.valid[a], single.valid[a])
+        if mode.endswith("drop"):
+            assert np.array_equal(grp.vel[a], np.asarray(sc.vel[a], np.float32).reshape(grp.vel[a].shape))
+            assert np.array_equal(single.vel[a], grp.vel[a])
+        else:
+            scale = max(np.abs(single.vel[a]).max(), 1e-30)
+            assert np.abs(grp.vel[a] - single.vel[a]).max() <= (1e-6 if p.doSolve == 0 else 1e-2) * scale
+    grp.close()
+    single.close()

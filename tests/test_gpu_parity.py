@@ -695,3 +695,47 @@ def test_bad_parameters_are_refused(gpu):
     with pytest.raises(RuntimeError, match="density"):
         gpu.upload(bad, p)
     assert gpu.step(sc, p) == abi.SUCCESS   # the context stays usable
+
+
+@pytest.mark.parametrize("keep", [1, 0])
+def test_do_solve_off_follows_the_reference(gpu, oracle_mod, keep):
+    """HDK_PolyStokes.C:513,566-583: with doSolve off the result stays INCOMPLETE; the valid field is still built; with
+    keepNonConvergedResults (the default) recovery and write-back run all the same — from the ZERO solution vector of assemble()
+    (AssembleSystem.cpp:469): u = McInv rhs_a on active faces, the tile's smoothed fit on reduced ones; with it off the velocity
+    field is left alone."""
+    sc, p = scenes.spheres(32, tile=8)
+    p.doSolve, p.keepNonConvergedResults = 0, keep
+    o = oracle_mod.Oracle()
+    ro = o.run(sc, p)
+    rc = gpu.step(sc, p)
+    assert rc == ro == abi.INCOMPLETE
+    for a in range(3):
+        assert np.array_equal(gpu.valid[a].ravel(), o.array("valid" + "XYZ"[a]))
+        vo = o.array("vel" + "XYZ"[a])
+        if keep:
+            assert np.abs(gpu.vel[a].ravel() - vo).max() <= 1e-6 * max(np.abs(vo).max(), 1e-30)
+            assert not np.array_equal(vo, np.asarray(sc.vel[a], np.float32).ravel())      # (the reference does change the field here)
+        else:
+            assert np.array_equal(gpu.vel[a].ravel(), np.asarray(sc.vel[a], np.float32).ravel())
+            assert np.array_equal(vo, np.asarray(sc.vel[a], np.float32).ravel())
+
+
+@pytest.mark.parametrize("keep", [1, 0])
+def test_noconverge_with_and_without_keeping_the_results(gpu, oracle_mod, keep):
+    """HDK_PolyStokes.C:566,590-605: a solve that runs out of iterations (PCG, then the BiCGStab retry) returns NOCONVERGE; its
+    iterate is written back only with keepNonConvergedResults."""
+    sc, p = scenes.blob(seed=6)
+    p.maxSolverIterations, p.keepNonConvergedResults = 5, keep
+    o = oracle_mod.Oracle()
+    ro = o.run(sc, p)
+    rc = gpu.step(sc, p)
+    assert rc == ro == abi.NOCONVERGE
+    assert o.stats.usedBiCGStab == 1 and gpu.stats.usedBiCGStab == 1
+    for a in range(3):
+        assert np.array_equal(gpu.valid[a].ravel(), o.array("valid" + "XYZ"[a]))
+        vo = o.array("vel" + "XYZ"[a])
+        if keep:      # five BiCGStab iterations from zero on both sides: the same iterate up to the summation order of the dots
+            assert np.abs(gpu.vel[a].ravel() - vo).max() <= 1e-3 * max(np.abs(vo).max(), 1e-30)
+        else:
+            assert np.array_equal(gpu.vel[a].ravel(), np.asarray(sc.vel[a], np.float32).ravel())
+            assert np.array_equal(vo, np.asarray(sc.vel[a], np.float32).ravel())
