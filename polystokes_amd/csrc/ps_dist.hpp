@@ -148,8 +148,14 @@ struct Rccl {
 Rccl& rccl() {
     static Rccl R;
     if (!R.h) {
+        // PS_RCCL_LIB (tests only): another library exporting the same eight entry points — tests/stub_rccl, the stand-in that lets
+        // this asynchronous branch run with several ranks on ONE GPU (real RCCL refuses duplicate devices)
+        if (const char* alt = getenv("PS_RCCL_LIB")) {
+            R.h = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
+            if (!R.h) throw Error(std::string("cannot load PS_RCCL_LIB: ") + dlerror());
+        }
         // a copy the process has already mapped (torch links its own) must be THE copy: two RCCLs on one device abort at exit
-        R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!R.h) R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
         if (!R.h) R.h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
         if (!R.h) R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!R.h) R.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -309,6 +315,8 @@ struct Dist {
     // everything queued on `from` so far happens before what is queued on `to` from now on
     void order(ps_context* c, int ev, bool mainToComm) {
         if (!c->commStream || c->commStream == c->stream) return;
+        static const int skipEv = getenv("PS_DIST_SKIP_ORDER") ? atoi(getenv("PS_DIST_SKIP_ORDER")) : -1;   // tests only: drop one ordering edge
+        if (ev == skipEv) return;                                                                             // (a transport that hides the race proves nothing)
         hipStream_t from = mainToComm ? c->stream : c->commStream, to = mainToComm ? c->commStream : c->stream;
         HIP_CHECK(hipEventRecord(c->distEv[ev], from));
         HIP_CHECK(hipStreamWaitEvent(to, c->distEv[ev], 0));

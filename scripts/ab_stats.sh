@@ -11,7 +11,7 @@ for round in 1 2; do
 for L in "$@"; do
   N=$(basename $L .so)_$round
   if [ "$L" = "HEAD" ]; then unset PS_LIB; else export PS_LIB=$R/$L; fi
-  rocprofv3 --kernel-trace --stats -d $OUT/$N -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/$N.json 2> $OUT/$N.err
+  rocprofv3 --kernel-trace --stats -d $OUT/$N -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-strong-512 > $OUT/$N.json 2> $OUT/$N.err
   echo "$N done" >> $OUT/progress
 done
 done

@@ -9,7 +9,7 @@ for round in 1 2; do
   i=0
   for S in "$@"; do
     i=$((i+1))
-    env $S python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $OUT/s${i}_$round.json 2> $OUT/s${i}_$round.err
+    env $S python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-512 ${BENCH_ARGS} > $OUT/s${i}_$round.json 2> $OUT/s${i}_$round.err
     python3 - "$OUT/s${i}_$round.json" "$S" "$round" <<'PY'
 import json, sys
 try:

@@ -9,18 +9,10 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 bad = 0
 single = polystokes_amd.Solver(0)
 only = os.environ.get("FUZZ_ONLY")
-DIMS = [(2, 2, 1), (2, 1, 2), (1, 2, 2), (2, 2, 2), (3, 1, 2), (1, 3, 2), (2, 2, 3)]
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from helpers import fuzz_brick_case          # the case generator lives with the tests (tests/test_gpu_multirank.py replays the hard seeds)
 for case in ([int(only)] if only else range(n_cases)):
-    rng = np.random.RandomState(seed0 + case)
-    dims = DIMS[int(rng.randint(len(DIMS)))]
-    tile = int(rng.choice([8, 16, 16]))
-    n = [16 * int(rng.randint(d, d + 2)) if d > 1 else int(rng.randint(16, 40)) for d in dims]
-    n = [max(v, 16 * d) for v, d in zip(n, dims)]
-    sc, p = scenes.blob(n[0], n[1], n[2], seed=seed0 + case, tile=tile, pad=int(rng.choice([1, 2])), variable_viscosity=bool(rng.randint(2)))
-    p.preconditioner = int(rng.choice([abi.PRE_IDENTITY, abi.PRE_DIAGONAL, abi.PRE_CHEBYSHEV]))
-    p.activeLiquidBoundaryLayerSize = int(rng.choice([1, 2, 3])); p.activeSolidBoundaryLayerSize = int(rng.choice([0, 1, 2]))
-    p.tolerance = float(os.environ.get("FUZZ_TOL", "1e-6"))
-    p.maxSolverIterations = 20000
+    sc, p, dims, n, tile = fuzz_brick_case(seed0 + case, float(os.environ.get("FUZZ_TOL", "1e-6")))
     rc1 = single.step(sc, p)
     world = dims[0] * dims[1] * dims[2]
     grp = polystokes_amd.Group(world, dims=dims)

@@ -10,11 +10,11 @@ mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done" > $OUT/progress
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-strong-512 > $OUT/stats.log 2>&1
 echo "stats done" >> $OUT/progress
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --maxit 20 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --maxit 20 --no-cpu-baseline --no-strong-512 > $OUT/pmc_fetch.log 2>&1
 echo "fetch done" >> $OUT/progress
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --maxit 20 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --maxit 20 --no-cpu-baseline --no-strong-512 > $OUT/pmc_write.log 2>&1
 echo "write done" >> $OUT/progress
 cd $R
 python3 scripts/pmc_summarize.py $OUT > $OUT/pmc_traffic.json

@@ -116,3 +116,23 @@ def merge_dof_field_brick(global_out, local, b, kind, global_n):
         sl_l.append(slice(k0, k1)); sl_g.append(slice(b.origin[a] + k0, b.origin[a] + k1))
     glo[tuple(sl_g)] = loc[tuple(sl_l)]
 
+
+
+# ---- the random brick cases of scripts/fuzz_bricks.py (seed -> scene, parameters, decomposition) ---------------------------------
+FUZZ_BRICK_DIMS = [(2, 2, 1), (2, 1, 2), (1, 2, 2), (2, 2, 2), (3, 1, 2), (1, 3, 2), (2, 2, 3)]
+
+
+def fuzz_brick_case(seed, tol=1e-6):
+    """One random blob scene with a free surface, its parameters and a brick decomposition, all drawn from RandomState(seed)."""
+    from polystokes_amd import scenes
+    rng = np.random.RandomState(seed)
+    dims = FUZZ_BRICK_DIMS[int(rng.randint(len(FUZZ_BRICK_DIMS)))]
+    tile = int(rng.choice([8, 16, 16]))
+    n = [16 * int(rng.randint(d, d + 2)) if d > 1 else int(rng.randint(16, 40)) for d in dims]
+    n = [max(v, 16 * d) for v, d in zip(n, dims)]
+    sc, p = scenes.blob(n[0], n[1], n[2], seed=seed, tile=tile, pad=int(rng.choice([1, 2])), variable_viscosity=bool(rng.randint(2)))
+    p.preconditioner = int(rng.choice([abi.PRE_IDENTITY, abi.PRE_DIAGONAL, abi.PRE_CHEBYSHEV]))
+    p.activeLiquidBoundaryLayerSize = int(rng.choice([1, 2, 3])); p.activeSolidBoundaryLayerSize = int(rng.choice([0, 1, 2]))
+    p.tolerance = float(tol)
+    p.maxSolverIterations = 20000
+    return sc, p, dims, n, tile

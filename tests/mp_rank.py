@@ -37,7 +37,24 @@ def main():
         s.set_brick(sl)
     else:
         s.set_slab(sl)
-    s.comm_init_tcp(rank, world, "127.0.0.1", port)
+    if os.environ.get("PS_TEST_TRANSPORT") == "stub":
+        # the asynchronous (RCCL) branch of the transport on the stand-in library of tests/stub_rccl (PS_RCCL_LIB): the unique id
+        # travels through a file next to the outputs
+        import time
+        uid_path = os.path.join(os.path.dirname(out), "%s.w%d.p%d.uid" % (case, world, port))
+        if rank == 0:
+            with open(uid_path + ".tmp", "wb") as f:
+                f.write(polystokes_amd.comm_unique_id())
+            os.replace(uid_path + ".tmp", uid_path)
+        t0 = time.time()
+        while not os.path.exists(uid_path):
+            time.sleep(0.01)
+            if time.time() - t0 > 120:
+                raise SystemExit("rank 0 never wrote the unique id")
+        s.comm_init(open(uid_path, "rb").read(), rank, world)
+        s.comm_selftest()
+    else:
+        s.comm_init_tcp(rank, world, "127.0.0.1", port)
     if case.endswith("_interrupt") and rank == world - 1:
         s.set_interrupt(lambda: True)     # ONE rank asks to stop: every rank must return PS_INCOMPLETE at the same batch
     try:
@@ -53,6 +70,7 @@ def main():
             res["owned%d" % a] = s.array("owned" + "XYZ"[a])
         res["labels"] = s.array("centerLabels")
         res["fused"] = int(s.array("fusedStep")[0])
+        res["overlap"] = int(bool(s.dist_stats()["overlap"]))
     np.savez(out, **res)
     s.close()
 

@@ -211,3 +211,27 @@ def test_config4_and_5_full_size_single_and_slabs(scene, n, worlds):
             # section 4, AMP).  The tight comparisons are on x (goldens, oracle parity) and on the small multirank scenes.
             assert np.isfinite(grp.vel[a]).all()
         grp.close()
+
+
+def test_velocities_of_decompositions_converge_at_full_size():
+    """The AMP statement as a test at BASELINE config 5's size: spheres 256^3 (mu = 1e4) solved to tol 1e-7 by the
+    single domain, by 4 z-slabs and by 2 x 2 x 2 bricks — at the node's default tolerance 1e-3 their velocities differ by tens of per
+    cent (every one of them satisfies the reference's stop rule), at 1e-7 by <= 5e-3 of the largest velocity (measured 1.6e-3 with
+    scripts/amp_check.py): what separates decompositions at the shipped tolerance is the stop rule, not the decomposition."""
+    import polystokes_amd
+    sc, p = scenes.spheres(256)
+    p.preconditioner, p.tolerance, p.maxSolverIterations = abi.PRE_DIAGONAL, 1e-7, 50000
+    s = polystokes_amd.Solver(0)
+    assert s.step(sc, p) == abi.SUCCESS
+    it1 = int(s.stats.solveData[1])
+    v1 = [v.copy() for v in s.vel]
+    s.close()
+    for world, dims in ((4, None), (8, (2, 2, 2))):
+        grp = polystokes_amd.Group(world, dims=dims)
+        assert grp.solve_scene(sc, p) == abi.SUCCESS
+        it2 = int(grp.stats.solveData[1])
+        assert abs(it1 - it2) <= 0.05 * it1, (world, it1, it2)
+        for a in range(3):
+            d = float(np.abs(grp.vel[a] - v1[a]).max() / max(np.abs(v1[a]).max(), 1e-30))
+            assert d <= 5e-3, (world, dims, a, d)
+        grp.close()

@@ -61,13 +61,67 @@ def _run_ranks(case, world, tmp_path, env=None):
                                   "cavity64_b2x2x1", "cavity_b2x1x2+fused"])
 def test_multiprocess_tcp_matches_single_domain(case, tmp_path):
     """"+fused": the four-kernel PCG step across the slabs (default from 2 M owned rows per rank), forced in the rank processes."""
-    import polystokes_amd
     env = {"PS_FUSED_R": "1"} if case.endswith("+fused") else None
     case = case.replace("+fused", "")
     world = mp_cases.WORLD[case]
     res = _run_ranks(case, world, tmp_path, env)     # children first: the parent's own GPU context comes after
     if env:
         assert all(int(r["fused"]) == 1 for r in res)
+    _compare_with_single_domain(case, world, res)
+
+
+STUB_LIB = os.path.join(HERE, "stub_rccl", "libps_stub_rccl.so")
+
+
+@pytest.mark.parametrize("case", ["cavity_w2+fused", "cavity_w3_jacobi+fused", "coil_w2+fused", "cavity64_b2x2x1+fused", "cavity_b2x1x2+fused",
+                                  "cavity_w2", "cavity_w2_chebyshev", "cavity_w2_bicgstab+fused"])
+def test_multiprocess_async_transport_matches_tcp_and_single_domain(case, tmp_path):
+    """The ASYNCHRONOUS transport branch (Dist::transport / allreduce with useRccl: every send, receive and all-reduce enqueued on the
+    comm stream, ordered against the solver stream by events only) with N > 1 ranks on ONE GPU: the rank processes load tests/stub_rccl
+    in place of librccl (PS_RCCL_LIB) — messages are stream-ordered device copies through hipIpcMemHandle-mapped mailboxes, ordered
+    across the processes by hipIpcEventHandle events, and nothing in it synchronises the host with the device.  (The TCP transport
+    calls hipStreamSynchronize twice per exchange and the in-process group shares one stream: both hide a missing order().)
+    Two processes as slabs, three as slabs, four as 2 x 2 x 1 and 2 x 1 x 2 bricks — the box admits 6 GPU processes, so the 2 x 2 x 2
+    case stays with the in-process groups — overlapped four-kernel step and five-kernel step: the same result as the single domain
+    and, bit for bit, as the run over TCP (same kernels, same reduction order)."""
+    if not os.path.exists(STUB_LIB):
+        pytest.fail("tests/stub_rccl/libps_stub_rccl.so is missing: __graft_entry__.build() compiles it")
+    fused = case.endswith("+fused")
+    case = case.replace("+fused", "")
+    world = mp_cases.WORLD[case]
+    env = {"PS_TEST_TRANSPORT": "stub", "PS_RCCL_LIB": STUB_LIB, "PS_DIST_OVERLAP": "1"}
+    if fused:
+        env["PS_FUSED_R"] = "1"
+    res = _run_ranks(case, world, tmp_path, env)
+    if fused:
+        assert all(int(r["fused"]) == 1 for r in res)
+        if "bicgstab" not in case:
+            assert all(int(r["overlap"]) == 1 for r in res)        # the exchanges really ran under the rows that do not need them
+    _compare_with_single_domain(case, world, res)
+    (tmp_path / "tcp").mkdir()
+    res_tcp = _run_ranks(case, world, tmp_path / "tcp", {"PS_FUSED_R": "1"} if fused else None)
+    for r in range(world):
+        assert int(res[r]["iters"]) == int(res_tcp[r]["iters"]) and int(res[r]["rc"]) == int(res_tcp[r]["rc"])
+        for a in range(3):
+            assert np.array_equal(res[r]["vel%d" % a], res_tcp[r]["vel%d" % a]), (case, r, a)
+
+
+def test_async_transport_exposes_a_missing_stream_order(tmp_path):
+    """The point of the stand-in: with the event that makes the solver stream wait for the unpacked halo values removed
+    (PS_DIST_SKIP_ORDER=1: Dist::order(c, 1, false)), the overlapped step over the asynchronous transport reads stale halo values and
+    the solve goes wrong — the same fault is invisible over TCP, whose host-side synchronisation happens to order the streams."""
+    case, world = "cavity_b2x1x2", 4
+    base_env = {"PS_FUSED_R": "1", "PS_DIST_SKIP_ORDER": "1"}
+    res = _run_ranks(case, world, tmp_path, dict(base_env, PS_TEST_TRANSPORT="stub", PS_RCCL_LIB=STUB_LIB))
+    (tmp_path / "ok").mkdir()
+    good = _run_ranks(case, world, tmp_path / "ok", {"PS_FUSED_R": "1", "PS_TEST_TRANSPORT": "stub", "PS_RCCL_LIB": STUB_LIB})
+    differs = any(int(res[r]["rc"]) != int(good[r]["rc"]) or int(res[r]["iters"]) != int(good[r]["iters"]) or
+                  (int(res[r]["rc"]) in (0, 1) and any(not np.array_equal(res[r]["vel%d" % a], good[r]["vel%d" % a]) for a in range(3))) for r in range(world))
+    assert differs, "the solve without the stream ordering came out bit-identical: the transport hides the race"
+
+
+def _compare_with_single_domain(case, world, res):
+    import polystokes_amd
     sc, p = mp_cases.make(case)
     single = polystokes_amd.Solver(0)
     rc1 = single.step(sc, p)
@@ -133,7 +187,7 @@ def test_bench_two_ranks_produces_one_line_whatever_the_transport(tmp_path):
         two_gpus = False
     env = dict(os.environ, MASTER_PORT=str(_free_port_base(1)))
     pr = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--res", "32", "--steps", "1", "--warmup", "1",
-                         "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, env=env)
+                         "--no-cpu-baseline", "--strong-res", "96"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, env=env)
     assert pr.returncode == 0, pr.stderr[-3000:]
     lines = [l for l in pr.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, pr.stdout[-2000:]
@@ -144,6 +198,16 @@ def test_bench_two_ranks_produces_one_line_whatever_the_transport(tmp_path):
         assert d["transport"] == "rccl"
     else:
         assert d["transport"].startswith("tcp (FALLBACK")
+    # the strong-scaling block of the same invocation (BASELINE config 4 at --strong-res: here the 96^3 coil in two slabs)
+    sb = d["strong_512"]
+    assert sb["n_gpus"] == 2 and sb["scaling"] == "strong" and sb["decomposition"] == "1x1x2 bricks" and sb["ms_per_step"] > 0 and sb["result"] == 1
+    single = polystokes_amd.Solver(0)
+    from polystokes_amd import scenes
+    sc, p = scenes.coil(96)
+    p.preconditioner = 5          # abi.PRE_DIAGONAL: bench.py's default --precond jacobi
+    single.step(sc, p)
+    assert abs(sb["cg_iterations"] - single.stats.solveData[1]) <= max(2, 0.02 * single.stats.solveData[1])
+    single.close()
 
 
 def test_bench_four_ranks_as_bricks(tmp_path):
@@ -152,7 +216,7 @@ def test_bench_four_ranks_as_bricks(tmp_path):
     import json
     env = dict(os.environ, MASTER_PORT=str(_free_port_base(1)))
     pr = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "4", "--bricks", "2x2x1", "--res", "32", "--steps", "1",
-                         "--warmup", "1", "--no-cpu-baseline", "--transport", "tcp"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, env=env)
+                         "--warmup", "1", "--no-cpu-baseline", "--no-strong-512", "--transport", "tcp"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, env=env)
     assert pr.returncode == 0, pr.stderr[-3000:]
     lines = [l for l in pr.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, pr.stdout[-2000:]
