@@ -3,15 +3,22 @@
 // ranks on a box with ONE GPU: real RCCL refuses several ranks on one device, the TCP transport synchronises the host with the device
 // twice per exchange and the in-process group shares one stream — both hide a missing ordering between the solver and the comm stream.
 //
-// Ranks = processes sharing GPU 0.  Every message is stream-ordered on the caller's stream, as in RCCL:
-//   send:  [wait for the receiver's "consumed" event of the slot's previous use]  copy into the receiver's mailbox (device memory of
-//          the receiver, mapped with hipIpcOpenMemHandle)  ->  record the slot's "ready" event (hipEventInterprocess)
-//   recv:  wait for the sender's "ready" event (hipIpcOpenEventHandle)  ->  copy out of the own mailbox  ->  record "consumed"
-// The host never waits for the DEVICE (no hipStreamSynchronize / hipEventSynchronize / hipDeviceSynchronize anywhere): it only waits,
-// through counters in a POSIX shared-memory block, until the peer has ENQUEUED the matching record — an inter-process event wait
-// binds to the records issued before it, so the record call has to come first in host time.  All-reduce = every rank sends its
-// values to every other rank through the same mailboxes, then one kernel adds the `world` contributions in rank order (the same
-// order on every rank: identical results everywhere, like ncclAllReduce's guarantee for a fixed communicator).
+// Ranks = processes sharing GPU 0.  Every message is stream-ordered on the caller's stream, as in RCCL, and NOTHING in it involves the
+// host after the communicator is built (no hipStreamSynchronize / hipEventSynchronize / hipDeviceSynchronize, no host-side handshake):
+//   send k:  [stream waits until the receiver has taken message k - 2, whose mailbox slot this one reuses]
+//            device copy into the receiver's mailbox (its device memory, mapped with hipIpcOpenMemHandle)
+//            -> hipStreamWriteValue32: the receiver's "ready" counter of this pair := k + 1
+//   recv k:  hipStreamWaitValue32 on the own "ready" counter >= k + 1  ->  device copy out of the own mailbox
+//            -> hipStreamWriteValue32: the sender's "consumed" counter of this pair := k + 1
+// The counters live in the same IPC-mapped allocations as the mailboxes; the stream memory operations order the copies of the two
+// processes on the device (measured with scripts/t_ipc_event.hip: a value wait enqueued 0.8 s before the other process' write
+// releases exactly then, the data behind it visible).
+// Why not hipIpcEventHandle events (what this was first built on): HIP's inter-process event carries a ring of 32 signals, and the
+// 33rd hipEventRecord / hipStreamWaitEvent pair on one event fails with hipErrorInvalidValue (seen here at message 64 of a pair with
+// two events) — a solve exchanges thousands of messages per pair.  The value waits have no such limit and need no "record before
+// wait" handshake on the host.
+// All-reduce = every rank sends its values to every other rank through the same mailboxes, then one kernel adds the `world`
+// contributions in rank order (the same order on every rank: identical results everywhere).
 // Loaded by tests only, through PS_RCCL_LIB (ps_dist.hpp).  Not part of the product.
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
@@ -35,86 +42,67 @@ constexpr int CH = 2;               // channel 0: send / recv payloads, channel 
 constexpr size_t AR_BYTES = 64 * 8; // an all-reduce carries <= 64 doubles
 constexpr int ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5;
 
-struct PairCtl {                    // ordered pair (src -> dst), one channel
-    std::atomic<uint64_t> sentEnq;  // messages whose copy + "ready" record the sender has enqueued
-    std::atomic<uint64_t> consEnq;  // messages whose wait + copy-out + "consumed" record the receiver has enqueued
-};
 struct RankCtl {
-    std::atomic<int> ready;                          // 1: handles below are valid; 2: peers opened
-    hipIpcMemHandle_t mailbox;                       // this rank's mailbox allocation
-    hipIpcEventHandle_t evReady[MAXW][CH][SLOTS];    // recorded by THIS rank as sender to [dst]
-    hipIpcEventHandle_t evCons[MAXW][CH][SLOTS];     // recorded by THIS rank as receiver from [src]
+    std::atomic<int> ready;                          // 1: the handle below is valid; 3: this rank has left
+    hipIpcMemHandle_t mailbox;                       // this rank's mailbox allocation (flags page + message slots)
 };
-struct Shm {
-    std::atomic<int> magic;
-    size_t slotBytes;
-    RankCtl rank[MAXW];
-    PairCtl pair[MAXW][MAXW][CH];                    // [src][dst][channel]
-};
+struct Shm { RankCtl rank[MAXW]; };                  // only the start-up handshake goes through the host
 
 struct Op { bool send; const void* sbuf; void* rbuf; size_t bytes; int peer; hipStream_t stream; };
 
+// A rank's allocation: [flags: 4 KB][per source rank: SLOTS payload slots + SLOTS all-reduce slots].
+// Flags (uint32 counters), all written by the PEER with hipStreamWriteValue32 and waited for locally:
+//   ready[src][ch]    at word  (src * CH + ch)            : messages src has delivered into my mailbox
+//   consumed[dst][ch] at word  256 + (dst * CH + ch)      : messages dst has taken out of ITS mailbox that came from me
+constexpr size_t FLAG_BYTES = 4096;
 struct Comm {
     int rank = 0, world = 1;
     Shm* shm = nullptr;
     char shmName[80] = {0};
     size_t slotBytes = 0;
-    char* mailbox = nullptr;                         // own: [src][channel][slot] regions
+    char* mailbox = nullptr;
     char* peerMailbox[MAXW] = {nullptr};
-    hipEvent_t myReady[MAXW][CH][SLOTS] = {}, myCons[MAXW][CH][SLOTS] = {};        // created here
-    hipEvent_t peerReady[MAXW][CH][SLOTS] = {}, peerCons[MAXW][CH][SLOTS] = {};    // opened: peer's ready (as sender to me) / consumed (as receiver from me)
-    uint64_t sendSeq[MAXW][CH] = {}, recvSeq[MAXW][CH] = {};
+    uint32_t sendSeq[MAXW][CH] = {}, recvSeq[MAXW][CH] = {};
     double* arStage = nullptr;                       // world x 64 doubles: the contributions lined up for the sum kernel
     size_t chBytes(int ch) const { return ch == 0 ? slotBytes : AR_BYTES; }
-    size_t regionOff(int src, int ch, int slot) const {    // inside a rank's mailbox
+    size_t regionOff(int src, int ch, int slot) const {    // inside a rank's allocation
         const size_t perSrc = SLOTS * (slotBytes + AR_BYTES);
-        return (size_t)src * perSrc + (ch == 0 ? 0 : SLOTS * slotBytes) + (size_t)slot * chBytes(ch);
+        return FLAG_BYTES + (size_t)src * perSrc + (ch == 0 ? 0 : SLOTS * slotBytes) + (size_t)slot * chBytes(ch);
     }
+    static uint32_t* readyFlag(char* base, int src, int ch) { return (uint32_t*)base + (src * CH + ch); }
+    static uint32_t* consFlag(char* base, int dst, int ch) { return (uint32_t*)base + 256 + (dst * CH + ch); }
 };
 
 thread_local int g_groupDepth = 0;
 thread_local std::vector<Op>* g_ops = nullptr;
 thread_local Comm* g_groupComm = nullptr;
 
-bool waitCounter(std::atomic<uint64_t>& c, uint64_t atLeast, const char* what) {
-    const auto t0 = std::chrono::steady_clock::now();
-    int spins = 0;
-    while (c.load(std::memory_order_acquire) < atLeast) {
-        if (++spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { std::fprintf(stderr, "[stub rccl] timed out waiting for %s\n", what); return false; }
-    }
-    return true;
-}
 #define STUB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "[stub rccl] %s -> %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return ncclUnhandledCudaError; } } while (0)
 
+const bool g_dbg = getenv("PS_STUB_DEBUG") != nullptr;
 int doSend(Comm* c, int ch, const void* buf, size_t bytes, int peer, hipStream_t st) {
     if (bytes > c->chBytes(ch)) { std::fprintf(stderr, "[stub rccl] message of %zu bytes exceeds the mailbox slot (%zu): raise PS_STUB_MAILBOX_MB\n", bytes, c->chBytes(ch)); return ncclInvalidArgument; }
-    const uint64_t k = c->sendSeq[peer][ch]++;
+    const uint32_t k = c->sendSeq[peer][ch]++;
     const int slot = (int)(k % SLOTS);
-    PairCtl& pc = c->shm->pair[c->rank][peer][ch];
-    if (k >= SLOTS) {   // the slot's previous message (k - SLOTS) must have been copied out: the receiver has enqueued that -> wait for its event on the stream
-        if (!waitCounter(pc.consEnq, k - SLOTS + 1, "the receiver to take an earlier message")) return ncclSystemError;
-        STUB_HIP(hipStreamWaitEvent(st, c->peerCons[peer][ch][slot], 0));
-    }
+    if (g_dbg) std::fprintf(stderr, "[stub %d] send ch %d -> %d, %zu B, k %u, stream %p\n", c->rank, ch, peer, bytes, k, (void*)st);
+    if (k >= (uint32_t)SLOTS)   // the slot's previous message (k - SLOTS) must have been copied out by the receiver
+        STUB_HIP(hipStreamWaitValue32(st, Comm::consFlag(c->mailbox, peer, ch), k - SLOTS + 1, hipStreamWaitValueGte, 0xffffffffu));
     if (bytes) STUB_HIP(hipMemcpyAsync(c->peerMailbox[peer] + c->regionOff(c->rank, ch, slot), buf, bytes, hipMemcpyDeviceToDevice, st));
-    STUB_HIP(hipEventRecord(c->myReady[peer][ch][slot], st));
-    pc.sentEnq.store(k + 1, std::memory_order_release);
+    STUB_HIP(hipStreamWriteValue32(st, Comm::readyFlag(c->peerMailbox[peer], c->rank, ch), k + 1, 0));
     return ncclSuccess;
 }
 int doRecv(Comm* c, int ch, void* buf, size_t bytes, int peer, hipStream_t st) {
     if (bytes > c->chBytes(ch)) return ncclInvalidArgument;
-    const uint64_t k = c->recvSeq[peer][ch]++;
+    const uint32_t k = c->recvSeq[peer][ch]++;
     const int slot = (int)(k % SLOTS);
-    PairCtl& pc = c->shm->pair[peer][c->rank][ch];
-    if (!waitCounter(pc.sentEnq, k + 1, "the sender to enqueue its message")) return ncclSystemError;
-    STUB_HIP(hipStreamWaitEvent(st, c->peerReady[peer][ch][slot], 0));
+    if (g_dbg) std::fprintf(stderr, "[stub %d] recv ch %d <- %d, %zu B, k %u, stream %p\n", c->rank, ch, peer, bytes, k, (void*)st);
+    STUB_HIP(hipStreamWaitValue32(st, Comm::readyFlag(c->mailbox, peer, ch), k + 1, hipStreamWaitValueGte, 0xffffffffu));
     if (bytes) STUB_HIP(hipMemcpyAsync(buf, c->mailbox + c->regionOff(peer, ch, slot), bytes, hipMemcpyDeviceToDevice, st));
-    STUB_HIP(hipEventRecord(c->myCons[peer][ch][slot], st));
-    pc.consEnq.store(k + 1, std::memory_order_release);
+    STUB_HIP(hipStreamWriteValue32(st, Comm::consFlag(c->peerMailbox[peer], c->rank, ch), k + 1, 0));
     return ncclSuccess;
 }
-// all sends of a group first, then its receives: no rank waits (on the host) for a message of the SAME group before having
-// enqueued its own — the exchange pattern of Dist::transport cannot deadlock whatever the order of the calls inside the group
+// all sends of a group first, then its receives: a stream never waits for a message of the SAME group before its own have been
+// enqueued — the exchange pattern of Dist::transport cannot deadlock whatever the order of the calls inside the group
 int flush(Comm* c, std::vector<Op>& ops) {
     {   // messages to self (ps_comm_selftest): the k-th send pairs with the k-th receive as one device copy
         std::vector<const Op*> ss, rr;
@@ -167,21 +155,13 @@ int ncclCommInitRank(void** comm, int world, StubUid id, int rank) {
     close(fd);
     if (c->shm == MAP_FAILED) { delete c; return ncclSystemError; }
     const size_t perSrc = SLOTS * (c->slotBytes + AR_BYTES);
-    STUB_HIP(hipMalloc((void**)&c->mailbox, perSrc * (size_t)world));
+    STUB_HIP(hipMalloc((void**)&c->mailbox, FLAG_BYTES + perSrc * (size_t)world));
+    STUB_HIP(hipMemset(c->mailbox, 0, FLAG_BYTES));                                   // every counter starts at 0
     STUB_HIP(hipMalloc((void**)&c->arStage, (size_t)MAXW * 64 * sizeof(double)));
     STUB_HIP(hipMemset(c->arStage, 0, (size_t)MAXW * 64 * sizeof(double)));
+    STUB_HIP(hipDeviceSynchronize());                                                 // (start-up only: the zeros are there before a peer can write)
     RankCtl& me = c->shm->rank[rank];
     if (world > 1) STUB_HIP(hipIpcGetMemHandle(&me.mailbox, c->mailbox));
-    for (int q = 0; q < world; ++q) {
-        if (q == rank) continue;
-        for (int ch = 0; ch < CH; ++ch)
-            for (int s = 0; s < SLOTS; ++s) {
-                STUB_HIP(hipEventCreateWithFlags(&c->myReady[q][ch][s], hipEventDisableTiming | hipEventInterprocess));
-                STUB_HIP(hipEventCreateWithFlags(&c->myCons[q][ch][s], hipEventDisableTiming | hipEventInterprocess));
-                STUB_HIP(hipIpcGetEventHandle(&me.evReady[q][ch][s], c->myReady[q][ch][s]));
-                STUB_HIP(hipIpcGetEventHandle(&me.evCons[q][ch][s], c->myCons[q][ch][s]));
-            }
-    }
     me.ready.store(1, std::memory_order_release);
     for (int q = 0; q < world; ++q) {
         if (q == rank) continue;
@@ -192,11 +172,6 @@ int ncclCommInitRank(void** comm, int world, StubUid id, int rank) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { std::fprintf(stderr, "[stub rccl] rank %d never arrived\n", q); return ncclSystemError; }
         }
         STUB_HIP(hipIpcOpenMemHandle((void**)&c->peerMailbox[q], pr.mailbox, hipIpcMemLazyEnablePeerAccess));
-        for (int ch = 0; ch < CH; ++ch)
-            for (int s = 0; s < SLOTS; ++s) {
-                STUB_HIP(hipIpcOpenEventHandle(&c->peerReady[q][ch][s], pr.evReady[rank][ch][s]));
-                STUB_HIP(hipIpcOpenEventHandle(&c->peerCons[q][ch][s], pr.evCons[rank][ch][s]));
-            }
     }
     *comm = c;
     return ncclSuccess;
@@ -240,17 +215,7 @@ int ncclCommDestroy(void* comm) {
     Comm* c = (Comm*)comm;
     if (!c) return ncclSuccess;
     (void)hipDeviceSynchronize();                    // teardown only: the mailboxes go away
-    for (int q = 0; q < c->world; ++q) {
-        if (q == c->rank) continue;
-        if (c->peerMailbox[q]) (void)hipIpcCloseMemHandle(c->peerMailbox[q]);
-        for (int ch = 0; ch < CH; ++ch)
-            for (int s = 0; s < SLOTS; ++s) {
-                if (c->myReady[q][ch][s]) (void)hipEventDestroy(c->myReady[q][ch][s]);
-                if (c->myCons[q][ch][s]) (void)hipEventDestroy(c->myCons[q][ch][s]);
-                if (c->peerReady[q][ch][s]) (void)hipEventDestroy(c->peerReady[q][ch][s]);
-                if (c->peerCons[q][ch][s]) (void)hipEventDestroy(c->peerCons[q][ch][s]);
-            }
-    }
+    for (int q = 0; q < c->world; ++q) if (q != c->rank && c->peerMailbox[q]) (void)hipIpcCloseMemHandle(c->peerMailbox[q]);
     // the last rank out removes the shared-memory name (the others may still hold their mappings)
     c->shm->rank[c->rank].ready.store(3, std::memory_order_release);
     bool last = true;

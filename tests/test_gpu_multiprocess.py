@@ -109,7 +109,7 @@ def test_multiprocess_async_transport_matches_tcp_and_single_domain(case, tmp_pa
 def test_async_transport_exposes_a_missing_stream_order(tmp_path):
     """The point of the stand-in: with the event that makes the solver stream wait for the unpacked halo values removed
     (PS_DIST_SKIP_ORDER=1: Dist::order(c, 1, false)), the overlapped step over the asynchronous transport reads stale halo values and
-    the solve goes wrong — the same fault is invisible over TCP, whose host-side synchronisation happens to order the streams."""
+    the solve goes wrong.  (Over TCP the host blocks in hipStreamSynchronize around every exchange, which can order the streams by accident.)"""
     case, world = "cavity_b2x1x2", 4
     base_env = {"PS_FUSED_R": "1", "PS_DIST_SKIP_ORDER": "1"}
     res = _run_ranks(case, world, tmp_path, dict(base_env, PS_TEST_TRANSPORT="stub", PS_RCCL_LIB=STUB_LIB))
