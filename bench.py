@@ -437,6 +437,14 @@ def main():
     # vectors); that figure over the same launch duration is reported beside it ("csr_equivalent": it can exceed the
     # HBM peak, which only says the kernel beats a CSR SpMV running at the roofline).  Every fraction in "other_kernels" is
     # that kernel's OWN stored bytes over its OWN measured duration (the fallbacks are timed as themselves).
+    # must-move bytes: the stored bytes minus the part of the 3 B/nnz matrix stream that chunks sharing a run read from cache —
+    # the vectors (each once), the per-row streams, the chunk records and the DISTINCT stream entries: what has to cross the HBM interface
+    # per launch.  `traffic / must_move_bytes` is the re-fetch factor of the gathers (S 2.08x, St 1.34x at the end of r03).
+    runs = [int(v) for v in solver.array("streamRuns")]          # S distinct, S entries, St distinct, St entries
+    if coded and c16:
+        for nm, (dist_e, all_e) in (("spmv_S", (runs[0], runs[1])), ("spmv_St", (runs[2], runs[3])), ("spmv_St_r", (runs[2], runs[3]))):
+            if nm in kern:
+                kern[nm]["must_move_bytes"] = kern[nm]["algorithmic_bytes"] - 3.0 * (all_e - dist_e)
     ms = kern[dom]["ms"]
     csr = kern["spmv_St_csr"]["algorithmic_bytes"]
     csr_gbps = csr / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -446,6 +454,7 @@ def main():
         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
         "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_ms": ms,
+        "must_move_bytes": kern[dom].get("must_move_bytes"),
         "numbering": {0: "voxel-major (kinds of DOF / faces of a voxel adjacent)", 3: "kind-major inside every k-plane of a 16^3 lattice block (DOFs and face rows)"}.get(int(rpl[1]), "mixed (%d)" % int(rpl[1])),
         "algorithmic_bytes_definition": ("stored format: 3*nnz (16-bit windowed column + int8 value code; padded slots of the row-per-lane layout NOT counted) + %s80 B per chunk "
                                          "+ 8*cols (t once) + 8*rows (p) + 1*rows (coded uInv) + %s") % ("" if ell else "1*rows (row length) + ", "16*rows (r read + written) + 4*rows (fp32 Jacobi diagonal); A p is not stored" if fused else "8*rows (y)") if (coded and c16) else
