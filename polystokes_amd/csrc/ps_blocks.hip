@@ -1001,7 +1001,9 @@ void ps_context::constructMatrixBlocks() {
             if (itemLong[(size_t)q] > 0 && itemOff[(size_t)q] + itemLong[(size_t)q] < itemOff[(size_t)q + 1]) skinCutsHost.push_back(itemOff[(size_t)q] + itemLong[(size_t)q]);
         }
         skinCutsHost.push_back(itemOff[(size_t)sbItems]);
-        std::vector<int32_t> rptr((size_t)regionCount + 1), cR, cS, cE, cptr((size_t)regionCount + 1);
+        std::vector<int32_t>& rptr = hostTab[6]; std::vector<int32_t>& cR = hostTab[7]; std::vector<int32_t>& cS = hostTab[8]; std::vector<int32_t>& cE = hostTab[9];
+        std::vector<int32_t>& cptr = hostTab[10];      // (kept with the context: their uploads need no synchronisation)
+        rptr.assign((size_t)regionCount + 1, 0); cR.clear(); cS.clear(); cE.clear(); cptr.assign((size_t)regionCount + 1, 0);
         for (int64_t r = 0; r <= regionCount; ++r) rptr[(size_t)r] = itemOff[(size_t)sbRegionItemPtrHost[(size_t)r]];
         regionRowPtrHost = rptr;
         for (int64_t r = 0; r < regionCount; ++r) {
@@ -1028,7 +1030,6 @@ void ps_context::constructMatrixBlocks() {
             HIP_CHECK(hipMemcpyAsync(rchunkEnd.p, cE.data(), cE.size() * 4, hipMemcpyHostToDevice, stream));
         }
         HIP_CHECK(hipMemcpyAsync(regionChunkPtr.p, cptr.data(), cptr.size() * 4, hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
     } else {
         nRChunks = 0;
         regionRowPtrHost.assign(1, 0);

@@ -254,6 +254,7 @@ struct ps_context {
     void ensureValues(ps::DevCSR& M);                    // decode the fp64 values of a coded block on demand (ps_blocks.hip)
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
+    std::vector<int32_t> hostTab[12];                     // host-built tables of one setup, alive until the next: asynchronous uploads without a synchronisation
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();
     int solve();
@@ -277,7 +278,7 @@ struct ps_context {
     void registerArrays();
 
     // helpers
-    int32_t orderedIndexAssign(int s, int mode, ps::DevBuf<int32_t>& out);   // ps_grid.hip
+    int32_t orderedIndexAssign(int s, int mode, ps::DevBuf<int32_t>& out, int counterSlot = -1);   // ps_grid.hip
     int64_t interleavedIndexAssign(int ngroups, const int* samples, const int* weights, int32_t* const* outs);
     int64_t interleavedIndexAssignEx(int ngroups, const int* samples, const int* weights, int32_t* const* outs, bool ownFilter,
                                      int64_t* ownedRange);

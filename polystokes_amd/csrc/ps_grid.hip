@@ -914,15 +914,18 @@ int64_t ps_context::exclusiveScanI32(int32_t* data, int64_t n) {
 }
 
 // serialAssignFieldIndices (Classifier.cpp:1738-1770) as a two-level scan over traversal positions.
-int32_t ps_context::orderedIndexAssign(int s, int mode, DevBuf<int32_t>& out) {
+// counterSlot >= 0: the total goes to counters[counterSlot] and the call returns -1 WITHOUT synchronising (the caller reads several
+// totals with one round trip: every host synchronisation of the setup costs ~30 us of idle device)
+int32_t ps_context::orderedIndexAssign(int s, int mode, DevBuf<int32_t>& out, int counterSlot) {
     const int64_t n = g.count(s);
     const int nb = gridFor(n, SCAN_TILE);
-    scanBlock.alloc((size_t)nb);
+    scanBlock.alloc((size_t)nb);           // (one buffer for consecutive calls: the launches are ordered on the stream; sized for the largest grid on first use)
     const int32_t* src = mode == 0 ? labels[s].p : cellScratch[0].p;
+    const int slot = counterSlot >= 0 ? counterSlot : 8;
     hipLaunchKernelGGL(k_ordered_count, dim3(nb), dim3(BS), 0, stream, g, s, mode, src, scanBlock.p);
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nb, counters.p + 8);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nb, counters.p + slot);
     hipLaunchKernelGGL(k_ordered_assign, dim3(nb), dim3(BS), 0, stream, g, s, mode, src, scanBlock.p, out.p);
-    return readCounter(8);
+    return counterSlot >= 0 ? -1 : readCounter(8);
 }
 
 // Solver.cpp:238-289
@@ -1086,14 +1089,22 @@ void ps_context::constructEdgesReducedIndices() {
 
 // Classifier.cpp:257-284
 void ps_context::constructActiveIndices() {
+    {   // the scan's block buffer must fit the largest of the seven grids BEFORE the first launch: a reallocation between the
+        // unsynchronised calls would free memory a queued kernel still uses
+        int64_t most = 0;
+        for (int s = 0; s < 7; ++s) most = std::max<int64_t>(most, g.count(s));
+        scanBlock.alloc((size_t)gridFor(most, SCAN_TILE));
+    }
     for (int s = 0; s < 7; ++s) {
         const int64_t n = g.count(s);
         hipLaunchKernelGGL(k_relabel, dim3(gridFor(n, BS)), dim3(BS), 0, stream, labels[s].p, n, (int)PS_GENERICFLUID, (int)PS_ACTIVEFLUID);
-        const int32_t cnt = orderedIndexAssign(s, 0, activeIdx[s]);
-        if (s == 0) nCenter = cnt;
-        else if (s <= 3) nFace[s - 1] = cnt;
-        else nEdge[s - 4] = cnt;
+        (void)orderedIndexAssign(s, 0, activeIdx[s], 48 + s);      // totals -> counters[48 .. 54], one round trip for the seven
     }
+    int32_t cnt[7];
+    HIP_CHECK(hipMemcpyAsync(cnt, counters.p + 48, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    nCenter = cnt[0];
+    for (int a = 0; a < 3; ++a) { nFace[a] = cnt[1 + a]; nEdge[a] = cnt[4 + a]; }
 }
 
 

@@ -571,7 +571,9 @@ void ps_context::computeCenterOfMasses() {
         HIP_CHECK(hipMemcpyAsync(regionOwned.p, ro.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
-    std::vector<int32_t> iR, iA, iS, ptr((size_t)R + 1, 0);
+    // (host tables kept with the context — hostTab* — so that their uploads need no synchronisation: the vectors outlive the copies)
+    std::vector<int32_t>& iR = hostTab[0]; std::vector<int32_t>& iA = hostTab[1]; std::vector<int32_t>& iS = hostTab[2]; std::vector<int32_t>& ptr = hostTab[3];
+    iR.clear(); iA.clear(); iS.clear(); ptr.assign((size_t)R + 1, 0);
     for (int64_t r = 0; r < R; ++r) {
         ptr[(size_t)r] = (int32_t)iR.size();
         for (int a = 0; a < 3; ++a) {
@@ -587,7 +589,8 @@ void ps_context::computeCenterOfMasses() {
     fbItems = (int64_t)iR.size();
     fbItemRegion.alloc(iR.size()); fbItemAxis.alloc(iR.size()); fbItemStart.alloc(iR.size()); fbRegionItemPtr.alloc(ptr.size());
     {   // skin-row enumeration items: the union face box of each region, FB_CHUNK positions per item
-        std::vector<int32_t> sR, sS;
+        std::vector<int32_t>& sR = hostTab[4]; std::vector<int32_t>& sS = hostTab[5];
+        sR.clear(); sS.clear();
         sbRegionItemPtrHost.assign((size_t)R + 1, 0);
         for (int64_t r = 0; r < R; ++r) {
             sbRegionItemPtrHost[(size_t)r] = (int32_t)sR.size();
@@ -601,13 +604,11 @@ void ps_context::computeCenterOfMasses() {
         sbItemRegion.alloc(sR.size()); sbItemStart.alloc(sS.size()); sbItemCount.alloc(sR.size() + 1);
         HIP_CHECK(hipMemcpyAsync(sbItemRegion.p, sR.data(), sR.size() * 4, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(sbItemStart.p, sS.data(), sS.size() * 4, hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));   // sR / sS are locals
     }
     HIP_CHECK(hipMemcpyAsync(fbItemRegion.p, iR.data(), iR.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(fbItemAxis.p, iA.data(), iA.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(fbItemStart.p, iS.data(), iS.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(fbRegionItemPtr.p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
     hipLaunchKernelGGL(k_com, dim3((unsigned)R), dim3(BS), 0, stream, g, dx, make_int3(gOff[0], gOff[1], gOff[2]), labels[0].p, reducedIdx[0].p, bbox.p, COM.p);
 }
 
