@@ -126,6 +126,11 @@ struct ps_context {
     ps::DevBuf<int32_t> fbItemRegion, fbItemAxis, fbItemStart;   // one item = <=FB_CHUNK face-box positions
     ps::DevBuf<int32_t> fbRegionItemPtr;                         // R+1
     int64_t fbItems = 0;
+    // classes of identical tiles (ps_tiles.hip:buildTileClasses): tileRep[r] = the region whose Mr / K region r copies (itself: sums its own);
+    // the face-box items of the representatives alone
+    ps::DevBuf<unsigned long long> tileSig; ps::DevBuf<int32_t> tileUnique, tileRep, repItemRegion, repItemAxis, repItemStart, repRegionItemPtr, repList;
+    int64_t tileReps = 0, repItems = 0;
+    void buildTileClasses();
     // skin-row enumeration: items of <= FB_CHUNK positions of a region's UNION face box (ex+1)(ey+1)(ez+1); a position yields up
     // to three rows (its X, Y, Z face) — rows are ordered (region, position x-fastest, axis), so the faces hanging off one
     // voxel are adjacent rows like the active ones
@@ -254,7 +259,7 @@ struct ps_context {
     void ensureValues(ps::DevCSR& M);                    // decode the fp64 values of a coded block on demand (ps_blocks.hip)
     void buildVal4(ps::DevCSR& M);                        // fp64 values in the compressed stream's layout (fallback / A-B)
     std::vector<int32_t> regionRowPtrHost;                // R+1 offsets into the reduced rows (host copy)
-    std::vector<int32_t> hostTab[12];                     // host-built tables of one setup, alive until the next: asynchronous uploads without a synchronisation
+    std::vector<int32_t> hostTab[20];                     // host-built tables of one setup, alive until the next: asynchronous uploads without a synchronisation
     void assembleSystemPressureStressFactored();          // ps_solve.hip
     void constructPreconditioner();
     int solve();
