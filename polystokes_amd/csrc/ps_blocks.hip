@@ -752,9 +752,15 @@ void ps_context::buildEll(ps::DevCSR& M) {
     HIP_CHECK(hipMemsetAsync(counters.p + 25, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(k_ell_plan, dim3((unsigned)nChunks), dim3(BS), 0, stream, (const int4*)M.chunkInfo.p, (const uint8_t*)M.len8.p, (const int32_t*)M.chunkRep.p,
                        colBegin.p, codeBegin.p, wpack.p, counters.p + 25);
-    const int64_t totCol = exclusiveScanI32(colBegin.p, nChunks + 1);
-    const int64_t totCode = exclusiveScanI32(codeBegin.p, nChunks + 1);
-    if (totCol < 0 || totCode < 0 || (uint64_t)totCol * 2 >= 0xffffffffull || readCounter(25) != 0) return;   // a row longer than 8 / 32-bit offsets: keep the other kernels
+    scanBlock.alloc((size_t)gridFor(nChunks + 1, 2048) + 16);                   // (both unsynchronised scans below use it)
+    (void)exclusiveScanI32(colBegin.p, nChunks + 1, 56);
+    (void)exclusiveScanI32(codeBegin.p, nChunks + 1, 57);
+    int32_t tot[2] = {0, 0}, tooLong = 0;                                        // one round trip for the two totals and the width check
+    HIP_CHECK(hipMemcpyAsync(tot, counters.p + 56, sizeof(tot), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&tooLong, counters.p + 25, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const int64_t totCol = tot[0], totCode = tot[1];
+    if (totCol < 0 || totCode < 0 || (uint64_t)totCol * 2 >= 0xffffffffull || tooLong != 0) return;   // a row longer than 8 / 32-bit offsets: keep the other kernels
     M.ellCols = totCol; M.ellCodes = totCode; M.ellUniqueCols = totCol;
     M.ecol.alloc((size_t)totCol + 64); M.ecode.alloc((size_t)totCode + 64); M.echunk.alloc((size_t)nChunks);
     hipLaunchKernelGGL(k_ell_fill, dim3((unsigned)nChunks), dim3(BS), 0, stream, (const int4*)M.chunkInfo.p, (const uint8_t*)M.len8.p, (const int32_t*)M.chunkRep.p,

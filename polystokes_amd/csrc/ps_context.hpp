@@ -288,7 +288,7 @@ struct ps_context {
     int64_t interleavedIndexAssignEx(int ngroups, const int* samples, const int* weights, int32_t* const* outs, bool ownFilter,
                                      int64_t* ownedRange);
     void buildInternalNumbering();                                            // ps_grid.hip
-    int64_t exclusiveScanI32(int32_t* data, int64_t n);                       // in place; returns total
+    int64_t exclusiveScanI32(int32_t* data, int64_t n, int counterSlot = -1);   // ps_grid.hip (counterSlot >= 0: total to counters[slot], no synchronisation)
     int32_t readCounter(int idx);
     void zeroCounters();
 };

@@ -899,18 +899,22 @@ int32_t ps_context::readCounter(int idx) {
 void ps_context::zeroCounters() { HIP_CHECK(hipMemsetAsync(counters.p, 0, 64 * sizeof(int32_t), stream)); }
 
 // In-place exclusive scan of a device int32 array; returns the total (host).
-int64_t ps_context::exclusiveScanI32(int32_t* data, int64_t n) {
-    if (n <= 0) return 0;
+// counterSlot >= 0: the total goes to counters[counterSlot] and the call returns -1 without synchronising (as orderedIndexAssign).  Consecutive
+// unsynchronised scans share scanBlock: it must already hold gridFor(largest n, SCAN_TILE) entries (a reallocation would free memory a
+// queued kernel uses) — the caller allocates it first.
+int64_t ps_context::exclusiveScanI32(int32_t* data, int64_t n, int counterSlot) {
+    if (n <= 0) { if (counterSlot >= 0) HIP_CHECK(hipMemsetAsync(counters.p + counterSlot, 0, sizeof(int32_t), stream)); return counterSlot >= 0 ? -1 : 0; }
+    const int slot = counterSlot >= 0 ? counterSlot : 8;
     const int nb = gridFor(n, SCAN_TILE);
     if (nb == 1) {
-        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, data, n, counters.p + 8);
-        return readCounter(8);
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, data, n, counters.p + slot);
+        return counterSlot >= 0 ? -1 : readCounter(8);
     }
     scanBlock.alloc((size_t)nb);
     hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(BS), 0, stream, data, n, scanBlock.p);
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nb, counters.p + 8);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, scanBlock.p, (int64_t)nb, counters.p + slot);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(BS), 0, stream, data, n, scanBlock.p);
-    return readCounter(8);
+    return counterSlot >= 0 ? -1 : readCounter(8);
 }
 
 // serialAssignFieldIndices (Classifier.cpp:1738-1770) as a two-level scan over traversal positions.
@@ -1167,18 +1171,18 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     DevBuf<int32_t>& bstart = scrStart4;      // scratch kept with the context (also the stream build's)
     bstart.alloc((size_t)nBlocks + 1);
     hipLaunchKernelGGL(k_il_assign, dim3(nbk), dim3(BS), 0, stream, D, g, cset(labels), scanBlock.p, o, counters.p + 10, bstart.p);
-    const int64_t total = readCounter(8);
-    {
-        std::vector<int32_t>& hs = ownedRange ? blockStartSys : blockStartRow;
-        hs.assign((size_t)nBlocks + 1, 0);
-        HIP_CHECK(hipMemcpyAsync(hs.data(), bstart.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        hs[(size_t)nBlocks] = (int32_t)total;
-        ilBlocks = nBlocks;
-    }
+    int32_t cnt[4] = {0, 0, 0, 0};                      // counters[8 .. 11]: the total, -, the two probes — one round trip with the block starts
+    std::vector<int32_t>& hs = ownedRange ? blockStartSys : blockStartRow;
+    hs.assign((size_t)nBlocks + 1, 0);
+    HIP_CHECK(hipMemcpyAsync(cnt, counters.p + 8, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(hs.data(), bstart.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const int64_t total = cnt[0];
+    hs[(size_t)nBlocks] = (int32_t)total;
+    ilBlocks = nBlocks;
     if (ownedRange) {
-        ownedRange[0] = D.probe[0] >= run ? total : readCounter(10);
-        ownedRange[1] = D.probe[1] >= run ? total : readCounter(11);
+        ownedRange[0] = D.probe[0] >= run ? total : cnt[2];
+        ownedRange[1] = D.probe[1] >= run ? total : cnt[3];
     }
     return total;
 }
