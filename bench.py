@@ -449,7 +449,7 @@ def main():
     csr = kern["spmv_St_csr"]["algorithmic_bytes"]
     csr_gbps = csr / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {
-        "bound": "hbm", "kernel": ("k_spmv_St_ell<%d,POL,FX> (one lane per row on the kind-major numbering; POL = cache policy of its streams%s)" % (mode, "; MODE 3: r -= alpha A p in the epilogue, FX = 3: the plain single-domain step (coded uInv, no halo rows)" if fused else "")) if ell else
+        "bound": "hbm", "kernel": ("k_spmv_St_ell<%d,POL,FX> (one lane per row on the kind-major numbering; POL = cache policy of its streams%s)" % (mode, "; MODE 3: r -= alpha A p in the epilogue, FX = 3: the plain single-domain step (coded uInv, no halo rows) — run as k_spmv_St_ell2<POL>, two 64-row units in flight per wave, unless PS_ST_DUAL=0" if fused else "")) if ell else
                                   ("k_spmv_St_pipe<%d,NV,%s,POL> (NV = 1 or 2 four-entry groups per lane, by the fullest chunk; POL = cache policy of its streams%s)" % (mode, "false" if coded else "true", "; MODE 3: r -= alpha A p in the epilogue" if fused else "") if c16 else "k_spmv_St<0,6,%s>" % ("true" if coded else "false")),
         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
         "traffic": traffic, "traffic_source": traffic_source,

@@ -895,3 +895,231 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
         if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[(fr.rStride > 0 ? fr.rStride : (int)gridDim.x) + blockIdx.x] = b1; }
     }
 }
+
+// ---- two units in flight per wave (r04; default for the single-domain operator product, PS_S_DUAL=0 switches back) -------------------
+// k_spmv_S_ell with twice the memory-level parallelism per wave: a workgroup takes TWO chunks per step, waves 0-1 the first, waves 2-3 the
+// second; a wave owns units 2 (w & 1) and 2 (w & 1) + 1 of its chunk and has the streams, the gathers and the epilogue loads of both in
+// flight before it sums either.  Same products, same order per row: bit-identical t; the per-workgroup partials of sum s.t group differently.
+template <int POL>
+__global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
+                                                    const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
+                                                    const double* __restrict__ x, int cols, int rows, int nA, double dt, double* __restrict__ out,
+                                                    const int* __restrict__ done, int nChunks, const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict,
+                                                    double* __restrict__ stPart) {
+    if (done && *done) return;
+    constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
+    __shared__ double dict[256];
+    dict[threadIdx.x] = mcDict[threadIdx.x];
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rX = bufRsrc(x, (size_t)cols * 8),
+                                 rMcc = bufRsrc(mcCode, (size_t)nA), rOut = bufRsrc(out, (size_t)rows * 8);
+    const unsigned lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int half = wv >> 1, u0 = 2 * (wv & 1);
+    double stAcc = 0.;
+    // pairs of consecutive chunks, runs of 32 pairs dealt to the XCDs round robin (workgroup b runs on XCD b & 7)
+    const int nPairs = (nChunks + 1) >> 1;
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3, per = gridDim.x >> 3;
+    // step q of this workgroup -> its chunk (or -1): the pair, then this wave's half of it
+    auto chunkAt = [&](int q) -> int {
+        const int pair = ((((q >> 5) << 3) + xcd) << 5) + (q & 31);
+        const int ch = 2 * pair + half;
+        return (pair < nPairs && ch < nChunks) ? ch : -1;
+    };
+    const int qEnd = ((nPairs + 255) >> 8) << 5;          // steps beyond the last run of 32 pairs per XCD
+    int q = l;
+    int chunk = q < qEnd ? chunkAt(q) : -1;
+    int4 ci = make_int4(0, 0, 0, 0);
+    int myBase = 0;
+    if (chunk >= 0) { ci = echunk[chunk]; myBase = winBase[chunk * 16 + (lane & 15)]; }
+    while (q < qEnd) {
+        const int qn = q + per;
+        const int nchunk = qn < qEnd ? chunkAt(qn) : -1;
+        int4 nci = make_int4(0, 0, 0, 0);
+        int nBase = 0;
+        if (chunk >= 0) {
+            const EllUnit ua = ellUnit(ci, u0), ub = ellUnit(ci, u0 + 1);
+            const EllRegs sa = ellLoad<SNT>(rCol, rCode, ua, lane), sb = ellLoad<SNT>(rCol, rCode, ub, lane);
+            if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }     // the next step's record, behind this step's streams
+            const unsigned rowA = (int)lane < ua.rows ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = (int)lane < ub.rows ? (unsigned)ub.row0 + lane : ROW_NONE;
+            const int mA = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)rowA, 0, NT ? PS_EPI_AUX : 0);
+            const int mB = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)rowB, 0, NT ? PS_EPI_AUX : 0);
+            const EllX XA = ellGatherW(ua.W, sa, myBase, rX);
+            const EllX XB = ellGatherW(ub.W, sb, myBase, rX);
+            const double a = ellSumW(ua.W, sa, XA, scale), b = ellSumW(ub.W, sb, XB, scale);
+            const double scA = (int)rowA < nA ? dt * dict[mA] : 1., scB = (int)rowB < nA ? dt * dict[mB] : 1.;
+            stAcc += (int)rowA < nA ? a * (a * scA) : 0.;
+            stAcc += (int)rowB < nA ? b * (b * scB) : 0.;
+            bufStoreF64nt<NT>(rOut, rowA * 8u, a * scA);
+            bufStoreF64nt<NT>(rOut, rowB * 8u, b * scB);
+        } else if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
+        q = qn; chunk = nchunk; ci = nci; myBase = nBase;
+    }
+    if (stPart) {
+        const double bs = blockReduceSum(stAcc);
+        if (threadIdx.x == 0) stPart[blockIdx.x] = bs;
+    }
+}
+
+// The same for the St kernel of the plain single-domain step (k_spmv_St_ell<3, POL, 3>: coded uInv, residual update in the epilogue): two
+// units in flight per wave, two chunks per workgroup and step (r04; default, PS_ST_DUAL=0 switches back).  Compiled for six waves per SIMD
+// (80 VGPRs): twelve units in flight per SIMD against the seven of the one-unit kernel.
+// CZ: the Chebyshev polynomial's first term on the new r in the epilogue (z_1 = dinv r / theta -> fr.cz, r.z partials from it; fr.dinvF unused)
+template <int POL, bool CZ>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_spmv_St_ell2(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
+                                                     const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
+                                                     const double* __restrict__ t, int cols, int rows, const double* __restrict__ xin,
+                                                     const int* __restrict__ done, int nChunks, const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr) {
+    if (done && *done) return;
+    constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
+    __shared__ double dict[256];
+    dict[threadIdx.x] = uDict[threadIdx.x];
+    double alpha;
+    {   // as k_spmv_St_ell MODE 3
+        CGScalars* sc = fr.sc;
+        auto sumArr = [&](const double* a, int cnt) { double acc = 0.; for (int i = threadIdx.x; i < cnt; i += BS) acc += a[i]; return blockSumAll(acc); };
+        const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+        if (fr.it > 0) {
+            const double xx = sumArr(fr.xxPart, fr.xxCount);
+            const double rr = sc->rr;
+            double rre = rr;                               // pcg.h:319-325
+            if (rr / xx < rre) rre = rr / xx;
+            const bool fire = rre < sc->tol2;
+            if (writer) { sc->xx = xx; sc->rre = rre; if (fire) { sc->done = 1; sc->iter = fr.it - 1; } }
+            if (fire) return;
+        }
+        const double pAp = -(sumArr(fr.sPart, fr.sCount) + sumArr(fr.tPart, fr.tCount) + 0.5 * sumArr(fr.uPart, fr.uCount));
+        alpha = sc->rsold2[fr.it & 1] / pAp;               // pcg.h:314
+        if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
+                                 rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows),
+                                 rFr = bufRsrc(fr.r, (size_t)rows * 8), rFd = bufRsrc(fr.dinvF, (!CZ && fr.dinvF) ? (size_t)rows * 4 : 0),
+                                 rF64 = bufRsrc(fr.dinv64, CZ ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * 8 : 0);
+    const unsigned lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int half = wv >> 1, u0 = 2 * (wv & 1);
+    double dacc = 0., dacc2 = 0.;
+    const int nPairs = (nChunks + 1) >> 1;
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3, per = gridDim.x >> 3;
+    auto chunkAt = [&](int q) -> int {
+        const int pair = ((((q >> 5) << 3) + xcd) << 5) + (q & 31);
+        const int ch = 2 * pair + half;
+        return (pair < nPairs && ch < nChunks) ? ch : -1;
+    };
+    const int qEnd = ((nPairs + 255) >> 8) << 5;
+    int q = l;
+    int chunk = q < qEnd ? chunkAt(q) : -1;
+    int4 ci = make_int4(0, 0, 0, 0);
+    int myBase = 0;
+    if (chunk >= 0) { ci = echunk[chunk]; myBase = winBase[chunk * 16 + (lane & 15)]; }
+    while (q < qEnd) {
+        const int qn = q + per;
+        const int nchunk = qn < qEnd ? chunkAt(qn) : -1;
+        int4 nci = make_int4(0, 0, 0, 0);
+        int nBase = 0;
+        if (chunk >= 0) {
+            const EllUnit ua = ellUnit(ci, u0), ub = ellUnit(ci, u0 + 1);
+            const EllRegs sa = ellLoad<SNT>(rCol, rCode, ua, lane), sb = ellLoad<SNT>(rCol, rCode, ub, lane);
+            if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
+            const bool liveA = (int)lane < ua.rows, liveB = (int)lane < ub.rows;
+            const unsigned rowA = liveA ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = liveB ? (unsigned)ub.row0 + lane : ROW_NONE;
+            const double eA = bufLoadF64epi<NT>(rE0, rowA * 8u), eB = bufLoadF64epi<NT>(rE0, rowB * 8u);
+            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_EPI_AUX : 0);
+            const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_EPI_AUX : 0);
+            const double crA = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(rowA * 8u), 0, NT ? PS_EPI_AUX : 0));
+            const double crB = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(rowB * 8u), 0, NT ? PS_EPI_AUX : 0));
+            float fdA = 1.f, fdB = 1.f;
+            double ciA = 0., ciB = 0.;
+            if (CZ) { ciA = bufLoadF64epi<NT>(rF64, rowA * 8u); ciB = bufLoadF64epi<NT>(rF64, rowB * 8u); }
+            else if (fr.dinvF) {
+                fdA = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(rowA * 4u), 0, NT ? PS_EPI_AUX : 0));
+                fdB = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(rowB * 4u), 0, NT ? PS_EPI_AUX : 0));
+            }
+            const EllX XA = ellGatherW(ua.W, sa, myBase, rT);
+            const EllX XB = ellGatherW(ub.W, sb, myBase, rT);
+            const double a = ellSumW(ua.W, sa, XA, scale), b = ellSumW(ub.W, sb, XB, scale);
+            double yA = -a; yA -= 0.5 * dict[ucA] * eA;
+            double yB = -b; yB -= 0.5 * dict[ucB] * eB;
+            const double rvA = liveA ? crA - alpha * yA : 0., rvB = liveB ? crB - alpha * yB : 0.;   // pcg.h:316
+            dacc += rvA * rvA; dacc += rvB * rvB;
+            if (CZ) {                                                        // k_cheb_first on these rows
+                const double vA = ciA * rvA * fr.invTheta, vB = ciB * rvB * fr.invTheta;
+                bufStoreF64nt<NT>(rFcz, rowA * 8u, vA); bufStoreF64nt<NT>(rFcz, rowB * 8u, vB);
+                dacc2 += rvA * vA; dacc2 += rvB * vB;
+            } else if (fr.dinvF) { dacc2 += rvA * ((double)fdA * rvA); dacc2 += rvB * ((double)fdB * rvB); }
+            bufStoreF64nt<NT>(rFr, rowA * 8u, rvA);
+            bufStoreF64nt<NT>(rFr, rowB * 8u, rvB);
+        } else if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
+        q = qn; chunk = nchunk; ci = nci; myBase = nBase;
+    }
+    const double b0 = blockReduceSum(dacc), b1 = (CZ || fr.dinvF) ? blockReduceSum(dacc2) : 0.;
+    if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[gridDim.x + blockIdx.x] = b1; }
+}
+
+// ... and for MODE 2 (one term of the Chebyshev preconditioner in the epilogue; coded uInv): two units in flight per wave.
+template <int POL>
+__global__ void __launch_bounds__(BS) k_spmv_St_ell2c(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
+                                                      const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
+                                                      const double* __restrict__ t, int cols, int rows, const double* __restrict__ xin, double* __restrict__ out,
+                                                      double* __restrict__ partial, const int* __restrict__ done, int nChunks, ChebArgs cheb,
+                                                      const uint8_t* __restrict__ uCode, const double* __restrict__ uDict) {
+    if (done && *done) return;
+    constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
+    __shared__ double dict[256];
+    dict[threadIdx.x] = uDict[threadIdx.x];
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
+                                 rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows), rOut = bufRsrc(out, (size_t)rows * 8),
+                                 rCr = bufRsrc(cheb.r, (size_t)rows * 8), rCi = bufRsrc(cheb.dinv, (size_t)rows * 8),
+                                 rCd = bufRsrc(cheb.zprev, cheb.zprev ? (size_t)rows * 8 : 0);
+    const unsigned lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int half = wv >> 1, u0 = 2 * (wv & 1);
+    double dacc = 0.;
+    const int nPairs = (nChunks + 1) >> 1;
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3, per = gridDim.x >> 3;
+    auto chunkAt = [&](int q) -> int {
+        const int pair = ((((q >> 5) << 3) + xcd) << 5) + (q & 31);
+        const int ch = 2 * pair + half;
+        return (pair < nPairs && ch < nChunks) ? ch : -1;
+    };
+    const int qEnd = ((nPairs + 255) >> 8) << 5;
+    int q = l;
+    int chunk = q < qEnd ? chunkAt(q) : -1;
+    int4 ci = make_int4(0, 0, 0, 0);
+    int myBase = 0;
+    if (chunk >= 0) { ci = echunk[chunk]; myBase = winBase[chunk * 16 + (lane & 15)]; }
+    while (q < qEnd) {
+        const int qn = q + per;
+        const int nchunk = qn < qEnd ? chunkAt(qn) : -1;
+        int4 nci = make_int4(0, 0, 0, 0);
+        int nBase = 0;
+        if (chunk >= 0) {
+            const EllUnit ua = ellUnit(ci, u0), ub = ellUnit(ci, u0 + 1);
+            const EllRegs sa = ellLoad<SNT>(rCol, rCode, ua, lane), sb = ellLoad<SNT>(rCol, rCode, ub, lane);
+            if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
+            const unsigned rowA = (int)lane < ua.rows ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = (int)lane < ub.rows ? (unsigned)ub.row0 + lane : ROW_NONE;
+            const double eA = bufLoadF64epi<NT>(rE0, rowA * 8u), eB = bufLoadF64epi<NT>(rE0, rowB * 8u);
+            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_EPI_AUX : 0);
+            const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_EPI_AUX : 0);
+            const double crA = bufLoadF64(rCr, rowA * 8u), crB = bufLoadF64(rCr, rowB * 8u);
+            const double ciA = bufLoadF64(rCi, rowA * 8u), ciB = bufLoadF64(rCi, rowB * 8u);
+            const double cdA = bufLoadF64(rCd, rowA * 8u), cdB = bufLoadF64(rCd, rowB * 8u);     // z_{j-1} (0: no buffer)
+            const EllX XA = ellGatherW(ua.W, sa, myBase, rT);
+            const EllX XB = ellGatherW(ub.W, sb, myBase, rT);
+            const double a = ellSumW(ua.W, sa, XA, scale), b = ellSumW(ub.W, sb, XB, scale);
+            double azA = -a; azA -= 0.5 * dict[ucA] * eA;
+            double azB = -b; azB -= 0.5 * dict[ucB] * eB;
+            const double yA = eA + (cheb.c1 * (eA - cdA) + cheb.c2 * (ciA * (crA - azA)));
+            const double yB = eB + (cheb.c1 * (eB - cdB) + cheb.c2 * (ciB * (crB - azB)));
+            dacc += crA * yA; dacc += crB * yB;                          // r.z of the updated z (0 past the last row: every load returned 0)
+            bufStoreF64nt<NT>(rOut, rowA * 8u, yA);
+            bufStoreF64nt<NT>(rOut, rowB * 8u, yB);
+        } else if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
+        q = qn; chunk = nchunk; ci = nci; myBase = nBase;
+    }
+    const double bs = blockReduceSum(dacc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+}

@@ -75,6 +75,17 @@ struct Launch {
             if (nChunks == 0) return;
             int xcdAware = this->xcdAware;
             const dim3 gr(pipeBlocks(nChunks, xcdAware, true, sCap())), bl(BS);
+            // two units in flight per wave (k_spmv_S_ell2; r04): 256^3, same box, two interleaved rounds: S 0.2809 / 0.2816 -> 0.2672 / 0.2609 ms in
+            // sequence, step 1128.6 / 1130.2 -> 1117.3 / 1118.5 ms (profiles/r04_s_dual.txt).  PS_S_DUAL=0: the one-unit kernel.
+            static const bool dual = !(getenv("PS_S_DUAL") && atoi(getenv("PS_S_DUAL")) == 0);
+            if (dual && mode == 0 && !sList && c->mcCoded && (gr.x & 7) == 0) {
+                const int pol = policy(M);
+#define PS_LAUNCH_S2(POL_) hipLaunchKernelGGL((k_spmv_S_ell2<POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                              M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, out, done, nChunks, (const uint8_t*)c->mcCode.p, c->mcDict.p, sPart)
+                if (pol == 3) PS_LAUNCH_S2(3); else if (pol == 1) PS_LAUNCH_S2(1); else PS_LAUNCH_S2(0);
+#undef PS_LAUNCH_S2
+                return;
+            }
 #define PS_LAUNCH_SE(MODE_, POL_) do { if (sList) PS_LAUNCH_SEL(MODE_, POL_, true); else PS_LAUNCH_SEL(MODE_, POL_, false); } while (0)
 #define PS_LAUNCH_SEL(MODE_, POL_, LIST_) hipLaunchKernelGGL((k_spmv_S_ell<MODE_, POL_, LIST_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
                                                      M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, c->McInv.p, out, done, nChunks, xcdAware, c->mcCoded ? c->mcCode.p : (const uint8_t*)nullptr, c->mcDict.p, sPart, sList)
@@ -172,6 +183,34 @@ struct Launch {
 #define PS_LAUNCH_TE2(MODE_) do { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TE(MODE_, 3); else if (pol == 1) PS_LAUNCH_TE(MODE_, 1); else PS_LAUNCH_TE(MODE_, 0); } while (0)
             // MODE 3 specialisations (k_spmv_St_ell: FX): coded uInv without the Chebyshev term, in a single domain (3) or on a slab rank (1)
             const bool coded3 = mode == 3 && c->uCoded && !fr.cz, single3 = coded3 && plain3Hint && !fr.yOut && !fr.red && fr.rStride == 0;
+            // two units in flight per wave (k_spmv_St_ell2; r04): 256^3, one box, interleaved rounds: St with the residual update 0.4251 / 0.4242 ->
+            // 0.3923 / 0.3918 ms in sequence at 5 waves per SIMD on 1280 workgroups, step 1124.5 / 1122.6 -> 1098.3 / 1096.6 ms; compiled for 6 waves per
+            // SIMD on 1536 workgroups another 0.6 % (profiles/r04_st_dual.txt).  PS_ST_DUAL=0: the one-unit kernel on 1792 workgroups.
+            static const bool dualC = !(getenv("PS_ST_DUAL") && atoi(getenv("PS_ST_DUAL")) == 0);
+            if (mode == 2 && dualC && c->uCoded && !stList && (gr.x & 7) == 0 && !c->slabEnabled) {   // a Chebyshev term, two units in flight per wave
+                const int pol = policy(M);
+#define PS_LAUNCH_T2C(POL_) hipLaunchKernelGGL((k_spmv_St_ell2c<POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, out, partial, done, nChunks, ca, (const uint8_t*)c->uCode.p, c->uDict.p)
+                if (pol == 3) PS_LAUNCH_T2C(3); else if (pol == 1) PS_LAUNCH_T2C(1); else PS_LAUNCH_T2C(0);
+#undef PS_LAUNCH_T2C
+                return;
+            }
+            if (mode == 3 && dualC && plain3Hint2 && c->uCoded && fr.cz && !fr.dinvF && !fr.yOut && !fr.red && fr.rStride == 0 && !stList && (gr.x & 7) == 0) {
+                const int pol = policy(M);   // the Chebyshev step's St launch (first term of the polynomial in the epilogue), two units in flight per wave
+#define PS_LAUNCH_T2Z(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, true>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr)
+                if (pol == 3) PS_LAUNCH_T2Z(3); else if (pol == 1) PS_LAUNCH_T2Z(1); else PS_LAUNCH_T2Z(0);
+#undef PS_LAUNCH_T2Z
+                return;
+            }
+            if (single3 && stDual() && !stList && (gr.x & 7) == 0) {
+                const int pol = policy(M);
+#define PS_LAUNCH_T2(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                              M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr)
+                if (pol == 3) PS_LAUNCH_T2(3); else if (pol == 1) PS_LAUNCH_T2(1); else PS_LAUNCH_T2(0);
+#undef PS_LAUNCH_T2
+                return;
+            }
             if (single3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 3); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 3); else PS_LAUNCH_TEX(3, 0, 3); }
             else if (coded3 && stOwnedOnly && stList) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEL(3, 3, 5, true); else if (pol == 1) PS_LAUNCH_TEL(3, 1, 5, true); else PS_LAUNCH_TEL(3, 0, 5, true); }
             else if (coded3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 1); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 1); else PS_LAUNCH_TEX(3, 0, 1); }
@@ -227,15 +266,21 @@ struct Launch {
     int sCap() const { return (c->S.ellok && c->S.packed && c->S.col16ok && pipeGrid == 4096) ? 6144 : 0; }
     // MODE 3 of the row-per-lane St kernel in its plain form (FX = 1: no Chebyshev first term, no halo rows, coded uInv) fits 7 workgroups per CU
     bool plain3Hint = false;
+    bool plain3Hint2 = false;   // the same for the Chebyshev step: single domain, coded uInv
     // Workgroups of the St kernel.  With the residual update in its epilogue (mode 3) it runs best on 6 per CU — measured at 256^3,
     // rocprof average in a solve: 1280 / 1536 workgroups 415 us, 1792 489, 2048 445, 2560 / 3072 425, 4096 430 (and every workgroup
     // less is 10 K partial sums less to read in the prologue); S and the other St modes keep 16 per CU (S: 300 us at 4096, 324 at
     // 1536, 339 at 1024).  PS_PIPE_GRID_ST overrides.
     // Row-per-lane kernel, plain MODE 3: 7 per CU — 1536 workgroups 0.418 ms, 1792 0.403, 2048 0.515 (the eighth does not fit: a second round),
     // 3584 / 5376 as 1792.
+    bool stDual() const {
+        static const bool on = !(getenv("PS_ST_DUAL") && atoi(getenv("PS_ST_DUAL")) == 0);
+        return on && plain3Hint && c->St.ellok && c->St.packed && c->St.col16ok && pipeGrid >= 1536;
+    }
     int stGridFor(int mode) const {
         if (stGrid > 0) return stGrid;
         if (mode != 3 || pipeGrid < 1536) return 0;
+        if (stDual()) return 1536;   // k_spmv_St_ell2: 80 VGPRs, six workgroups per CU
         return (plain3Hint && c->St.ellok && c->St.packed && pipeGrid >= 1792) ? 1792 : 1536;
     }
     int stBlocks(int mode = 0) const {   // number of partials the St kernel writes: one per block
@@ -265,6 +310,7 @@ Launch mk(ps_context* c, const int* done) {
     if (L.xcdAware > 0) L.xcdAware |= (run & 7) << 16;
     L.ntSpmv = c->ntLevel() >= 1;
     L.plain3Hint = c->uCoded && c->P.preconditioner != PS_PRE_CHEBYSHEV && !c->slabEnabled;
+    L.plain3Hint2 = c->uCoded && c->P.preconditioner == PS_PRE_CHEBYSHEV && !c->slabEnabled;
     return L;
 }
 constexpr int64_t FUSED_STEP_MIN_ROWS = 2000000;   // see solve()

@@ -8,7 +8,7 @@ import json
 import sys
 
 out_dir = sys.argv[1]
-KEYS = {"k_spmv_St_pipe<3": "k_spmv_St_r", "k_cg_update_xp_u(": "k_cg_update_xp_u", "k_tile_apply<0": "k_tile_apply", "k_spmv_St_pipe<0": "k_spmv_St", "k_spmv_S_pipe<0": "k_spmv_S", "k_spmv_S_ell<0": "k_spmv_S", "k_spmv_St_ell<3": "k_spmv_St_r", "k_spmv_St_ell<0": "k_spmv_St", "k_cg_update_r(": "k_cg_update_r", "k_cg_update_xp(": "k_cg_update_xp",
+KEYS = {"k_spmv_St_pipe<3": "k_spmv_St_r", "k_cg_update_xp_u(": "k_cg_update_xp_u", "k_tile_apply<0": "k_tile_apply", "k_spmv_St_pipe<0": "k_spmv_St", "k_spmv_S_pipe<0": "k_spmv_S", "k_spmv_S_ell<0": "k_spmv_S", "k_spmv_S_ell2<": "k_spmv_S", "k_spmv_St_ell<3": "k_spmv_St_r", "k_spmv_St_ell2<": "k_spmv_St_r", "k_spmv_St_ell<0": "k_spmv_St", "k_cg_update_r(": "k_cg_update_r", "k_cg_update_xp(": "k_cg_update_xp",
         "k_tile_gather": "k_tile_gather", "k_tile_expand": "k_tile_expand"}
 
 
