@@ -900,12 +900,12 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
 // k_spmv_S_ell with twice the memory-level parallelism per wave: a workgroup takes TWO chunks per step, waves 0-1 the first, waves 2-3 the
 // second; a wave owns units 2 (w & 1) and 2 (w & 1) + 1 of its chunk and has the streams, the gathers and the epilogue loads of both in
 // flight before it sums either.  Same products, same order per row: bit-identical t; the per-workgroup partials of sum s.t group differently.
-template <int POL>
+template <int POL, bool LIST>
 __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                     const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                     const double* __restrict__ x, int cols, int rows, int nA, double dt, double* __restrict__ out,
                                                     const int* __restrict__ done, int nChunks, const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict,
-                                                    double* __restrict__ stPart) {
+                                                    double* __restrict__ stPart, const int32_t* __restrict__ list) {   // LIST: as k_spmv_S_ell (nChunks = entries of the list)
     if (done && *done) return;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
     __shared__ double dict[256];
@@ -924,7 +924,7 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__
     auto chunkAt = [&](int q) -> int {
         const int pair = ((((q >> 5) << 3) + xcd) << 5) + (q & 31);
         const int ch = 2 * pair + half;
-        return (pair < nPairs && ch < nChunks) ? ch : -1;
+        return (pair < nPairs && ch < nChunks) ? (LIST ? list[ch] : ch) : -1;
     };
     const int qEnd = ((nPairs + 255) >> 8) << 5;          // steps beyond the last run of 32 pairs per XCD
     int q = l;
@@ -965,11 +965,14 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__
 // units in flight per wave, two chunks per workgroup and step (r04; default, PS_ST_DUAL=0 switches back).  Compiled for six waves per SIMD
 // (80 VGPRs): twelve units in flight per SIMD against the seven of the one-unit kernel.
 // CZ: the Chebyshev polynomial's first term on the new r in the epilogue (z_1 = dinv r / theta -> fr.cz, r.z partials from it; fr.dinvF unused)
-template <int POL, bool CZ>
+// DIST: a rank of a decomposition — alpha and ||x||^2 from the all-reduced sums (fr.red), partials at fr.rStride; with LIST the launch over
+// the chunks of OWNED rows only that runs under the exchange (ps_dist.hpp; k_spmv_St_ell's FX bit 2)
+template <int POL, bool CZ, bool DIST, bool LIST>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_spmv_St_ell2(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                      const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                      const double* __restrict__ t, int cols, int rows, const double* __restrict__ xin,
-                                                     const int* __restrict__ done, int nChunks, const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr) {
+                                                     const int* __restrict__ done, int nChunks, const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, FusedR fr,
+                                                     const int32_t* __restrict__ list) {
     if (done && *done) return;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
     __shared__ double dict[256];
@@ -980,7 +983,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
         auto sumArr = [&](const double* a, int cnt) { double acc = 0.; for (int i = threadIdx.x; i < cnt; i += BS) acc += a[i]; return blockSumAll(acc); };
         const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
         if (fr.it > 0) {
-            const double xx = sumArr(fr.xxPart, fr.xxCount);
+            const double xx = DIST ? fr.red[1] : sumArr(fr.xxPart, fr.xxCount);
             const double rr = sc->rr;
             double rre = rr;                               // pcg.h:319-325
             if (rr / xx < rre) rre = rr / xx;
@@ -988,7 +991,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
             if (writer) { sc->xx = xx; sc->rre = rre; if (fire) { sc->done = 1; sc->iter = fr.it - 1; } }
             if (fire) return;
         }
-        const double pAp = -(sumArr(fr.sPart, fr.sCount) + sumArr(fr.tPart, fr.tCount) + 0.5 * sumArr(fr.uPart, fr.uCount));
+        const double pAp = DIST ? -fr.red[0] : -(sumArr(fr.sPart, fr.sCount) + sumArr(fr.tPart, fr.tCount) + 0.5 * sumArr(fr.uPart, fr.uCount));
         alpha = sc->rsold2[fr.it & 1] / pAp;               // pcg.h:314
         if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
     }
@@ -1006,7 +1009,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     auto chunkAt = [&](int q) -> int {
         const int pair = ((((q >> 5) << 3) + xcd) << 5) + (q & 31);
         const int ch = 2 * pair + half;
-        return (pair < nPairs && ch < nChunks) ? ch : -1;
+        return (pair < nPairs && ch < nChunks) ? (LIST ? list[ch] : ch) : -1;
     };
     const int qEnd = ((nPairs + 255) >> 8) << 5;
     int q = l;
@@ -1055,7 +1058,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
         q = qn; chunk = nchunk; ci = nci; myBase = nBase;
     }
     const double b0 = blockReduceSum(dacc), b1 = (CZ || fr.dinvF) ? blockReduceSum(dacc2) : 0.;
-    if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[gridDim.x + blockIdx.x] = b1; }
+    if (threadIdx.x == 0) { fr.rPart[blockIdx.x] = b0; fr.rPart[((DIST && fr.rStride > 0) ? fr.rStride : (int)gridDim.x) + blockIdx.x] = b1; }
 }
 
 // ... and for MODE 2 (one term of the Chebyshev preconditioner in the epilogue; coded uInv): two units in flight per wave.

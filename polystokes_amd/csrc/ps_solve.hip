@@ -78,12 +78,14 @@ struct Launch {
             // two units in flight per wave (k_spmv_S_ell2; r04): 256^3, same box, two interleaved rounds: S 0.2809 / 0.2816 -> 0.2672 / 0.2609 ms in
             // sequence, step 1128.6 / 1130.2 -> 1117.3 / 1118.5 ms (profiles/r04_s_dual.txt).  PS_S_DUAL=0: the one-unit kernel.
             static const bool dual = !(getenv("PS_S_DUAL") && atoi(getenv("PS_S_DUAL")) == 0);
-            if (dual && mode == 0 && !sList && c->mcCoded && (gr.x & 7) == 0) {
+            if (dual && mode == 0 && c->mcCoded && (gr.x & 7) == 0) {
                 const int pol = policy(M);
-#define PS_LAUNCH_S2(POL_) hipLaunchKernelGGL((k_spmv_S_ell2<POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                              M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, out, done, nChunks, (const uint8_t*)c->mcCode.p, c->mcDict.p, sPart)
+#define PS_LAUNCH_S2L(POL_, LIST_) hipLaunchKernelGGL((k_spmv_S_ell2<POL_, LIST_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                              M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, out, done, nChunks, (const uint8_t*)c->mcCode.p, c->mcDict.p, sPart, sList)
+#define PS_LAUNCH_S2(POL_) do { if (sList) PS_LAUNCH_S2L(POL_, true); else PS_LAUNCH_S2L(POL_, false); } while (0)
                 if (pol == 3) PS_LAUNCH_S2(3); else if (pol == 1) PS_LAUNCH_S2(1); else PS_LAUNCH_S2(0);
 #undef PS_LAUNCH_S2
+#undef PS_LAUNCH_S2L
                 return;
             }
 #define PS_LAUNCH_SE(MODE_, POL_) do { if (sList) PS_LAUNCH_SEL(MODE_, POL_, true); else PS_LAUNCH_SEL(MODE_, POL_, false); } while (0)
@@ -197,21 +199,28 @@ struct Launch {
             }
             if (mode == 3 && dualC && plain3Hint2 && c->uCoded && fr.cz && !fr.dinvF && !fr.yOut && !fr.red && fr.rStride == 0 && !stList && (gr.x & 7) == 0) {
                 const int pol = policy(M);   // the Chebyshev step's St launch (first term of the polynomial in the epilogue), two units in flight per wave
-#define PS_LAUNCH_T2Z(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, true>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr)
+#define PS_LAUNCH_T2Z(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, true, false, false>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, (const int32_t*)nullptr)
                 if (pol == 3) PS_LAUNCH_T2Z(3); else if (pol == 1) PS_LAUNCH_T2Z(1); else PS_LAUNCH_T2Z(0);
 #undef PS_LAUNCH_T2Z
                 return;
             }
             if (single3 && stDual() && !stList && (gr.x & 7) == 0) {
                 const int pol = policy(M);
-#define PS_LAUNCH_T2(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                              M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr)
+#define PS_LAUNCH_T2(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, false, false>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                              M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, (const int32_t*)nullptr)
                 if (pol == 3) PS_LAUNCH_T2(3); else if (pol == 1) PS_LAUNCH_T2(1); else PS_LAUNCH_T2(0);
 #undef PS_LAUNCH_T2
                 return;
             }
             if (single3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 3); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 3); else PS_LAUNCH_TEX(3, 0, 3); }
+            else if (coded3 && stOwnedOnly && stList && dualC && fr.red && (gr.x & 7) == 0) {   // a rank's launch over owned rows only, two units in flight per wave
+                const int pol = policy(M);
+#define PS_LAUNCH_T2D(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, true, true>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, stList)
+                if (pol == 3) PS_LAUNCH_T2D(3); else if (pol == 1) PS_LAUNCH_T2D(1); else PS_LAUNCH_T2D(0);
+#undef PS_LAUNCH_T2D
+            }
             else if (coded3 && stOwnedOnly && stList) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEL(3, 3, 5, true); else if (pol == 1) PS_LAUNCH_TEL(3, 1, 5, true); else PS_LAUNCH_TEL(3, 0, 5, true); }
             else if (coded3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 1); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 1); else PS_LAUNCH_TEX(3, 0, 1); }
             else if (mode == 0) PS_LAUNCH_TE2(0); else if (mode == 1) PS_LAUNCH_TE2(1); else if (mode == 2) PS_LAUNCH_TE2(2); else PS_LAUNCH_TE2(3);
