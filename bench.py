@@ -510,17 +510,17 @@ def main():
                 "samples": {"exchange": min(d["exchange_samples"] for d in allst), "allreduce": min(d["allreduce_samples"] for d in allst)},
                 "note": "exchange = one transport timed with events on the rank's comm stream at the end of every 25-iteration batch; it runs UNDER the S / St chunks that need no halo value when overlap is true",
             }
+    if world == 1:
+        # the boundary as the Houdini shim uses it: host fp32 fields in, velocity / valid fields out (polystokes_step)
+        t0 = time.perf_counter()
+        solver.step(sc, p)
+        out["pcie_inclusive_ms"] = (time.perf_counter() - t0) * 1e3
     # BASELINE config 4 / north_star's "1 -> 8-GPU scaling curve at 512^3" from the SAME invocation: the 512^3 coiling column cut
     # N ways (1: single domain; 2: z-slabs; 4: 2x2x1 bricks; 8: 2x2x2 bricks), 1 warm-up + 3 timed steps, after the headline
     # measurement and on the same communicator — a driver that only passes --gpus N still records the strong series.
     redundant = strong and scene_name == "coil" and n == args.strong_res
     if not args.no_strong_512 and not redundant and args.maxit == 0:
         out["strong_512"] = strong_block(solver, world, rank, dist, pre, transport_used, args.strong_res, barrier)
-    if world == 1:
-        # the boundary as the Houdini shim uses it: host fp32 fields in, velocity / valid fields out (polystokes_step)
-        t0 = time.perf_counter()
-        solver.step(sc, p)
-        out["pcie_inclusive_ms"] = (time.perf_counter() - t0) * 1e3
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.precond != "chebyshev" and scene_name == "cavity":   # the CPU leg times the reference's own (Jacobi / identity) PCG iteration on the headline scene
         out["cpu_baseline"] = cpu_baseline(n ** 3, nsys, iters, dict(tile=16, pad=2, precond=kw["precond"]), args.cpu_sample_res)
     if rank == 0:
