@@ -652,7 +652,8 @@ struct Dist {
             exchangeAddY(&ps_context::dinv);
             for (ps_context* c : R) {
                 const int64_t n = c->ownHi - c->ownLo;
-                if (jac) HIP_CHECK(hipMemsetAsync(c->dinvF.p, 0, (size_t)std::max<int64_t>(c->nSystem, 1) * sizeof(float), c->stream));   // (halo rows: never read as a diagonal)
+                if (jac && c->dinvF.p && c->nSystem > 0)       // (a rank without any DOF has no diagonal: constructPreconditioner returns before allocating it)
+                    HIP_CHECK(hipMemsetAsync(c->dinvF.p, 0, (size_t)c->nSystem * sizeof(float), c->stream));   // halo rows: never read as a diagonal
                 if (n > 0) {
                     hipLaunchKernelGGL(k_invert_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, n);
                     if (jac) hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);

@@ -292,3 +292,20 @@ def test_fuzz_brick_mismatches_vanish_with_the_tolerance(seed):
         assert np.abs(grp.vel[a] - single.vel[a]).max() <= 1e-4 * scale, (seed, a, np.abs(grp.vel[a] - single.vel[a]).max() / scale)
     grp.close()
     single.close()
+
+
+def test_bricks_classification_that_reaches_beyond_the_halo_is_refused():
+    """A limitation found by `scripts/fuzz_bricks.py 40 4200` (seed 4219; the r03 library behaves the same): with tilePadding = 1 the
+    reference's fixReducedRegionBoundaries (Classifier.cpp:1073-1172) demotes the REDUCED cells on both sides of a one-cell padding
+    layer, so the classification of the tile next to a cut depends on the cell just OUTSIDE the 16-cell halo block — and, through
+    fixSmallReducedRegions (:1174-1262), a whole thin region next to the cut can then exist in the rank's view and not in the global
+    one (the CPU oracle run on the rank's sub-grid reproduces it: `scripts/brick_diag.py 4219`).  The library does not solve on
+    inconsistent labels: the ranks compare the counts and key hashes of their exchange lists and EVERY rank fails with a message."""
+    import polystokes_amd
+    from helpers import fuzz_brick_case
+    sc, p, dims, n, tile = fuzz_brick_case(4219)
+    assert p.tilePadding == 1
+    grp = polystokes_amd.Group(dims[0] * dims[1] * dims[2], dims=dims)
+    with pytest.raises(polystokes_amd.PolyStokesError, match="exchange lists disagree"):
+        grp.solve_scene(sc, p)
+    grp.close()
