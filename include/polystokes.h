@@ -268,7 +268,8 @@ int32_t ps_comm_selftest(ps_context* ctx);   /* collective: all-reduce, grouped 
 /* What the last distributed solve of this rank did (no reference counterpart: the reference is single-process, its only parallelism
  * is lib/include/ApplyPressureStressMatrix.h:122-164): out8 = { bytes sent per CG iteration over the rank's cuts, owned DOFs,
  * 1 if the halo exchanges overlapped with the interior rows, sum [ms] and count of sampled x-exchange transports, sum [ms] and
- * count of sampled scalar all-reduces (incl. synchronisation), 0 }. */
+ * count of sampled scalar all-reduces (incl. synchronisation), cells of the rank's halo blocks whose label was replaced by the
+ * owner's during setup (the classification reaches beyond a halo block: boundary layers, fixReducedRegionBoundaries) }. */
 int32_t ps_dist_stats(ps_context* ctx, double* out8);
 /* Host-staged transport instead of RCCL (pack -> D2H -> TCP -> H2D -> unpack; scalar all-reduce through rank 0):
  * one process per rank, several ranks may share one GPU (RCCL refuses duplicate devices) — the route by which the

@@ -173,12 +173,12 @@ class Solver:
 
     def dist_stats(self):
         """What this rank's last distributed solve did (ps_dist_stats): dict of bytes per iteration over its cuts, owned DOFs,
-        whether the exchanges overlapped, sampled transport / all-reduce times."""
+        whether the exchanges overlapped, sampled transport / all-reduce times, halo cells whose label the owners' exchange changed."""
         v = (C.c_double * 8)()
         self._check(self.L.ps_dist_stats(self.h, v))
         return {"halo_bytes_per_iter": v[0], "owned_dofs": v[1], "overlap": bool(v[2]),
                 "exchange_ms_per_transport": (v[3] / v[4]) if v[4] else None, "exchange_samples": int(v[4]),
-                "allreduce_ms": (v[5] / v[6]) if v[6] else None, "allreduce_samples": int(v[6])}
+                "allreduce_ms": (v[5] / v[6]) if v[6] else None, "allreduce_samples": int(v[6]), "halo_label_changes": int(v[7])}
 
     def comm_init(self, uid_bytes, rank, world):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)

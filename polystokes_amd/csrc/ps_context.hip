@@ -124,35 +124,68 @@ void ps_context::fillDimData(ps_stats* st) const {   // Solver.cpp:578-593
     dd[24] = (double)regionCount; dd[25] = dx; dd[26] = dt;
 }
 
-// HDK_PolyStokes.C:344-476: everything between setupClockStart() and setupClockEnd()
+// HDK_PolyStokes.C:344-476: everything between setupClockStart() and setupClockEnd().
+// Three phases, so that the ranks of a decomposition can exchange the cell labels of their halo blocks at the two points where the
+// reference's classification looks further than a halo block reaches (ps_dist.hpp: Dist::exchangeLabels):
+//   0: weights, classifyCells, constructReducedRegions                  -> labels before the regions exist
+//   1: classifyFaces / Edges, connected components, fixReducedRegionBoundaries   -> labels after the boundary fix
+//   2: fixSmallReducedRegions and everything after it
+// A single domain runs them back to back.
+namespace {
+struct SetupState {
+    StageTimer T;
+    std::clock_t c0;
+    std::chrono::high_resolution_clock::time_point w0;
+    explicit SetupState(hipStream_t s) : T(s), c0(std::clock()), w0(std::chrono::high_resolution_clock::now()) {}
+};
+}
 int ps_context::setup(ps_stats* stats) {
-    if (!uploaded) throw Error("ps_upload_fields has not been called");
-    isSetup = false; isSolved = false;   // a setup that throws must not leave the previous step's system looking valid
-    arrays.clear();
-    HIP_CHECK(hipSetDevice(device));
-    const std::clock_t c0 = std::clock();
-    const auto w0 = std::chrono::high_resolution_clock::now();
-    StageTimer T(stream);
-    bboxValid = false;
-    // Solver ctor: labels / indices start UNASSIGNED (Solver.cpp:86-152)
-    for (int s = 0; s < 7; ++s) {
-        const int64_t n = g.count(s);
-        const dim3 gr(gridFor(n, 256)), bl(256);
-        hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, labels[s].p, n, (int32_t)PS_UNASSIGNED);
-        hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, activeIdx[s].p, n, (int32_t)PS_UNASSIGNED);
-        hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, reducedIdx[s].p, n, (int32_t)PS_UNASSIGNED);
+    for (int ph = 0; ph < 3; ++ph) setupPhase(ph);
+    if (stats) *stats = lastStats;
+    return PS_SUCCESS;
+}
+void ps_context::setupPhase(int phase) {
+    if (phase == 0) {
+        if (!uploaded) throw Error("ps_upload_fields has not been called");
+        isSetup = false; isSolved = false;   // a setup that throws must not leave the previous step's system looking valid
+        setupPhaseDone = -1;
+        arrays.clear();
+        HIP_CHECK(hipSetDevice(device));
+        setupState = std::make_shared<SetupState>(stream);
     }
-    regionCount = 0;
-    T.mark(0);
-    buildIntegrationWeightsAlt();
-    T.mark(1);
-    classifyCells();
-    if (P.doReducedRegions) constructReducedRegions(); else constructOnlyActiveRegions();
-    classifyFaces();
-    classifyEdges();
-    T.mark(2);
+    if (!setupState || setupPhaseDone != phase - 1) throw Error("setup phases out of order");
+    HIP_CHECK(hipSetDevice(device));
+    SetupState& Z = *std::static_pointer_cast<SetupState>(setupState);
+    StageTimer& T = Z.T;
+    if (phase == 0) {
+        bboxValid = false;
+        // Solver ctor: labels / indices start UNASSIGNED (Solver.cpp:86-152)
+        for (int s = 0; s < 7; ++s) {
+            const int64_t n = g.count(s);
+            const dim3 gr(gridFor(n, 256)), bl(256);
+            hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, labels[s].p, n, (int32_t)PS_UNASSIGNED);
+            hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, activeIdx[s].p, n, (int32_t)PS_UNASSIGNED);
+            hipLaunchKernelGGL(k_fill32, gr, bl, 0, stream, reducedIdx[s].p, n, (int32_t)PS_UNASSIGNED);
+        }
+        regionCount = 0;
+        T.mark(0);
+        buildIntegrationWeightsAlt();
+        T.mark(1);
+        classifyCells();
+        if (P.doReducedRegions) constructReducedRegions(); else constructOnlyActiveRegions();
+        setupPhaseDone = 0;
+        return;
+    }
+    if (phase == 1) {
+        classifyFaces();
+        classifyEdges();
+        T.mark(2);
+        if (P.doReducedRegions) constructCenterReducedIndices(0);
+        setupPhaseDone = 1;
+        return;
+    }
     if (P.doReducedRegions) {
-        constructCenterReducedIndices();
+        constructCenterReducedIndices(1);
         constructFacesReducedIndices();
         constructEdgesReducedIndices();
     }
@@ -181,8 +214,8 @@ int ps_context::setup(ps_stats* stats) {
     lastStats.result = PS_INCOMPLETE;
     fillDimData(&lastStats);
     lastStats.solveData[0] = -1; lastStats.solveData[1] = -1; lastStats.solveData[2] = -1; lastStats.solveData[3] = -1;
-    lastStats.solveData[4] = 1000.0 * (double)(std::clock() - c0) / CLOCKS_PER_SEC;
-    lastStats.solveData[5] = std::chrono::duration<double, std::milli>(w1 - w0).count();
+    lastStats.solveData[4] = 1000.0 * (double)(std::clock() - Z.c0) / CLOCKS_PER_SEC;
+    lastStats.solveData[5] = std::chrono::duration<double, std::milli>(w1 - Z.w0).count();
     lastStats.stage_ms[PS_STAGE_WEIGHTS] = T.ms(0, 1);
     lastStats.stage_ms[PS_STAGE_CLASSIFY] = T.ms(1, 2);
     lastStats.stage_ms[PS_STAGE_REGIONS] = T.ms(2, 3);
@@ -191,10 +224,10 @@ int ps_context::setup(ps_stats* stats) {
     lastStats.stage_ms[PS_STAGE_BLOCKS] = T.ms(5, 6);
     lastStats.stage_ms[PS_STAGE_ASSEMBLE] = T.ms(6, 7);
     lastStats.stage_ms[PS_STAGE_PRECOND] = T.ms(7, 8);
+    setupState.reset();
+    setupPhaseDone = 2;
     isSetup = true; isSolved = false;
     registerArrays();
-    if (stats) *stats = lastStats;
-    return PS_SUCCESS;
 }
 
 // HDK_PolyStokes.C:509-583: solve(), buildValidFaces, recoverVelocityFromPressureStress, applySolutionToVelocity

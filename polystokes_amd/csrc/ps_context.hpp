@@ -2,6 +2,7 @@
 // same stage methods, same state, but every field lives in HBM and every stage is a HIP kernel launch.
 #pragma once
 #include <map>
+#include <memory>
 
 #include "ps_common.hpp"
 
@@ -203,6 +204,8 @@ struct ps_context {
     hipEvent_t distEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // what one distributed solve did (ps_dist_stats): bytes per iteration over the cuts, sampled transport / all-reduce times
     double distStats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ps::DevBuf<int32_t> labelFlags;          // Dist::exchangeLabels: labels changed, REDUCED cells without a component
+    int64_t haloLabelChanges = 0;            // halo cells whose label the owners' exchange changed in the last setup (both passes)
     void* rcclComm = nullptr;                // ncclComm_t when one process per GPU
     void* hostComm = nullptr;                // host-staged TCP transport (ps_comm_init_tcp): same algorithm without RCCL
     uint64_t hashLowHalo[3] = {0, 0, 0}, hashLowOwn[3] = {0, 0, 0}, hashUpHalo[3] = {0, 0, 0}, hashUpOwn[3] = {0, 0, 0};   // order-sensitive hashes of the lists' global keys
@@ -239,7 +242,7 @@ struct ps_context {
     void constructOnlyActiveRegions();
     void classifyFaces();
     void classifyEdges();
-    void constructCenterReducedIndices();
+    void constructCenterReducedIndices(int part);         // 0: components + fixReducedRegionBoundaries, 1: fixSmallReducedRegions
     void constructFacesReducedIndices();
     void constructEdgesReducedIndices();
     void constructActiveIndices();
@@ -278,6 +281,9 @@ struct ps_context {
 
     // orchestration (ps_context.hip)
     int setup(ps_stats* stats);
+    void setupPhase(int phase);              // 0, 1, 2 in this order (setup() = all three); between them Dist exchanges the halo's cell labels
+    std::shared_ptr<void> setupState;        // stage timer and clocks of the setup in flight
+    int setupPhaseDone = -1;
     int solveStage(ps_stats* stats);
     void fillDimData(ps_stats* st) const;
     void registerArrays();

@@ -110,6 +110,60 @@ __global__ void k_invert_diag(double* __restrict__ d, int64_t n) {
         d[i] = v != 0. ? 1. / v : 1.;
     }
 }
+// ---- the cell labels of a rank's halo blocks, taken from their owners (Dist::exchangeLabels) ----------------------------------------
+// Layers [q0, q0 + h) along axis a over the FULL cross-section of the local grid (the halo parts of the other axes included: the
+// axes are exchanged x, y, z, each forwarding what the previous brought, as the values of the solve are); entry j = layer * cs + u2 * d1 + u1
+// with (u1, u2) the two other coordinates in ascending axis order.  Two neighbours along a have the same cross-section.
+__device__ inline int64_t labelCell(const int3 d, int a, int q0, int64_t j) {
+    const int d1 = a == 0 ? d.y : d.x, d2 = a == 2 ? d.y : d.z;
+    const int64_t cs = (int64_t)d1 * d2;
+    const int layer = (int)(j / cs);
+    const int64_t rem = j - (int64_t)layer * cs;
+    const int u1 = (int)(rem % d1), u2 = (int)(rem / d1);
+    const int q = q0 + layer;
+    return a == 0 ? lin3(d, q, u1, u2) : (a == 1 ? lin3(d, u1, q, u2) : lin3(d, u1, u2, q));
+}
+__global__ void k_labels_pack(const int32_t* __restrict__ lab, int3 d, int a, int qLo, int64_t nLo, int32_t* __restrict__ outLo, int qUp, int64_t nUp,
+                              int32_t* __restrict__ outUp) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nLo + nUp; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nLo) outLo[i] = lab[labelCell(d, a, qLo, i)];
+        else outUp[i - nLo] = lab[labelCell(d, a, qUp, i - nLo)];
+    }
+}
+// reg != null (after fixReducedRegionBoundaries): a cell the owner kept REDUCED has the component it had before the fix (reg0), any
+// other cell none.  flags[0] += labels changed, flags[1] += REDUCED cells without a component (the views disagree before the fix: refused)
+// pass 0 (reg == null): nbrMask bit 2b / 2b+1 = a neighbour below / above along axis b; a label that changes `reach` or more cells
+// away from every end of the view that is a cut cannot come from the classification's reach: the ranks were handed different
+// fields for the same cells (flags[2])
+__global__ void k_labels_unpack(int32_t* __restrict__ lab, int32_t* __restrict__ reg, const int32_t* __restrict__ reg0, int3 d, int a, int qLo, int64_t nLo,
+                                const int32_t* __restrict__ inLo, int qUp, int64_t nUp, const int32_t* __restrict__ inUp, int32_t* __restrict__ flags,
+                                int nbrMask, int reach) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nLo + nUp; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool low = i < nLo;
+        const int64_t c = low ? labelCell(d, a, qLo, i) : labelCell(d, a, qUp, i - nLo);
+        const int32_t v = low ? inLo[i] : inUp[i - nLo];
+        if (lab[c] != v) {
+            atomicAdd(&flags[0], 1);
+            lab[c] = v;
+            if (!reg) {
+                const int3 q = unlin3(d, c);
+                const int qq[3] = {q.x, q.y, q.z}, dd[3] = {d.x, d.y, d.z};
+                int dist = INT_MAX;
+                for (int b = 0; b < 3; ++b) {
+                    if (nbrMask & (1 << (2 * b))) dist = min(dist, qq[b]);
+                    if (nbrMask & (2 << (2 * b))) dist = min(dist, dd[b] - 1 - qq[b]);
+                }
+                if (dist >= reach) atomicAdd(&flags[2], 1);
+            }
+        }
+        if (reg) {
+            const int32_t r = v == PS_REDUCED ? reg0[c] : (int32_t)PS_UNASSIGNED;
+            if (v == PS_REDUCED && r < 0) atomicAdd(&flags[1], 1);
+            reg[c] = r;
+        }
+    }
+}
+
 struct SumPtrs { double* p[16]; int n; };
 __global__ void k_sum_across(SumPtrs P, int count) {
     const int i = threadIdx.x;
@@ -479,6 +533,74 @@ struct Dist {
         HIP_CHECK(hipStreamSynchronize(R[0]->stream));
         return out;
     }
+    // The cell labels of every rank's halo blocks := the owners' labels.  The reference's classification is not local: the boundary layers
+    // reach up to three cells, fixReducedRegionBoundaries (Classifier.cpp:1073-1172) one cell beyond a region's tile — beyond the halo
+    // block — and fixSmallReducedRegions (:1174-1262) turns a cell demoted THERE into a whole region kept or dropped next to the cut
+    // (tilePadding 1: scripts/brick_diag.py).  A rank's OWNED cells are at least a halo block away from where its view ends, so the
+    // owner is always right.  pass 0: after classifyCells / constructReducedRegions (labels only); pass 1: after the boundary fix
+    // (labels + the cell's component from before the fix).  Both go through the transport of the solve's x-exchange.
+    static int nbrMask(const ps_context* c) { int m = 0; for (int b = 0; b < 3; ++b) m |= (c->brick.hasLower[b] ? 1 : 0) << (2 * b) | (c->brick.hasUpper[b] ? 2 : 0) << (2 * b); return m; }
+    void exchangeLabels(int pass) {
+        bool any = false;
+        for (int a = 0; a < 3; ++a) any = any || axisUsed(a);
+        if (!any) return;
+        if (useTcp) { ps_context* c = R[0]; int lo[3], up[3]; for (int a = 0; a < 3; ++a) { lo[a] = c->nbrLo(a); up[a] = c->nbrUp(a); } hc()->connectNeighbours(lo, up); }
+        for (ps_context* c : R) {
+            c->labelFlags.alloc(4);
+            HIP_CHECK(hipMemsetAsync(c->labelFlags.p, 0, 4 * sizeof(int32_t), c->stream));
+            order(c, 0, true);
+        }
+        for (int a = 0; a < 3; ++a) {
+            if (!axisUsed(a)) continue;
+            struct Geo { int3 d; int hLo, hUp; int64_t nLo, nUp, keep[4]; };
+            std::vector<Geo> G(R.size());
+            for (size_t q = 0; q < R.size(); ++q) {
+                ps_context* c = R[q];
+                Geo& z = G[q];
+                z.d = c->g.dims(0);
+                const int da = a == 0 ? z.d.x : (a == 1 ? z.d.y : z.d.z);
+                const int64_t cross = (int64_t)z.d.x * z.d.y * z.d.z / da;
+                z.hLo = c->brick.hasLower[a] ? c->brick.lo[a] : 0;
+                z.hUp = c->brick.hasUpper[a] ? da - c->brick.hi[a] : 0;
+                z.nLo = (int64_t)z.hLo * cross; z.nUp = (int64_t)z.hUp * cross;
+                z.keep[0] = c->nLowOwn[a]; z.keep[1] = c->nLowHalo[a]; z.keep[2] = c->nUpOwn[a]; z.keep[3] = c->nUpHalo[a];
+                const size_t mx = (size_t)(std::max(z.nLo, z.nUp) + 1) / 2 + 8;   // int32 labels in the double buffers of the exchanges
+                c->sendLo[a].alloc(mx); c->sendUp[a].alloc(mx); c->recvLo[a].alloc(mx); c->recvUp[a].alloc(mx);
+                c->nLowOwn[a] = c->nLowHalo[a] = (z.nLo + 1) / 2; c->nUpOwn[a] = c->nUpHalo[a] = (z.nUp + 1) / 2;
+                // what goes down: my first hLo owned layers (the lower rank's upper halo block); up: my last hUp owned layers
+                if (z.nLo + z.nUp > 0)
+                    hipLaunchKernelGGL(k_labels_pack, dim3(gridFor(z.nLo + z.nUp, BS)), dim3(BS), 0, cs(c, true), (const int32_t*)c->labels[0].p, z.d, a, c->brick.lo[a], z.nLo,
+                                       (int32_t*)c->sendLo[a].p, c->brick.hi[a] - z.hUp, z.nUp, (int32_t*)c->sendUp[a].p);
+            }
+            auto restore = [&]() { for (size_t q = 0; q < R.size(); ++q) { ps_context* c = R[q]; c->nLowOwn[a] = G[q].keep[0]; c->nLowHalo[a] = G[q].keep[1]; c->nUpOwn[a] = G[q].keep[2]; c->nUpHalo[a] = G[q].keep[3]; } };
+            try { transport(0, true, a); } catch (...) { restore(); throw; }
+            restore();
+            for (size_t q = 0; q < R.size(); ++q) {
+                ps_context* c = R[q];
+                const Geo& z = G[q];
+                if (z.nLo + z.nUp > 0)
+                    hipLaunchKernelGGL(k_labels_unpack, dim3(gridFor(z.nLo + z.nUp, BS)), dim3(BS), 0, cs(c, true), c->labels[0].p, pass ? c->reducedIdx[0].p : (int32_t*)nullptr,
+                                       (const int32_t*)c->cellScratch[2].p, z.d, a, 0, z.nLo, (const int32_t*)c->recvLo[a].p, c->brick.hi[a], z.nUp,
+                                       (const int32_t*)c->recvUp[a].p, c->labelFlags.p, nbrMask(c),
+                                       c->P.activeLiquidBoundaryLayerSize + c->P.activeSolidBoundaryLayerSize + c->P.tilePadding + 2);   // (ps_set_brick: <= 16)
+            }
+        }
+        bool bad = false, differ = false;
+        for (ps_context* c : R) {
+            order(c, 1, false);
+            int32_t fl[3] = {0, 0, 0};
+            HIP_CHECK(hipMemcpyAsync(fl, c->labelFlags.p, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (pass == 0) c->haloLabelChanges = 0;
+            c->haloLabelChanges += fl[0];
+            bad = bad || fl[1] != 0;
+            differ = differ || fl[2] != 0;
+        }
+        if (sumFlag(bad || differ ? 1. : 0.) > 0.)
+            throw Error(differ ? "the labels of a halo block differ from their owner's deeper inside the block than the classification reaches: the ranks were handed different fields for the same cells"
+                        : (bad ? "the labels of a halo block cannot be reconciled with their owner's (REDUCED cells the rank's own classification never had)"
+                               : "another rank found the labels of a halo block in disagreement with their owner's"));
+    }
     // neighbours must agree on the exchange lists: same lengths AND the same keys (position in the cut's cross-section, kind) in the
     // same order (ps_context::buildHaloLists hashes them) — equal counts of different DOF sets would otherwise pair the wrong entries.
     void checkLists() {
@@ -760,6 +882,7 @@ struct Dist {
             c->distStats[0] = 8. * (double)c->exchangeEntries();   // bytes this rank sends per iteration (x layers + A p contributions)
             c->distStats[1] = (double)(c->ownHi - c->ownLo);                                        // owned DOFs
             c->distStats[2] = overlap ? 1. : 0.;
+            c->distStats[7] = (double)c->haloLabelChanges;
         }
         if (fused) {
             for (size_t q = 0; q < R.size(); ++q) {
@@ -1083,13 +1206,18 @@ int distStep(Dist& D, ps_stats* stats) {
     for (ps_context* c : D.R) c->redbuf.alloc(8);
     // a rank whose local setup throws must tell the others before they enter the first exchange (they would wait for ever)
     std::string failure;
-    for (ps_context* c : D.R) {
-        try { c->setup(nullptr); }
-        catch (const ps::Error& e) { failure = e.msg; }
-        catch (const std::exception& e) { failure = e.what(); }
+    D.ensureStreams();
+    for (int phase = 0; phase < 3; ++phase) {
+        for (ps_context* c : D.R) {
+            if (!failure.empty()) break;
+            try { c->setupPhase(phase); }
+            catch (const ps::Error& e) { failure = e.msg; }
+            catch (const std::exception& e) { failure = e.what(); }
+        }
+        if (D.sumFlag(failure.empty() ? 0. : 1.) > 0.)
+            throw Error(failure.empty() ? std::string("another rank failed during setup") : failure);
+        if (phase < 2 && (phase == 0 || D.R[0]->P.doReducedRegions)) D.exchangeLabels(phase);
     }
-    if (D.sumFlag(failure.empty() ? 0. : 1.) > 0.)
-        throw Error(failure.empty() ? std::string("another rank failed during setup") : failure);
     D.finishSetup();
     D.syncAll();
     const auto w1 = std::chrono::high_resolution_clock::now();
@@ -1165,6 +1293,13 @@ int32_t ps_set_brick(ps_context* c, const ps_brick* bk) {
             if (c->P.doReducedRegions && c->P.doTile && (lo % c->P.tileSize || (bk->hasUpper[a] && hi % c->P.tileSize))) throw Error("cuts must be multiples of the tile size");
             if (lo < 0 || hi > n[a] || lo >= hi) throw Error("bad owned range");
             if ((bk->hasLower[a] && lo < 16) || (bk->hasUpper[a] && n[a] - hi < 16)) throw Error("a halo of at least 16 cells is required next to a cut");
+            // one halo block per cut, the same on both sides of it (the ranks exchange the labels of whole halo blocks: Dist::exchangeLabels)
+            if (bk->world > 1) {
+                int al = L;
+                if (c->P.doReducedRegions && c->P.doTile) { int x = L, y = c->P.tileSize; while (y) { const int t = x % y; x = y; y = t; } al = L / x * c->P.tileSize; }
+                if ((bk->hasLower[a] && lo != al) || (bk->hasUpper[a] && n[a] - hi != al)) throw Error("the halo next to a cut must be one block of lcm(16, tileSize) cells");
+                if ((bk->hasLower[a] || bk->hasUpper[a]) && hi - lo < al) throw Error("a brick must be at least one halo block thick");
+            }
             if (!bk->hasLower[a] && lo != 0) throw Error("without a lower neighbour the owned range must start at 0");
             if (!bk->hasUpper[a] && hi != n[a]) throw Error("without an upper neighbour the owned range must end at the last cell");
         }

@@ -989,9 +989,13 @@ void ps_context::classifyEdges() {
 }
 
 // Classifier.cpp:217-239
-void ps_context::constructCenterReducedIndices() {
+// part 0: connected components + fixReducedRegionBoundaries; part 1: fixSmallReducedRegions.  Between the two the ranks of a
+// decomposition replace the labels of their halo blocks by the owners' (Dist::exchangeLabels): the boundary fix looks one cell beyond a
+// region's tile, i.e. beyond the halo block, and what it demotes there decides whether a thin region survives part 1.
+void ps_context::constructCenterReducedIndices(int part) {
     const int64_t n = g.count(0);
     const dim3 gr(gridFor(n, BS)), bl(BS);
+    if (part == 0) {
     int32_t* cc = cellScratch[0].p;
     // connected components
     uint8_t* link = (uint8_t*)cellScratch[2].p;
@@ -1010,6 +1014,9 @@ void ps_context::constructCenterReducedIndices() {
         view.p = nullptr; view.n = 0;
     }
     hipLaunchKernelGGL(k_cc_assign, gr, bl, 0, stream, g, labels[0].p, cc, rootRank, reducedIdx[0].p);
+    // a rank keeps the components as they were before the fix: a cell the owner did NOT demote gets its region back (cellScratch[2]:
+    // the link bits are no longer needed, the fix works in scratch 0 and 1)
+    if (slabEnabled) HIP_CHECK(hipMemcpyAsync(cellScratch[2].p, reducedIdx[0].p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
 
     // fixReducedRegionBoundaries (:1073-1172)
     if (regionCount > 1) {
@@ -1035,6 +1042,8 @@ void ps_context::constructCenterReducedIndices() {
             }
             if (!applied) break;
         }
+    }
+    return;
     }
 
     // fixSmallReducedRegions (:1174-1262)

@@ -30,7 +30,7 @@ def main():
         loc = partition.local_scene(sc, sl)
     if case.endswith("_failrank") and rank == 1:
         # this rank sees air in a patch of its own first layers: its labels on the cut differ from what rank 0 computes
-        # from its halo copy, so the exchange lists disagree (same tile structure, other DOF sets)
+        # from its halo copy: the owners' label exchange finds the two views of the same cells in disagreement
         loc.surface[sl.zLoOwned:sl.zLoOwned + 3, 5:12, 5:12] = 1.0
     s.upload(loc, p)
     if dims is not None:

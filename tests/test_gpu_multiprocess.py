@@ -166,12 +166,15 @@ def test_multiprocess_interrupt_stops_every_rank(tmp_path):
 
 
 def test_multiprocess_list_mismatch_fails_every_rank(tmp_path):
-    """Ranks that disagree about the labels on a cut (here: rank 1 was handed other data than rank 0's halo copy) detect it
-    through the counts / key hashes of their exchange lists, and EVERY rank returns FAILED instead of pairing wrong entries
-    or waiting for ever."""
+    """Ranks that were handed different fields for the same cells (here: rank 1 sees air in a patch of its own first layers, rank 0's
+    halo copy does not): rank 0 finds the owner's labels differing from its copy deeper inside the halo block than the classification
+    reaches (Dist::exchangeLabels), and EVERY rank returns FAILED instead of solving on inconsistent data or waiting for ever.
+    (Until r04 the halo labels were the rank's own and the same case was caught one step later, by the counts / key hashes of the
+    exchange lists — that check is still there: `checkLists`.)"""
     res = _run_ranks("cavity_w2_failrank", 2, tmp_path)
     assert [int(r["rc"]) for r in res] == [-1, -1], [str(r["err"]) for r in res]
-    assert all("exchange lists" in str(r["err"]) for r in res), [str(r["err"]) for r in res]
+    assert all("labels of a halo block" in str(r["err"]) for r in res), [str(r["err"]) for r in res]
+    assert "different fields" in str(res[0]["err"])
 
 
 def test_bench_two_ranks_produces_one_line_whatever_the_transport(tmp_path):
