@@ -4,7 +4,8 @@ import numpy as np
 import polystokes_amd
 from polystokes_amd import _abi as abi
 from helpers import fuzz_brick_case
-for seed in (4237, 4226, 4211, 4230):
+seeds = [int(v) for v in sys.argv[1:]] or [4237, 4226, 4211, 4230]     # usage: fuzz_bricks_seeds_tol.py [seed ...]
+for seed in seeds:
     for tol in (1e-6, 1e-9):
         sc, p, dims, n, tile = fuzz_brick_case(seed, tol); p.maxSolverIterations = 100000
         s = polystokes_amd.Solver(0); rc1 = s.step(sc, p); it1 = int(s.stats.solveData[1])
