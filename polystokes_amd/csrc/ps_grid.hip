@@ -395,6 +395,55 @@ __global__ void k_cc_step(Grid g, const uint8_t* __restrict__ link, int32_t* cc,
     if (v2 < m) m = v2;
     if (m < mine) { atomicMin(&cc[c], m); *changed = 1; }
 }
+// The same propagation inside one box of B^3 cells (B = tile size: with doTile a component never leaves its tile, the padding layer
+// between two tiles is ACTIVE), labels in LDS, to the box's fix point — one launch instead of a dozen k_cc_step passes over the grid
+// and two host round trips less.  Links that leave the box are left to k_cc_step, which runs afterwards until nothing changes
+// (once, when every component is tile-local): the fix point — the smallest order index of each component — is the same.
+__global__ void __launch_bounds__(256) k_cc_local(Grid g, int B, const uint8_t* __restrict__ link, int32_t* __restrict__ cc) {
+    extern __shared__ int32_t shcc[];
+    const int3 d = g.dims(0);
+    const int x0 = blockIdx.x * B, y0 = blockIdx.y * B, z0 = blockIdx.z * B;
+    const int ex = min(B, d.x - x0), ey = min(B, d.y - y0), ez = min(B, d.z - z0);
+    const int nb = ex * ey * ez;
+    uint8_t* shlk = (uint8_t*)(shcc + B * B * B);
+    int any = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const int lx = i % ex, ly = (i / ex) % ey, lz = i / (ex * ey);
+        const int64_t c = lin3(d, x0 + lx, y0 + ly, z0 + lz);
+        const int v = cc[c];
+        int lk = link[c];
+        // links that leave the box: not followed here
+        if (lx == 0) lk &= ~1; if (lx == ex - 1) lk &= ~2;
+        if (ly == 0) lk &= ~4; if (ly == ey - 1) lk &= ~8;
+        if (lz == 0) lk &= ~16; if (lz == ez - 1) lk &= ~32;
+        shcc[i] = v;
+        shlk[i] = (uint8_t)lk;
+        any |= (v != INT_MAX && lk != 0) ? 1 : 0;
+    }
+    if (!__syncthreads_or(any)) return;                                  // no REDUCED cell with a link inside the box
+    const int st[3] = {1, ex, ex * ey};
+    for (int guard = 0; guard < 4 * B * B; ++guard) {                    // (a component's longest shortest path inside the box)
+        int changed = 0;
+        for (int i = threadIdx.x; i < nb; i += 256) {
+            const int lk = shlk[i];
+            if (!lk) continue;
+            const int mine = shcc[i];
+            int m = mine;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (lk & (1 << (2 * a))) { const int v = shcc[i - st[a]]; if (v < m) m = v; }
+                if (lk & (2 << (2 * a))) { const int v = shcc[i + st[a]]; if (v < m) m = v; }
+            }
+            if (m < mine) { atomicMin(&shcc[i], m); changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        if (!shlk[i]) continue;
+        const int lx = i % ex, ly = (i / ex) % ey, lz = i / (ex * ey);
+        cc[lin3(d, x0 + lx, y0 + ly, z0 + lz)] = shcc[i];
+    }
+}
 // cell region id = rank (in traversal order) of its component's first cell
 __global__ void k_cc_assign(Grid g, const int32_t* __restrict__ lab, const int32_t* __restrict__ cc,
                             const int32_t* __restrict__ rootRank, int32_t* __restrict__ region) {
@@ -1000,9 +1049,15 @@ void ps_context::constructCenterReducedIndices(int part) {
     // connected components
     uint8_t* link = (uint8_t*)cellScratch[2].p;
     hipLaunchKernelGGL(k_cc_init, gr, bl, 0, stream, g, labels[0].p, cset(liquidW), cc, link);
+    // tile-local components first, in LDS (5 bytes per cell of a tile, within the 64 KB a launch gets without asking: tiles up to 23^3)
+    static const bool localOff = getenv("PS_CC_LOCAL") && atoi(getenv("PS_CC_LOCAL")) == 0;   // A/B: the grid-wide passes alone
+    const int B = P.tileSize;
+    const bool local = !localOff && P.doTile && P.tilePadding >= 1 && B >= 4 && (size_t)B * B * B * 5 <= 64 * 1024;
+    if (local)
+        hipLaunchKernelGGL(k_cc_local, dim3((g.nx + B - 1) / B, (g.ny + B - 1) / B, (g.nz + B - 1) / B), dim3(256), (size_t)B * B * B * 5, stream, g, B, (const uint8_t*)link, cc);
     for (int guard = 0; guard < 100000; ++guard) {
         zeroCounters();
-        for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < ((local && guard == 0) ? 1 : 4); ++it)
             hipLaunchKernelGGL(k_cc_step, gr, bl, 0, stream, g, (const uint8_t*)link, cc, counters.p);
         if (!readCounter(0)) break;
     }
