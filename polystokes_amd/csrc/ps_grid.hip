@@ -427,13 +427,17 @@ __global__ void __launch_bounds__(256) k_cc_local(Grid g, int B, const uint8_t* 
         for (int i = threadIdx.x; i < nb; i += 256) {
             const int lk = shlk[i];
             if (!lk) continue;
+            // the six reads at once (a link that is not there reads the cell itself): one LDS latency per cell instead of up to seven
+            int v[6];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                v[2 * a] = shcc[(lk & (1 << (2 * a))) ? i - st[a] : i];
+                v[2 * a + 1] = shcc[(lk & (2 << (2 * a))) ? i + st[a] : i];
+            }
             const int mine = shcc[i];
             int m = mine;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (lk & (1 << (2 * a))) { const int v = shcc[i - st[a]]; if (v < m) m = v; }
-                if (lk & (2 << (2 * a))) { const int v = shcc[i + st[a]]; if (v < m) m = v; }
-            }
+            for (int q = 0; q < 6; ++q) m = min(m, v[q]);
             if (m < mine) { atomicMin(&shcc[i], m); changed = 1; }
         }
         if (!__syncthreads_or(changed)) break;
