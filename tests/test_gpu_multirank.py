@@ -335,3 +335,27 @@ def test_bricks_classification_that_reaches_beyond_the_halo(seed):
         assert np.abs(grp.vel[a] - single.vel[a]).max() <= 1e-4 * scale, (seed, a, np.abs(grp.vel[a] - single.vel[a]).max() / scale)
     grp.close()
     single.close()
+
+
+@pytest.mark.parametrize("dims", [(2, 1, 2), (1, 1, 3)])
+def test_bricks_without_reduced_regions_match_single_domain(dims):
+    """doReducedRegions off (the uniform Stokes solve, BASELINE config 1's mode) under a decomposition: only the first of the two label
+    exchanges runs (there are no regions to fix); iterations equal, velocities to 1e-6 at tol 1e-8, every view holds the global labels."""
+    import polystokes_amd
+    sc, p = scenes.blob(48, 32, 48, seed=5, tile=16, pad=2)
+    p.doReducedRegions = 0
+    p.preconditioner = abi.PRE_DIAGONAL
+    p.tolerance = 1e-8
+    single = polystokes_amd.Solver(0)
+    rc1 = single.step(sc, p)
+    grp = polystokes_amd.Group(dims[0] * dims[1] * dims[2], dims=dims)
+    rc2 = grp.solve_scene(sc, p)
+    assert rc1 == rc2 == abi.SUCCESS
+    assert int(single.stats.solveData[1]) == int(grp.stats.solveData[1])
+    _views_hold_the_global_cell_labels(single, grp, sc)
+    for a in range(3):
+        assert np.array_equal(grp.valid[a], single.valid[a])
+        scale = max(np.abs(single.vel[a]).max(), 1e-30)
+        assert np.abs(grp.vel[a] - single.vel[a]).max() <= 1e-6 * scale
+    grp.close()
+    single.close()
