@@ -6,7 +6,7 @@ from polystokes_amd import _abi as abi
 from helpers import fuzz_brick_case
 seeds = [int(v) for v in sys.argv[1:]] or [4237, 4226, 4211, 4230]     # usage: fuzz_bricks_seeds_tol.py [seed ...]
 for seed in seeds:
-    for tol in (1e-6, 1e-9):
+    for tol in ([float(v) for v in os.environ["TOLS"].split(",")] if os.environ.get("TOLS") else (1e-6, 1e-9)):
         sc, p, dims, n, tile = fuzz_brick_case(seed, tol); p.maxSolverIterations = 100000
         s = polystokes_amd.Solver(0); rc1 = s.step(sc, p); it1 = int(s.stats.solveData[1])
         g = polystokes_amd.Group(dims[0] * dims[1] * dims[2], dims=dims); rc2 = g.solve_scene(sc, p); it2 = int(g.stats.solveData[1])
