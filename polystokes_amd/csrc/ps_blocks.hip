@@ -737,8 +737,8 @@ __global__ void __launch_bounds__(BS) k_ell_fill(const int4* __restrict__ chunkI
 // Row-per-lane form of M's compressed stream (needs the windowed stream of buildCol16 and coded values)
 void ps_context::buildEll(ps::DevCSR& M) {
     M.ellok = false;
-    static const bool off = (getenv("PS_NO_ELL") && atoi(getenv("PS_NO_ELL")) != 0) ||            // A/B: keep the 4-entries-per-lane kernels
-                            (getenv("PS_PIPE_GRID") && atoi(getenv("PS_PIPE_GRID")) == 0);       // (one-shot CSR kernels asked for)
+    static const bool off = (PS_ENV("PS_NO_ELL") && atoi(PS_ENV("PS_NO_ELL")) != 0) ||            // A/B: keep the 4-entries-per-lane kernels
+                            (PS_ENV("PS_PIPE_GRID") && atoi(PS_ENV("PS_PIPE_GRID")) == 0);       // (one-shot CSR kernels asked for)
     if (off || !M.col16ok || !M.packed || M.nChunks == 0 || (uint64_t)std::max(M.rows, M.cols) * 8 >= 0xffff8000ull) return;
     const int nChunks = M.nChunks;
     DevBuf<int32_t>& colBegin = scrEllCol; DevBuf<int32_t>& codeBegin = scrEllCode; DevBuf<int32_t>& wpack = scrEllW;
@@ -763,7 +763,7 @@ void ps_context::buildEll(ps::DevCSR& M) {
                        (const uint16_t*)M.col16.p, (const int8_t*)M.code4.p, (const int32_t*)colBegin.p, (const int32_t*)codeBegin.p, (const int32_t*)wpack.p,
                        M.ecol.p, M.ecode.p, M.echunk.p, M.winBase.p);
     M.ellok = true;
-    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] row-per-lane stream: %d chunks, %lld column slots and %lld code bytes in the distinct runs (nnz %lld)\n",
+    if (PS_ENV_VERBOSE()) std::fprintf(stderr, "[polystokes] row-per-lane stream: %d chunks, %lld column slots and %lld code bytes in the distinct runs (nnz %lld)\n",
                                            nChunks, (long long)totCol, (long long)totCode, (long long)M.nnz);
 }
 namespace {
@@ -792,7 +792,7 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
     M.ellok = false;
     M.nChunks = 0;
     M.val4.free();
-    const char* e = getenv("PS_COL32");
+    const char* e = PS_ENV("PS_COL32");
     if (M.rows == 0 || M.nnz == 0 || (e && atoi(e) != 0)) return;
     // Chunk table.  `cuts` (ascending row indices, first 0, last M.rows; may be empty) are where the numbering's lattice blocks
     // and the tiles' skin-row ranges begin.  A range of >= CHUNK_ALIGN_MIN rows starts its own chunk — equivalent blocks then
@@ -801,7 +801,7 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
     std::vector<int2> rowsOf;
     {
         constexpr int CHUNK_ALIGN_MIN = 512;
-        static const bool plain = getenv("PS_CHUNK_PLAIN") && atoi(getenv("PS_CHUNK_PLAIN")) != 0;   // A/B: uniform 256-row chunks
+        static const bool plain = PS_ENV("PS_CHUNK_PLAIN") && atoi(PS_ENV("PS_CHUNK_PLAIN")) != 0;   // A/B: uniform 256-row chunks
         bool ok = !plain && cuts.size() >= 2 && cuts.front() == 0 && (int64_t)cuts.back() == M.rows;
         for (size_t i = 1; ok && i < cuts.size(); ++i) ok = cuts[i] >= cuts[i - 1];
         auto emit = [&](int64_t lo, int64_t hi) { for (int64_t r = lo; r < hi; r += BS) rowsOf.push_back(make_int2((int)r, (int)std::min<int64_t>(BS, hi - r))); };
@@ -840,8 +840,8 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
                        M.code4.p, M.winBase.p, M.chunkInfo.p, M.len8.p, counters.p + slot, M.chunkRep.p, nChunks);
     M.col16ok = readCounter(slot) == 0;
     if (M.col16ok && !M.packed) buildVal4(M);
-    static const bool noShare = getenv("PS_NO_SHARED_RUNS") && atoi(getenv("PS_NO_SHARED_RUNS")) != 0;
-    static const bool weakHash = getenv("PS_WEAK_CHUNK_HASH") && atoi(getenv("PS_WEAK_CHUNK_HASH")) != 0;   // test: force hash collisions
+    static const bool noShare = PS_ENV("PS_NO_SHARED_RUNS") && atoi(PS_ENV("PS_NO_SHARED_RUNS")) != 0;
+    static const bool weakHash = PS_ENV("PS_WEAK_CHUNK_HASH") && atoi(PS_ENV("PS_WEAK_CHUNK_HASH")) != 0;   // test: force hash collisions
     if (M.col16ok && M.packed && shareRuns && !noShare && nChunks > 1) {          // coded values only: the fp64 values of equal codes need not be equal bits
         unsigned cap = 1024;
         while (cap < 4u * (unsigned)nChunks) cap <<= 1;
@@ -861,7 +861,7 @@ void ps_context::buildCol16(ps::DevCSR& M, int slot, const std::vector<int32_t>&
         HIP_CHECK(hipStreamSynchronize(stream));
         M.uniqueLen = (int64_t)u;
     }
-    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] compressed stream: rows %lld nnz %lld, %d chunks, fullest %d (nv %d), ok %d, distinct runs hold %lld of %lld entries\n",
+    if (PS_ENV_VERBOSE()) std::fprintf(stderr, "[polystokes] compressed stream: rows %lld nnz %lld, %d chunks, fullest %d (nv %d), ok %d, distinct runs hold %lld of %lld entries\n",
                                            (long long)M.rows, (long long)M.nnz, nChunks, maxLen, M.nv, (int)M.col16ok, (long long)M.uniqueLen, (long long)M.streamLen);
 }
 
@@ -928,7 +928,7 @@ __global__ void k_dict_finish(unsigned long long* table) { if (table[threadIdx.x
 }  // namespace
 void ps_context::buildDiagonalCodes() {
     uCoded = mcCoded = false;
-    const char* e = getenv("PS_NO_DIAG_CODES");
+    const char* e = PS_ENV("PS_NO_DIAG_CODES");
     if (e && atoi(e) != 0) return;
     auto build = [&](const DevBuf<double>& vals, int64_t n, DevBuf<uint8_t>& code, DevBuf<double>& dict) -> bool {
         if (n <= 0) return false;
@@ -944,7 +944,7 @@ void ps_context::buildDiagonalCodes() {
     };
     uCoded = build(uInv, nSystem, uCode, uDict);
     mcCoded = build(McInv, nActiveVs, mcCode, mcDict);
-    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] diagonal value sets: uInv %s, McInv %s\n", uCoded ? "coded (<= 256 values)" : "fp64", mcCoded ? "coded" : "fp64");
+    if (PS_ENV_VERBOSE()) std::fprintf(stderr, "[polystokes] diagonal value sets: uInv %s, McInv %s\n", uCoded ? "coded (<= 256 values)" : "fp64", mcCoded ? "coded" : "fp64");
 }
 
 // the compressed streams of S and St.  share = false (bench.py's "_fp64" kernels: the fp64-value stream as a system with arbitrary
@@ -1068,7 +1068,7 @@ void ps_context::constructMatrixBlocks() {
     // in setup and to keep (2.5 GB at 256^3).  They are written when the codes are refused (PS_FORCE_FP64_VALUES=1) or turn out not to fit:
     // the fill kernels then run once more with the value arrays.
     {
-        const char* e = getenv("PS_FORCE_FP64_VALUES");
+        const char* e = PS_ENV("PS_FORCE_FP64_VALUES");
         forceFp64Values = e && atoi(e) != 0;
     }
     auto fillS = [&](bool withValues) {

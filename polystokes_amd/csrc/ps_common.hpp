@@ -15,6 +15,30 @@
 
 #define PS_RD PS_REDUCED_DOF   // 26 (quadratic regions) or 11 (-DPS_AFFINE_REGIONS)
 
+// Environment switches.  The lab build (libpolystokes_hip.so: tests, A/B measurements) reads the PS_* variables named at their points of
+// use; the RELEASE build (-DPS_RELEASE: libpolystokes_hip_release.so, what the Houdini shim links) reads NONE of them — PS_ENV(...) is a
+// null pointer at preprocessing time, so not even the names reach the binary (tests/test_abi_cpu.py checks its strings) — except
+// PS_VERBOSE, which only prints.  A drop-in DSO inside another program must not change its results with a stray variable.
+#include <stdio.h>
+#include <stdlib.h>
+#ifdef PS_RELEASE
+#define PS_ENV(name) (static_cast<const char*>(nullptr))
+#else
+#define PS_ENV(name) getenv(name)
+#endif
+#define PS_ENV_VERBOSE() getenv("PS_VERBOSE")
+// the lab build names, once, every switch that changes RESULTS or loads code when it finds it set
+#ifdef PS_RELEASE
+#define PS_ENV_LOUD(name) (static_cast<const char*>(nullptr))
+#else
+#define PS_ENV_LOUD(name) ps_env_loud(name)
+inline const char* ps_env_loud(const char* name) {
+    const char* v = getenv(name);
+    if (v) fprintf(stderr, "[polystokes] WARNING: test-only switch %s=%s is active in this process (lab build; the release build ignores it)\n", name, v);
+    return v;
+}
+#endif
+
 #define HIP_CHECK(x)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (x);                                                                      \
@@ -232,6 +256,10 @@ __host__ __device__ inline void unpackFace(uint32_t q, int& i, int& j, int& k, i
     i = q & 1023; j = (q >> 10) & 1023; k = (q >> 20) & 1023; axis = q >> 30;
 }
 
+inline bool debugPoisonOn() {
+    static const bool on = [] { const char* e = PS_ENV_LOUD("PS_DEBUG_POISON"); return e && atoi(e) != 0; }();
+    return on;
+}
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -247,8 +275,7 @@ struct DevBuf {
     // PS_DEBUG_POISON=1 (tests only): whatever alloc() hands out — a fresh block or the buffer a previous step left — is filled with
     // 0xff bytes (NaN / -1) first, so that a kernel consuming words nobody wrote this step shows up in the results
     void poison() {
-        static const bool on = getenv("PS_DEBUG_POISON") && atoi(getenv("PS_DEBUG_POISON")) != 0;
-        if (!on || !p) return;
+        if (!debugPoisonOn() || !p) return;
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemset((void*)p, 0xff, n * sizeof(T)));
         HIP_CHECK(hipDeviceSynchronize());

@@ -204,7 +204,7 @@ Rccl& rccl() {
     if (!R.h) {
         // PS_RCCL_LIB (tests only): another library exporting the same eight entry points — tests/stub_rccl, the stand-in that lets
         // this asynchronous branch run with several ranks on ONE GPU (real RCCL refuses duplicate devices)
-        if (const char* alt = getenv("PS_RCCL_LIB")) {
+        if (const char* alt = PS_ENV_LOUD("PS_RCCL_LIB")) {
             R.h = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
             if (!R.h) throw Error(std::string("cannot load PS_RCCL_LIB: ") + dlerror());
         }
@@ -369,7 +369,7 @@ struct Dist {
     // everything queued on `from` so far happens before what is queued on `to` from now on
     void order(ps_context* c, int ev, bool mainToComm) {
         if (!c->commStream || c->commStream == c->stream) return;
-        static const int skipEv = getenv("PS_DIST_SKIP_ORDER") ? atoi(getenv("PS_DIST_SKIP_ORDER")) : -1;   // tests only: drop one ordering edge
+        static const int skipEv = [] { const char* e = PS_ENV_LOUD("PS_DIST_SKIP_ORDER"); return e ? atoi(e) : -1; }();   // tests only: drop one ordering edge
         if (ev == skipEv) return;                                                                             // (a transport that hides the race proves nothing)
         hipStream_t from = mainToComm ? c->stream : c->commStream, to = mainToComm ? c->commStream : c->stream;
         HIP_CHECK(hipEventRecord(c->distEv[ev], from));
@@ -734,7 +734,7 @@ struct Dist {
             c->distListsOk = false;
             for (int q = 0; q < 4; ++q) c->nDistList[q] = 0;
             Launch L = mk(c, nullptr);
-            static const bool off = getenv("PS_DIST_OVERLAP") && atoi(getenv("PS_DIST_OVERLAP")) == 0;   // A/B: the sequential exchange
+            static const bool off = PS_ENV("PS_DIST_OVERLAP") && atoi(PS_ENV("PS_DIST_OVERLAP")) == 0;   // A/B: the sequential exchange
             if (off || !L.listsOk() || c->S.nChunks == 0 || c->St.nChunks == 0) continue;
             const int nS = c->S.nChunks, nT = c->St.nChunks;
             DevBuf<int32_t>& flags = c->scrVals;               // setup scratch
@@ -848,7 +848,7 @@ struct Dist {
         // neighbours, who subtract alpha times it (k_dist_fixup).  Same rule as the single-domain solve: coded streams on every
         // rank and >= FUSED_STEP_MIN_ROWS owned rows on the largest (PS_FUSED_R = 0 / 1 forces); decided from values every rank
         // knows or agrees on, so all ranks take the same branch.
-        static const int fusedEnv = getenv("PS_FUSED_R") ? atoi(getenv("PS_FUSED_R")) : -1;
+        static const int fusedEnv = PS_ENV("PS_FUSED_R") ? atoi(PS_ENV("PS_FUSED_R")) : -1;
         bool fused = !cheb && fusedEnv != 0;
         for (size_t q = 0; q < R.size(); ++q) fused = fused && loc[q].L.fusedOk() && loc[q].n > 0;
         {

@@ -1054,7 +1054,7 @@ void ps_context::constructCenterReducedIndices(int part) {
     uint8_t* link = (uint8_t*)cellScratch[2].p;
     hipLaunchKernelGGL(k_cc_init, gr, bl, 0, stream, g, labels[0].p, cset(liquidW), cc, link);
     // tile-local components first, in LDS (5 bytes per cell of a tile, within the 64 KB a launch gets without asking: tiles up to 23^3)
-    static const bool localOff = getenv("PS_CC_LOCAL") && atoi(getenv("PS_CC_LOCAL")) == 0;   // A/B: the grid-wide passes alone
+    static const bool localOff = PS_ENV("PS_CC_LOCAL") && atoi(PS_ENV("PS_CC_LOCAL")) == 0;   // A/B: the grid-wide passes alone
     const int B = P.tileSize;
     const bool local = !localOff && P.doTile && P.tilePadding >= 1 && B >= 4 && (size_t)B * B * B * 5 <= 64 * 1024;
     if (local)
@@ -1266,10 +1266,10 @@ void ps_context::buildInternalNumbering() {
         // Default: kind-major when the row-per-lane kernels will run — the stencil values must be codable, which the weights decide:
         // face fluid weights x cell / edge liquid weights, all multiples of 1/8 (checked here, the fill kernels verify every entry);
         // systems with other weights stream fp64 values through the 4-entries-per-lane kernels, which want the voxel-major order.
-        static const bool noEll = getenv("PS_NO_ELL") && atoi(getenv("PS_NO_ELL")) != 0;
-        static const bool forceF64 = getenv("PS_FORCE_FP64_VALUES") && atoi(getenv("PS_FORCE_FP64_VALUES")) != 0;
-        static const bool col32 = getenv("PS_COL32") && atoi(getenv("PS_COL32")) != 0;
-        static const bool oneShot = getenv("PS_PIPE_GRID") && atoi(getenv("PS_PIPE_GRID")) == 0;
+        static const bool noEll = PS_ENV("PS_NO_ELL") && atoi(PS_ENV("PS_NO_ELL")) != 0;
+        static const bool forceF64 = PS_ENV("PS_FORCE_FP64_VALUES") && atoi(PS_ENV("PS_FORCE_FP64_VALUES")) != 0;
+        static const bool col32 = PS_ENV("PS_COL32") && atoi(PS_ENV("PS_COL32")) != 0;
+        static const bool oneShot = PS_ENV("PS_PIPE_GRID") && atoi(PS_ENV("PS_PIPE_GRID")) == 0;
         int mode = 0;
         if (!noEll && !forceF64 && !col32 && !oneShot) {
             HIP_CHECK(hipMemsetAsync(counters.p + 40, 0, sizeof(int32_t), stream));
@@ -1277,7 +1277,7 @@ void ps_context::buildInternalNumbering() {
             for (int s2 : {0, 4, 5, 6}) hipLaunchKernelGGL(k_dyadic_check, dim3(1024), dim3(BS), 0, stream, (const float*)liquidW[s2].p, g.count(s2), counters.p + 40);
             if (readCounter(40) == 0) mode = 3;
         }
-        const char* e = getenv("PS_IL");
+        const char* e = PS_ENV("PS_IL");
         ilPlaneMajor = e ? (atoi(e) & 3) : mode;
     }
     const int64_t nC = nCenter, nPq = nCenter;

@@ -77,7 +77,7 @@ struct Launch {
             const dim3 gr(pipeBlocks(nChunks, xcdAware, true, sCap())), bl(BS);
             // two units in flight per wave (k_spmv_S_ell2; r04): 256^3, same box, two interleaved rounds: S 0.2809 / 0.2816 -> 0.2672 / 0.2609 ms in
             // sequence, step 1128.6 / 1130.2 -> 1117.3 / 1118.5 ms (profiles/r04_s_dual.txt).  PS_S_DUAL=0: the one-unit kernel.
-            static const bool dual = !(getenv("PS_S_DUAL") && atoi(getenv("PS_S_DUAL")) == 0);
+            static const bool dual = !(PS_ENV("PS_S_DUAL") && atoi(PS_ENV("PS_S_DUAL")) == 0);
             if (dual && mode == 0 && c->mcCoded && (gr.x & 7) == 0) {
                 const int pol = policy(M);
 #define PS_LAUNCH_S2L(POL_, LIST_) hipLaunchKernelGGL((k_spmv_S_ell2<POL_, LIST_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
@@ -118,7 +118,7 @@ struct Launch {
         if (c->regionCount == 0) return;
         double* sred = ts + nA;
         const dim3 gr((unsigned)c->regionCount);
-        static const bool noFuse = getenv("PS_TILE_SPLIT") && atoi(getenv("PS_TILE_SPLIT")) != 0;   // A/B: force the three-kernel form
+        static const bool noFuse = PS_ENV("PS_TILE_SPLIT") && atoi(PS_ENV("PS_TILE_SPLIT")) != 0;   // A/B: force the three-kernel form
         if (c->maxRegionRows <= TILE_FUSED_MAX_ROWS && !noFuse) {   // one workgroup per region: gather, 26x26 block, expand
 #define PS_TILE_APPLY(MODE_, TB_) hipLaunchKernelGGL((k_tile_apply<MODE_, TB_>), gr, dim3(TB_), 0, c->stream, c->regionRowPtr.p, c->rrowFace.p, c->COM.p, c->dx, make_int3(c->gOff[0], c->gOff[1], c->gOff[2]), c->Binv.p, \
                                                 c->rhsR.p, c->invDt, sred, c->vreg.p, done, wvPart)
@@ -126,7 +126,7 @@ struct Launch {
             // at 256^3 (4096 tiles of 3204 rows): 0.080 ms with 64 threads, 0.087 / 0.106 / 0.166 with 128 / 256 / 512; at 32^3
             // (8 tiles) one wavefront per tile serialises 50 rows per lane behind memory latency (60 us per CG iteration
             // against 43 with 256 threads per tile; 1024 threads: 50, the block reduction over 16 waves costs more than it hides).
-            static const int tbEnv = getenv("PS_TILE_TB") ? atoi(getenv("PS_TILE_TB")) : 0;
+            static const int tbEnv = PS_ENV("PS_TILE_TB") ? atoi(PS_ENV("PS_TILE_TB")) : 0;
             int tb = tbEnv;
             if (!tb) {
                 tb = 64;
@@ -188,7 +188,7 @@ struct Launch {
             // two units in flight per wave (k_spmv_St_ell2; r04): 256^3, one box, interleaved rounds: St with the residual update 0.4251 / 0.4242 ->
             // 0.3923 / 0.3918 ms in sequence at 5 waves per SIMD on 1280 workgroups, step 1124.5 / 1122.6 -> 1098.3 / 1096.6 ms; compiled for 6 waves per
             // SIMD on 1536 workgroups another 0.6 % (profiles/r04_st_dual.txt).  PS_ST_DUAL=0: the one-unit kernel on 1792 workgroups.
-            static const bool dualC = !(getenv("PS_ST_DUAL") && atoi(getenv("PS_ST_DUAL")) == 0);
+            static const bool dualC = !(PS_ENV("PS_ST_DUAL") && atoi(PS_ENV("PS_ST_DUAL")) == 0);
             if (mode == 2 && dualC && c->uCoded && !stList && (gr.x & 7) == 0 && !c->slabEnabled) {   // a Chebyshev term, two units in flight per wave
                 const int pol = policy(M);
 #define PS_LAUNCH_T2C(POL_) hipLaunchKernelGGL((k_spmv_St_ell2c<POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
@@ -283,7 +283,7 @@ struct Launch {
     // Row-per-lane kernel, plain MODE 3: 7 per CU — 1536 workgroups 0.418 ms, 1792 0.403, 2048 0.515 (the eighth does not fit: a second round),
     // 3584 / 5376 as 1792.
     bool stDual() const {
-        static const bool on = !(getenv("PS_ST_DUAL") && atoi(getenv("PS_ST_DUAL")) == 0);
+        static const bool on = !(PS_ENV("PS_ST_DUAL") && atoi(PS_ENV("PS_ST_DUAL")) == 0);
         return on && plain3Hint && c->St.ellok && c->St.packed && c->St.col16ok && pipeGrid >= 1536;
     }
     int stGridFor(int mode) const {
@@ -303,18 +303,18 @@ Launch mk(ps_context* c, const int* done) {
     L.rowsS = (int)c->nRows; L.rowsSt = (int)c->nSystem; L.nA = (int)c->nActiveVs; L.nP = (int)c->nPressures;
     static int pg = -1;
     if (pg < 0) {
-        const char* g = getenv("PS_PIPE_GRID");   // A/B switch: 0 = one-shot kernels
+        const char* g = PS_ENV("PS_PIPE_GRID");   // A/B switch: 0 = one-shot kernels
         pg = g ? atoi(g) : 4096;                   // persistent pipelined kernels, 16 blocks per CU, by default
     }
     L.pipeGrid = pg;
-    static const int sg = getenv("PS_PIPE_GRID_ST") ? atoi(getenv("PS_PIPE_GRID_ST")) : 0;
+    static const int sg = PS_ENV("PS_PIPE_GRID_ST") ? atoi(PS_ENV("PS_PIPE_GRID_ST")) : 0;
     L.stGrid = pg > 0 ? sg : 0;
     static int xa = -1;
-    if (xa < 0) { const char* e = getenv("PS_XCD"); xa = e ? atoi(e) : 64; }   // chunks per XCD run (rounded down to a power of two); 0: plain walk.  64: same kernel times as 4 / 16 / 256 on the row-per-lane kernels, a fifth less HBM-side traffic than 16 (FETCH_SIZE of S 0.64 / 0.54 / 0.44 / 0.42 M KiB at 4 / 16 / 64 / 256)
+    if (xa < 0) { const char* e = PS_ENV("PS_XCD"); xa = e ? atoi(e) : 64; }   // chunks per XCD run (rounded down to a power of two); 0: plain walk.  64: same kernel times as 4 / 16 / 256 on the row-per-lane kernels, a fifth less HBM-side traffic than 16 (FETCH_SIZE of S 0.64 / 0.54 / 0.44 / 0.42 M KiB at 4 / 16 / 64 / 256)
     L.xcdAware = xa > 0 ? xa : 0;
     // log2 of the consecutive chunks a workgroup takes in a row (ChunkWalk): 2 chunks on the row-per-lane kernels (256^3, same box: S 0.264 ->
     // 0.257 ms, St with the residual update 0.431 -> 0.408; 4 / 8 / 16 chunks: S 0.282 / 0.274 / 0.273, St 0.412 / 0.412 / 0.428)
-    static const int wr = getenv("PS_WG_RUN") ? atoi(getenv("PS_WG_RUN")) : -1;
+    static const int wr = PS_ENV("PS_WG_RUN") ? atoi(PS_ENV("PS_WG_RUN")) : -1;
     const int run = wr >= 0 ? wr : ((c->S.ellok && c->St.ellok) ? 1 : 0);
     if (L.xcdAware > 0) L.xcdAware |= (run & 7) << 16;
     L.ntSpmv = c->ntLevel() >= 1;
@@ -386,12 +386,12 @@ void ps_context::constructPreconditioner() {
 // iteration at level 0 / 1 / 2 (cavity): 64^3 (0.8 M rows) 58.6 / 60.6 / 61.2; 96^3 (2.6 M) 97.9 / 104.8 / 103.4; 128^3 (5.9 M) 194.0 /
 // 187.4 / 191.8; 160^3 (11.4 M) 341.7 / 337.7 / 336.0; 192^3 (19.4 M) 558 / 535 / 530; 224^3 (30.6 M) 858 / 838 / 810.
 int ps_context::ntLevel() const {
-    static const int env = getenv("PS_NT_LEVEL") ? atoi(getenv("PS_NT_LEVEL")) : -1;
+    static const int env = PS_ENV("PS_NT_LEVEL") ? atoi(PS_ENV("PS_NT_LEVEL")) : -1;
     if (env >= 0) return env;
     return nSystem < NT_LEVEL1_MIN_ROWS ? 0 : (nSystem < NT_LEVEL2_MIN_ROWS ? 1 : 2);
 }
 
-static double chebRatio() { static const double r = getenv("PS_CHEB_RATIO") ? atof(getenv("PS_CHEB_RATIO")) : PS_CHEB_INTERVAL_RATIO; return r; }   // lmax / lmin (PS_CHEB_RATIO: experiments only — the oracle uses the constant)
+static double chebRatio() { static const double r = PS_ENV("PS_CHEB_RATIO") ? atof(PS_ENV("PS_CHEB_RATIO")) : PS_CHEB_INTERVAL_RATIO; return r; }   // lmax / lmin (PS_CHEB_RATIO: experiments only — the oracle uses the constant)
 double ps_context::chebTheta() const { return 0.5 * (chebLmax + chebLmax / chebRatio()); }   // centre of the interval [lmax/250, lmax]
 
 void ps_context::estimateLambdaMax() {
@@ -523,7 +523,7 @@ int ps_context::solve() {
     // partials 64 to 1 in the producers with a ticket per group costs more than it saves: one device-scope atomic per workgroup,
     // +30 us per iteration with write-through stores and no fence, +650 us with __threadfence(), which flushes the XCD's L2.)
     // PS_FUSED_R = 0 / 1 forces it off / on (on only where the kernels exist).
-    static const int fusedEnv = getenv("PS_FUSED_R") ? atoi(getenv("PS_FUSED_R")) : -1;
+    static const int fusedEnv = PS_ENV("PS_FUSED_R") ? atoi(PS_ENV("PS_FUSED_R")) : -1;
     const bool fused = fusedEnv != 0 && (fusedEnv > 0 || n >= FUSED_STEP_MIN_ROWS) && L.fusedOk();
     fusedStepHost = fused ? 1 : 0;
     const int sBlocks = fused ? L.sBlocks() : 0;

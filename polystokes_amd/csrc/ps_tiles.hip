@@ -708,14 +708,14 @@ void runOuter(ps_context* c, double* out676, double* out26) {
     if (c->regionCount == 0 || c->fbItems == 0) return;
     c->partials.alloc((size_t)c->fbItems * OUTW);
     TileArgs A = makeArgs(c);
-    static const bool useMfma = !(getenv("PS_TILE_VALU") && atoi(getenv("PS_TILE_VALU")) != 0);
+    static const bool useMfma = !(PS_ENV("PS_TILE_VALU") && atoi(PS_ENV("PS_TILE_VALU")) != 0);
     // Which blocks are shared (PS_TILE_CLASS_MASK; bit 0: Mr, bit 1: K).  Default: K only.  A copied block differs from the tile's own sums
     // by the rounding of `index * dx - COM` at the representative's position (Mr 3e-16, K 4e-14 relative to the oracle's either way).  On
     // the stiff 48^3 spheres at tol 1e-8 — where a 1e-15 change of B moves the velocities by 1e-5..1e-4, the AMP sensitivity of
     // DESIGN.md section 4 — the distance to the oracle's velocities is 6.8e-5 with own sums, 7.3e-5 with K shared and 1.04e-4 with Mr
     // shared (scripts/ladder_tile_classes.py): Mr carries the tile's rigid modes, which the large pressure-stress terms cancel against.
     // So Mr (2.3 of the 7.8 ms at 256^3) stays per tile and the tolerance ladder of tests/test_gpu_parity.py keeps its bounds.
-    static const int clsMask = getenv("PS_TILE_CLASS_MASK") ? atoi(getenv("PS_TILE_CLASS_MASK")) : 2;
+    static const int clsMask = PS_ENV("PS_TILE_CLASS_MASK") ? atoi(PS_ENV("PS_TILE_CLASS_MASK")) : 2;
     if (MODE != MODE_LSQ && ((MODE == MODE_MASS ? 1 : 2) & clsMask) && c->tileReps > 0 && c->tileReps < c->regionCount) {   // one sum per class of identical tiles, copied to the others
         A.itemRegion = c->repItemRegion.p; A.itemAxis = c->repItemAxis.p; A.itemStart = c->repItemStart.p;
         if (useMfma) hipLaunchKernelGGL(k_region_outer_mfma<MODE>, dim3((unsigned)c->repItems), dim3(BS), 0, c->stream, A, c->partials.p);
@@ -802,7 +802,7 @@ void ps_context::computeCenterOfMasses() {
 void ps_context::buildTileClasses() {
     tileReps = 0; repItems = 0;
     const int64_t R = regionCount;
-    static const bool off = getenv("PS_NO_TILE_CLASSES") && atoi(getenv("PS_NO_TILE_CLASSES")) != 0;   // A/B: every tile sums its own blocks
+    static const bool off = PS_ENV("PS_NO_TILE_CLASSES") && atoi(PS_ENV("PS_NO_TILE_CLASSES")) != 0;   // A/B: every tile sums its own blocks
     if (off || R < 2) return;
     TileArgs A = makeArgs(this);
     unsigned cap = 1024;
@@ -844,7 +844,7 @@ void ps_context::buildTileClasses() {
     HIP_CHECK(hipMemcpyAsync(repItemStart.p, iS.data(), iS.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(repRegionItemPtr.p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(repList.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
-    if (getenv("PS_VERBOSE")) std::fprintf(stderr, "[polystokes] tile classes: %lld of %lld tiles sum their own Mr / K\n", (long long)tileReps, (long long)R);
+    if (PS_ENV_VERBOSE()) std::fprintf(stderr, "[polystokes] tile classes: %lld of %lld tiles sum their own Mr / K\n", (long long)tileReps, (long long)R);
 }
 
 void ps_context::computeLeastSquaresFits() {

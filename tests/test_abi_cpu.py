@@ -27,6 +27,26 @@ def test_library_exports_every_declared_symbol():
     assert L.ps_abi_version() == 1
 
 
+def test_release_build_reads_no_environment_switch():
+    """the library the Houdini shim links (-DPS_RELEASE) exports the same ABI and holds none of the lab build's
+    PS_* switch names (PS_ENV in ps_common.hpp is a null pointer at preprocessing time there) — PS_VERBOSE, which only prints, stays."""
+    import polystokes_amd
+    rel = os.path.join(ROOT, "polystokes_amd", "libpolystokes_hip_release.so")
+    assert os.path.exists(rel), "build it: make -C polystokes_amd/csrc"
+    blob = open(rel, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"PS_[A-Z][A-Z0-9_]{2,}", blob))
+    assert names <= {"PS_VERBOSE"}, names
+    lab = set(m.decode() for m in re.findall(rb"PS_[A-Z][A-Z0-9_]{2,}", open(polystokes_amd.LIB_PATH, "rb").read()))
+    assert {"PS_DIST_SKIP_ORDER", "PS_RCCL_LIB", "PS_DEBUG_POISON"} <= lab          # the lab build does read them (and says so on stderr)
+    L = ctypes.CDLL(rel)
+    for s in polystokes_amd.EXPORTED_SYMBOLS:
+        assert hasattr(L, s), s
+    L.ps_abi_version.restype = ctypes.c_int32
+    assert L.ps_abi_version() == 1
+    shim = open(os.path.join(ROOT, "shim", "CMakeLists.txt")).read()
+    assert "libpolystokes_hip_release.so" in shim
+
+
 def test_struct_layout_matches_header():
     import polystokes_amd
     from polystokes_amd import _abi as abi
