@@ -143,6 +143,44 @@ def _latest_traffic(kernel="k_spmv_St"):
         return None, None
 
 
+def box_calibration():
+    """What THIS box's memory system reaches on a plain device-to-device copy, and which box it is (the
+    4-13 % spread of the headline between runs is a spread between BOXES — profiles/r05_cold_warm.md — every kernel of the iteration,
+    the pure streaming ones included, moves with this number; one box repeats to 0.1 % over 30 steps, an idle minute and a second process)."""
+    import subprocess
+    import torch
+    out = {}
+    try:
+        n = 1 << 27                                              # 1 GiB of doubles
+        a = torch.empty(n, dtype=torch.float64, device="cuda").fill_(1.0)
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        out["d2d_copy_GBps"] = 2.0 * n * 8 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9      # bytes read + written
+        del a, b
+        torch.cuda.empty_cache()
+    except Exception as e:                                       # noqa: BLE001
+        out["d2d_copy_error"] = str(e)[:200]
+    try:
+        txt = subprocess.run(["rocm-smi", "--showuniqueid", "--showclocks", "--showmaxpower", "--showmemvendor", "--showvbios"], capture_output=True, text=True, timeout=30).stdout
+        import re
+        for key, pat in (("unique_id", r"Unique ID:\s*(\S+)"), ("fclk_MHz", r"fclk clock level: \S+ \((\d+)Mhz\)"), ("mclk_MHz", r"mclk clock level: \S+ \((\d+)Mhz\)"),
+                         ("max_power_W", r"Max Graphics Package Power \(W\):\s*([0-9.]+)"), ("vbios", r"VBIOS version:\s*(\S+)"), ("mem_vendor", r"GPU memory vendor:\s*(\S+)")):
+            m = re.search(pat, txt)
+            if m:
+                out[key] = m.group(1)
+    except Exception:                                            # noqa: BLE001
+        pass
+    return out
+
+
 def _spawn(args):
     """`bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run BEFORE this process touches the
     GPU (no exec of a process that has initialised HIP), wait, return their exit code."""
@@ -390,6 +428,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    box = box_calibration() if rank == 0 else None
     for _ in range(args.warmup):
         solver.step_device()
     barrier()
@@ -500,6 +539,7 @@ def main():
         "system_dofs": nsys_total, "dof_iterations_per_s": nsys_total * iters / (solve_ms * 1e-3) if solve_ms > 0 else 0.0, "active_faces": solver.nA, "regions": solver.nRegions, "result": int(st.result),
         "stage_ms": {abi.STAGE_NAMES[i]: float(st.stage_ms[i]) for i in range(len(abi.STAGE_NAMES))},
         "roofline": roofline,
+        "box": box,
     }
     if transport_used:
         out["transport"] = transport_used
