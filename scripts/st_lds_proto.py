@@ -21,9 +21,12 @@ if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.joi
     os.makedirs(os.path.dirname(so), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-w",
                            os.path.join(ROOT, "scripts", "t_st_lds.hip"), "-o", so])
+import torch
+torch.cuda.init()                                          # torch's HIP runtime first: it finds no device once the library has initialised its own
 import polystokes_amd
 from polystokes_amd import scenes
 T0 = time.time()
+CAP = int(os.environ.get("ST_LDS_CAP", "9728"))            # doubles per image: two workgroups per CU
 
 
 def log(*a):
@@ -36,13 +39,14 @@ s.upload(sc, p)
 s.setup()
 nx, ny, nz = sc.nx, sc.ny, sc.nz
 nA, nP = s.nA, s.nP
-ptr = s.array("St.ptr").astype(np.int64)
-col = s.array("St.col").astype(np.int64)
-code = s.array("St.code").astype(np.int8)
+which = sys.argv[4] if len(sys.argv) > 4 else "St"          # St: rows = DOFs, image of t;  S: rows = face rows, image of p
+ptr = s.array(which + ".ptr").astype(np.int64)
+col = s.array(which + ".col").astype(np.int64)
+code = s.array(which + ".code").astype(np.int8)
 rows = ptr.size - 1
 nnz = col.size
 tLen = int(col.max()) + 1
-log("St: rows %d nnz %d cols %d (nA %d)" % (rows, nnz, tLen, nA))
+log("%s: rows %d nnz %d cols %d (nA %d)" % (which, rows, nnz, tLen, nA))
 sysPerm, rowPerm = s.array("sysPerm").astype(np.int64), s.array("rowPerm").astype(np.int64)
 nbx, nby = (nx + 16) >> 4, (ny + 16) >> 4          # (edge / face grids reach index n: one more block per axis is harmless)
 
@@ -62,67 +66,123 @@ faceBlk = block_of(["face%sActiveIndices" % a for a in "XYZ"], fd, rowPerm, [0, 
 cd = (nx, ny, nz)
 ed = [(nx, ny + 1, nz + 1), (nx + 1, ny, nz + 1), (nx + 1, ny + 1, nz)]
 nE = [int((s.array(e + "ActiveIndices") >= 0).sum()) for e in ("edgeYZ", "edgeXZ", "edgeXY")]
+nDof = 4 * nP + sum(nE)
 dofBlk = block_of(["centerActiveIndices"] * 4 + ["edgeYZActiveIndices", "edgeXZActiveIndices", "edgeXYActiveIndices"], [cd] * 4 + ed, sysPerm,
-                  [0, nP, 2 * nP, 3 * nP, 4 * nP, 4 * nP + nE[0], 4 * nP + nE[0] + nE[1]], rows)
+                  [0, nP, 2 * nP, 3 * nP, 4 * nP, 4 * nP + nE[0], 4 * nP + nE[0] + nE[1]], nDof)
 assert (faceBlk >= 0).all() and (dofBlk >= 0).all()
 assert (np.diff(dofBlk) >= 0).all() and (np.diff(faceBlk) >= 0).all(), "the internal numbering is not block-major"
-# the lattice blocks that hold DOF rows
-bstart = np.concatenate(([0], np.flatnonzero(np.diff(dofBlk)) + 1))
-bid = dofBlk[bstart]
-nB = bstart.size
-d0 = bstart
-d1 = np.concatenate((bstart[1:], [rows]))
-# active face rows of each of those blocks: [a0, a1)
-a0 = np.searchsorted(faceBlk, bid, "left")
-a1 = np.searchsorted(faceBlk, bid, "right")
 reg = s.array("reducedRowRegion").astype(np.int64)
 assert (np.diff(reg) >= 0).all()
 nReg = int(reg.max()) + 1 if reg.size else 0
 regPtr = np.searchsorted(reg, np.arange(nReg + 1), "left")
 lens = np.diff(ptr)
-rowB = np.repeat(np.arange(nB), d1 - d0)                  # block (dense id) of every DOF row
-nzB = np.repeat(rowB, lens)                                # ... of every entry
-# the tile of a block = the region its rows reference most
-skin = col >= nA
-key = nzB[skin] * (nReg + 1) + reg[col[skin] - nA]
-uk, cnt = np.unique(key, return_counts=True)
-ub, ur = uk // (nReg + 1), uk % (nReg + 1)
-best = np.full(nB, -1, np.int64)
-order = np.lexsort((cnt, ub))                              # last entry per block = most frequent
-lastOf = np.flatnonzero(np.concatenate((ub[order][1:] != ub[order][:-1], [True])))
-best[ub[order][lastOf]] = ur[order][lastOf]
-s0 = np.where(best >= 0, nA + regPtr[np.maximum(best, 0)], 0)
-s1 = np.where(best >= 0, nA + regPtr[np.maximum(best, 0) + 1], 0)
-# ranges start on even entries (16-byte pieces), lengths padded to whole 128-double pieces
-a0e = a0 & ~1
-lenA = ((a1 - a0e + 127) // 128) * 128
-lenA[a1 == a0] = 0
-s0e = s0 & ~1
-lenS = ((s1 - s0e + 127) // 128) * 128
-lenS[s1 == s0] = 0
-inA = (col >= a0e[nzB]) & (col < (a0e + lenA)[nzB])
-inS = (~inA) & (col >= s0e[nzB]) & (col < (s0e + lenS)[nzB])
-rest = ~(inA | inS)
-hkey = (nzB[rest] << 32) | (col[rest] >> 1)
-hu, hinv = np.unique(hkey, return_inverse=True)
-hb = hu >> 32
-haloBase = np.searchsorted(hb, np.arange(nB), "left")
-nPairs = np.searchsorted(hb, np.arange(nB), "right") - haloBase
+
+
+def most_frequent(keyA, keyB, nAkeys):
+    """for every value of keyA (0 .. nAkeys - 1): the value of keyB that accompanies it most often (-1: never seen)"""
+    m = int(keyB.max()) + 2 if keyB.size else 2
+    uk, cnt = np.unique(keyA * m + keyB, return_counts=True)
+    ua, ubv = uk // m, uk % m
+    best_ = np.full(nAkeys, -1, np.int64)
+    order = np.lexsort((cnt, ua))
+    lastOf = np.flatnonzero(np.concatenate((ua[order][1:] != ua[order][:-1], [True]))) if ua.size else np.zeros(0, np.int64)
+    best_[ua[order][lastOf]] = ubv[order][lastOf]
+    return best_
+
+
+# HOME lattice block of every row; a "block" below = a run of consecutive rows with one home
+if which == "St":
+    rowHome = dofBlk
+else:
+    rowOfNz0 = np.repeat(np.arange(rows), lens)
+    sk = rowOfNz0 >= nA
+    regHome = most_frequent(reg[rowOfNz0[sk] - nA], dofBlk[col[sk]], nReg)
+    rowHome = np.concatenate((faceBlk, regHome[reg]))
+    del rowOfNz0, sk
+bstart = np.concatenate(([0], np.flatnonzero(np.diff(rowHome)) + 1))
+bid = rowHome[bstart]
+nBlk = bstart.size
+bd0 = bstart
+bd1 = np.concatenate((bstart[1:], [rows]))
+rowBlk = np.repeat(np.arange(nBlk), bd1 - bd0)            # run ("block", dense id) of every row
+nzBlk = np.repeat(rowBlk, lens)                            # ... of every entry
+if which == "St":
+    # range 1: the active face rows of the home block; range 2: the skin rows of its tile = the region its rows reference most
+    ba0 = np.searchsorted(faceBlk, bid, "left")
+    ba1 = np.searchsorted(faceBlk, bid, "right")
+    skin = col >= nA
+    best = most_frequent(nzBlk[skin], reg[col[skin] - nA], nBlk)
+    bs0 = np.where(best >= 0, nA + regPtr[np.maximum(best, 0)], 0)
+    bs1 = np.where(best >= 0, nA + regPtr[np.maximum(best, 0) + 1], 0)
+    del skin
+else:
+    # range 1: the DOFs of the home block; no second range
+    ba0 = np.searchsorted(dofBlk, bid, "left")
+    ba1 = np.searchsorted(dofBlk, bid, "right")
+    bs0 = np.zeros(nBlk, np.int64); bs1 = np.zeros(nBlk, np.int64)
+inAblk = (col >= ba0[nzBlk]) & (col < ba1[nzBlk])
+inSblk = (col >= bs0[nzBlk]) & (col < bs1[nzBlk])
+if which == "S":
+    # skin rows are ordered (region, length class, axis, position): any part of them touches DOFs all over the block — their image is the
+    # LIST of the 16-byte pairs they touch, no range
+    inAblk &= (bd0 < nA)[nzBlk]
+# ITEMS: a block, or — where the image of a whole block does not fit — a block's units dealt evenly to K parts.  Per item the two
+# ranges are the tight [min, max] of the columns its rows touch inside the block's active rows / its tile's skin rows.
+relB = np.arange(rows) - bd0[rowBlk]
+nUb = (bd1 - bd0 + 63) // 64
+K = np.ones(nBlk, np.int64)
+BIG = np.int64(1) << 40
+for attempt in range(8):
+    itemStart = np.concatenate(([0], np.cumsum(K)))
+    rowB = itemStart[rowBlk] + ((relB >> 6) * K[rowBlk]) // nUb[rowBlk]
+    nB = int(itemStart[-1])
+    first = np.flatnonzero(np.concatenate(([True], rowB[1:] != rowB[:-1])))
+    assert first.size == nB
+    d0 = first
+    d1 = np.concatenate((first[1:], [rows]))
+    nzB = np.repeat(rowB, lens)
+    nzFirst = ptr[d0]
+    okI = ptr[d1] > nzFirst                                 # items with entries
+    def red(fn, arr, fill):
+        out = np.full(nB, fill, np.int64)
+        out[okI] = fn.reduceat(arr, nzFirst[okI])
+        return out
+    aMin = red(np.minimum, np.where(inAblk, col, BIG), BIG); aMax = red(np.maximum, np.where(inAblk, col, -1), -1)
+    sMin = red(np.minimum, np.where(inSblk, col, BIG), BIG); sMax = red(np.maximum, np.where(inSblk, col, -1), -1)
+    a0e = np.where(aMax >= 0, aMin & ~1, 0); lenA = np.where(aMax >= 0, ((aMax + 1 - a0e + 127) // 128) * 128, 0)
+    s0e = np.where(sMax >= 0, sMin & ~1, 0); lenS = np.where(sMax >= 0, ((sMax + 1 - s0e + 127) // 128) * 128, 0)
+    inA = (col >= a0e[nzB]) & (col < (a0e + lenA)[nzB])
+    inS = (~inA) & (col >= s0e[nzB]) & (col < (s0e + lenS)[nzB])
+    rest = ~(inA | inS)
+    hkey = (nzB[rest] << 32) | (col[rest] >> 1)
+    hu, hinv = np.unique(hkey, return_inverse=True)
+    hb = hu >> 32
+    haloBase = np.searchsorted(hb, np.arange(nB), "left")
+    nPairs = np.searchsorted(hb, np.arange(nB), "right") - haloBase
+    img = 2 + lenA + lenS + ((nPairs + 63) // 64) * 128
+    over = img > CAP
+    log("attempt %d: %d items of %d blocks, %d over the cap of %d doubles (max %d)" % (attempt, nB, nBlk, int(over.sum()), CAP, int(img.max())))
+    if not over.any():
+        break
+    blkOfItem = np.repeat(np.arange(nBlk), K)
+    grow = np.zeros(nBlk, bool); grow[blkOfItem[over]] = True
+    K = np.where(grow, np.minimum(K + 1, nUb), K)
+assert not over.any()
 haloPairs = (hu & 0xffffffff).astype(np.int32)
 pos = np.empty(nnz, np.int64)
 pos[inA] = 2 + col[inA] - a0e[nzB[inA]]
 pos[inS] = 2 + lenA[nzB[inS]] + col[inS] - s0e[nzB[inS]]
 b_r = nzB[rest]
 pos[rest] = 2 + lenA[b_r] + lenS[b_r] + 2 * (hinv - haloBase[b_r]) + (col[rest] & 1)
-img = 2 + lenA + lenS + ((nPairs + 63) // 64) * 128
-log("blocks %d; image doubles per block: mean %.0f p99 %.0f max %d; halo pairs mean %.0f max %d; in A %.3f in S %.3f halo %.3f of the entries"
-    % (nB, img.mean(), np.percentile(img, 99), img.max(), nPairs.mean(), nPairs.max(), inA.mean(), inS.mean(), rest.mean()))
+log("items %d (blocks %d); image doubles per item: mean %.0f p99 %.0f max %d; halo pairs mean %.0f max %d; in A %.3f in S %.3f halo %.3f of the entries"
+    % (nB, nBlk, img.mean(), np.percentile(img, 99), img.max(), nPairs.mean(), nPairs.max(), inA.mean(), inS.mean(), rest.mean()))
 assert pos.max() < 65536
-counts = {"scene": "%s%d" % (scene, res), "blocks": int(nB), "rows": int(rows), "nnz": int(nnz), "image_doubles_mean": float(img.mean()), "image_doubles_p99": float(np.percentile(img, 99)),
+counts = {"scene": "%s%d" % (scene, res), "blocks": int(nBlk), "items": int(nB), "cap_doubles": CAP, "rows": int(rows), "nnz": int(nnz), "image_doubles_mean": float(img.mean()),
+          "image_doubles_p99": float(np.percentile(img, 99)),
           "image_doubles_max": int(img.max()), "halo_pairs_mean": float(nPairs.mean()), "halo_pairs_max": int(nPairs.max()),
           "entries_from_active_range": float(inA.mean()), "entries_from_skin_range": float(inS.mean()), "entries_from_halo": float(rest.mean()),
           "staged_doubles_per_gathered_entry": float(img.sum() / nnz), "staged_doubles_over_t_entries": float(img.sum() / tLen),
-          "dma_pieces_per_block_mean": float((img / 128).mean())}
+          "dma_pieces_per_item_mean": float((img / 128).mean())}
 # ---- row-per-lane units (64 rows, never across a block), even width = the unit's longest row
 rel = np.arange(rows) - d0[rowB]
 nU = (d1 - d0 + 63) // 64
@@ -198,55 +258,57 @@ json.dump(counts, open(os.path.join(ROOT, "gpurun_out", tag + "_counts.json"), "
 log(json.dumps(counts))
 
 # ---- run it
-import torch
 dev = "cuda"
 gen = np.random.default_rng(7)
-tvec = np.zeros(tLen + 256); tvec[:tLen] = gen.standard_normal(tLen)
+xvec = np.zeros(tLen + 256); xvec[:tLen] = gen.standard_normal(tLen)        # the gathered vector (t for St, p for S)
 pvec = gen.standard_normal(rows); rvec = gen.standard_normal(rows)
 ucode = gen.integers(0, 256, rows).astype(np.uint8); udict = gen.random(256)
 dinv = gen.random(rows).astype(np.float32)
-scale, alpha = 0.5, 0.37
+scale, alpha, dtv = 0.5, 0.37, 0.01
 import scipy.sparse as sp
-St = sp.csr_matrix((code.astype(np.float64) * scale, col, ptr), shape=(rows, tLen))
-y = -(St @ tvec[:tLen]) - 0.5 * udict[ucode] * pvec
-rexp = rvec - alpha * y
+Mx = sp.csr_matrix((code.astype(np.float64) * scale, col, ptr), shape=(rows, tLen)) @ xvec[:tLen]
+if which == "St":
+    rexp = rvec - alpha * (-Mx - 0.5 * udict[ucode] * pvec)
+else:
+    rexp = np.where(np.arange(rows) < nA, dtv * udict[ucode] * Mx, Mx)
 L = C.CDLL(so)
 L.st_lds_launch.restype = C.c_int
 tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-T = dict(desc=tt(desc), units=tt(unitsC), ecol=tt(ecolC.view(np.int16)), ecode=tt(ecodeC), halo=tt(haloPairs if haloPairs.size else np.zeros(1, np.int32)), t=tt(tvec), p=tt(pvec),
+T = dict(desc=tt(desc), units=tt(unitsC), ecol=tt(ecolC.view(np.int16)), ecode=tt(ecodeC), halo=tt(haloPairs if haloPairs.size else np.zeros(1, np.int32)), t=tt(xvec), p=tt(pvec),
          uc=tt(ucode), ud=tt(udict), dinv=tt(dinv))
 ldsBytes = int(((img.max() * 8 + 1023) // 1024) * 1024)
-assert ldsBytes <= 80 * 1024 - 4096, "image of %d bytes: more than two workgroups per CU can hold" % ldsBytes
-results = {"lds_bytes": ldsBytes}
+results = {"lds_bytes": ldsBytes, "matrix": which}
+MODE = 0 if which == "St" else 1
 
 
-def launch(stage, grid, reps_):
+def launch(stage, nu, grid, reps_):
     r = tt(rvec)
     part = torch.zeros(2 * grid, dtype=torch.float64, device=dev)
     ms = C.c_float(0)
-    rc = L.st_lds_launch(C.c_int(stage), C.c_int(grid), C.c_int(ldsBytes), C.c_void_p(T["desc"].data_ptr()), C.c_int(nB), C.c_void_p(T["units"].data_ptr()),
+    rc = L.st_lds_launch(C.c_int(stage + 4 * MODE + (8 if nu == 4 else 0)), C.c_int(grid), C.c_int(ldsBytes), C.c_void_p(T["desc"].data_ptr()), C.c_int(nB), C.c_void_p(T["units"].data_ptr()),
                          C.c_void_p(T["ecol"].data_ptr()), C.c_void_p(T["ecode"].data_ptr()), C.c_uint(ecolC.nbytes), C.c_uint(ecodeC.nbytes), C.c_void_p(T["halo"].data_ptr()),
-                         C.c_void_p(T["t"].data_ptr()), C.c_int(tLen), C.c_void_p(T["p"].data_ptr()), C.c_void_p(T["uc"].data_ptr()), C.c_void_p(T["ud"].data_ptr()),
-                         C.c_void_p(r.data_ptr()), C.c_void_p(T["dinv"].data_ptr()), C.c_int(rows), C.c_double(scale), C.c_double(alpha), C.c_void_p(part.data_ptr()),
+                         C.c_void_p(T["t"].data_ptr()), C.c_int(nA if MODE == 1 else tLen), C.c_void_p(T["p"].data_ptr()), C.c_void_p(T["uc"].data_ptr()), C.c_void_p(T["ud"].data_ptr()),
+                         C.c_void_p(r.data_ptr()), C.c_void_p(T["dinv"].data_ptr()), C.c_int(rows), C.c_double(scale), C.c_double(dtv if MODE == 1 else alpha), C.c_void_p(part.data_ptr()),
                          C.c_int(reps_), C.byref(ms))
     assert rc == 0, rc
     return r.cpu().numpy(), part.cpu().numpy(), ms.value
 
 
-for stage in (0, 1):
-    rgot, part, _ = launch(stage, 512, 1)
+VARIANTS = [(0, 2, (512,)), (0, 4, (512,)), (1, 2, (512,)), (2, 2, (256,)), (2, 4, (256,))]
+for stage, nu, grids in VARIANTS:
+    rgot, part, _ = launch(stage, nu, grids[0], 1)
     err = np.abs(rgot - rexp).max() / np.abs(rexp).max()
-    rr = part[:512].sum()
-    log("stage %d: max rel err of r %.2e; r.r %.12e vs %.12e" % (stage, err, rr, (rexp * rexp).sum()))
+    log("stage %d, %d units in flight: max rel err %.2e" % (stage, nu, err))
     assert err < 1e-12
-    results["err_stage%d" % stage] = float(err)
-for stage in (0, 1):
-    for grid in (256, 512, 768, 1024):
-        _, _, ms = launch(stage, grid, 20)
-        log("stage %d grid %4d: %.4f ms" % (stage, grid, ms))
-        results["ms_stage%d_grid%d" % (stage, grid)] = ms
+    results["err_stage%d_nu%d" % (stage, nu)] = float(err)
+for rnd in range(2):
+    for stage, nu, grids in VARIANTS:
+        for grid in grids:
+            _, _, ms = launch(stage, nu, grid, 20)
+            log("stage %d, %d units in flight, grid %4d: %.4f ms" % (stage, nu, grid, ms))
+            results["ms_stage%d_nu%d_grid%d_r%d" % (stage, nu, grid, rnd)] = ms
 s.step_device()
-for nm in ("spmv_St_r", "spmv_St"):
+for nm in (("spmv_St_r", "spmv_St") if which == "St" else ("spmv_S",)):
     results["product_seq_" + nm] = s.bench_kernel("seq:" + nm, 20)[0]
     results["product_replayed_" + nm] = s.bench_kernel(nm, 20)[0]
 log(json.dumps(results))

@@ -12,7 +12,6 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
-constexpr int TB = 512;                       // 8 waves per workgroup, two workgroups per CU (LDS: <= 80 KB each)
 struct BlockDesc { int d0, nUnits, unitBase, colBase, codeBase, a0, lenA, s0, lenS, haloBase, nPairs, pad; };
 __device__ inline __amdgpu_buffer_rsrc_t bufRsrc(const void* p, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
@@ -51,28 +50,30 @@ __device__ inline double waveReduceSum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
-// STAGE: 0 = LDS-DMA (asynchronous), 1 = through registers (global_load + ds_write)
-template <int STAGE>
-__global__ void __launch_bounds__(TB) k_st_lds(const BlockDesc* __restrict__ blocks, int nBlocks, const int4* __restrict__ units, const uint16_t* __restrict__ ecol,
+// STAGE: 0 = LDS-DMA into ONE image per workgroup (512 threads, two workgroups per CU take turns), 1 = the same through registers (global_load +
+// ds_write), 2 = LDS-DMA, TWO images per workgroup of 1024 threads (one per CU): the next item's image is in flight while this one is computed
+// MODE 0: the St product of the PCG step (image of t; rows = DOFs).  MODE 1: the S product, out = (row < nA ? dt dict[mcCode] : 1) (S x)[row], partials of
+// sum over the active rows of s (s sc) (image of x = p; rows = face rows; arguments reused: tLen = nA, uCode = mcCode, r = out, alpha = dt)
+// NU: 64-row units a wave has in flight
+template <int STAGE, int MODE, int NU, int NT>
+__global__ void __launch_bounds__(NT) k_st_lds(const BlockDesc* __restrict__ blocks, int nBlocks, const int4* __restrict__ units, const uint16_t* __restrict__ ecol,
                                                const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes, const int32_t* __restrict__ haloPairs,
                                                const double* __restrict__ t, int tLen, const double* __restrict__ p, const uint8_t* __restrict__ uCode,
                                                const double* __restrict__ uDict, double* __restrict__ r, const float* __restrict__ dinvF, int rows, double scale,
                                                double alpha, double* __restrict__ rPart, int imgCap) {
-    extern __shared__ __attribute__((aligned(16))) double img[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double dict[256];
-    __shared__ double wsum[2][TB / 64];
+    __shared__ double wsum[2][NT / 64];
+    constexpr int NW = NT / 64;
     if (threadIdx.x < 256) dict[threadIdx.x] = uDict[threadIdx.x];
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rP = bufRsrc(p, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows),
-                                 rR = bufRsrc(r, (size_t)rows * 8), rD = bufRsrc(dinvF, (size_t)rows * 4);
+                                 rR = bufRsrc(r, (size_t)rows * 8), rD = bufRsrc(dinvF, (size_t)rows * 4), rMc = bufRsrc(uCode, (size_t)tLen);
     const unsigned lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double dacc = 0., dacc2 = 0.;
-    for (int b = blockIdx.x; b < nBlocks; b += gridDim.x) {
-        const BlockDesc bd = blocks[b];
-        // ---- stage the image: pieces of 64 lanes x 16 bytes = 128 doubles, dealt to the eight waves
+    auto stage = [&](const BlockDesc& bd, double* img) {       // pieces of 64 lanes x 16 bytes = 128 doubles, dealt to the waves
         const int nA = bd.lenA >> 7, nS = bd.lenS >> 7, nH = (bd.nPairs + 63) >> 6;     // lenA, lenS: multiples of 128 doubles (padded by the host)
-        if (threadIdx.x < 2) img[threadIdx.x] = 0.;
-        for (int k = wv; k < nA + nS + nH; k += TB / 64) {
+        for (int k = wv; k < nA + nS + nH; k += NW) {
             const double* src;
             int dst;
             if (k < nA) { src = t + bd.a0 + k * 128 + lane * 2; dst = 2 + k * 128; }
@@ -82,59 +83,103 @@ __global__ void __launch_bounds__(TB) k_st_lds(const BlockDesc* __restrict__ blo
                 const int pr = q < bd.nPairs ? haloPairs[bd.haloBase + q] : 0;
                 src = t + 2 * (size_t)pr; dst = 2 + bd.lenA + bd.lenS + (k - nA - nS) * 128;
             }
-            if (STAGE == 0) __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(img + dst), 16, 0, 0);
+            if (STAGE != 1) __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(img + dst), 16, 0, 0);
             else { const double2 v = *reinterpret_cast<const double2*>(src); *reinterpret_cast<double2*>(img + dst + lane * 2) = v; }
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0)
-        __syncthreads();
-        // ---- the block's units: wave w takes units w, w + 8, ... two in flight
-        for (int u = wv; u < bd.nUnits; u += 2 * (TB / 64)) {
-            const int ub = u + TB / 64;
-            const int4 da = units[bd.unitBase + u];
-            const int4 db = ub < bd.nUnits ? units[bd.unitBase + ub] : make_int4(0, 0, 0, 0);
-            const int Wa = da.w >> 8, Wb = db.w >> 8, na = da.w & 255, nb = db.w & 255;
-            const Regs sa = loadUnit(rCol, rCode, Wa, bd.colBase + da.x, bd.codeBase + da.y, lane), sb = loadUnit(rCol, rCode, Wb, bd.colBase + db.x, bd.codeBase + db.y, lane);
-            const bool liveA = (int)lane < na, liveB = (int)lane < nb;
-            const unsigned rowA = liveA ? (unsigned)(bd.d0 + da.z) + lane : 0x1fffffffu, rowB = liveB ? (unsigned)(bd.d0 + db.z) + lane : 0x1fffffffu;
-            const double eA = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rP, (int)(rowA * 8u), 0, 2));
-            const double eB = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rP, (int)(rowB * 8u), 0, 2));
-            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, 2), ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, 2);
-            const double crA = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rR, (int)(rowA * 8u), 0, 2));
-            const double crB = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rR, (int)(rowB * 8u), 0, 2));
-            const float fdA = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)(rowA * 4u), 0, 2));
-            const float fdB = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)(rowB * 4u), 0, 2));
-            const double a = rowSumW(Wa, sa, img, scale), bsum = rowSumW(Wb, sb, img, scale);
-            double yA = -a; yA -= 0.5 * dict[ucA] * eA;
-            double yB = -bsum; yB -= 0.5 * dict[ucB] * eB;
-            const double rvA = liveA ? crA - alpha * yA : 0., rvB = liveB ? crB - alpha * yB : 0.;
-            dacc += rvA * rvA; dacc += rvB * rvB;
-            dacc2 += rvA * ((double)fdA * rvA); dacc2 += rvB * ((double)fdB * rvB);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rvA), rR, (int)(rowA * 8u), 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rvB), rR, (int)(rowB * 8u), 0, 2);
+    };
+    if (threadIdx.x < 2) { lds[threadIdx.x] = 0.; if (STAGE == 2) lds[imgCap + threadIdx.x] = 0.; }
+    int b = blockIdx.x, buf = 0;
+    BlockDesc bd{}, nbd{};
+    if (b < nBlocks) { bd = blocks[b]; if (STAGE == 2) stage(bd, lds); }
+    for (; b < nBlocks; b += gridDim.x, buf ^= (STAGE == 2 ? 1 : 0)) {
+        double* img = lds + buf * imgCap;
+        if (STAGE != 2) stage(bd, img);
+        __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): this wave's share of the image
+        __syncthreads();                                       // everybody's; and (STAGE 2) nobody reads the other image any more
+        const int nb = b + gridDim.x;
+        if (nb < nBlocks) { nbd = blocks[nb]; if (STAGE == 2) stage(nbd, lds + (buf ^ 1) * imgCap); }
+        // ---- the item's units: wave w takes units w, w + NW, ... NU of them in flight
+        for (int u = wv; u < bd.nUnits; u += NU * NW) {
+            int W[NU], nr[NU];
+            unsigned row[NU];
+            Regs sg[NU];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {
+                const int uq = u + q * NW;
+                const int4 d = uq < bd.nUnits ? units[bd.unitBase + uq] : make_int4(0, 0, 0, 0);
+                W[q] = d.w >> 8; nr[q] = d.w & 255;
+                sg[q] = loadUnit(rCol, rCode, W[q], bd.colBase + d.x, bd.codeBase + d.y, lane);
+                row[q] = (int)lane < nr[q] ? (unsigned)(bd.d0 + d.z) + lane : 0x1fffffffu;
+            }
+            if (MODE == 0) {
+                double e[NU], cr[NU];
+                int uc[NU];
+                float fd[NU];
+#pragma unroll
+                for (int q = 0; q < NU; ++q) {
+                    e[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rP, (int)(row[q] * 8u), 0, 2));
+                    uc[q] = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row[q], 0, 2);
+                    cr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rR, (int)(row[q] * 8u), 0, 2));
+                    fd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)(row[q] * 4u), 0, 2));
+                }
+#pragma unroll
+                for (int q = 0; q < NU; ++q) {
+                    const double a = rowSumW(W[q], sg[q], img, scale);
+                    double y = -a; y -= 0.5 * dict[uc[q]] * e[q];
+                    const double rv = (int)lane < nr[q] ? cr[q] - alpha * y : 0.;
+                    dacc += rv * rv;
+                    dacc2 += rv * ((double)fd[q] * rv);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rv), rR, (int)(row[q] * 8u), 0, 2);
+                }
+            } else {
+                int mc[NU];
+#pragma unroll
+                for (int q = 0; q < NU; ++q) mc[q] = (int)__builtin_amdgcn_raw_buffer_load_b8(rMc, (int)row[q], 0, 2);   // tLen = nA: past it 0 without an access
+#pragma unroll
+                for (int q = 0; q < NU; ++q) {
+                    const double a = rowSumW(W[q], sg[q], img, scale);
+                    const double sc = (int)row[q] < tLen ? alpha * dict[mc[q]] : 1.;
+                    dacc += (int)row[q] < tLen ? a * (a * sc) : 0.;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a * sc), rR, (int)(row[q] * 8u), 0, 2);
+                }
+            }
         }
-        __syncthreads();                                       // the image is reused
+        if (STAGE != 2) __syncthreads();                       // the image is reused
+        bd = nbd;
     }
     const double s0 = waveReduceSum(dacc), s1 = waveReduceSum(dacc2);
     if (lane == 0) { wsum[0][wv] = s0; wsum[1][wv] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double a = 0., c = 0.;
-        for (int i = 0; i < TB / 64; ++i) { a += wsum[0][i]; c += wsum[1][i]; }
+        for (int i = 0; i < NW; ++i) { a += wsum[0][i]; c += wsum[1][i]; }
         rPart[blockIdx.x] = a; rPart[gridDim.x + blockIdx.x] = c;
     }
 }
-extern "C" int st_lds_launch(int stage, int grid, int ldsBytes, const void* blocks, int nBlocks, const void* units, const void* ecol, const void* ecode, unsigned colBytes,
+extern "C" int st_lds_launch(int variant, int grid, int ldsBytes, const void* blocks, int nBlocks, const void* units, const void* ecol, const void* ecode, unsigned colBytes,
                              unsigned codeBytes, const void* haloPairs, const void* t, int tLen, const void* p, const void* uCode, const void* uDict, void* r,
                              const void* dinvF, int rows, double scale, double alpha, void* rPart, int reps, float* msOut) {
-    auto k = stage == 0 ? k_st_lds<0> : k_st_lds<1>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) return -1;
+    // variant = stage + 4 * mode + 8 * (units in flight == 4)
+    const int stage = variant & 3, mode = (variant >> 2) & 1, nu4 = (variant >> 3) & 1;
+    typedef void (*K)(const BlockDesc*, int, const int4*, const uint16_t*, const int8_t*, unsigned, unsigned, const int32_t*, const double*, int, const double*, const uint8_t*,
+                      const double*, double*, const float*, int, double, double, double*, int);
+    K k = nullptr;
+    int nt = stage == 2 ? 1024 : 512;
+#define PICK(S_, M_, N_, T_) if (stage == S_ && mode == M_ && nu4 == (N_ == 4)) k = k_st_lds<S_, M_, N_, T_>;
+    PICK(0, 0, 2, 512) PICK(1, 0, 2, 512) PICK(2, 0, 2, 1024) PICK(0, 0, 4, 512) PICK(1, 0, 4, 512) PICK(2, 0, 4, 1024)
+    PICK(0, 1, 2, 512) PICK(1, 1, 2, 512) PICK(2, 1, 2, 1024) PICK(0, 1, 4, 512) PICK(1, 1, 4, 512) PICK(2, 1, 4, 1024)
+#undef PICK
+    if (!k) return -4;
+    const int imgCap = ldsBytes / 8;
+    const int dyn = stage == 2 ? 2 * ldsBytes : ldsBytes;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return -1;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(k, dim3(grid), dim3(TB), ldsBytes, 0, (const BlockDesc*)blocks, nBlocks, (const int4*)units, (const uint16_t*)ecol, (const int8_t*)ecode, colBytes, codeBytes,
+        hipLaunchKernelGGL(k, dim3(grid), dim3(nt), dyn, 0, (const BlockDesc*)blocks, nBlocks, (const int4*)units, (const uint16_t*)ecol, (const int8_t*)ecode, colBytes, codeBytes,
                            (const int32_t*)haloPairs, (const double*)t, tLen, (const double*)p, (const uint8_t*)uCode, (const double*)uDict, (double*)r, (const float*)dinvF, rows,
-                           scale, alpha, (double*)rPart, ldsBytes / 8);
+                           scale, alpha, (double*)rPart, imgCap);
     hipEventRecord(e1, 0);
     if (hipEventSynchronize(e1) != hipSuccess) return -2;
     hipEventElapsedTime(msOut, e0, e1);

@@ -37,6 +37,13 @@ CASES = {
     "cavity64_t32p3_L3S3": lambda: _shipped(scenes.cavity(64, tile=32, pad=3)),
     "blob_t32p3_L3S3": lambda: _shipped(scenes.blob(52, 44, 48, seed=3, tile=32, pad=3)),
 }
+# Oracle-pinned fixtures at real sizes on the HEADLINE parameter set: the size-switched paths of the library (the
+# four-kernel PCG step from 2 M rows, the non-temporal cache policy from 4 M rows) engage here by size, unforced.  Same digest form;
+# consumed by the GPU test only (the oracle needs minutes per case: the CPU suite does not re-run them — `make_golden_large.py huge`).
+HUGE = {
+    "cavity128_t16p2_jacobi": lambda: scenes.cavity(128, tile=16, pad=2),      # 5.9 M system DOFs, BASELINE config 3 at half resolution
+    "coil128": lambda: scenes.coil(128, tile=16, pad=2),                        # BASELINE config 2 at its stated size
+}
 INT_ARRAYS = [s + k for s in abi.SAMPLE_NAMES for k in ("Labels", "ActiveIndices", "ReducedIndices")] + ["validX", "validY", "validZ"]
 
 
@@ -68,7 +75,7 @@ def digest(get, stats, apply):
 
 def build(name):
     from oracle import ps_oracle
-    sc, p = CASES[name]()
+    sc, p = (CASES.get(name) or HUGE[name])()
     o = ps_oracle.Oracle()
     rc = o.run(sc, p)
     d = digest(o.array, o.stats, o.apply)
@@ -113,6 +120,13 @@ if __name__ == "__main__":
             print("wrote velocities of", name)
         sys.exit(0)
     here = os.path.dirname(os.path.abspath(__file__))
+    if len(sys.argv) > 1 and sys.argv[1] == "huge":    # python tests/golden/make_golden_large.py huge [case]
+        import time
+        for name in (sys.argv[2:] or list(HUGE)):
+            t0 = time.time()
+            np.savez_compressed(os.path.join(here, "large_" + name + ".npz"), **build(name))
+            print("wrote", name, "in %.0f s" % (time.time() - t0), flush=True)
+        sys.exit(0)
     for name in CASES:
         np.savez_compressed(os.path.join(here, "large_" + name + ".npz"), **build(name))
         print("wrote", name)
