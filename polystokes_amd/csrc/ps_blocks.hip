@@ -748,7 +748,7 @@ void ps_context::buildEll(ps::DevCSR& M) {
     HIP_CHECK(hipMemsetAsync(counters.p + 25, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(k_ell_plan, dim3((unsigned)nChunks), dim3(BS), 0, stream, (const int4*)M.chunkInfo.p, (const uint8_t*)M.len8.p, (const int32_t*)M.chunkRep.p,
                        colBegin.p, codeBegin.p, wpack.p, counters.p + 25);
-    scanBlock.alloc((size_t)gridFor(nChunks + 1, 2048) + 16);                   // (both unsynchronised scans below use it)
+    scanBlock.alloc((size_t)gridFor(nChunks + 1, PS_SCAN_TILE) + 16);                   // (both unsynchronised scans below use it)
     (void)exclusiveScanI32(colBegin.p, nChunks + 1, 56);
     (void)exclusiveScanI32(codeBegin.p, nChunks + 1, 57);
     int32_t tot[2] = {0, 0}, tooLong = 0;                                        // one round trip for the two totals and the width check

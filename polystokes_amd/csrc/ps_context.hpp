@@ -306,6 +306,7 @@ void ps_dist_release(ps_context* c);                       // ps_solve.hip: dest
 
 namespace ps {
 constexpr int FB_CHUNK = 4096;   // face-box positions per work item (per-region dense reductions)
+constexpr int PS_SCAN_TILE = 2048;   // entries per workgroup of the scan kernels (ps_grid.hip: SCAN_TILE; asserted equal there): sizes their block-sum scratch
 constexpr int RC_ROWS = 1280;    // reduced rows per chunk in the three-kernel tile apply (regions too large for one workgroup)
 constexpr int TILE_FUSED_MAX_ROWS = 32768;   // regions up to this many skin rows: one workgroup gathers, solves and expands (k_tile_apply)
 }  // namespace ps

@@ -539,6 +539,50 @@ struct Dist {
     // (tilePadding 1: scripts/brick_diag.py).  A rank's OWNED cells are at least a halo block away from where its view ends, so the
     // owner is always right.  pass 0: after classifyCells / constructReducedRegions (labels only); pass 1: after the boundary fix
     // (labels + the cell's component from before the fix).  Both go through the transport of the solve's x-exchange.
+    // Before the first label transport: the two ranks of every cut agree on what they are about to exchange.  The message sizes of
+    // exchangeLabels are derived on each side from its own brick (halo layers x cross-section) with no length in the message: ranks
+    // configured with different tile sizes or cross-sections would wait in a receive for ever or read each other's labels at the wrong
+    // cells.  One double per side and axis — (cross-section, halo layers, tileSize), exact in a double — through the same transport,
+    // compared with what this rank expects from that side; any mismatch fails EVERY rank with a message.
+    static double cutKey(const ps_context* c, int a, int layers) {
+        const int3 d = c->g.dims(0);
+        const int b = a == 0 ? d.y : d.x, e = a == 2 ? d.y : d.z;
+        return (((double)b * 4096. + (double)e) * 64. + (double)layers) * 64. + (double)c->P.tileSize;      // < 2^42
+    }
+    void handshakeCuts() {
+        bool bad = false;
+        for (int a = 0; a < 3; ++a) {
+            if (!axisUsed(a)) continue;
+            std::vector<int64_t> keep(R.size() * 4);
+            std::vector<double> want(R.size() * 2);
+            for (size_t q = 0; q < R.size(); ++q) {
+                ps_context* c = R[q];
+                const int3 d = c->g.dims(0);
+                const int da = a == 0 ? d.x : (a == 1 ? d.y : d.z);
+                c->sendLo[a].alloc(8); c->sendUp[a].alloc(8); c->recvLo[a].alloc(8); c->recvUp[a].alloc(8);
+                want[2 * q] = c->brick.hasLower[a] ? cutKey(c, a, c->brick.lo[a]) : 0.;
+                want[2 * q + 1] = c->brick.hasUpper[a] ? cutKey(c, a, da - c->brick.hi[a]) : 0.;
+                HIP_CHECK(hipMemcpyAsync(c->sendLo[a].p, &want[2 * q], 8, hipMemcpyHostToDevice, cs(c, true)));
+                HIP_CHECK(hipMemcpyAsync(c->sendUp[a].p, &want[2 * q + 1], 8, hipMemcpyHostToDevice, cs(c, true)));
+                keep[4 * q] = c->nLowOwn[a]; keep[4 * q + 1] = c->nLowHalo[a]; keep[4 * q + 2] = c->nUpOwn[a]; keep[4 * q + 3] = c->nUpHalo[a];
+                c->nLowOwn[a] = c->nLowHalo[a] = c->nUpOwn[a] = c->nUpHalo[a] = 1;
+            }
+            auto restore = [&]() { for (size_t q = 0; q < R.size(); ++q) { ps_context* c = R[q]; c->nLowOwn[a] = keep[4 * q]; c->nLowHalo[a] = keep[4 * q + 1]; c->nUpOwn[a] = keep[4 * q + 2]; c->nUpHalo[a] = keep[4 * q + 3]; } };
+            try { transport(0, true, a); } catch (...) { restore(); throw; }
+            restore();
+            for (size_t q = 0; q < R.size(); ++q) {
+                ps_context* c = R[q];
+                double got[2] = {0., 0.};
+                if (c->brick.hasLower[a]) HIP_CHECK(hipMemcpyAsync(&got[0], c->recvLo[a].p, 8, hipMemcpyDeviceToHost, cs(c, true)));
+                if (c->brick.hasUpper[a]) HIP_CHECK(hipMemcpyAsync(&got[1], c->recvUp[a].p, 8, hipMemcpyDeviceToHost, cs(c, true)));
+                HIP_CHECK(hipStreamSynchronize(cs(c, true)));
+                bad = bad || (c->brick.hasLower[a] && got[0] != want[2 * q]) || (c->brick.hasUpper[a] && got[1] != want[2 * q + 1]);
+            }
+        }
+        if (sumFlag(bad ? 1. : 0.) > 0.)
+            throw Error(bad ? "the rank across a cut was configured differently (cross-section, halo layers or tileSize of the two bricks disagree): refusing to exchange labels"
+                            : "another pair of ranks disagrees about the cut between their bricks (cross-section, halo layers or tileSize)");
+    }
     static int nbrMask(const ps_context* c) { int m = 0; for (int b = 0; b < 3; ++b) m |= (c->brick.hasLower[b] ? 1 : 0) << (2 * b) | (c->brick.hasUpper[b] ? 2 : 0) << (2 * b); return m; }
     void exchangeLabels(int pass) {
         bool any = false;
@@ -550,6 +594,7 @@ struct Dist {
             HIP_CHECK(hipMemsetAsync(c->labelFlags.p, 0, 4 * sizeof(int32_t), c->stream));
             order(c, 0, true);
         }
+        if (pass == 0) handshakeCuts();
         for (int a = 0; a < 3; ++a) {
             if (!axisUsed(a)) continue;
             struct Geo { int3 d; int hLo, hUp; int64_t nLo, nUp, keep[4]; };
@@ -1327,7 +1372,7 @@ int32_t ps_set_slab(ps_context* c, const ps_slab* slab) {   // z-slabs: the deco
 
 // What the last distributed solve of this rank did: [0] bytes it sends per iteration over its cuts, [1] owned DOFs, [2] 1 if the
 // exchanges ran under the rows that do not need them, [3] / [4] summed ms / samples of one x-exchange transport (comm stream events,
-// batch ends), [5] / [6] summed ms / samples of one scalar all-reduce incl. its synchronisation (host clock, batch ends), [7] 0
+// batch ends), [5] / [6] summed ms / samples of one scalar all-reduce incl. its synchronisation (host clock, batch ends), [7] halo cells whose label the owners' exchange changed (Dist::exchangeLabels)
 int32_t ps_dist_stats(ps_context* c, double* out8) {
     if (!c || !out8) return PS_FAILED;
     for (int q = 0; q < 8; ++q) out8[q] = c->distStats[q];

@@ -654,6 +654,7 @@ __global__ void k_valid(const int32_t* __restrict__ lab, int64_t n, float* __res
 // ---- scans --------------------------------------------------------------------------------------
 constexpr int SCAN_ITEMS = 8;                      // per thread
 constexpr int SCAN_TILE = BS * SCAN_ITEMS;         // per block
+static_assert(SCAN_TILE == PS_SCAN_TILE, "ps_context.hpp: PS_SCAN_TILE");
 
 __device__ inline int blockExclusiveScan(int v, int* total) {
     __shared__ int waveSums[BS / 64];

@@ -739,3 +739,53 @@ def test_noconverge_with_and_without_keeping_the_results(gpu, oracle_mod, keep):
         else:
             assert np.array_equal(gpu.vel[a].ravel(), np.asarray(sc.vel[a], np.float32).ravel())
             assert np.array_equal(vo, np.asarray(sc.vel[a], np.float32).ravel())
+
+
+_TILE_CLASS_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import polystokes_amd
+from polystokes_amd import scenes
+from polystokes_amd._abi import Scene, default_params
+n = 64
+dx = 1.0 / n
+z, y, x = np.meshgrid((np.arange(n) + 0.5) * dx, (np.arange(n) + 0.5) * dx, (np.arange(n) + 0.5) * dx, indexing="ij", sparse=True)
+surface = (y - 0.64) + 0.0 * x + 0.0 * z                                   # a pool with a flat free surface (cuts the fifth tile layer)
+visc = 50.0 * (1.0 + 0.5 * np.sin(2 * np.pi * x * (n / 16.0)) * np.cos(2 * np.pi * z * (n / 16.0))) + 0.0 * y   # varies inside a tile, repeats tile to tile
+sc = Scene(n, n, n, dx, 1.0 / 24.0, 1000.0, [0.0, -1.0, 0.0], surface, np.float32(1.0), visc, name="pool_varvisc")
+p = default_params(tileSize=16, tilePadding=2)
+s = polystokes_amd.Solver(0)
+s.upload(sc, p)
+s.setup()
+np.savez(sys.argv[2], K=s.array("reducedViscosityMatrices"), Binv=s.array("Inv_Mr_plus_2JDtuDJ"), Mr=s.array("reducedMassMatrices"), R=np.int64(s.nRegions))
+s.close()
+'''
+
+
+@pytest.mark.skipif(os.environ.get("PS_TEST_CHILD") == "1", reason="child run")
+def test_shared_tile_blocks_equal_the_tiles_own_sums(tmp_path):
+    """ADVICE r04: K is shared between tiles of one class (same labels, regions, viscosity samples; ps_tiles.hip:buildTileClasses) — on by
+    default.  On a free-surface scene whose viscosity varies INSIDE every tile (and repeats from tile to tile, so that classes exist) the
+    shared blocks must equal the blocks every tile sums for itself (PS_NO_TILE_CLASSES=1) to rounding: K and BInv <= 1e-12 relative per
+    block; Mr is never shared: bit-identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env in (("shared", {}), ("own", {"PS_NO_TILE_CLASSES": "1"})):
+        f = str(tmp_path / (tag + ".npz"))
+        pr = subprocess.run([sys.executable, "-c", _TILE_CLASS_CHILD, root, f], env=dict(os.environ, PS_VERBOSE="1", **env), stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert pr.returncode == 0, pr.stdout[-3000:]
+        out[tag] = (np.load(f), pr.stdout)
+    a, b = out["shared"][0], out["own"][0]
+    R = int(a["R"])
+    assert R == int(b["R"]) and R >= 32
+    import re
+    m = re.search(r"tile classes: (\d+) of (\d+) tiles sum their own", out["shared"][1])
+    assert m and int(m.group(1)) < int(m.group(2)) // 2, out["shared"][1][-500:]            # classes do exist on this scene
+    assert np.array_equal(a["Mr"], b["Mr"])
+    for nm in ("K", "Binv"):
+        A, B = a[nm].reshape(R, -1), b[nm].reshape(R, -1)
+        rel = np.abs(A - B).max(axis=1) / np.abs(B).max(axis=1)
+        assert rel.max() <= 1e-12, (nm, rel.max())
