@@ -176,6 +176,9 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
     __shared__ double Ms[30], wv[PS_RD], vv[PS_RD], Vs[30];
     const int r = blockIdx.x;
     const int r0 = regionRowPtr[r], r1 = regionRowPtr[r + 1];
+#ifdef PS_EXP_TILE_FACE0
+    rrowFace -= r0;      // TIMING EXPERIMENT (wrong results): every tile reads the face words of region 0 — what sharing them per class could buy at most
+#endif
     const double cx = COM[(int64_t)r * 3], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // few regions (TB = 256: small grids, latency bound): a lane requests all its ~13 rows at once; many regions (TB = 64): 4 at a
