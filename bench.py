@@ -169,6 +169,8 @@ def box_calibration():
     except Exception as e:                                       # noqa: BLE001
         out["d2d_copy_error"] = str(e)[:200]
     try:
+        if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+            raise RuntimeError("under a profiler: no child processes")
         txt = subprocess.run(["rocm-smi", "--showuniqueid", "--showclocks", "--showmaxpower", "--showmemvendor", "--showvbios"], capture_output=True, text=True, timeout=30).stdout
         import re
         for key, pat in (("unique_id", r"Unique ID:\s*(\S+)"), ("fclk_MHz", r"fclk clock level: \S+ \((\d+)Mhz\)"), ("mclk_MHz", r"mclk clock level: \S+ \((\d+)Mhz\)"),

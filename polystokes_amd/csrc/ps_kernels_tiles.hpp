@@ -103,6 +103,14 @@ __device__ inline double vToAxisCoeff(const double* v, int q) {
     }
 }
 #endif
+// The library is compiled with -ffp-contract=off (the fp32 SDF sampling must match the CPU restatement bit for bit).  The moment sums and the
+// expansion of the tile apply are fp64 dot products with no such constraint (parity bound: 1e-10 on the operator): PS_TILE_FMA fuses them —
+// half the VALU instructions of the kernel's two loops (r05; -DPS_TILE_NO_FMA: the separate multiply and add of r01 - r04).
+#ifdef PS_TILE_NO_FMA
+#define PS_TILE_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define PS_TILE_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#endif
 // one lane's share of the moments over the rows rr = first, first + stride, ... < end
 constexpr int TILE_FACE_CACHE = 16;   // packed faces a lane keeps in registers between the gather and the expand of k_tile_apply
 template <bool CACHE, int U>
@@ -135,7 +143,7 @@ __device__ inline void tileAccumulate(int first, int stride, int end, const uint
             faceMonomials(f[u], dx, off, cx, cy, cz, mu, &axis);
             const double s0 = axis == 0 ? s[u] : 0., s1 = axis == 1 ? s[u] : 0., s2 = axis == 2 ? s[u] : 0.;
 #pragma unroll
-            for (int m = 0; m < 10; ++m) { M[m] += mu[m] * s0; M[10 + m] += mu[m] * s1; M[20 + m] += mu[m] * s2; }
+            for (int m = 0; m < 10; ++m) { M[m] = PS_TILE_FMA(mu[m], s0, M[m]); M[10 + m] = PS_TILE_FMA(mu[m], s1, M[10 + m]); M[20 + m] = PS_TILE_FMA(mu[m], s2, M[20 + m]); }
         }
     }
 }
@@ -176,9 +184,6 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
     __shared__ double Ms[30], wv[PS_RD], vv[PS_RD], Vs[30];
     const int r = blockIdx.x;
     const int r0 = regionRowPtr[r], r1 = regionRowPtr[r + 1];
-#ifdef PS_EXP_TILE_FACE0
-    rrowFace -= r0;      // TIMING EXPERIMENT (wrong results): every tile reads the face words of region 0 — what sharing them per class could buy at most
-#endif
     const double cx = COM[(int64_t)r * 3], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // few regions (TB = 256: small grids, latency bound): a lane requests all its ~13 rows at once; many regions (TB = 64): 4 at a
@@ -253,7 +258,7 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
             const double* V = Vs + 10 * axis;                        // LDS broadcast-ish reads (3 distinct rows per wave)
             double t = 0.;
 #pragma unroll
-            for (int m = 0; m < 10; ++m) t += mu[m] * V[m];
+            for (int m = 0; m < 10; ++m) t = PS_TILE_FMA(mu[m], V[m], t);
             sred[base + u * TB] = t;
         }
     }
