@@ -112,8 +112,10 @@ __device__ inline double vToAxisCoeff(const double* v, int q) {
 #define PS_TILE_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #endif
 // one lane's share of the moments over the rows rr = first, first + stride, ... < end
-constexpr int TILE_FACE_CACHE = 16;   // packed faces a lane keeps in registers between the gather and the expand of k_tile_apply
-template <bool CACHE, int U>
+// packed faces a lane keeps in registers between the gather and the expand of k_tile_apply: all of a lane's rows in the 256-thread form (few tiles:
+// latency bound), 12 in the one-wave-per-tile form (126 VGPRs: the fourth wave per SIMD, i.e. all 4096 tiles of the 256^3 cavity resident at once)
+template <int TB> struct TileFaceCache { static constexpr int N = TB >= 256 ? 16 : 12; };
+template <bool CACHE, int U, int FC>
 __device__ inline void tileAccumulate(int first, int stride, int end, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx, int3 off,
                                       double cx, double cy, double cz, double* __restrict__ M, uint32_t* __restrict__ fcache) {
     // U (face, s) pairs are requested together: independent loads in flight, then the arithmetic
@@ -128,9 +130,9 @@ __device__ inline void tileAccumulate(int first, int stride, int end, const uint
             f[u] = ok ? __builtin_nontemporal_load(rrowFace + rr) : 0u;
             s[u] = ok ? __builtin_nontemporal_load(sred + rr) : 0.;   // 0 past the end: contributes nothing
         }
-        if (CACHE && it < TILE_FACE_CACHE / U) {
+        if (CACHE && it < FC / U) {
 #pragma unroll
-            for (int q = 0; q < TILE_FACE_CACHE / U; ++q)
+            for (int q = 0; q < FC / U; ++q)
                 if (q == it) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) fcache[q * U + u] = f[u];
@@ -141,9 +143,31 @@ __device__ inline void tileAccumulate(int first, int stride, int end, const uint
             double mu[10];
             int axis;
             faceMonomials(f[u], dx, off, cx, cy, cz, mu, &axis);
-            const double s0 = axis == 0 ? s[u] : 0., s1 = axis == 1 ? s[u] : 0., s2 = axis == 2 ? s[u] : 0.;
+            // A region's rows are ordered (item, long / short, AXIS, position) (ps_blocks.hip: k_skin): the 64 consecutive rows a wave takes
+            // in one slot lie on ONE axis except where they straddle one of the few category boundaries.  The three axes' ten moments are
+            // updated in turn, a block skipped (scalar branch) when no live lane of the wave is on its axis: the skipped updates would add
+            // mu * 0 — every partial sum keeps its value, the VALU work of the loop falls from 30 to ~11 fused multiply-adds per row (r05)
+            const bool real = base + u * stride < end;
+#ifdef PS_TILE_NO_SKIP   // A/B build (scripts/build_variant.sh): all three blocks, always
+            const unsigned long long on0 = 1ull | (unsigned long long)real, on1 = 1ull, on2 = 1ull;
+#else
+            const unsigned long long on0 = __ballot(real && axis == 0), on1 = __ballot(real && axis == 1), on2 = __ballot(real && axis == 2);
+#endif
+            if (on0 != 0ull) {
+                const double sa = axis == 0 ? s[u] : 0.;
 #pragma unroll
-            for (int m = 0; m < 10; ++m) { M[m] = PS_TILE_FMA(mu[m], s0, M[m]); M[10 + m] = PS_TILE_FMA(mu[m], s1, M[10 + m]); M[20 + m] = PS_TILE_FMA(mu[m], s2, M[20 + m]); }
+                for (int m = 0; m < 10; ++m) M[m] = PS_TILE_FMA(mu[m], sa, M[m]);
+            }
+            if (on1 != 0ull) {
+                const double sa = axis == 1 ? s[u] : 0.;
+#pragma unroll
+                for (int m = 0; m < 10; ++m) M[10 + m] = PS_TILE_FMA(mu[m], sa, M[10 + m]);
+            }
+            if (on2 != 0ull) {
+                const double sa = axis == 2 ? s[u] : 0.;
+#pragma unroll
+                for (int m = 0; m < 10; ++m) M[20 + m] = PS_TILE_FMA(mu[m], sa, M[20 + m]);
+            }
         }
     }
 }
@@ -160,7 +184,7 @@ __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ 
     double M[30];
 #pragma unroll
     for (int n = 0; n < 30; ++n) M[n] = 0.;
-    tileAccumulate<false, 4>(chunkStart[ch] + (int)threadIdx.x, 64, chunkEnd[ch], rrowFace, sred, dx, off, COM[(int64_t)r * 3], COM[(int64_t)r * 3 + 1], COM[(int64_t)r * 3 + 2], M, nullptr);
+    tileAccumulate<false, 4, 4>(chunkStart[ch] + (int)threadIdx.x, 64, chunkEnd[ch], rrowFace, sred, dx, off, COM[(int64_t)r * 3], COM[(int64_t)r * 3 + 1], COM[(int64_t)r * 3 + 2], M, nullptr);
 #pragma unroll
     for (int n = 0; n < 30; ++n) {
         const double v = waveSumToLane63(M[n]);
@@ -189,12 +213,13 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
     // few regions (TB = 256: small grids, latency bound): a lane requests all its ~13 rows at once; many regions (TB = 64): 4 at a
     // time, occupancy hides the latency
     constexpr int U = TB >= 256 ? 16 : 4;
-    uint32_t fcache[TILE_FACE_CACHE];
+    constexpr int FC = TileFaceCache<TB>::N;
+    uint32_t fcache[FC];
     if (MODE != 2) {
         double M[30];
 #pragma unroll
         for (int n = 0; n < 30; ++n) M[n] = 0.;
-        tileAccumulate<MODE == 0, U>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, off, cx, cy, cz, M, fcache);
+        tileAccumulate<MODE == 0, U, FC>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, off, cx, cy, cz, M, fcache);
 #pragma unroll
         for (int n = 0; n < 30; ++n) {
             const double v = waveSumToLane63(M[n]);
@@ -238,9 +263,9 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
     int it = 0;
     for (int base = r0 + (int)threadIdx.x; base < r1; base += U * TB, ++it) {
         uint32_t f[U];
-        if (MODE == 0 && it < TILE_FACE_CACHE / U) {   // the faces this lane already decoded in the gather
+        if (MODE == 0 && it < FC / U) {   // the faces this lane already decoded in the gather
 #pragma unroll
-            for (int q = 0; q < TILE_FACE_CACHE / U; ++q)
+            for (int q = 0; q < FC / U; ++q)
                 if (q == it) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) f[u] = fcache[q * U + u];
