@@ -111,6 +111,33 @@ __device__ inline double vToAxisCoeff(const double* v, int q) {
 #else
 #define PS_TILE_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #endif
+// The 30 moments of a wave, summed over its 64 lanes, through LDS: 30 x (six DPP steps of two moves and an add) was 540 of the ~5000 VALU
+// instructions a wave spends on a tile, in a kernel that is VALU-bound (profiles/r05_tile_apply_valu.txt).  Here the lanes store fifteen values at a
+// time, lane l then adds the sixteen lanes 16 (l >> 4) .. of value l & 15 in lane order, and the four segment sums of a value are added in
+// segment order: ~110 instructions, a fixed summation order (lanes 0..15, 16..31, 32..47, 48..63, then the four).  scratch: 15 x 65 + 64 doubles of
+// the wave's own; out[0..29] written by the lanes that hold the totals; the caller synchronises before reading out.
+constexpr int TILE_RED_SCRATCH = 15 * 65 + 64;
+__device__ inline void waveSum30(const double* M, double* __restrict__ scratch, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int m = 0; m < 15; ++m) scratch[m * 65 + lane] = M[15 * h + m];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double p = 0.;
+        if (n < 15) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) p += scratch[n * 65 + 16 * q + j];
+        }
+        scratch[15 * 65 + lane] = p;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 15) out[15 * h + lane] = ((scratch[15 * 65 + lane] + scratch[15 * 65 + 16 + lane]) + scratch[15 * 65 + 32 + lane]) + scratch[15 * 65 + 48 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 // one lane's share of the moments over the rows rr = first, first + stride, ... < end
 // packed faces a lane keeps in registers between the gather and the expand of k_tile_apply: all of a lane's rows in the 256-thread form (few tiles:
 // latency bound), 12 in the one-wave-per-tile form (126 VGPRs: the fourth wave per SIMD, i.e. all 4096 tiles of the 256^3 cavity resident at once)
@@ -205,11 +232,12 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
                                                    double* __restrict__ vreg, const int* __restrict__ done, double* __restrict__ wvPart) {
     if (done && *done) return;
     __shared__ double msum[TB / 64][30];
+    __shared__ double redScratch[MODE != 2 ? TB / 64 : 1][MODE != 2 ? TILE_RED_SCRATCH : 1];
     __shared__ double Ms[30], wv[PS_RD], vv[PS_RD], Vs[30];
     const int r = blockIdx.x;
     const int r0 = regionRowPtr[r], r1 = regionRowPtr[r + 1];
     const double cx = COM[(int64_t)r * 3], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;
     // few regions (TB = 256: small grids, latency bound): a lane requests all its ~13 rows at once; many regions (TB = 64): 4 at a
     // time, occupancy hides the latency
     constexpr int U = TB >= 256 ? 16 : 4;
@@ -220,11 +248,15 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
 #pragma unroll
         for (int n = 0; n < 30; ++n) M[n] = 0.;
         tileAccumulate<MODE == 0, U, FC>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, off, cx, cy, cz, M, fcache);
+#ifdef PS_TILE_DPP_REDUCE   // A/B build: the DPP ladder per moment of r01 - r04
 #pragma unroll
         for (int n = 0; n < 30; ++n) {
             const double v = waveSumToLane63(M[n]);
-            if (lane == 63) msum[wave][n] = v;
+            if ((threadIdx.x & 63) == 63) msum[wave][n] = v;
         }
+#else
+        waveSum30(M, redScratch[wave], msum[wave]);
+#endif
         __syncthreads();
         if (threadIdx.x < 30) {
             double s = 0.;
