@@ -976,6 +976,7 @@ void ps_context::constructMatrixBlocks() {
     valScale = invDx / 64.;
     HIP_CHECK(hipMemsetAsync(counters.p + 20, 0, sizeof(int32_t), stream));
     buildInternalNumbering();   // sysIdx[], faceRow[] (active rows), permSys, permRow
+    haloForward = false;        // one exchange round unless Dist::decideExchangeMode finds a row that reaches a diagonal neighbour's sample
     buildHaloLists();
     BlockArgs A = makeArgs(this);
     // reduced rows

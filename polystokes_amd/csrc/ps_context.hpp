@@ -205,6 +205,9 @@ struct ps_context {
     // what one distributed solve did (ps_dist_stats): bytes per iteration over the cuts, sampled transport / all-reduce times
     double distStats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     ps::DevBuf<int32_t> labelFlags;          // Dist::exchangeLabels: labels changed, REDUCED cells without a component
+    ps::DevBuf<unsigned char> scrMark;       // setup scratch of Dist::decideExchangeMode
+    bool haloForward = false;                // the exchange lists carry the copies of an earlier axis's exchange (three forwarding rounds x -> y -> z); false: every
+                                             // list holds the sender's OWN samples only and the three axes travel in ONE round (ps_dist.hpp: Dist::decideExchangeMode)
     int64_t haloLabelChanges = 0;            // halo cells whose label the owners' exchange changed in the last setup (both passes)
     void* rcclComm = nullptr;                // ncclComm_t when one process per GPU
     void* hostComm = nullptr;                // host-staged TCP transport (ps_comm_init_tcp): same algorithm without RCCL

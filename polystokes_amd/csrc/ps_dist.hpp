@@ -41,6 +41,28 @@ __global__ void k_unpack2(const int32_t* __restrict__ listA, int64_t nA, const d
     if (i < nA) { if (ADD) v[listA[i]] += bufA[i]; else v[listA[i]] = bufA[i]; }
     else if (i < nA + nB) { if (ADD) v[listB[i - nA]] += bufB[i - nA]; else v[listB[i - nA]] = bufB[i - nA]; }
 }
+// one round: the lists of all three axes in one launch (entries [end[q - 1], end[q]) use list q / buffer q).  Values only: the halo samples of
+// different axes are different samples (no corner copies in this mode), so the scatter has no conflicts; the ADDING unpack of the contributions
+// stays one launch per axis — a DOF next to two cuts receives from both, in a fixed order.
+struct Lists6 { const int32_t* list[6]; double* buf[6]; int64_t end[6]; };
+__global__ void k_pack6(Lists6 L, const double* __restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.end[5]) return;
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) q += i >= L.end[k] ? 1 : 0;
+    const int64_t j = i - (q > 0 ? L.end[q - 1] : 0);
+    L.buf[q][j] = v[L.list[q][j]];
+}
+__global__ void k_unpack6(Lists6 L, double* __restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.end[5]) return;
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) q += i >= L.end[k] ? 1 : 0;
+    const int64_t j = i - (q > 0 ? L.end[q - 1] : 0);
+    v[L.list[q][j]] = L.buf[q][j];
+}
 // the received contributions whose DOF is not this rank's own (it sits on an earlier axis's upper halo plane: see buildHaloLists) are added
 // to the rank's copy, which the exchange along that earlier axis passes on
 __global__ void k_relay2(const int32_t* __restrict__ listA, int64_t nA, const double* __restrict__ bufA, const int32_t* __restrict__ listB, int64_t nB,
@@ -49,6 +71,18 @@ __global__ void k_relay2(const int32_t* __restrict__ listA, int64_t nA, const do
     if (i >= nA + nB) return;
     const int j = i < nA ? listA[i] : listB[i - nA];
     if (j >= ownHi) v[j] += i < nA ? bufA[i] : bufB[i - nA];
+}
+// Exchange mode (Dist::decideExchangeMode): mark the halo samples the one-round lists deliver, then count the columns of this rank's rows that
+// lie outside its owned range and are NOT marked — samples only a forwarded copy (a diagonal neighbour's) could bring
+__global__ void k_mark_list(const int32_t* __restrict__ list, int64_t n, unsigned char* __restrict__ mark) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mark[list[i]] = 1;
+}
+__global__ void k_count_unmarked_halo(const int32_t* __restrict__ col, int64_t nnz, int ownLo, int ownHi, const unsigned char* __restrict__ mark, int32_t* __restrict__ misses) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int c = col[e];
+    if ((c < ownLo || c >= ownHi) && !mark[c]) atomicAdd(misses, 1);
 }
 // Which chunks of S gather a halo value (a column outside the owned DOF range)?  One wave per chunk.
 __global__ void __launch_bounds__(64) k_chunk_flags_S(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const int4* __restrict__ chunkInfo,
@@ -448,11 +482,42 @@ struct Dist {
             hipLaunchKernelGGL(k_unpack2<ADD>, dim3(gridFor(nA + nB, BS)), dim3(BS), 0, st, (own ? c->listLowOwn[a] : c->listLowHalo[a]).p, nA, c->recvLo[a].p,
                                (own ? c->listUpOwn[a] : c->listUpHalo[a]).p, nB, c->recvUp[a].p, v);
     }
+    // all axes of one rank at once (the one-round mode): own = true: my cut layers -> send buffers (pack) / false: my halo samples
+    Lists6 lists6(ps_context* c, bool own, bool send) const {
+        Lists6 L;
+        int64_t run = 0;
+        for (int a = 0; a < 3; ++a) {
+            L.list[2 * a] = (own ? c->listLowOwn[a] : c->listLowHalo[a]).p; L.list[2 * a + 1] = (own ? c->listUpOwn[a] : c->listUpHalo[a]).p;
+            L.buf[2 * a] = send ? c->sendLo[a].p : c->recvLo[a].p; L.buf[2 * a + 1] = send ? c->sendUp[a].p : c->recvUp[a].p;
+            run += own ? c->nLowOwn[a] : c->nLowHalo[a]; L.end[2 * a] = run;
+            run += own ? c->nUpOwn[a] : c->nUpHalo[a]; L.end[2 * a + 1] = run;
+        }
+        return L;
+    }
+    void packAll(ps_context* c, bool own, const double* v, hipStream_t st) {
+        const Lists6 L = lists6(c, own, true);
+        if (L.end[5] > 0) hipLaunchKernelGGL(k_pack6, dim3(gridFor(L.end[5], BS)), dim3(BS), 0, st, L, v);
+    }
+    void unpackAllValues(ps_context* c, double* v, hipStream_t st) {
+        const Lists6 L = lists6(c, false, false);
+        if (L.end[5] > 0) hipLaunchKernelGGL(k_unpack6, dim3(gridFor(L.end[5], BS)), dim3(BS), 0, st, L, v);
+    }
     bool axisUsed(int a) const { for (const ps_context* c : R) if (c->brick.hasLower[a] || c->brick.hasUpper[a]) return true; return false; }
     // The exchanges run axis after axis, each one forwarding what the previous ones brought (ps_grid.hip: buildHaloLists): values x, y, z;
     // contributions z, y, x.  With cuts along one axis only (slabs) that is one pack / transport / unpack, as before.
     // values of the cut layers -> the neighbours' halo copies, on the stream `onComm` selects
+    // ONE round (r05, the default: ps_context::haloForward false): every list holds samples of the sender's own, so the three axes are packed,
+    // sent and unpacked together — with bricks 2 transports per iteration instead of 6, no relay kernels.  Legal whenever no row of any
+    // rank reaches a sample of a DIAGONAL neighbour (decideExchangeMode checks it on the matrices; it happens only when a tile's skin rows lie on a
+    // cut plane, i.e. with tilePadding 1): then the forwarding rounds below run as before.
+    bool forwarding() const { return R[0]->haloForward; }
     void valuesOut(DevBuf<double> ps_context::*vec, bool onComm) {
+        if (!forwarding()) {
+            for (ps_context* c : R) packAll(c, true, (c->*vec).p, cs(c, onComm));
+            transport(0, onComm);
+            for (ps_context* c : R) unpackAllValues(c, (c->*vec).p, cs(c, onComm));
+            return;
+        }
         for (int a = 0; a < 3; ++a) {
             if (!axisUsed(a)) continue;
             for (ps_context* c : R) pack(c, true, (c->*vec).p, cs(c, onComm), a);
@@ -463,6 +528,13 @@ struct Dist {
     // the halo rows' contributions -> their owners.  addOwned: the owners add them into vec (b, the Jacobi diagonal, A p of the plain step);
     // else only the copies on the way are updated (the owners of the fused step correct r from the receive buffers: fixup)
     void contributionsBack(DevBuf<double> ps_context::*vec, bool onComm, bool addOwned) {
+        if (!forwarding()) {   // one round: what arrives is for DOFs of this rank's own (added here in the order z, y, x of the forwarding rounds: the same sums)
+            for (ps_context* c : R) packAll(c, false, (c->*vec).p, cs(c, onComm));
+            transport(1, onComm);
+            if (addOwned)
+                for (int a = 2; a >= 0; --a) if (axisUsed(a)) for (ps_context* c : R) unpack<true>(c, true, (c->*vec).p, cs(c, onComm), a);
+            return;
+        }
         for (int a = 2; a >= 0; --a) {
             if (!axisUsed(a)) continue;
             for (ps_context* c : R) pack(c, false, (c->*vec).p, cs(c, onComm), a);
@@ -793,7 +865,7 @@ struct Dist {
             hipLaunchKernelGGL(k_chunk_flags_St, dim3(gridFor(nT, BS)), dim3(BS), 0, c->stream, (const int32_t*)c->St.ptr.p, (const int4*)c->St.chunkInfo.p, nT,
                                (int)c->ownLo, (int)c->ownHi, flags.p);
             for (int a = 0; a < 3; ++a)
-                if (c->nLowOwn[a] + c->nUpOwn[a] > 0)
+                if (forwarding() && c->nLowOwn[a] + c->nUpOwn[a] > 0)
                     hipLaunchKernelGGL(k_chunk_flags_relay, dim3(gridFor(c->nLowOwn[a] + c->nUpOwn[a], BS)), dim3(BS), 0, c->stream, (const int32_t*)c->listLowOwn[a].p, c->nLowOwn[a],
                                        (const int32_t*)c->listUpOwn[a].p, c->nUpOwn[a], (int)c->ownHi, (const int4*)c->St.chunkInfo.p, nT, flags.p);
             HIP_CHECK(hipMemcpyAsync(h.data(), flags.p, (size_t)nT * 4, hipMemcpyDeviceToHost, c->stream));
@@ -808,9 +880,36 @@ struct Dist {
             c->distListsOk = true;
         }
     }
+    // One exchange round or three forwarding rounds?  The lists were built without forwarded copies (ps_context::constructMatrixBlocks).  Every
+    // rank checks on its own S — all of whose rows are its own — that each column outside its owned DOF range is a sample those lists deliver;
+    // if ANY rank finds one that is not (agreed through the scalar all-reduce), every rank rebuilds its lists with the forwarded copies and the
+    // exchanges run axis after axis as in r03 / r04.  PS_DIST_FORWARD=1 (lab build) forces the forwarding rounds.
+    void decideExchangeMode() {
+        static const bool force = PS_ENV("PS_DIST_FORWARD") && atoi(PS_ENV("PS_DIST_FORWARD")) != 0;
+        bool need = force;
+        for (ps_context* c : R) {
+            if (need || c->nSystem == 0 || c->S.nnz == 0) continue;
+            DevBuf<unsigned char>& mark = c->scrMark;
+            mark.alloc((size_t)c->nSystem);
+            HIP_CHECK(hipMemsetAsync(mark.p, 0, (size_t)c->nSystem, c->stream));
+            HIP_CHECK(hipMemsetAsync(c->counters.p + 41, 0, sizeof(int32_t), c->stream));
+            for (int a = 0; a < 3; ++a) {
+                if (c->nLowHalo[a] > 0) hipLaunchKernelGGL(k_mark_list, dim3(gridFor(c->nLowHalo[a], BS)), dim3(BS), 0, c->stream, (const int32_t*)c->listLowHalo[a].p, c->nLowHalo[a], mark.p);
+                if (c->nUpHalo[a] > 0) hipLaunchKernelGGL(k_mark_list, dim3(gridFor(c->nUpHalo[a], BS)), dim3(BS), 0, c->stream, (const int32_t*)c->listUpHalo[a].p, c->nUpHalo[a], mark.p);
+            }
+            hipLaunchKernelGGL(k_count_unmarked_halo, dim3(gridFor(c->S.nnz, BS)), dim3(BS), 0, c->stream, (const int32_t*)c->S.col.p, (int64_t)c->S.nnz, (int)c->ownLo, (int)c->ownHi,
+                               (const unsigned char*)mark.p, c->counters.p + 41);
+            if (c->readCounter(41) != 0) need = true;
+        }
+        const bool fwd = sumFlag(need ? 1. : 0.) > 0.;
+        for (ps_context* c : R)
+            if (fwd != c->haloForward) { c->haloForward = fwd; c->buildHaloLists(); }
+        if (PS_ENV_VERBOSE()) std::fprintf(stderr, "[polystokes] exchanges of the solve: %s\n", fwd ? "three forwarding rounds (a row reaches a diagonal neighbour's sample)" : "one round");
+    }
     void finishSetup() {
         for (ps_context* c : R) c->redbuf.alloc(8);
         ensureStreams();
+        decideExchangeMode();
         checkLists();
         buildLists();
         exchangeAddY(&ps_context::b);

@@ -1351,7 +1351,8 @@ void ps_context::buildHaloLists() {
         // (x, y, z for values; z, y, x for contributions), so what a rank holds there is the copy it received from / will pass on to its
         // neighbour along b — that is how an edge on two cuts reaches the rank diagonally below (the skin rows of a tile in the corner of its
         // brick touch such edges, and a tile's rows belong to the tile's owner whatever plane they lie on).
-        for (int b = 0; b < 3; ++b) { r0[b] = brick.lo[b]; r1[b] = brick.hi[b] + ((Own::onPlane(s, b) && (!brick.hasUpper[b] || b < axis)) ? 1 : 0); }
+        // (haloForward false: no such copies — every list holds samples of the sender's own; Dist::decideExchangeMode checks that nothing else is needed)
+        for (int b = 0; b < 3; ++b) { r0[b] = brick.lo[b]; r1[b] = brick.hi[b] + ((Own::onPlane(s, b) && (!brick.hasUpper[b] || (haloForward && b < axis))) ? 1 : 0); }
         const int b = axis == 0 ? 1 : 0, c = axis == 2 ? 1 : 2;
         const size_t n = (size_t)(r1[b] - r0[b]) * (size_t)(r1[c] - r0[c]);
         out.assign(n, -1);

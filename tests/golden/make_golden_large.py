@@ -43,6 +43,7 @@ CASES = {
 HUGE = {
     "cavity128_t16p2_jacobi": lambda: scenes.cavity(128, tile=16, pad=2),      # 5.9 M system DOFs, BASELINE config 3 at half resolution
     "coil128": lambda: scenes.coil(128, tile=16, pad=2),                        # BASELINE config 2 at its stated size
+    "spheres128": lambda: scenes.spheres(128, tile=16, pad=2),                  # BASELINE config 5's geometry (moving solids, mu = 1e4) at 128^3
 }
 INT_ARRAYS = [s + k for s in abi.SAMPLE_NAMES for k in ("Labels", "ActiveIndices", "ReducedIndices")] + ["validX", "validY", "validZ"]
 

@@ -247,3 +247,32 @@ def test_rccl_communicator_next_to_a_live_torch_context():
     after = [l for l in pr.stdout.splitlines() if l.startswith("rccl mapped after:")]
     assert after and after[0].count("librccl") == 1, pr.stdout[-2000:]
     assert " rc 1 " in after[0] and "closed" in pr.stdout
+
+
+def test_bench_single_gpu_line_keeps_the_contract():
+    """`python bench.py` (N = 1) on a small stand-in (64^3 cavity, 64^3 coil for the strong block, a 32^3 CPU sample): ONE JSON line with the
+    driver's keys, the roofline and cpu_baseline objects, and r05's additions — the identity / Chebyshev lines beside the Jacobi headline
+     and the box calibration."""
+    import json
+    pr = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--res", "64", "--steps", "2", "--warmup", "1", "--strong-res", "64",
+                         "--cpu-sample-res", "32"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [l for l in pr.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is False and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "ms/step" and d["value"] == d["ms_per_step"] > 0
+    assert "jacobi-PCG" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and c["unit"].startswith("ms/step")
+    o = d["other_preconditioners"]
+    assert set(o) == {"identity", "chebyshev4"}
+    for v in o.values():
+        assert v["result"] == 1 and v["ms_per_step"] > 0 and v["cg_iterations"] > 0
+    assert o["chebyshev4"]["cg_iterations"] < d["cg_iterations"]      # the polynomial cuts the count
+    assert d["box"]["d2d_copy_GBps"] > 500.0
+    assert d["strong_512"]["n_gpus"] == 1 and d["strong_512"]["result"] == 1

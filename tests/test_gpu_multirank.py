@@ -132,6 +132,23 @@ def test_bricks_and_slabs_with_the_four_kernel_step_forced():
     assert pr.returncode == 0, pr.stdout[-3000:]
 
 
+@pytest.mark.skipif(__import__("os").environ.get("PS_TEST_CHILD") == "1", reason="this IS the child run")
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_bricks_with_the_forwarding_rounds_forced(fused):
+    """r05: the exchanges of the solve run as ONE round (every list holds the sender's own samples; Dist::decideExchangeMode checks on the
+    matrices that no row reaches a diagonal neighbour's sample) and fall back to the three forwarding rounds x -> y -> z of r03 / r04 only
+    when one does (tilePadding 1: the seeds of test_bricks_classification_that_reaches_beyond_the_halo).  The brick cases once more in a child
+    with the forwarding rounds forced (PS_DIST_FORWARD=1), with the five- and the four-kernel step: both modes must reproduce the single domain."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PS_DIST_FORWARD="1", PS_FUSED_R=fused, PS_TEST_CHILD="1")
+    pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                         "-k", "test_bricks_match_single_domain or test_bricks_without_reduced_regions"],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    assert pr.returncode == 0, pr.stdout[-3000:]
+
+
 def test_rccl_entry_points_world1():
     """dlopen'ed RCCL on the solver stream: communicator init, all-reduce, grouped send/recv (to self)."""
     import polystokes_amd
