@@ -186,14 +186,23 @@ struct ps_context {
     ps::DevBuf<int32_t> regionOwned;         // R flags
     ps::DevBuf<int32_t> blockMap;            // sequence position -> lattice block (owned blocks first); empty: lattice order
     int blockMapOwned = -1, blockMapFor = 0; // owned lattice blocks (-1: the map has to be rebuilt: ps_set_brick), blocks it was built for
-    // exchange lists per axis a (internal system indices, canonical order over the cut's cross-section): the neighbour's layer my
-    // rows touch (halo) and my layer the neighbour's rows touch (own), below and above
-    ps::DevBuf<int32_t> listLowHalo[3], listLowOwn[3], listUpHalo[3], listUpOwn[3];
-    int64_t nLowHalo[3] = {0, 0, 0}, nLowOwn[3] = {0, 0, 0}, nUpHalo[3] = {0, 0, 0}, nUpOwn[3] = {0, 0, 0};
-    ps::DevBuf<double> sendLo[3], sendUp[3], recvLo[3], recvUp[3], redbuf;
-    int nbrLo(int a) const { const int st = a == 0 ? 1 : (a == 1 ? brick.dims[0] : brick.dims[0] * brick.dims[1]); return brick.hasLower[a] ? brick.rank - st : -1; }
-    int nbrUp(int a) const { const int st = a == 0 ? 1 : (a == 1 ? brick.dims[0] : brick.dims[0] * brick.dims[1]); return brick.hasUpper[a] ? brick.rank + st : -1; }
-    int64_t exchangeEntries() const { int64_t n = 0; for (int a = 0; a < 3; ++a) n += nLowOwn[a] + nUpOwn[a] + nLowHalo[a] + nUpHalo[a]; return n; }
+    // exchange lists per LINK (internal system indices, canonical order over the cut's cross-section): the neighbour's samples my rows touch (halo)
+    // and mine the neighbour's rows touch (own), below and above.  Links 0..2: the face neighbours along x, y, z.  Links 3..5 (one-round mode
+    // only, r05): the DIAGONAL neighbours across two cuts — (x, y), (x, z), (y, z) — "below" = one brick down along both axes, "above" = one up along
+    // both.  Only one kind of sample crosses a diagonal: the edge stress that lives on both cut planes (XY / XZ / YZ edges on the corner line), which
+    // the skin rows of a tile that ends at both planes touch (a tile's rows belong to the tile's owner whatever plane they lie on) — so a diagonal
+    // link has an upper halo list and a lower own list, the other two are empty.
+    static constexpr int NLINK = 6;
+    ps::DevBuf<int32_t> listLowHalo[NLINK], listLowOwn[NLINK], listUpHalo[NLINK], listUpOwn[NLINK];
+    int64_t nLowHalo[NLINK] = {0, 0, 0, 0, 0, 0}, nLowOwn[NLINK] = {0, 0, 0, 0, 0, 0}, nUpHalo[NLINK] = {0, 0, 0, 0, 0, 0}, nUpOwn[NLINK] = {0, 0, 0, 0, 0, 0};
+    ps::DevBuf<double> sendLo[NLINK], sendUp[NLINK], recvLo[NLINK], recvUp[NLINK], redbuf;
+    static void linkAxes(int l, int& a, int& b) { a = l < 3 ? l : (l == 5 ? 1 : 0); b = l < 3 ? -1 : (l == 3 ? 1 : 2); }
+    int axisStride(int a) const { return a == 0 ? 1 : (a == 1 ? brick.dims[0] : brick.dims[0] * brick.dims[1]); }
+    bool linkLower(int l) const { int a, b; linkAxes(l, a, b); return brick.hasLower[a] && (b < 0 || brick.hasLower[b]); }
+    bool linkUpper(int l) const { int a, b; linkAxes(l, a, b); return brick.hasUpper[a] && (b < 0 || brick.hasUpper[b]); }
+    int nbrLo(int l) const { int a, b; linkAxes(l, a, b); return linkLower(l) ? brick.rank - axisStride(a) - (b >= 0 ? axisStride(b) : 0) : -1; }
+    int nbrUp(int l) const { int a, b; linkAxes(l, a, b); return linkUpper(l) ? brick.rank + axisStride(a) + (b >= 0 ? axisStride(b) : 0) : -1; }
+    int64_t exchangeEntries() const { int64_t n = 0; for (int a = 0; a < NLINK; ++a) n += nLowOwn[a] + nUpOwn[a] + nLowHalo[a] + nUpHalo[a]; return n; }
     // Overlap of the halo exchanges with the rows that do not need them (ps_dist.hpp: Dist::solve).  Chunk lists of the row-per-lane
     // kernels: [0] S chunks without a halo column, [1] S chunks with one; [2] St chunks holding halo rows with entries (their A p goes
     // to the neighbour), [3] St chunks of owned rows only.  St chunks of halo rows without entries are in neither: never launched.
@@ -211,7 +220,7 @@ struct ps_context {
     int64_t haloLabelChanges = 0;            // halo cells whose label the owners' exchange changed in the last setup (both passes)
     void* rcclComm = nullptr;                // ncclComm_t when one process per GPU
     void* hostComm = nullptr;                // host-staged TCP transport (ps_comm_init_tcp): same algorithm without RCCL
-    uint64_t hashLowHalo[3] = {0, 0, 0}, hashLowOwn[3] = {0, 0, 0}, hashUpHalo[3] = {0, 0, 0}, hashUpOwn[3] = {0, 0, 0};   // order-sensitive hashes of the lists' global keys
+    uint64_t hashLowHalo[NLINK] = {0, 0, 0, 0, 0, 0}, hashLowOwn[NLINK] = {0, 0, 0, 0, 0, 0}, hashUpHalo[NLINK] = {0, 0, 0, 0, 0, 0}, hashUpOwn[NLINK] = {0, 0, 0, 0, 0, 0};   // order-sensitive hashes of the lists' global keys
     ps::DevBuf<ps::CGScalars> benchScal;     // scratch of ps_bench_kernel
     ps::DevBuf<double> benchOnes, benchZeros;
     bool ownsStream = true;

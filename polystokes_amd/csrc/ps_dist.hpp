@@ -44,22 +44,23 @@ __global__ void k_unpack2(const int32_t* __restrict__ listA, int64_t nA, const d
 // one round: the lists of all three axes in one launch (entries [end[q - 1], end[q]) use list q / buffer q).  Values only: the halo samples of
 // different axes are different samples (no corner copies in this mode), so the scatter has no conflicts; the ADDING unpack of the contributions
 // stays one launch per axis — a DOF next to two cuts receives from both, in a fixed order.
-struct Lists6 { const int32_t* list[6]; double* buf[6]; int64_t end[6]; };
+constexpr int NLIST = 2 * ps_context::NLINK;
+struct Lists6 { const int32_t* list[NLIST]; double* buf[NLIST]; int64_t end[NLIST]; };   // (two lists per link: below, above)
 __global__ void k_pack6(Lists6 L, const double* __restrict__ v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.end[5]) return;
+    if (i >= L.end[NLIST - 1]) return;
     int q = 0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) q += i >= L.end[k] ? 1 : 0;
+    for (int k = 0; k < NLIST - 1; ++k) q += i >= L.end[k] ? 1 : 0;
     const int64_t j = i - (q > 0 ? L.end[q - 1] : 0);
     L.buf[q][j] = v[L.list[q][j]];
 }
 __global__ void k_unpack6(Lists6 L, double* __restrict__ v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.end[5]) return;
+    if (i >= L.end[NLIST - 1]) return;
     int q = 0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) q += i >= L.end[k] ? 1 : 0;
+    for (int k = 0; k < NLIST - 1; ++k) q += i >= L.end[k] ? 1 : 0;
     const int64_t j = i - (q > 0 ? L.end[q - 1] : 0);
     v[L.list[q][j]] = L.buf[q][j];
 }
@@ -267,14 +268,16 @@ Rccl& rccl() {
 struct HostComm {
     int rank = 0, world = 1;
     int fdListen = -1, fdRoot = -1;
-    int fdLo[3] = {-1, -1, -1}, fdUp[3] = {-1, -1, -1};   // the neighbour below / above along every axis (connected once the brick is known)
-    int nbrLo[3] = {-1, -1, -1}, nbrUp[3] = {-1, -1, -1};
+    static constexpr int NL = ps_context::NLINK;
+    int fdLo[NL] = {-1, -1, -1, -1, -1, -1}, fdUp[NL] = {-1, -1, -1, -1, -1, -1};   // the neighbour below / above of every link (faces 0..2, diagonals 3..5; connected once the brick is known)
+    int nbrLo[NL] = {-1, -1, -1, -1, -1, -1}, nbrUp[NL] = {-1, -1, -1, -1, -1, -1};
     std::string host; int basePort = 0;
     std::vector<int> fdLeaf;            // rank 0: connection of every other rank (index = rank)
     std::vector<std::array<int, 3>> pending;   // accepted connections nobody has asked for yet: (fd, rank, kind)
-    std::vector<double> hs[6], hr[6];
+    std::vector<double> hs[2 * NL], hr[2 * NL];
     ~HostComm() {
-        for (int fd : {fdListen, fdRoot, fdLo[0], fdLo[1], fdLo[2], fdUp[0], fdUp[1], fdUp[2]}) if (fd >= 0) ::close(fd);
+        for (int fd : {fdListen, fdRoot}) if (fd >= 0) ::close(fd);
+        for (int a = 0; a < NL; ++a) { if (fdLo[a] >= 0) ::close(fdLo[a]); if (fdUp[a] >= 0) ::close(fdUp[a]); }
         for (int fd : fdLeaf) if (fd >= 0) ::close(fd);
         for (auto& q : pending) ::close(q[0]);
     }
@@ -348,15 +351,15 @@ struct HostComm {
     // links to the face neighbours (lo[a] / up[a]: their ranks, -1 = none): a rank connects to its lower neighbours and accepts its upper ones
     void connectNeighbours(const int* lo, const int* up) {
         bool same = true;
-        for (int a = 0; a < 3; ++a) same = same && lo[a] == nbrLo[a] && up[a] == nbrUp[a];
+        for (int a = 0; a < NL; ++a) same = same && lo[a] == nbrLo[a] && up[a] == nbrUp[a];
         if (same) return;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < NL; ++a) {
             if (fdLo[a] >= 0) { ::close(fdLo[a]); fdLo[a] = -1; }
             if (fdUp[a] >= 0) { ::close(fdUp[a]); fdUp[a] = -1; }
             nbrLo[a] = lo[a]; nbrUp[a] = up[a];
         }
-        for (int a = 0; a < 3; ++a) if (lo[a] >= 0) fdLo[a] = connectTo(host.c_str(), basePort + lo[a], rank, 10 + a);
-        for (int a = 0; a < 3; ++a) if (up[a] >= 0) fdUp[a] = acceptFrom(up[a], 10 + a);
+        for (int a = 0; a < NL; ++a) if (lo[a] >= 0) fdLo[a] = connectTo(host.c_str(), basePort + lo[a], rank, 10 + a);
+        for (int a = 0; a < NL; ++a) if (up[a] >= 0) fdUp[a] = acceptFrom(up[a], 10 + a);
     }
     // neighbour exchange along one axis, ordered so that the chain of ranks along it cannot deadlock: with the lower neighbour receive
     // first, with the upper send first
@@ -411,17 +414,17 @@ struct Dist {
     }
     // sizes: kind 0 = x exchange (send own layers, receive halo), kind 1 = y exchange (send halo contributions, receive for own); every
     // axis with a neighbour, all of them in ONE group of sends and receives (each face neighbour is its own xGMI link)
-    static int64_t nSendLo(const ps_context* c, int kind, int a) { return c->brick.hasLower[a] ? (kind == 0 ? c->nLowOwn[a] : c->nLowHalo[a]) : 0; }
-    static int64_t nSendUp(const ps_context* c, int kind, int a) { return c->brick.hasUpper[a] ? (kind == 0 ? c->nUpOwn[a] : c->nUpHalo[a]) : 0; }
-    static int64_t nRecvLo(const ps_context* c, int kind, int a) { return c->brick.hasLower[a] ? (kind == 0 ? c->nLowHalo[a] : c->nLowOwn[a]) : 0; }
-    static int64_t nRecvUp(const ps_context* c, int kind, int a) { return c->brick.hasUpper[a] ? (kind == 0 ? c->nUpHalo[a] : c->nUpOwn[a]) : 0; }
+    static int64_t nSendLo(const ps_context* c, int kind, int a) { return c->linkLower(a) ? (kind == 0 ? c->nLowOwn[a] : c->nLowHalo[a]) : 0; }
+    static int64_t nSendUp(const ps_context* c, int kind, int a) { return c->linkUpper(a) ? (kind == 0 ? c->nUpOwn[a] : c->nUpHalo[a]) : 0; }
+    static int64_t nRecvLo(const ps_context* c, int kind, int a) { return c->linkLower(a) ? (kind == 0 ? c->nLowHalo[a] : c->nLowOwn[a]) : 0; }
+    static int64_t nRecvUp(const ps_context* c, int kind, int a) { return c->linkUpper(a) ? (kind == 0 ? c->nUpHalo[a] : c->nUpOwn[a]) : 0; }
     void transport(int kind, bool onComm = false, int only = -1) {   // only >= 0: that axis alone
         if (useRccl) {
             ps_context* c = R[0];
             hipStream_t st = cs(c, onComm);
             Rccl& L = rccl();
             ncclCheck(L.GroupStart(), "ncclGroupStart");
-            for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < ps_context::NLINK; ++a) {
                 if (only >= 0 && a != only) continue;
                 const int64_t sLo = nSendLo(c, kind, a), sUp = nSendUp(c, kind, a), rLo = nRecvLo(c, kind, a), rUp = nRecvUp(c, kind, a);
                 if (sLo) ncclCheck(L.Send(c->sendLo[a].p, (size_t)sLo, NCCL_DOUBLE, c->nbrLo(a), c->rcclComm, st), "ncclSend");
@@ -436,7 +439,7 @@ struct Dist {
             ps_context* c = R[0];
             HostComm& H = *hc();
             hipStream_t st = cs(c, onComm);
-            for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < ps_context::NLINK; ++a) {
                 if (only >= 0 && a != only) continue;
                 const size_t sLo = (size_t)nSendLo(c, kind, a), sUp = (size_t)nSendUp(c, kind, a);
                 H.hs[2 * a].resize(sLo + 1); H.hs[2 * a + 1].resize(sUp + 1);
@@ -445,10 +448,10 @@ struct Dist {
                 if (sUp) HIP_CHECK(hipMemcpyAsync(H.hs[2 * a + 1].data(), c->sendUp[a].p, sUp * 8, hipMemcpyDeviceToHost, st));
             }
             HIP_CHECK(hipStreamSynchronize(st));
-            for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < ps_context::NLINK; ++a)
                 if (only < 0 || a == only) H.exchange(a, H.hs[2 * a].data(), (size_t)nSendLo(c, kind, a), H.hr[2 * a].data(), (size_t)nRecvLo(c, kind, a), H.hs[2 * a + 1].data(),
                            (size_t)nSendUp(c, kind, a), H.hr[2 * a + 1].data(), (size_t)nRecvUp(c, kind, a));
-            for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < ps_context::NLINK; ++a) {
                 if (only >= 0 && a != only) continue;
                 const size_t rLo = (size_t)nRecvLo(c, kind, a), rUp = (size_t)nRecvUp(c, kind, a);
                 if (rLo) HIP_CHECK(hipMemcpyAsync(c->recvLo[a].p, H.hr[2 * a].data(), rLo * 8, hipMemcpyHostToDevice, st));
@@ -459,7 +462,7 @@ struct Dist {
         }
         for (size_t q = 0; q < R.size(); ++q) {   // in-process ranks share one stream: plain device copies
             ps_context* c = R[q];
-            for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < ps_context::NLINK; ++a) {
                 if (only >= 0 && a != only) continue;
                 const int64_t sLo = nSendLo(c, kind, a), sUp = nSendUp(c, kind, a);
                 if (sLo) HIP_CHECK(hipMemcpyAsync(R[(size_t)c->nbrLo(a)]->recvUp[a].p, c->sendLo[a].p, (size_t)sLo * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -486,7 +489,7 @@ struct Dist {
     Lists6 lists6(ps_context* c, bool own, bool send) const {
         Lists6 L;
         int64_t run = 0;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < ps_context::NLINK; ++a) {
             L.list[2 * a] = (own ? c->listLowOwn[a] : c->listLowHalo[a]).p; L.list[2 * a + 1] = (own ? c->listUpOwn[a] : c->listUpHalo[a]).p;
             L.buf[2 * a] = send ? c->sendLo[a].p : c->recvLo[a].p; L.buf[2 * a + 1] = send ? c->sendUp[a].p : c->recvUp[a].p;
             run += own ? c->nLowOwn[a] : c->nLowHalo[a]; L.end[2 * a] = run;
@@ -496,13 +499,13 @@ struct Dist {
     }
     void packAll(ps_context* c, bool own, const double* v, hipStream_t st) {
         const Lists6 L = lists6(c, own, true);
-        if (L.end[5] > 0) hipLaunchKernelGGL(k_pack6, dim3(gridFor(L.end[5], BS)), dim3(BS), 0, st, L, v);
+        if (L.end[NLIST - 1] > 0) hipLaunchKernelGGL(k_pack6, dim3(gridFor(L.end[NLIST - 1], BS)), dim3(BS), 0, st, L, v);
     }
     void unpackAllValues(ps_context* c, double* v, hipStream_t st) {
         const Lists6 L = lists6(c, false, false);
-        if (L.end[5] > 0) hipLaunchKernelGGL(k_unpack6, dim3(gridFor(L.end[5], BS)), dim3(BS), 0, st, L, v);
+        if (L.end[NLIST - 1] > 0) hipLaunchKernelGGL(k_unpack6, dim3(gridFor(L.end[NLIST - 1], BS)), dim3(BS), 0, st, L, v);
     }
-    bool axisUsed(int a) const { for (const ps_context* c : R) if (c->brick.hasLower[a] || c->brick.hasUpper[a]) return true; return false; }
+    bool axisUsed(int a) const { for (const ps_context* c : R) if (c->linkLower(a) || c->linkUpper(a)) return true; return false; }   // (a: a link, 0 .. NLINK - 1)
     // The exchanges run axis after axis, each one forwarding what the previous ones brought (ps_grid.hip: buildHaloLists): values x, y, z;
     // contributions z, y, x.  With cuts along one axis only (slabs) that is one pack / transport / unpack, as before.
     // values of the cut layers -> the neighbours' halo copies, on the stream `onComm` selects
@@ -532,7 +535,7 @@ struct Dist {
             for (ps_context* c : R) packAll(c, false, (c->*vec).p, cs(c, onComm));
             transport(1, onComm);
             if (addOwned)
-                for (int a = 2; a >= 0; --a) if (axisUsed(a)) for (ps_context* c : R) unpack<true>(c, true, (c->*vec).p, cs(c, onComm), a);
+                for (int a = ps_context::NLINK - 1; a >= 0; --a) if (axisUsed(a)) for (ps_context* c : R) unpack<true>(c, true, (c->*vec).p, cs(c, onComm), a);   // (diagonals first, then z, y, x)
             return;
         }
         for (int a = 2; a >= 0; --a) {
@@ -551,7 +554,7 @@ struct Dist {
     // to two cuts is corrected twice, each launch sees the r the previous one left); partials of the changes of r.r / r.z: [axis][2][gFix] (zeroed once per solve: an axis
     // without lists leaves its part alone)
     void fixup(ps_context* c, const CGScalars* sc, bool jac, double* fX, int gFix) {
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < ps_context::NLINK; ++a) {
             double* part = fX + (size_t)a * 2 * (size_t)gFix;
             if (c->nLowOwn[a] + c->nUpOwn[a] > 0)
                 hipLaunchKernelGGL(k_dist_fixup, dim3(gFix), dim3(BS), 0, c->stream, sc, (const int32_t*)c->listLowOwn[a].p, c->nLowOwn[a], (const double*)c->recvLo[a].p,
@@ -660,7 +663,7 @@ struct Dist {
         bool any = false;
         for (int a = 0; a < 3; ++a) any = any || axisUsed(a);
         if (!any) return;
-        if (useTcp) { ps_context* c = R[0]; int lo[3], up[3]; for (int a = 0; a < 3; ++a) { lo[a] = c->nbrLo(a); up[a] = c->nbrUp(a); } hc()->connectNeighbours(lo, up); }
+        if (useTcp) { ps_context* c = R[0]; int lo[ps_context::NLINK], up[ps_context::NLINK]; for (int a = 0; a < ps_context::NLINK; ++a) { lo[a] = c->nbrLo(a); up[a] = c->nbrUp(a); } hc()->connectNeighbours(lo, up); }
         for (ps_context* c : R) {
             c->labelFlags.alloc(4);
             HIP_CHECK(hipMemsetAsync(c->labelFlags.p, 0, 4 * sizeof(int32_t), c->stream));
@@ -721,13 +724,14 @@ struct Dist {
     // neighbours must agree on the exchange lists: same lengths AND the same keys (position in the cut's cross-section, kind) in the
     // same order (ps_context::buildHaloLists hashes them) — equal counts of different DOF sets would otherwise pair the wrong entries.
     void checkLists() {
+        constexpr int NL = ps_context::NLINK;   // the three face links and the three diagonal links alike
         auto enc = [](int64_t n, uint64_t h, double* o) { o[0] = (double)n; o[1] = (double)(h & 0xffffffu); o[2] = (double)((h >> 24) & 0xffffffu); o[3] = (double)((h >> 48) & 0xffffu); };
         auto same = [](const double* a, const double* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]; };
         if (!useRccl && !useTcp) {
             for (size_t q = 0; q < R.size(); ++q)
-                for (int a = 0; a < 3; ++a) {
+                for (int a = 0; a < NL; ++a) {
                     const ps_context* lo = R[q];
-                    if (!lo->brick.hasUpper[a]) continue;
+                    if (!lo->linkUpper(a)) continue;
                     const ps_context* up = R[(size_t)lo->nbrUp(a)];
                     if (lo->nUpHalo[a] != up->nLowOwn[a] || lo->nUpOwn[a] != up->nLowHalo[a] || lo->hashUpHalo[a] != up->hashLowOwn[a] || lo->hashUpOwn[a] != up->hashLowHalo[a])
                         throw Error("exchange lists disagree across the cut between ranks " + std::to_string(lo->brick.rank) + " and " + std::to_string(up->brick.rank));
@@ -735,31 +739,31 @@ struct Dist {
             return;
         }
         ps_context* c = R[0];
-        if (useTcp) { int lo[3], up[3]; for (int a = 0; a < 3; ++a) { lo[a] = c->nbrLo(a); up[a] = c->nbrUp(a); } hc()->connectNeighbours(lo, up); }
-        double mineLo[3][8], mineUp[3][8];
-        int64_t keep[3][4];
-        for (int a = 0; a < 3; ++a) {
+        if (useTcp) { int lo[NL], up[NL]; for (int a = 0; a < NL; ++a) { lo[a] = c->nbrLo(a); up[a] = c->nbrUp(a); } hc()->connectNeighbours(lo, up); }
+        double mineLo[NL][8], mineUp[NL][8];
+        int64_t keep[NL][4];
+        for (int a = 0; a < NL; ++a) {
             enc(c->nLowOwn[a], c->hashLowOwn[a], mineLo[a]); enc(c->nLowHalo[a], c->hashLowHalo[a], mineLo[a] + 4);   // what I send down
             enc(c->nUpOwn[a], c->hashUpOwn[a], mineUp[a]); enc(c->nUpHalo[a], c->hashUpHalo[a], mineUp[a] + 4);       // what I send up
             HIP_CHECK(hipMemcpyAsync(c->sendLo[a].p, mineLo[a], 64, hipMemcpyHostToDevice, c->stream));
             HIP_CHECK(hipMemcpyAsync(c->sendUp[a].p, mineUp[a], 64, hipMemcpyHostToDevice, c->stream));
             keep[a][0] = c->nLowOwn[a]; keep[a][1] = c->nLowHalo[a]; keep[a][2] = c->nUpOwn[a]; keep[a][3] = c->nUpHalo[a];
-            c->nLowOwn[a] = c->nLowHalo[a] = c->brick.hasLower[a] ? 8 : 0; c->nUpOwn[a] = c->nUpHalo[a] = c->brick.hasUpper[a] ? 8 : 0;   // ship 8 doubles each way through the x-exchange path
+            c->nLowOwn[a] = c->nLowHalo[a] = c->linkLower(a) ? 8 : 0; c->nUpOwn[a] = c->nUpHalo[a] = c->linkUpper(a) ? 8 : 0;   // ship 8 doubles each way through the x-exchange path
         }
-        auto restore = [&]() { for (int a = 0; a < 3; ++a) { c->nLowOwn[a] = keep[a][0]; c->nLowHalo[a] = keep[a][1]; c->nUpOwn[a] = keep[a][2]; c->nUpHalo[a] = keep[a][3]; } };
+        auto restore = [&]() { for (int a = 0; a < NL; ++a) { c->nLowOwn[a] = keep[a][0]; c->nLowHalo[a] = keep[a][1]; c->nUpOwn[a] = keep[a][2]; c->nUpHalo[a] = keep[a][3]; } };
         order(c, 0, true);
         try { transport(0, true); order(c, 1, false); } catch (...) { restore(); throw; }
         restore();
         // the lower rank's (UpHalo, UpOwn) must equal my (LowOwn, LowHalo); the upper rank's (LowHalo, LowOwn) my (UpOwn, UpHalo):
         // received from below: its (UpOwn, UpHalo); from above: its (LowOwn, LowHalo)
         bool bad = false;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < NL; ++a) {
             double lo[8] = {0}, up[8] = {0};
-            if (c->brick.hasLower[a]) HIP_CHECK(hipMemcpyAsync(lo, c->recvLo[a].p, 64, hipMemcpyDeviceToHost, c->stream));
-            if (c->brick.hasUpper[a]) HIP_CHECK(hipMemcpyAsync(up, c->recvUp[a].p, 64, hipMemcpyDeviceToHost, c->stream));
+            if (c->linkLower(a)) HIP_CHECK(hipMemcpyAsync(lo, c->recvLo[a].p, 64, hipMemcpyDeviceToHost, c->stream));
+            if (c->linkUpper(a)) HIP_CHECK(hipMemcpyAsync(up, c->recvUp[a].p, 64, hipMemcpyDeviceToHost, c->stream));
             HIP_CHECK(hipStreamSynchronize(c->stream));
-            if (c->brick.hasLower[a] && !(same(lo, mineLo[a] + 4) && same(lo + 4, mineLo[a]))) bad = true;
-            if (c->brick.hasUpper[a] && !(same(up, mineUp[a] + 4) && same(up + 4, mineUp[a]))) bad = true;
+            if (c->linkLower(a) && !(same(lo, mineLo[a] + 4) && same(lo + 4, mineLo[a]))) bad = true;
+            if (c->linkUpper(a) && !(same(up, mineUp[a] + 4) && same(up + 4, mineUp[a]))) bad = true;
         }
         if (sumFlag(bad ? 1. : 0.) > 0.) throw Error(bad ? "exchange lists disagree with a neighbour (labels differ across the cut: halo too thin for the layer sizes?)"
                                                           : "another rank found its exchange lists in disagreement");
@@ -893,7 +897,7 @@ struct Dist {
             mark.alloc((size_t)c->nSystem);
             HIP_CHECK(hipMemsetAsync(mark.p, 0, (size_t)c->nSystem, c->stream));
             HIP_CHECK(hipMemsetAsync(c->counters.p + 41, 0, sizeof(int32_t), c->stream));
-            for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < ps_context::NLINK; ++a) {
                 if (c->nLowHalo[a] > 0) hipLaunchKernelGGL(k_mark_list, dim3(gridFor(c->nLowHalo[a], BS)), dim3(BS), 0, c->stream, (const int32_t*)c->listLowHalo[a].p, c->nLowHalo[a], mark.p);
                 if (c->nUpHalo[a] > 0) hipLaunchKernelGGL(k_mark_list, dim3(gridFor(c->nUpHalo[a], BS)), dim3(BS), 0, c->stream, (const int32_t*)c->listUpHalo[a].p, c->nUpHalo[a], mark.p);
             }
@@ -1039,11 +1043,11 @@ struct Dist {
                     f.tB = l.L.stBlocksFor(c->nDistList[2], 3); f.stBF = f.tB + l.L.stBlocksFor(c->nDistList[3], 3);
                 }
                 int64_t mostOwn = 1;
-                for (int a = 0; a < 3; ++a) mostOwn = std::max(mostOwn, c->nLowOwn[a] + c->nUpOwn[a]);
+                for (int a = 0; a < ps_context::NLINK; ++a) mostOwn = std::max(mostOwn, c->nLowOwn[a] + c->nUpOwn[a]);
                 f.gFix = (int)std::min<int64_t>(256, (mostOwn + BS - 1) / BS);   // workgroups of one axis's k_dist_fixup; its partials: [axis][2][gFix]
-                c->fusedPart.alloc((size_t)f.sBlocks + (size_t)c->regionCount + VGRID + 2 * (size_t)f.stBF + 6 * (size_t)f.gFix + 16);
+                c->fusedPart.alloc((size_t)f.sBlocks + (size_t)c->regionCount + VGRID + 2 * (size_t)f.stBF + 2 * ps_context::NLINK * (size_t)f.gFix + 16);
                 f.fS = c->fusedPart.p; f.fT = f.fS + f.sBlocks; f.fU = f.fT + c->regionCount; f.fR = f.fU + VGRID; f.fX = f.fR + 2 * f.stBF;
-                HIP_CHECK(hipMemsetAsync(f.fX, 0, 6 * (size_t)f.gFix * sizeof(double), c->stream));
+                HIP_CHECK(hipMemsetAsync(f.fX, 0, 2 * ps_context::NLINK * (size_t)f.gFix * sizeof(double), c->stream));
                 l.L.sPart = f.fS; l.L.wvPart = f.fT;
                 c->fusedStepHost = 1;
                 const uint8_t* ucode = c->uCoded ? c->uCode.p + l.lo : nullptr;
@@ -1108,7 +1112,7 @@ struct Dist {
                         FBuf& f = fb[q];
                         order(c, 5, false);
                         fixup(c, l.sc, jac, f.fX, f.gFix);
-                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, 3, c->redbuf.p);
+                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, ps_context::NLINK, c->redbuf.p);
                     }
                     allreduce(2);
                     for (size_t q = 0; q < R.size(); ++q) {
@@ -1149,7 +1153,7 @@ struct Dist {
                         Loc& l = loc[q];
                         FBuf& f = fb[q];
                         fixup(c, l.sc, jac, f.fX, f.gFix);
-                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, 3, c->redbuf.p);
+                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, ps_context::NLINK, c->redbuf.p);
                     }
                     allreduce(2);
                     for (size_t q = 0; q < R.size(); ++q) {

@@ -1339,7 +1339,7 @@ __global__ void k_slice(const int32_t* __restrict__ src, int3 d, int axis, int l
 }
 }  // namespace
 void ps_context::buildHaloLists() {
-    for (int a = 0; a < 3; ++a) nLowHalo[a] = nLowOwn[a] = nUpHalo[a] = nUpOwn[a] = 0;
+    for (int a = 0; a < NLINK; ++a) { nLowHalo[a] = nLowOwn[a] = nUpHalo[a] = nUpOwn[a] = 0; hashLowHalo[a] = hashLowOwn[a] = hashUpHalo[a] = hashUpOwn[a] = 0; }
     if (!slabEnabled) return;
     DevBuf<int32_t>& scr = scrSlice;
     // the slice of sample grid s perpendicular to `axis` at `layer`, over the positions this rank owns along the two other axes (the
@@ -1401,6 +1401,40 @@ void ps_context::buildHaloLists() {
         const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo[a], nLowOwn[a]), std::max(nUpHalo[a], nUpOwn[a])) + 8;   // >= 8: Dist::checkLists ships counts + hashes through these buffers
         sendLo[a].alloc(mx); sendUp[a].alloc(mx); recvLo[a].alloc(mx); recvUp[a].alloc(mx);
         HIP_CHECK(hipStreamSynchronize(stream));                                           // (the host vectors go out of scope)
+    }
+    // The diagonal links (one-round mode only; in the forwarding mode these samples travel as copies through two axis exchanges): the edge stresses
+    // on the corner line of two cuts.  Link 3 + d, d = (x, y), (x, z), (y, z): the edge grid that lives on both planes (XY = 6, XZ = 5, YZ = 4), the third
+    // axis c over this rank's owned layers — the diagonal brick owns the same layers (the bricks of a row share their ranges).
+    //   above: the line (plane hi_a, plane hi_b) belongs to the brick one up along both: my halo, touched by the skin rows of my tile in that corner;
+    //   below: the line (plane lo_a, plane lo_b) is mine, touched by the rows of the brick one down along both.
+    for (int d = 0; d < 3; ++d) {
+        const int l = 3 + d, a = d == 2 ? 1 : 0, b = d == 0 ? 1 : 2, c = 3 - a - b, s = d == 0 ? 6 : (d == 1 ? 5 : 4);
+        std::vector<int32_t> upHalo, lowOwn;
+        auto lineOf = [&](int pa, int pb, std::vector<int32_t>& list, uint64_t& h) {
+            const int3 dm = g.dims(s);
+            if (pa < 0 || pa >= comp(dm, a) || pb < 0 || pb >= comp(dm, b)) return;
+            int r0[3], r1[3];
+            r0[a] = pa; r1[a] = pa + 1; r0[b] = pb; r1[b] = pb + 1; r0[c] = brick.lo[c]; r1[c] = brick.hi[c];
+            const int n = r1[c] - r0[c];
+            if (n <= 0) return;
+            // k_slice cuts a layer along `axis` over the ranges of the two other axes, lower axis fastest: here the layer pa along a, one position along b
+            const int o1 = a == 0 ? 1 : 0, o2 = a == 2 ? 1 : 2;     // the two other axes of a, in k_slice's order
+            const size_t cnt = (size_t)(r1[o1] - r0[o1]) * (size_t)(r1[o2] - r0[o2]);
+            scrSlice.alloc(cnt);
+            hipLaunchKernelGGL(k_slice, dim3(gridFor((int64_t)cnt, BS)), dim3(BS), 0, stream, (const int32_t*)sysIdx[s].p, dm, a, pa, make_int3(r0[0], r0[1], r0[2]),
+                               make_int3(r1[0], r1[1], r1[2]), scrSlice.p);
+            std::vector<int32_t> sl(cnt);
+            HIP_CHECK(hipMemcpyAsync(sl.data(), scrSlice.p, cnt * 4, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            for (size_t q = 0; q < sl.size(); ++q) if (sl[q] >= 0) { list.push_back(sl[q]); mix(h, (uint64_t)q * 8 + (uint64_t)s); }
+        };
+        if (!haloForward && linkUpper(l)) lineOf(brick.hi[a], brick.hi[b], upHalo, hashUpHalo[l]);
+        if (!haloForward && linkLower(l)) lineOf(brick.lo[a], brick.lo[b], lowOwn, hashLowOwn[l]);
+        std::vector<int32_t> none;
+        up(none, listLowHalo[l], nLowHalo[l]); up(lowOwn, listLowOwn[l], nLowOwn[l]); up(upHalo, listUpHalo[l], nUpHalo[l]); up(none, listUpOwn[l], nUpOwn[l]);
+        const size_t mx = (size_t)std::max(nLowOwn[l], nUpHalo[l]) + 8;
+        sendLo[l].alloc(mx); sendUp[l].alloc(mx); recvLo[l].alloc(mx); recvUp[l].alloc(mx);
+        HIP_CHECK(hipStreamSynchronize(stream));
     }
 }
 
