@@ -214,6 +214,10 @@ struct ps_context {
     // what one distributed solve did (ps_dist_stats): bytes per iteration over the cuts, sampled transport / all-reduce times
     double distStats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     ps::DevBuf<int32_t> labelFlags;          // Dist::exchangeLabels: labels changed, REDUCED cells without a component
+    std::vector<int32_t> hostOwnList[2 * NLINK];   // host copies of listLowOwn / listUpOwn (index 2 l / 2 l + 1): Dist::buildFixup merges them per DOF
+    ps::DevBuf<int32_t> fixDof, fixSrc;      // the merged fix-up of the fused step (k_dist_fixup_merged): DOFs that receive contributions, their sources
+    ps::DevBuf<const double*> fixBufs;       // ... and the table of the twelve receive buffers
+    int64_t nFix = 0;
     ps::DevBuf<unsigned char> scrMark;       // setup scratch of Dist::decideExchangeMode
     bool haloForward = false;                // the exchange lists carry the copies of an earlier axis's exchange (three forwarding rounds x -> y -> z); false: every
                                              // list holds the sender's OWN samples only and the three axes travel in ONE round (ps_dist.hpp: Dist::decideExchangeMode)

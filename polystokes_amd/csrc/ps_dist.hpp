@@ -553,7 +553,41 @@ struct Dist {
     // r_j -= alpha * (the neighbours' share of (A p)_j) on the OWNED DOFs next to a cut, from the receive buffers of every axis (a DOF next
     // to two cuts is corrected twice, each launch sees the r the previous one left); partials of the changes of r.r / r.z: [axis][2][gFix] (zeroed once per solve: an axis
     // without lists leaves its part alone)
+    // the merged fix-up list of a rank (k_dist_fixup_merged): every owned DOF that receives contributions, with its sources in link order
+    // (diagonals last; a halo copy of the forwarding mode — index >= ownHi — is not a DOF of this rank and is left out, as k_dist_fixup skips it)
+    void buildFixup(ps_context* c) {
+        c->nFix = 0;
+        std::vector<std::pair<int32_t, int32_t>> ent;                       // (DOF, (list index << 4) | buffer), in link order
+        for (int a = 0; a < ps_context::NLINK; ++a)
+            for (int side = 0; side < 2; ++side) {
+                const std::vector<int32_t>& L = c->hostOwnList[2 * a + side];
+                if (L.size() >= (size_t)(1 << 27)) return;                  // (would not fit the encoding: the per-link launches stay)
+                for (size_t i = 0; i < L.size(); ++i) if (L[i] < (int32_t)c->ownHi) ent.push_back({L[i], (int32_t)((i << 4) | (size_t)(2 * a + side))});
+            }
+        if (ent.empty()) return;
+        std::stable_sort(ent.begin(), ent.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first < y.first; });
+        std::vector<int32_t> dof, cnt;
+        for (size_t i = 0; i < ent.size(); ++i) { if (dof.empty() || dof.back() != ent[i].first) { dof.push_back(ent[i].first); cnt.push_back(0); } ++cnt.back(); }
+        for (int32_t k : cnt) if (k > FIX_MAXSRC) return;                   // (cannot happen with six links; the per-link launches stay if it does)
+        const size_t n = dof.size();
+        std::vector<int32_t> src((size_t)FIX_MAXSRC * n, -1);
+        size_t e = 0;
+        for (size_t i = 0; i < n; ++i) for (int32_t k = 0; k < cnt[i]; ++k) src[(size_t)k * n + i] = ent[e++].second;
+        std::vector<const double*> bufs(12);
+        for (int a = 0; a < ps_context::NLINK; ++a) { bufs[(size_t)2 * a] = c->recvLo[a].p; bufs[(size_t)2 * a + 1] = c->recvUp[a].p; }
+        c->fixDof.alloc(n); c->fixSrc.alloc(src.size()); c->fixBufs.alloc(12);
+        HIP_CHECK(hipMemcpyAsync(c->fixDof.p, dof.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(c->fixSrc.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(c->fixBufs.p, bufs.data(), 12 * sizeof(const double*), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));                          // (the host vectors go out of scope)
+        c->nFix = (int64_t)n;
+    }
     void fixup(ps_context* c, const CGScalars* sc, bool jac, double* fX, int gFix) {
+        if (c->nFix > 0) {                                                   // one launch; its partials are the first of the sets k_sum_rr adds up (the others stay zero)
+            hipLaunchKernelGGL(k_dist_fixup_merged, dim3(gFix), dim3(BS), 0, c->stream, sc, (const int32_t*)c->fixDof.p, (const int32_t*)c->fixSrc.p, c->nFix,
+                               (const double* const*)c->fixBufs.p, c->r.p, jac ? (const float*)c->dinvF.p : (const float*)nullptr, fX);
+            return;
+        }
         for (int a = 0; a < ps_context::NLINK; ++a) {
             double* part = fX + (size_t)a * 2 * (size_t)gFix;
             if (c->nLowOwn[a] + c->nUpOwn[a] > 0)
@@ -851,6 +885,8 @@ struct Dist {
     // Chunk lists of the row-per-lane kernels (ps_context::distList): which chunks can run before the halo values have arrived /
     // while this rank's contributions to its neighbours travel.  Built from two flag kernels and a host pass per setup.
     void buildLists() {
+        static const bool mergedFix = !(PS_ENV("PS_DIST_FIXUP_MERGED") && atoi(PS_ENV("PS_DIST_FIXUP_MERGED")) == 0);   // A/B: 0 = one k_dist_fixup launch per link
+        for (ps_context* c : R) { c->nFix = 0; if (mergedFix) buildFixup(c); }
         for (ps_context* c : R) {
             c->distListsOk = false;
             for (int q = 0; q < 4; ++q) c->nDistList[q] = 0;

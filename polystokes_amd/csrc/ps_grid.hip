@@ -1340,6 +1340,7 @@ __global__ void k_slice(const int32_t* __restrict__ src, int3 d, int axis, int l
 }  // namespace
 void ps_context::buildHaloLists() {
     for (int a = 0; a < NLINK; ++a) { nLowHalo[a] = nLowOwn[a] = nUpHalo[a] = nUpOwn[a] = 0; hashLowHalo[a] = hashLowOwn[a] = hashUpHalo[a] = hashUpOwn[a] = 0; }
+    for (auto& v : hostOwnList) v.clear();
     if (!slabEnabled) return;
     DevBuf<int32_t>& scr = scrSlice;
     // the slice of sample grid s perpendicular to `axis` at `layer`, over the positions this rank owns along the two other axes (the
@@ -1398,6 +1399,7 @@ void ps_context::buildHaloLists() {
             cellsOf(a, hi - 1, upOwn, hashUpOwn[a]);                                      // mine, touched by their faces on the plane hi
         }
         up(lowHalo, listLowHalo[a], nLowHalo[a]); up(lowOwn, listLowOwn[a], nLowOwn[a]); up(upHalo, listUpHalo[a], nUpHalo[a]); up(upOwn, listUpOwn[a], nUpOwn[a]);
+        hostOwnList[2 * a] = lowOwn; hostOwnList[2 * a + 1] = upOwn;
         const size_t mx = (size_t)std::max<int64_t>(std::max(nLowHalo[a], nLowOwn[a]), std::max(nUpHalo[a], nUpOwn[a])) + 8;   // >= 8: Dist::checkLists ships counts + hashes through these buffers
         sendLo[a].alloc(mx); sendUp[a].alloc(mx); recvLo[a].alloc(mx); recvUp[a].alloc(mx);
         HIP_CHECK(hipStreamSynchronize(stream));                                           // (the host vectors go out of scope)
@@ -1432,6 +1434,7 @@ void ps_context::buildHaloLists() {
         if (!haloForward && linkLower(l)) lineOf(brick.lo[a], brick.lo[b], lowOwn, hashLowOwn[l]);
         std::vector<int32_t> none;
         up(none, listLowHalo[l], nLowHalo[l]); up(lowOwn, listLowOwn[l], nLowOwn[l]); up(upHalo, listUpHalo[l], nUpHalo[l]); up(none, listUpOwn[l], nUpOwn[l]);
+        hostOwnList[2 * l] = lowOwn; hostOwnList[2 * l + 1].clear();
         const size_t mx = (size_t)std::max(nLowOwn[l], nUpHalo[l]) + 8;
         sendLo[l].alloc(mx); sendUp[l].alloc(mx); recvLo[l].alloc(mx); recvUp[l].alloc(mx);
         HIP_CHECK(hipStreamSynchronize(stream));

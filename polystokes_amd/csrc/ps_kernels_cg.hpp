@@ -374,19 +374,48 @@ __global__ void __launch_bounds__(BS) k_dist_fixup(const CGScalars* __restrict__
     const double s0 = blockReduceSum(a0), s1 = blockReduceSum(a1);
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
 }
-// out = {r.r, r.z} of this rank: the St kernel's partials plus the corrections of the k_dist_fixup launches (fixSets of them, each
-// [2][fixCount])   (one block)
+// out = {r.r, r.z} of this rank: the St kernel's partials plus the corrections of the fix-up ([2][fixCount] per set; r05: ONE set — the merged
+// fix-up k_dist_fixup_merged — and the two corrections folded thread by thread before ONE reduction each: this one-block kernel sits on the
+// critical path of every rank-iteration and took 17 us with 2 + 2 x 6 block reductions)   (one block)
 __global__ void __launch_bounds__(BS) k_sum_rr(const CGScalars* __restrict__ sc, const double* __restrict__ rPart, int rCount, const double* __restrict__ fixPart, int fixCount,
                                                int fixSets, double* __restrict__ out) {
     if (sc->done) return;
-    const double a = sumPartials(rPart, rCount); __syncthreads();
-    const double b = sumPartials(rPart + rCount, rCount); __syncthreads();
-    double c = 0., d = 0.;
-    for (int q = 0; q < fixSets; ++q) {
-        c += sumPartials(fixPart + (size_t)q * 2 * fixCount, fixCount); __syncthreads();
-        d += sumPartials(fixPart + (size_t)q * 2 * fixCount + fixCount, fixCount); __syncthreads();
+    double a = 0., b = 0., c = 0., d = 0.;
+    for (int i = threadIdx.x; i < rCount; i += BS) { a += rPart[i]; b += rPart[rCount + i]; }
+    for (int q = 0; q < fixSets; ++q)
+        for (int i = threadIdx.x; i < fixCount; i += BS) { c += fixPart[(size_t)q * 2 * fixCount + i]; d += fixPart[(size_t)q * 2 * fixCount + fixCount + i]; }
+    const double sa = blockReduceSum(a); __syncthreads();
+    const double sb = blockReduceSum(b); __syncthreads();
+    const double sc_ = blockReduceSum(c); __syncthreads();
+    const double sd = blockReduceSum(d);
+    if (threadIdx.x == 0) { out[0] = sa + sc_; out[1] = sb + sd; }
+}
+// The fix-up of the fused step in ONE launch (r05): a thread owns a DOF that receives contributions — from up to MAXSRC links (a DOF next to two or
+// three cuts) — and applies them in link order, each to the r the previous one left: the arithmetic of the per-link launches of k_dist_fixup, DOF by
+// DOF, without the launches (3 - 6 per rank-iteration at ~6 us each).  src[k][i] = (list index << 4) | buffer (0 .. 11: recvLo / recvUp of the six
+// links, a pointer table in device memory), -1 = none; built once per setup (Dist::buildFixup).
+constexpr int FIX_MAXSRC = 4;
+__global__ void __launch_bounds__(BS) k_dist_fixup_merged(const CGScalars* __restrict__ sc, const int32_t* __restrict__ dof, const int32_t* __restrict__ src, int64_t n, const double* const* __restrict__ bufs,
+                                                          double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ partial) {
+    if (sc->done) return;
+    const double alpha = sc->alpha;
+    double a0 = 0., a1 = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const int j = dof[i];
+        const double ro = r[j];
+        double rn = ro;
+#pragma unroll
+        for (int k = 0; k < FIX_MAXSRC; ++k) {
+            const int e = src[(size_t)k * (size_t)n + (size_t)i];
+            if (e >= 0) rn -= alpha * bufs[e & 15][e >> 4];
+        }
+        r[j] = rn;
+        const double d = rn * rn - ro * ro;
+        a0 += d;
+        if (dinv) a1 += (double)dinv[j] * d;
     }
-    if (threadIdx.x == 0) { out[0] = a + c; out[1] = b + d; }
+    const double s0 = blockReduceSum(a0), s1 = blockReduceSum(a1);
+    if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
 }
 
 // ---- generic vector helpers (BiCGStab fallback, rare) -----------------------------------------------
