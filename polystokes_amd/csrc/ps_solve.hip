@@ -322,7 +322,8 @@ Launch mk(ps_context* c, const int* done) {
     L.plain3Hint2 = c->uCoded && c->P.preconditioner == PS_PRE_CHEBYSHEV && !c->slabEnabled;
     return L;
 }
-constexpr int64_t FUSED_STEP_MIN_ROWS = 2000000;   // see solve()
+constexpr int64_t FUSED_STEP_MIN_ROWS = 1200000;   // see solve() (r05: 2 M -> 1.2 M: the coil 128^3 of BASELINE config 2, 1.49 M rows, solves 3 % faster in four kernels — 10.55 against 10.86 ms,
+                                                    // two rounds on one box; the 64^3 cavity, 0.8 M rows, stays faster in five: 57.3 against 58.8 us per iteration)
 constexpr int64_t NT_LEVEL1_MIN_ROWS = 4000000, NT_LEVEL2_MIN_ROWS = 10000000;   // see ps_context::ntLevel
 int dotBlocks(int64_t n) { return (int)std::min<int64_t>(VGRID, std::max<int64_t>(1, (n + BS - 1) / BS)); }
 }  // namespace
@@ -519,7 +520,7 @@ int ps_context::solve() {
     // Every St workgroup sums the partials of three producers in its prologue (up to 4096 + regions + 1024 + 1024 values, from
     // L2): a fixed cost per iteration, against 16 B per row saved.  Measured us per iteration, four / five kernels (St on 1536
     // workgroups, shared runs): 64^3 (0.8 M rows) 58.8 / 57.3, 96^3 (2.6 M) 93.2 / 95.6, 128^3 (5.9 M) 164.8 / 175.5, 160^3 (11.4 M)
-    // 285.9 / 309.3, 192^3 (19.4 M) 466.7 / 506.5, 256^3 (45 M) 1147 / 1248 (before shared runs) -> on from 2 M rows.  (Folding the
+    // 285.9 / 309.3, 192^3 (19.4 M) 466.7 / 506.5, 256^3 (45 M) 1147 / 1248 (before shared runs) -> on from 1.2 M rows (FUSED_STEP_MIN_ROWS).  (Folding the
     // partials 64 to 1 in the producers with a ticket per group costs more than it saves: one device-scope atomic per workgroup,
     // +30 us per iteration with write-through stores and no fence, +650 us with __threadfence(), which flushes the XCD's L2.)
     // PS_FUSED_R = 0 / 1 forces it off / on (on only where the kernels exist).

@@ -60,7 +60,7 @@ def _run_ranks(case, world, tmp_path, env=None):
                                   "cavity_w2+fused", "cavity_w3_jacobi+fused", "coil_w2+fused", "cavity_w2_bicgstab+fused",
                                   "cavity64_b2x2x1", "cavity_b2x1x2+fused"])
 def test_multiprocess_tcp_matches_single_domain(case, tmp_path):
-    """"+fused": the four-kernel PCG step across the slabs (default from 2 M owned rows per rank), forced in the rank processes."""
+    """"+fused": the four-kernel PCG step across the slabs (default from 1.2 M owned rows per rank), forced in the rank processes."""
     env = {"PS_FUSED_R": "1"} if case.endswith("+fused") else None
     case = case.replace("+fused", "")
     world = mp_cases.WORLD[case]

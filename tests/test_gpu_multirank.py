@@ -121,7 +121,7 @@ def test_bricks_match_single_domain(case):
 @pytest.mark.skipif(__import__("os").environ.get("PS_TEST_CHILD") == "1", reason="this IS the child run")
 def test_bricks_and_slabs_with_the_four_kernel_step_forced():
     """The four-kernel PCG step across the cuts (the St kernel corrects r on owned rows, the halo rows' A p travels back axis after axis,
-    k_relay2 / k_dist_fixup) switches on from 2 M owned rows per rank: force it (PS_FUSED_R=1) through the brick and slab cases in a child."""
+    k_relay2 / k_dist_fixup) switches on from 1.2 M owned rows per rank: force it (PS_FUSED_R=1) through the brick and slab cases in a child."""
     import os
     import subprocess
     import sys

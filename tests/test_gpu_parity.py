@@ -564,7 +564,7 @@ def test_fallback_kernel_paths_agree(gpu, tmp_path, env):
     p.tolerance = 1e-8
     p.maxSolverIterations = 20000
     assert gpu.step(sc, p) == abi.SUCCESS
-    assert int(gpu.array("fusedStep")[0]) == 0    # small system: five-kernel PCG step (the four-kernel one runs from 2 M rows, or PS_FUSED_R=1)
+    assert int(gpu.array("fusedStep")[0]) == 0    # small system: five-kernel PCG step (the four-kernel one runs from 1.2 M rows, or PS_FUSED_R=1)
     out = str(tmp_path / "alt.npz")
     code = (
         "import sys, numpy as np\n"
@@ -614,7 +614,7 @@ def test_repeated_solves_are_bit_identical(gpu, precond):
 
 @pytest.mark.parametrize("precond,degree", [(abi.PRE_IDENTITY, 0), (abi.PRE_DIAGONAL, 0), (abi.PRE_CHEBYSHEV, 4), (abi.PRE_CHEBYSHEV, 1)])
 def test_four_kernel_step_matches_and_is_reproducible(gpu, tmp_path, precond, degree):
-    """The four-kernel PCG step (residual update inside the St kernel, p.Ap from the factored form; default from 2 M rows)
+    """The four-kernel PCG step (residual update inside the St kernel, p.Ap from the factored form; default from 1.2 M rows)
     forced on a small grid in a child process: same iteration count as the five-kernel step to +-1, same x to rounding,
     and 100 solves give one outcome bit for bit.  With the Chebyshev preconditioner the same St kernel also forms the
     polynomial's first term on the rows it updates (degree 1: that term is the whole preconditioner)."""
