@@ -752,9 +752,11 @@ void ps_context::buildEll(ps::DevCSR& M) {
     (void)exclusiveScanI32(colBegin.p, nChunks + 1, 56);
     (void)exclusiveScanI32(codeBegin.p, nChunks + 1, 57);
     int32_t tot[2] = {0, 0}, tooLong = 0;                                        // one round trip for the two totals and the width check
-    HIP_CHECK(hipMemcpyAsync(tot, counters.p + 56, sizeof(tot), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(&tooLong, counters.p + 25, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    {
+        int32_t w[33];
+        fetchCounters(25, 33, w);                                                // counters[25 .. 57] in one copy
+        tooLong = w[0]; tot[0] = w[31]; tot[1] = w[32];
+    }
     const int64_t totCol = tot[0], totCode = tot[1];
     if (totCol < 0 || totCode < 0 || (uint64_t)totCol * 2 >= 0xffffffffull || tooLong != 0) return;   // a row longer than 8 / 32-bit offsets: keep the other kernels
     M.ellCols = totCol; M.ellCodes = totCode; M.ellUniqueCols = totCol;

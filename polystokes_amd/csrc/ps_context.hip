@@ -529,6 +529,7 @@ void ps_context_destroy(ps_context* c) {
     (void)hipStreamSynchronize(c->stream);
     ps_dist_release(c);   // communicator / sockets first, then the stream they use
     hipStream_t s = c->ownsStream ? c->stream : nullptr;
+    if (c->pinnedCounters) (void)hipHostFree(c->pinnedCounters);
     delete c;
     if (s) (void)hipStreamDestroy(s);
 }

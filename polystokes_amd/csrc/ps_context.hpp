@@ -312,6 +312,8 @@ struct ps_context {
     void buildInternalNumbering();                                            // ps_grid.hip
     int64_t exclusiveScanI32(int32_t* data, int64_t n, int counterSlot = -1);   // ps_grid.hip (counterSlot >= 0: total to counters[slot], no synchronisation)
     int32_t readCounter(int idx);
+    void fetchCounters(int idx, int n, int32_t* out);   // counters[idx .. idx + n) in one round trip through the page-locked mirror (synchronises the stream: copies queued before it have landed too)
+    int32_t* pinnedCounters = nullptr;       // page-locked mirror of `counters` (64 words): a count read lands there directly instead of through the runtime's staging copy
     void zeroCounters();
 };
 

@@ -945,10 +945,26 @@ Set7<const T> cset(DevBuf<T>* b) {
 
 // ---------------------------------------------------------------------------------------------------
 int32_t ps_context::readCounter(int idx) {
+    // into page-locked memory (r05): a device-to-host copy of 4 bytes into a stack variable goes through the runtime's staging buffer — about half of the
+    // ~30 us a count-only round trip of the setup costs (36 of them per setup: profiles/r05_setup_timeline_coil128.txt)
+    if (!pinnedCounters && hipHostMalloc((void**)&pinnedCounters, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) pinnedCounters = nullptr;
+    if (pinnedCounters) {
+        HIP_CHECK(hipMemcpyAsync(pinnedCounters + idx, counters.p + idx, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return pinnedCounters[idx];
+    }
     int32_t v = 0;
     HIP_CHECK(hipMemcpyAsync(&v, counters.p + idx, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     return v;
+}
+// several counters in one round trip (synchronises the stream)
+void ps_context::fetchCounters(int idx, int n, int32_t* out) {
+    if (!pinnedCounters && hipHostMalloc((void**)&pinnedCounters, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) pinnedCounters = nullptr;
+    int32_t* dst = pinnedCounters ? pinnedCounters + idx : out;
+    HIP_CHECK(hipMemcpyAsync(dst, counters.p + idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (pinnedCounters) for (int q = 0; q < n; ++q) out[q] = pinnedCounters[idx + q];
 }
 void ps_context::zeroCounters() { HIP_CHECK(hipMemsetAsync(counters.p, 0, 64 * sizeof(int32_t), stream)); }
 
@@ -1090,8 +1106,7 @@ void ps_context::constructCenterReducedIndices(int part) {
                 zeroCounters();
                 hipLaunchKernelGGL(k_fix_eval, gr, bl, 0, stream, g, labels[0].p, reducedIdx[0].p, F0, F1, anyF, counters.p);
                 int32_t fl[2];
-                HIP_CHECK(hipMemcpyAsync(fl, counters.p, sizeof(fl), hipMemcpyDeviceToHost, stream));
-                HIP_CHECK(hipStreamSynchronize(stream));
+                fetchCounters(0, 2, fl);
                 std::swap(F0, F1);
                 anyF = fl[1];
                 if (!fl[0]) break;
@@ -1174,8 +1189,7 @@ void ps_context::constructActiveIndices() {
         (void)orderedIndexAssign(s, 0, activeIdx[s], 48 + s);      // totals -> counters[48 .. 54], one round trip for the seven
     }
     int32_t cnt[7];
-    HIP_CHECK(hipMemcpyAsync(cnt, counters.p + 48, sizeof(cnt), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    fetchCounters(48, 7, cnt);
     nCenter = cnt[0];
     for (int a = 0; a < 3; ++a) { nFace[a] = cnt[1 + a]; nEdge[a] = cnt[4 + a]; }
 }
@@ -1243,9 +1257,8 @@ int64_t ps_context::interleavedIndexAssignEx(int ngroups, const int* samples, co
     int32_t cnt[4] = {0, 0, 0, 0};                      // counters[8 .. 11]: the total, -, the two probes — one round trip with the block starts
     std::vector<int32_t>& hs = ownedRange ? blockStartSys : blockStartRow;
     hs.assign((size_t)nBlocks + 1, 0);
-    HIP_CHECK(hipMemcpyAsync(cnt, counters.p + 8, sizeof(cnt), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(hs.data(), bstart.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    fetchCounters(8, 4, cnt);                            // (synchronises: the block starts have landed too)
     const int64_t total = cnt[0];
     hs[(size_t)nBlocks] = (int32_t)total;
     ilBlocks = nBlocks;
