@@ -256,6 +256,24 @@ __host__ __device__ inline void unpackFace(uint32_t q, int& i, int& j, int& k, i
     i = q & 1023; j = (q >> 10) & 1023; k = (q >> 20) & 1023; axis = q >> 30;
 }
 
+// The Jacobi diagonal as the PCG kernels read it (ps_context::dinvF): 16 bits per DOF — the upper half of the fp32 value of 1 / A_jj, rounded
+// to nearest even (sign, 8 exponent bits, 7 mantissa bits: 0.4 % relative).  The preconditioner is ANY fixed positive diagonal: the
+// recurrences, the stop test and every sum stay fp64, x converges to the same tolerance; what changes is the operator D^-1 A whose
+// spectrum sets the iteration count — by the rounding of D (r05: 987 iterations at 256^3 either way).  It is read by both step kernels
+// of every iteration: 8 B/DOF as fp32 — the 6 % a Jacobi iteration cost over an identity one — 4 B/DOF now.  -DPS_DIAG_FP32: the fp32 copy of r02-r05.
+#ifdef PS_DIAG_FP32
+typedef float diag_t;
+__host__ __device__ inline double diagValue(diag_t v) { return (double)v; }
+__host__ __device__ inline diag_t diagStore(double v) { return (float)v; }
+#else
+typedef uint16_t diag_t;
+__host__ __device__ inline double diagValue(diag_t v) { return (double)__builtin_bit_cast(float, (uint32_t)v << 16); }
+__host__ __device__ inline diag_t diagStore(double v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, (float)v);
+    return (diag_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+}
+#endif
+
 inline bool debugPoisonOn() {
     static const bool on = [] { const char* e = PS_ENV_LOUD("PS_DEBUG_POISON"); return e && atoi(e) != 0; }();
     return on;

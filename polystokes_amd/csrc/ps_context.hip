@@ -764,15 +764,16 @@ int32_t ps_bench_kernel(ps_context* c, const char* kernel, int32_t iters, double
             const double dMc = (c16(c->S) && c->mcCoded) ? 1. : 8., dU = (c16(c->St) && c->uCoded) ? 1. : 8.;
             const double bS = winS + perNnzS * entS + ptrS * (rowsS + 1) + 8. * rowsS + 8. * rowsT + dMc * (double)c->nActiveVs;
             const double bT = winT + perNnzT * entT + ptrT * (rowsT + 1) + 8. * rowsT + 8. * rowsS + 8. * rowsT + dU * rowsT;
+            const double dg = c->P.preconditioner == PS_PRE_DIAGONAL ? (double)sizeof(ps::diag_t) : 0.;   // the stored Jacobi diagonal (ps_common.hpp)
             if (kb == "spmv_S") *algorithmic_bytes = bS;
             else if (kb == "spmv_St") *algorithmic_bytes = bT;
-            // fused residual update: r read and written in place of the A p store, + the fp32 Jacobi diagonal
-            else if (kb == "spmv_St_r") *algorithmic_bytes = bT + (c->P.preconditioner == PS_PRE_DIAGONAL ? 12. : 8.) * rowsT;
-            else if (kb == "cg_update_xp_u") *algorithmic_bytes = ((c->P.preconditioner == PS_PRE_DIAGONAL ? 44. : 40.) + (c->uCoded ? 1. : 8.)) * rowsT;
+            // fused residual update: r read and written in place of the A p store, + the stored Jacobi diagonal
+            else if (kb == "spmv_St_r") *algorithmic_bytes = bT + (8. + dg) * rowsT;
+            else if (kb == "cg_update_xp_u") *algorithmic_bytes = (40. + dg + (c->uCoded ? 1. : 8.)) * rowsT;
             else if (kb == "apply") *algorithmic_bytes = bS + bT + (double)c->nReducedRows * (8. + 4. + 8. + 8. + 4.);
             else if (kb == "tiles") *algorithmic_bytes = (double)c->nReducedRows * (8. + 4. + 8. + 4.);   // s in, t out, packed face x2
-            else if (kb == "cg_update_r") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 28. : 24.) * rowsT;   // fp32 diagonal
-            else if (kb == "cg_update_xp") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 44. : 40.) * rowsT;
+            else if (kb == "cg_update_r") *algorithmic_bytes = (24. + dg) * rowsT;
+            else if (kb == "cg_update_xp") *algorithmic_bytes = (40. + dg) * rowsT;
             else if (kb == "cg_update_xr") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 56. : 48.) * rowsT;
             else if (kb == "cg_update_p") *algorithmic_bytes = (c->P.preconditioner == PS_PRE_DIAGONAL ? 32. : 24.) * rowsT;
             else *algorithmic_bytes = 0;

@@ -165,7 +165,7 @@ struct ps_context {
     int32_t streamRunsHost[4] = {0, 0, 0, 0};
     int32_t rowPerLaneHost[2] = {0, 0};
     void buildDiagonalCodes();
-    ps::DevBuf<float> dinvF;   // the Jacobi diagonal as the PCG kernels read it (fp32 storage, see constructPreconditioner)
+    ps::DevBuf<ps::diag_t> dinvF;   // the Jacobi diagonal as the PCG kernels read it (16-bit storage: ps_common.hpp diag_t, see constructPreconditioner)
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
     ps::DevBuf<double> chebPartials, chebPartials2;   // r.z partials of the Chebyshev polynomial's last term
     double chebLmax = 8.4;                            // upper end of the Chebyshev interval (estimateLambdaMax)

@@ -585,7 +585,7 @@ struct Dist {
     void fixup(ps_context* c, const CGScalars* sc, bool jac, double* fX, int gFix) {
         if (c->nFix > 0) {                                                   // one launch; its partials are the first of the sets k_sum_rr adds up (the others stay zero)
             hipLaunchKernelGGL(k_dist_fixup_merged, dim3(gFix), dim3(BS), 0, c->stream, sc, (const int32_t*)c->fixDof.p, (const int32_t*)c->fixSrc.p, c->nFix,
-                               (const double* const*)c->fixBufs.p, c->r.p, jac ? (const float*)c->dinvF.p : (const float*)nullptr, fX);
+                               (const double* const*)c->fixBufs.p, c->r.p, jac ? (const diag_t*)c->dinvF.p : (const diag_t*)nullptr, fX);
             return;
         }
         for (int a = 0; a < ps_context::NLINK; ++a) {
@@ -593,7 +593,7 @@ struct Dist {
             if (c->nLowOwn[a] + c->nUpOwn[a] > 0)
                 hipLaunchKernelGGL(k_dist_fixup, dim3(gFix), dim3(BS), 0, c->stream, sc, (const int32_t*)c->listLowOwn[a].p, c->nLowOwn[a], (const double*)c->recvLo[a].p,
                                    (const int32_t*)c->listUpOwn[a].p, c->nUpOwn[a], (const double*)c->recvUp[a].p, c->r.p,
-                                   jac ? (const float*)c->dinvF.p : (const float*)nullptr, part, (int)c->ownHi);
+                                   jac ? (const diag_t*)c->dinvF.p : (const diag_t*)nullptr, part, (int)c->ownHi);
         }
     }
     void exchangeX(DevBuf<double> ps_context::*vec) {
@@ -959,10 +959,10 @@ struct Dist {
             for (ps_context* c : R) {
                 const int64_t n = c->ownHi - c->ownLo;
                 if (jac && c->dinvF.p && c->nSystem > 0)       // (a rank without any DOF has no diagonal: constructPreconditioner returns before allocating it)
-                    HIP_CHECK(hipMemsetAsync(c->dinvF.p, 0, (size_t)c->nSystem * sizeof(float), c->stream));   // halo rows: never read as a diagonal
+                    HIP_CHECK(hipMemsetAsync(c->dinvF.p, 0, (size_t)c->nSystem * sizeof(diag_t), c->stream));   // halo rows: never read as a diagonal
                 if (n > 0) {
                     hipLaunchKernelGGL(k_invert_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, n);
-                    if (jac) hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);
+                    if (jac) hipLaunchKernelGGL(k_to_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);
                 }
             }
         }
@@ -975,7 +975,7 @@ struct Dist {
         const double tol = c0->P.tolerance;
         const bool jac = c0->P.preconditioner == PS_PRE_DIAGONAL, cheb = c0->P.preconditioner == PS_PRE_CHEBYSHEV;
         if (c0->P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { c0->err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
-        struct Loc { int64_t n, lo; int vb, stBlocks; const float* dv; CGScalars* sc; Launch L; };
+        struct Loc { int64_t n, lo; int vb, stBlocks; const diag_t* dv; CGScalars* sc; Launch L; };
         std::vector<Loc> loc(R.size());
         for (size_t q = 0; q < R.size(); ++q) {
             ps_context* c = R[q];
@@ -1131,7 +1131,7 @@ struct Dist {
                         ps_context* c = R[q];
                         Loc& l = loc[q];
                         FBuf& f = fb[q];
-                        FusedR fr{l.sc, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, it, c->r.p, jac ? c->dinvF.p : (const float*)nullptr, f.fR, nullptr, 0., nullptr,
+                        FusedR fr{l.sc, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, it, c->r.p, jac ? c->dinvF.p : (const diag_t*)nullptr, f.fR, nullptr, 0., nullptr,
                                   (const double*)c->redbuf.p, (int)c->ownLo, (int)c->ownHi, c->Ap.p, f.stBF};
                         l.L.stList = c->distList[2].p; l.L.nStList = c->nDistList[2];
                         l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
@@ -1178,7 +1178,7 @@ struct Dist {
                         ps_context* c = R[q];
                         Loc& l = loc[q];
                         FBuf& f = fb[q];
-                        const FusedR fr{l.sc, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, it, c->r.p, jac ? c->dinvF.p : (const float*)nullptr, f.fR, nullptr, 0., nullptr,
+                        const FusedR fr{l.sc, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, it, c->r.p, jac ? c->dinvF.p : (const diag_t*)nullptr, f.fR, nullptr, 0., nullptr,
                                         (const double*)c->redbuf.p, (int)c->ownLo, (int)c->ownHi, c->Ap.p};
                         l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                     }

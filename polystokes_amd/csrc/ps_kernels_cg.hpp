@@ -25,14 +25,22 @@
 #define PS_VEC_NT_PL 0     // p as read by k_cg_update_xp
 #endif
 #ifndef PS_VEC_NT_D
-#define PS_VEC_NT_D 1      // the fp32 Jacobi diagonal (read by both step kernels, half an iteration apart)
+#define PS_VEC_NT_D 1      // the stored Jacobi diagonal (read by both step kernels, half an iteration apart)
 #endif
-__device__ inline float2 ldF2(const float2* p, bool nt) {
-    if (!nt) return *p;
+// two consecutive entries of the stored Jacobi diagonal (ps_common.hpp: diag_t) as doubles; i2 = index of the pair
+__device__ inline double2 ldDiag2(const diag_t* __restrict__ d, int64_t i2, bool nt) {
+#ifdef PS_DIAG_FP32
     typedef float psf2 __attribute__((ext_vector_type(2)));
-    const psf2 v = __builtin_nontemporal_load(reinterpret_cast<const psf2*>(p));
-    return make_float2(v.x, v.y);
+    const psf2* q = reinterpret_cast<const psf2*>(d) + i2;
+    const psf2 v = nt ? __builtin_nontemporal_load(q) : *q;
+    return make_double2((double)v.x, (double)v.y);
+#else
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(d) + i2;
+    const uint32_t v = nt ? __builtin_nontemporal_load(q) : *q;
+    return make_double2((double)__builtin_bit_cast(float, v << 16), (double)__builtin_bit_cast(float, v & 0xFFFF0000u));
+#endif
 }
+constexpr uintptr_t DIAG_PAIR_MASK = 2 * sizeof(diag_t) - 1;
 typedef double psd2 __attribute__((ext_vector_type(2)));
 __device__ inline double2 ldD2(const double2* p, bool nt) {
     if (!nt) return *p;
@@ -60,21 +68,21 @@ __global__ void __launch_bounds__(BS) k_cg_init(const double* __restrict__ b, co
     const double s = blockReduceSum(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
-// r = b; x = 0; z = pre(r); p = z; partial rsold = r.z — with the fp32-stored Jacobi diagonal of the main PCG path
-__global__ void __launch_bounds__(BS) k_cg_init_f(const double* __restrict__ b, const float* __restrict__ dinv, double* __restrict__ x,
+// r = b; x = 0; z = pre(r); p = z; partial rsold = r.z — with the stored Jacobi diagonal of the main PCG path (diag_t)
+__global__ void __launch_bounds__(BS) k_cg_init_f(const double* __restrict__ b, const diag_t* __restrict__ dinv, double* __restrict__ x,
                                                   double* __restrict__ r, double* __restrict__ p, int64_t n, double* __restrict__ partial) {
     double acc = 0.;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = b[i];
-        const double z = dinv ? (double)dinv[i] * rv : rv;
+        const double z = dinv ? diagValue(dinv[i]) * rv : rv;
         x[i] = 0.; r[i] = rv; p[i] = z;
         acc += rv * z;
     }
     const double s = blockReduceSum(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
-__global__ void k_to_float(const double* __restrict__ a, float* __restrict__ out, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)a[i];
+__global__ void k_to_diag(const double* __restrict__ a, diag_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = diagStore(a[i]);
 }
 __device__ inline double sumLocal(const double* __restrict__ partial, int count) {   // this thread's share (fixed stride order)
     double acc = 0.;
@@ -211,7 +219,7 @@ __global__ void __launch_bounds__(BS) k_cg_check(CGScalars* sc, const double* __
 // [stop test of iteration it-1] ; alpha ; r -= alpha Ap ; partials of r.r and r.z
 __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ pApPartial, int pApCount,
                                                     const double* __restrict__ xxPartial, int xxCount, int it, const double* __restrict__ Ap,
-                                                    const float* __restrict__ dinv, double* __restrict__ r, int64_t n, double* __restrict__ partial) {
+                                                    const diag_t* __restrict__ dinv, double* __restrict__ r, int64_t n, double* __restrict__ partial) {
     if (sc->done) return;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
     double pAp, xx = 0.;
@@ -225,9 +233,9 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double*
     if (writer) { sc->pAp = pAp; sc->alpha = alpha; }
     double arr = 0., arz = 0.;
     const bool nt = sc->vecNT != 0;
-    const bool vec = ((((uintptr_t)Ap | (uintptr_t)r) & 15) == 0) && (((uintptr_t)dinv & 7) == 0);
+    const bool vec = ((((uintptr_t)Ap | (uintptr_t)r) & 15) == 0) && (((uintptr_t)dinv & DIAG_PAIR_MASK) == 0);
     const int64_t n2 = vec ? n / 2 : 0;
-    const double2* A2 = (const double2*)Ap; const float2* d2 = (const float2*)dinv;
+    const double2* A2 = (const double2*)Ap;
     double2* r2 = (double2*)r;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
         const double2 av = ldD2(A2 + i, nt && PS_VEC_NT_AP);
@@ -235,13 +243,13 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double*
         rv.x = rv.x - alpha * av.x; rv.y = rv.y - alpha * av.y;
         stD2(r2 + i, rv, nt && PS_VEC_NT_R);
         arr += rv.x * rv.x; arr += rv.y * rv.y;
-        if (dinv) { const float2 dv = ldF2(d2 + i, nt && PS_VEC_NT_D); arz += rv.x * ((double)dv.x * rv.x); arz += rv.y * ((double)dv.y * rv.y); }
+        if (dinv) { const double2 dv = ldDiag2(dinv, i, nt && PS_VEC_NT_D); arz += rv.x * (dv.x * rv.x); arz += rv.y * (dv.y * rv.y); }
     }
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = r[i] - alpha * Ap[i];
         r[i] = rv;
         arr += rv * rv;
-        if (dinv) arz += rv * ((double)dinv[i] * rv);
+        if (dinv) arz += rv * (diagValue(dinv[i]) * rv);
     }
     const double s0 = blockReduceSum(arr), s2 = dinv ? blockReduceSum(arz) : 0.;
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s2; }
@@ -251,7 +259,7 @@ __global__ void __launch_bounds__(BS) k_cg_update_r(CGScalars* sc, const double*
 // share of the next p . A p — from the coded diagonal (1 B per entry + 256-entry table in LDS) or the fp64 one.
 template <bool UPP>
 __device__ inline void cgUpdateXp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
-                                  int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
+                                  int it, const double* __restrict__ r, const diag_t* __restrict__ dinv, double* __restrict__ x,
                                   double* __restrict__ p, int64_t n, double* __restrict__ partial,
                                   const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
     if (sc->done) return;
@@ -268,14 +276,14 @@ __device__ inline void cgUpdateXp(CGScalars* sc, const double* __restrict__ red,
     const bool nt = sc->vecNT != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rr = rr; sc->rz = rz; sc->beta = beta; sc->rsold2[(it + 1) & 1] = rz; sc->rsold = rz; }
     double axx = 0., aup = 0.;
-    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x) & 15) == 0) && (((uintptr_t)dinv & 7) == 0) &&
+    const bool vec = ((((uintptr_t)p | (uintptr_t)r | (uintptr_t)x) & 15) == 0) && (((uintptr_t)dinv & DIAG_PAIR_MASK) == 0) &&
                      (!UPP || ((((uintptr_t)uCode & 1) == 0) && (((uintptr_t)uInv & 15) == 0)));
     const int64_t n2 = vec ? n / 2 : 0;
-    const double2* r2 = (const double2*)r; const float2* d2 = (const float2*)dinv;
+    const double2* r2 = (const double2*)r;
     double2* p2 = (double2*)p; double2* x2 = (double2*)x;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
         double2 z = ldD2(r2 + i, nt && PS_VEC_NT_RX);
-        if (dinv) { const float2 dv = ldF2(d2 + i, nt && PS_VEC_NT_D); z.x = (double)dv.x * z.x; z.y = (double)dv.y * z.y; }
+        if (dinv) { const double2 dv = ldDiag2(dinv, i, nt && PS_VEC_NT_D); z.x = dv.x * z.x; z.y = dv.y * z.y; }
         double2 pv = ldD2(p2 + i, nt && PS_VEC_NT_PL), xv = ldD2(x2 + i, nt && PS_VEC_NT_X);
         xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
         pv.x = z.x + beta * pv.x; pv.y = z.y + beta * pv.y;
@@ -289,7 +297,7 @@ __device__ inline void cgUpdateXp(CGScalars* sc, const double* __restrict__ red,
         }
     }
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
-        const double z = dinv ? (double)dinv[i] * r[i] : r[i];
+        const double z = dinv ? diagValue(dinv[i]) * r[i] : r[i];
         const double pv = p[i];
         const double xv = x[i] + alpha * pv;
         const double pn = z + beta * pv;
@@ -305,12 +313,12 @@ __device__ inline void cgUpdateXp(CGScalars* sc, const double* __restrict__ red,
     }
 }
 __global__ void __launch_bounds__(BS) k_cg_update_xp(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
-                                                     int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
+                                                     int it, const double* __restrict__ r, const diag_t* __restrict__ dinv, double* __restrict__ x,
                                                      double* __restrict__ p, int64_t n, double* __restrict__ partial) {
     cgUpdateXp<false>(sc, red, rPartial, rCount, jacobi, it, r, dinv, x, p, n, partial, nullptr, nullptr, nullptr, nullptr);
 }
 __global__ void __launch_bounds__(BS) k_cg_update_xp_u(CGScalars* sc, const double* __restrict__ red, const double* __restrict__ rPartial, int rCount, int jacobi,
-                                                       int it, const double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ x,
+                                                       int it, const double* __restrict__ r, const diag_t* __restrict__ dinv, double* __restrict__ x,
                                                        double* __restrict__ p, int64_t n, double* __restrict__ partial,
                                                        const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
     cgUpdateXp<true>(sc, red, rPartial, rCount, jacobi, it, r, dinv, x, p, n, partial, uCode, uDict, uInv, uPart);
@@ -357,7 +365,7 @@ __global__ void __launch_bounds__(1024) k_fused_local_sum(const CGScalars* __res
 // c of (A p)_j (its halo rows): r_j -= alpha c, and the partial sums of r.r / r.z are corrected by the change of r_j^2.
 __global__ void __launch_bounds__(BS) k_dist_fixup(const CGScalars* __restrict__ sc, const int32_t* __restrict__ listA, int64_t nA, const double* __restrict__ bufA,
                                                    const int32_t* __restrict__ listB, int64_t nB, const double* __restrict__ bufB, double* __restrict__ r,
-                                                   const float* __restrict__ dinv, double* __restrict__ partial, int ownHi) {
+                                                   const diag_t* __restrict__ dinv, double* __restrict__ partial, int ownHi) {
     if (sc->done) return;
     const double alpha = sc->alpha;
     double a0 = 0., a1 = 0.;
@@ -369,7 +377,7 @@ __global__ void __launch_bounds__(BS) k_dist_fixup(const CGScalars* __restrict__
         r[j] = rn;
         const double d = rn * rn - ro * ro;
         a0 += d;
-        if (dinv) a1 += (double)dinv[j] * d;
+        if (dinv) a1 += diagValue(dinv[j]) * d;
     }
     const double s0 = blockReduceSum(a0), s1 = blockReduceSum(a1);
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
@@ -396,7 +404,7 @@ __global__ void __launch_bounds__(BS) k_sum_rr(const CGScalars* __restrict__ sc,
 // links, a pointer table in device memory), -1 = none; built once per setup (Dist::buildFixup).
 constexpr int FIX_MAXSRC = 4;
 __global__ void __launch_bounds__(BS) k_dist_fixup_merged(const CGScalars* __restrict__ sc, const int32_t* __restrict__ dof, const int32_t* __restrict__ src, int64_t n, const double* const* __restrict__ bufs,
-                                                          double* __restrict__ r, const float* __restrict__ dinv, double* __restrict__ partial) {
+                                                          double* __restrict__ r, const diag_t* __restrict__ dinv, double* __restrict__ partial) {
     if (sc->done) return;
     const double alpha = sc->alpha;
     double a0 = 0., a1 = 0.;
@@ -412,7 +420,7 @@ __global__ void __launch_bounds__(BS) k_dist_fixup_merged(const CGScalars* __res
         r[j] = rn;
         const double d = rn * rn - ro * ro;
         a0 += d;
-        if (dinv) a1 += (double)dinv[j] * d;
+        if (dinv) a1 += diagValue(dinv[j]) * d;
     }
     const double s0 = blockReduceSum(a0), s1 = blockReduceSum(a1);
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }

@@ -187,7 +187,7 @@ struct FusedR {
     const double* uPart; int uCount;      // k_cg_update_xp / k_uinv_pp: 1/2 sum uInv p^2 is formed here (partials hold sum uInv p^2)
     const double* xxPart; int xxCount;    // ||x||^2 partials of the previous k_cg_update_xp (stop test of the previous iteration)
     int it;
-    double* r; const float* dinvF;        // residual (updated in place), fp32 Jacobi diagonal (null: identity)
+    double* r; const diag_t* dinvF;       // residual (updated in place), stored Jacobi diagonal (ps_common.hpp: diag_t; null: identity)
     double* rPart;                        // out: partials of r.r at [block], of r.z at [gridDim + block]
     // Chebyshev preconditioner: the polynomial's first term on the new r, z_1 = dinv r / theta -> cz (null: not asked for; then r.z
     // above is that of the Jacobi diagonal)
@@ -255,6 +255,15 @@ __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, d
 // touched once per launch should not sweep the caches of a 45 M-row system, but a system that fits in the 256 MB memory-side
 // cache (or nearly) is served from it between kernels if they are allowed to stay; and a matrix stream whose runs are SHARED
 // between chunks (DevCSR::uniqueLen) is read again and again — it must stay cached (non-temporal it is 11 % slower than unshared).
+// entry `row` of the stored Jacobi diagonal (diag_t: 16 bits, the upper half of an fp32 value; fp32 under -DPS_DIAG_FP32) as a float — 0 past the buffer
+template <bool NT> __device__ inline float bufLoadDiag(__amdgpu_buffer_rsrc_t r, unsigned row) {
+#ifdef PS_DIAG_FP32
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(row * 4u), 0, NT ? PS_EPI_AUX : 0));
+#else
+    const uint32_t h = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)(row * 2u), 0, NT ? PS_EPI_AUX : 0);
+    return __builtin_bit_cast(float, h << 16);
+#endif
+}
 template <bool NT> __device__ inline double bufLoadF64epi(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, NT ? PS_EPI_AUX : 0));
 }
@@ -490,7 +499,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                  rOut = bufRsrc(out, (size_t)rows * 8),
                                  rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
                                  rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
-                                 rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0),
+                                 rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
                                  rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
                                  rFy = bufRsrc(fr.yOut, (MODE == 3 && fr.yOut) ? (size_t)rows * 8 : 0);
     const ChunkWalk W(xcdAware);
@@ -521,7 +530,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         float fdv = 1.f;
         if (MODE == 3) {
             cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, NT ? PS_EPI_AUX : 0));
-            if (fr.dinvF) fdv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(row * 4u), 0, NT ? PS_EPI_AUX : 0));
+            if (fr.dinvF) fdv = bufLoadDiag<NT>(rFd, row);
             if (fr.cz) ci = bufLoadF64epi<NT>(rF64, row * 8u);
         }
         double xv[4 * NV];
@@ -807,7 +816,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
                                  rOut = bufRsrc(out, (size_t)rows * 8),
                                  rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
                                  rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, coded ? (size_t)rows : 0),
-                                 rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * 4 : 0),
+                                 rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
                                  rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
                                  rFy = bufRsrc(fr.yOut, (MODE == 3 && fr.yOut) ? (size_t)rows * 8 : 0);
     const ChunkWalk Wk(xcdAware);
@@ -836,7 +845,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
             float fdv = 1.f;
             if (MODE == 3) {
                 cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, NT ? PS_EPI_AUX : 0));
-                if (fr.dinvF) fdv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(row * 4u), 0, NT ? PS_EPI_AUX : 0));
+                if (fr.dinvF) fdv = bufLoadDiag<NT>(rFd, row);
                 if (fr.cz) ci = bufLoadF64epi<NT>(rF64, row * 8u);
             }
             const EllX X = ellGatherW(cu.W, cur, myBase, rT);
@@ -998,7 +1007,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows),
-                                 rFr = bufRsrc(fr.r, (size_t)rows * 8), rFd = bufRsrc(fr.dinvF, (!CZ && fr.dinvF) ? (size_t)rows * 4 : 0),
+                                 rFr = bufRsrc(fr.r, (size_t)rows * 8), rFd = bufRsrc(fr.dinvF, (!CZ && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
                                  rF64 = bufRsrc(fr.dinv64, CZ ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * 8 : 0);
     const unsigned lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1037,8 +1046,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
             double ciA = 0., ciB = 0.;
             if (CZ) { ciA = bufLoadF64epi<NT>(rF64, rowA * 8u); ciB = bufLoadF64epi<NT>(rF64, rowB * 8u); }
             else if (fr.dinvF) {
-                fdA = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(rowA * 4u), 0, NT ? PS_EPI_AUX : 0));
-                fdB = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rFd, (int)(rowB * 4u), 0, NT ? PS_EPI_AUX : 0));
+                fdA = bufLoadDiag<NT>(rFd, rowA);
+                fdB = bufLoadDiag<NT>(rFd, rowB);
             }
             const EllX XA = ellGatherW(ua.W, sa, myBase, rT);
             const EllX XB = ellGatherW(ub.W, sb, myBase, rT);

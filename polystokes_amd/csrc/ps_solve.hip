@@ -367,12 +367,12 @@ void ps_context::constructPreconditioner() {
     hipLaunchKernelGGL(k_jacobi_diag, dim3(gridFor(nSystem, 256)), dim3(256), 0, stream, St.ptr.p, St.col.p, (const double*)St.val.p, (const int8_t*)St.code.p, valScale, (int)nSystem,
                        (int)nPressures, (int)nActiveVs, dt, McInv.p, uInv.p, rrowFace.p, rrowRegion.p, COM.p, dx, make_int3(gOff[0], gOff[1], gOff[2]), Binv.p, dinv.p,
                        slabEnabled ? 0 : 1);
-    // The PCG kernels read the diagonal in fp32 (4 instead of 8 bytes per DOF in both vector kernels).  Any positive
-    // diagonal is a valid preconditioner; the Jacobi option itself is an extension (the reference's is a stub,
-    // Preconditioners.cpp:37-41).  The fp64 array stays for export / tests; with a slab the conversion follows the
-    // cross-rank completion of the diagonal (Dist::finishSetup).
+    // The PCG kernels read the diagonal in 16 bits (ps_common.hpp: diag_t — 2 instead of 8 bytes per DOF in both step kernels; fp32 until
+    // r05).  Any positive diagonal is a valid preconditioner; the Jacobi option itself is an extension (the reference's is a stub,
+    // Preconditioners.cpp:37-41).  The fp64 array stays for export / tests / the Chebyshev polynomial; with a slab the conversion
+    // follows the cross-rank completion of the diagonal (Dist::finishSetup).
     dinvF.alloc((size_t)nSystem);
-    if (!slabEnabled) hipLaunchKernelGGL(k_to_float, dim3(dotBlocks(nSystem)), dim3(BS), 0, stream, dinv.p, dinvF.p, nSystem);
+    if (!slabEnabled) hipLaunchKernelGGL(k_to_diag, dim3(dotBlocks(nSystem)), dim3(BS), 0, stream, dinv.p, dinvF.p, nSystem);
     if (P.preconditioner == PS_PRE_CHEBYSHEV && !slabEnabled) estimateLambdaMax();   // with a slab: Dist::finishSetup, across the ranks
 }
 
@@ -491,7 +491,7 @@ int ps_context::solve() {
     if (P.solverType != PS_PCG_MATRIX_VECTOR_PRODUCTS) { err = "Unsupported Solver."; return PS_UNSUPPORTED_SOLVER; }
     if (n == 0) { solveIterations = 0; solveError = 0; return PS_SUCCESS; }
     const bool cheb = P.preconditioner == PS_PRE_CHEBYSHEV;
-    const float* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinvF.p : nullptr;
+    const diag_t* dv = (P.preconditioner == PS_PRE_DIAGONAL) ? dinvF.p : nullptr;
     const int vb = dotBlocks(n);
     CGScalars* sc = scal.p;
     const int* done = &sc->done;
@@ -799,7 +799,7 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         const int64_t n = c->nSystem;
         const int vb = dotBlocks(n);
         const double* dv = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinv.p : nullptr;
-        const float* dvf = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinvF.p : nullptr;
+        const diag_t* dvf = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinvF.p : nullptr;
         c->tmp4.alloc((size_t)n); c->tmp5.alloc((size_t)n);
         c->dotPartials.alloc((size_t)std::max(3 * std::max(vb, VGRID), 2 * L.stBlocks()) + 16);
         const uint8_t* ucode = c->uCoded ? c->uCode.p : nullptr;
