@@ -863,7 +863,7 @@ struct Dist {
         for (ps_context* c : R) {
             const int64_t n = c->ownHi - c->ownLo, lo = c->ownLo;
             hipLaunchKernelGGL(k_cheb_first, dim3(dotBlocks(std::max<int64_t>(n, 1))), dim3(BS), 0, c->stream, (const CGScalars*)c->scal.p, (const double*)(c->*Rv).p + lo,
-                               (const double*)c->dinv.p + lo, 1. / theta, c->tmp1.p + lo, n, c->chebPartials.p);
+                               (const diag_t*)c->dinvF.p + lo, 1. / theta, c->tmp1.p + lo, n, c->chebPartials.p);
         }
         for (int j = 1; j < k; ++j) {
             const double rhoN = 1. / (2. * sigma - rho);
@@ -872,7 +872,7 @@ struct Dist {
             for (ps_context* c : R) {
                 const int64_t n = c->ownHi - c->ownLo, lo = c->ownLo;
                 hipLaunchKernelGGL(k_cheb_step, dim3(dotBlocks(std::max<int64_t>(n, 1))), dim3(BS), 0, c->stream, (const CGScalars*)c->scal.p, (const double*)(c->*Rv).p + lo,
-                                   (const double*)c->dinv.p + lo, (const double*)c->tmp5.p + lo, c1, c2, (const double*)(c->*cur).p + lo,
+                                   (const diag_t*)c->dinvF.p + lo, (const double*)c->tmp5.p + lo, c1, c2, (const double*)(c->*cur).p + lo,
                                    j == 1 ? (const double*)nullptr : (const double*)(c->*other).p + lo, (c->*other).p + lo, n, c->chebPartials.p);
             }
             std::swap(cur, other);
@@ -958,11 +958,11 @@ struct Dist {
             exchangeAddY(&ps_context::dinv);
             for (ps_context* c : R) {
                 const int64_t n = c->ownHi - c->ownLo;
-                if (jac && c->dinvF.p && c->nSystem > 0)       // (a rank without any DOF has no diagonal: constructPreconditioner returns before allocating it)
+                if (c->dinvF.p && c->nSystem > 0)       // (a rank without any DOF has no diagonal: constructPreconditioner returns before allocating it)
                     HIP_CHECK(hipMemsetAsync(c->dinvF.p, 0, (size_t)c->nSystem * sizeof(diag_t), c->stream));   // halo rows: never read as a diagonal
                 if (n > 0) {
                     hipLaunchKernelGGL(k_invert_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, n);
-                    if (jac) hipLaunchKernelGGL(k_to_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);
+                    hipLaunchKernelGGL(k_to_diag, dim3(dotBlocks(n)), dim3(BS), 0, c->stream, c->dinv.p + c->ownLo, c->dinvF.p + c->ownLo, n);
                 }
             }
         }

@@ -439,13 +439,13 @@ __global__ void __launch_bounds__(BS) k_sum1(const double* __restrict__ partial,
 }
 // ---- Chebyshev-Jacobi polynomial preconditioner (PS_PRE_CHEBYSHEV) -------------------------------------------------
 // first term: z_1 = dinv r / theta ; partial of r.z (used when the polynomial has this one term only)
-__global__ void __launch_bounds__(BS) k_cheb_first(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
+__global__ void __launch_bounds__(BS) k_cheb_first(const CGScalars* __restrict__ sc, const double* __restrict__ r, const diag_t* __restrict__ dinv,
                                                    double invTheta, double* __restrict__ z, int64_t n, double* __restrict__ partial) {
     if (sc && sc->done) return;
     double acc = 0.;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = r[i];
-        const double v = dinv[i] * rv * invTheta;
+        const double v = diagValue(dinv[i]) * rv * invTheta;
         z[i] = v;
         acc += rv * v;
     }
@@ -454,14 +454,14 @@ __global__ void __launch_bounds__(BS) k_cheb_first(const CGScalars* __restrict__
 }
 // a later term, unfused form (the St kernel's MODE 2 epilogue does the same per row): Az = A z_j given; z_{j+1} -> znext, which may be
 // the z_{j-1} buffer (zprev null: z_{j-1} = 0)
-__global__ void __launch_bounds__(BS) k_cheb_step(const CGScalars* __restrict__ sc, const double* __restrict__ r, const double* __restrict__ dinv,
+__global__ void __launch_bounds__(BS) k_cheb_step(const CGScalars* __restrict__ sc, const double* __restrict__ r, const diag_t* __restrict__ dinv,
                                                   const double* __restrict__ Az, double c1, double c2, const double* __restrict__ z, const double* zprev,
                                                   double* znext, int64_t n, double* __restrict__ partial) {
     if (sc && sc->done) return;
     double acc = 0.;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = r[i], zj = z[i];
-        const double zn = zj + (c1 * (zj - (zprev ? zprev[i] : 0.)) + c2 * (dinv[i] * (rv - Az[i])));
+        const double zn = zj + (c1 * (zj - (zprev ? zprev[i] : 0.)) + c2 * (diagValue(dinv[i]) * (rv - Az[i])));
         znext[i] = zn;
         acc += rv * zn;
     }
@@ -549,6 +549,9 @@ __global__ void __launch_bounds__(BS) k_sum_to(const double* __restrict__ partia
     if (threadIdx.x == 0) out[0] = s;
 }
 // out = a .* b
+__global__ void k_mul_diag(double* __restrict__ out, const diag_t* __restrict__ d, const double* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = diagValue(d[i]) * b[i];
+}
 __global__ void k_mulv(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
 }

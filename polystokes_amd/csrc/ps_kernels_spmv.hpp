@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St(const int32_t* __restrict__ ptr,
 // three-term form (no difference vector to keep):  Az = (A z_j)[row];  z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 dinv (r - Az);
 // partial += r z_{j+1}.  z_j is the kernel's x (xin), z_{j-1} is read from zprev (null: zero) and z_{j+1} goes to `out` — the
 // caller passes the z_{j-1} buffer: every row is read and then written by the same thread.
-struct ChebArgs { const double* r; const double* dinv; const double* zprev; double c1, c2; };
+struct ChebArgs { const double* r; const diag_t* dinv; const double* zprev; double c1, c2; };   // dinv: the stored diagonal (ps_common.hpp)
 // MODE 3 of the St kernel: the residual update of the PCG step inside the epilogue.  x . A x is known BEFORE the kernel starts,
 // from the factored form:  x.Ax = -( sum_active s_f t_f  +  sum_tiles w.v  +  1/2 sum_j uInv_j x_j^2 )  (partials of the S kernel,
 // of the tile kernel and of k_cg_update_xp) — so every workgroup forms alpha itself and does r -= alpha (A p) on its rows with
@@ -191,7 +191,7 @@ struct FusedR {
     double* rPart;                        // out: partials of r.r at [block], of r.z at [gridDim + block]
     // Chebyshev preconditioner: the polynomial's first term on the new r, z_1 = dinv r / theta -> cz (null: not asked for; then r.z
     // above is that of the Jacobi diagonal)
-    const double* dinv64; double invTheta; double* cz;
+    const diag_t* dinvC; double invTheta; double* cz;
     // Slab decomposition (ps_dist.hpp): red = {S + T + 1/2 U summed over the ranks, ||x||^2 over the ranks} replaces the partial
     // sums above; only rows in [ownLo, ownHi) are this rank's DOFs — the others (halo DOFs) carry contributions to a neighbour's
     // rows: their y goes to yOut and the owner subtracts alpha times it afterwards (k_dist_fixup).  Single domain: red = null,
@@ -497,10 +497,10 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
                                  rLen = bufRsrc(len8, (size_t)rows), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(MODE == 1 ? add : xin, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8),
-                                 rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
+                                 rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * sizeof(diag_t) : 0),
                                  rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, uCode ? (size_t)rows : 0),
                                  rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
-                                 rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
+                                 rF64 = bufRsrc(fr.dinvC, (MODE == 3 && fr.cz) ? (size_t)rows * sizeof(diag_t) : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
                                  rFy = bufRsrc(fr.yOut, (MODE == 3 && fr.yOut) ? (size_t)rows * 8 : 0);
     const ChunkWalk W(xcdAware);
     int it = 0;
@@ -526,12 +526,12 @@ __global__ void __launch_bounds__(BS) k_spmv_St_pipe(const uint16_t* __restrict_
         double e1 = 0., cr = 0., ci = 0., cd = 0.;
         int uc = 0;
         if (MODE != 1) { if (uCode) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)srow, 0, BNT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
-        if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }   // cd = z_{j-1} (0: no buffer)
+        if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = (double)bufLoadDiag<false>(rCi, row); cd = bufLoadF64(rCd, row * 8u); }   // cd = z_{j-1} (0: no buffer)
         float fdv = 1.f;
         if (MODE == 3) {
             cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, NT ? PS_EPI_AUX : 0));
             if (fr.dinvF) fdv = bufLoadDiag<NT>(rFd, row);
-            if (fr.cz) ci = bufLoadF64epi<NT>(rF64, row * 8u);
+            if (fr.cz) ci = (double)bufLoadDiag<NT>(rF64, row);
         }
         double xv[4 * NV];
 #pragma unroll
@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
     if (done && *done) return;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
     static_assert(FX == 0 || MODE == 3, "FX: MODE 3 only");
-    if (FX & 1) { fr.cz = nullptr; fr.dinv64 = nullptr; uInv = nullptr; }                                              // (the launch site guarantees uCode != null)
+    if (FX & 1) { fr.cz = nullptr; fr.dinvC = nullptr; uInv = nullptr; }                                              // (the launch site guarantees uCode != null)
     if (FX & 2) { fr.yOut = nullptr; fr.rStride = 0; fr.red = nullptr; fr.ownLo = 0; fr.ownHi = rows; }
     if (FX & 4) { fr.yOut = nullptr; fr.ownLo = 0; fr.ownHi = rows; }   // a rank of a decomposition, chunks of OWNED rows only (the launch under the exchange): no halo row to hand on
     const bool coded = (FX & 1) ? true : uCode != nullptr;
@@ -814,10 +814,10 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(MODE == 1 ? add : xin, (size_t)rows * 8), rE1 = bufRsrc(uInv, (size_t)rows * 8),
                                  rOut = bufRsrc(out, (size_t)rows * 8),
-                                 rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * 8 : 0),
+                                 rCr = bufRsrc(cheb.r, MODE == 2 ? (size_t)rows * 8 : 0), rCi = bufRsrc(cheb.dinv, MODE == 2 ? (size_t)rows * sizeof(diag_t) : 0),
                                  rCd = bufRsrc(cheb.zprev, (MODE == 2 && cheb.zprev) ? (size_t)rows * 8 : 0), rUc = bufRsrc(uCode, coded ? (size_t)rows : 0),
                                  rFr = bufRsrc(fr.r, MODE == 3 ? (size_t)rows * 8 : 0), rFd = bufRsrc(fr.dinvF, (MODE == 3 && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
-                                 rF64 = bufRsrc(fr.dinv64, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
+                                 rF64 = bufRsrc(fr.dinvC, (MODE == 3 && fr.cz) ? (size_t)rows * sizeof(diag_t) : 0), rFcz = bufRsrc(fr.cz, (MODE == 3 && fr.cz) ? (size_t)rows * 8 : 0),
                                  rFy = bufRsrc(fr.yOut, (MODE == 3 && fr.yOut) ? (size_t)rows * 8 : 0);
     const ChunkWalk Wk(xcdAware);
     const unsigned lane = threadIdx.x & 63;
@@ -841,12 +841,12 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
             double e1 = 0., cr = 0., ci = 0., cd = 0.;
             int uc = 0;
             if (MODE != 1) { if (coded) uc = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)row, 0, NT ? PS_EPI_AUX : 0); else e1 = bufLoadF64epi<NT>(rE1, row * 8u); }
-            if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = bufLoadF64(rCi, row * 8u); cd = bufLoadF64(rCd, row * 8u); }   // cd = z_{j-1} (0: no buffer)
+            if (MODE == 2) { cr = bufLoadF64(rCr, row * 8u); ci = (double)bufLoadDiag<false>(rCi, row); cd = bufLoadF64(rCd, row * 8u); }   // cd = z_{j-1} (0: no buffer)
             float fdv = 1.f;
             if (MODE == 3) {
                 cr = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(row * 8u), 0, NT ? PS_EPI_AUX : 0));
                 if (fr.dinvF) fdv = bufLoadDiag<NT>(rFd, row);
-                if (fr.cz) ci = bufLoadF64epi<NT>(rF64, row * 8u);
+                if (fr.cz) ci = (double)bufLoadDiag<NT>(rF64, row);
             }
             const EllX X = ellGatherW(cu.W, cur, myBase, rT);
             // (2) behind them: the next unit's stream and the record of the chunk after it
@@ -1008,7 +1008,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows),
                                  rFr = bufRsrc(fr.r, (size_t)rows * 8), rFd = bufRsrc(fr.dinvF, (!CZ && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
-                                 rF64 = bufRsrc(fr.dinv64, CZ ? (size_t)rows * 8 : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * 8 : 0);
+                                 rF64 = bufRsrc(fr.dinvC, CZ ? (size_t)rows * sizeof(diag_t) : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * 8 : 0);
     const unsigned lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int half = wv >> 1, u0 = 2 * (wv & 1);
@@ -1044,7 +1044,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const double crB = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(rowB * 8u), 0, NT ? PS_EPI_AUX : 0));
             float fdA = 1.f, fdB = 1.f;
             double ciA = 0., ciB = 0.;
-            if (CZ) { ciA = bufLoadF64epi<NT>(rF64, rowA * 8u); ciB = bufLoadF64epi<NT>(rF64, rowB * 8u); }
+            if (CZ) { ciA = (double)bufLoadDiag<NT>(rF64, rowA); ciB = (double)bufLoadDiag<NT>(rF64, rowB); }
             else if (fr.dinvF) {
                 fdA = bufLoadDiag<NT>(rFd, rowA);
                 fdB = bufLoadDiag<NT>(rFd, rowB);
@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell2c(const uint16_t* __restrict
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows), rOut = bufRsrc(out, (size_t)rows * 8),
-                                 rCr = bufRsrc(cheb.r, (size_t)rows * 8), rCi = bufRsrc(cheb.dinv, (size_t)rows * 8),
+                                 rCr = bufRsrc(cheb.r, (size_t)rows * 8), rCi = bufRsrc(cheb.dinv, (size_t)rows * sizeof(diag_t)),
                                  rCd = bufRsrc(cheb.zprev, cheb.zprev ? (size_t)rows * 8 : 0);
     const unsigned lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell2c(const uint16_t* __restrict
             const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_EPI_AUX : 0);
             const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_EPI_AUX : 0);
             const double crA = bufLoadF64(rCr, rowA * 8u), crB = bufLoadF64(rCr, rowB * 8u);
-            const double ciA = bufLoadF64(rCi, rowA * 8u), ciB = bufLoadF64(rCi, rowB * 8u);
+            const double ciA = (double)bufLoadDiag<false>(rCi, rowA), ciB = (double)bufLoadDiag<false>(rCi, rowB);
             const double cdA = bufLoadF64(rCd, rowA * 8u), cdB = bufLoadF64(rCd, rowB * 8u);     // z_{j-1} (0: no buffer)
             const EllX XA = ellGatherW(ua.W, sa, myBase, rT);
             const EllX XB = ellGatherW(ub.W, sb, myBase, rT);

@@ -438,7 +438,7 @@ int ps_context::chebyshevApply(const double* rvec, double* zA, double* zB, doubl
     const int vb = dotBlocks(n);
     const int* done = sc ? &sc->done : nullptr;
     Launch L = mk(this, done);
-    if (!firstDone) hipLaunchKernelGGL(k_cheb_first, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, 1. / theta, zA, n, rzPartial);
+    if (!firstDone) hipLaunchKernelGGL(k_cheb_first, dim3(vb), dim3(BS), 0, stream, sc, rvec, (const diag_t*)dinvF.p, 1. / theta, zA, n, rzPartial);
     int count = firstDone ? 0 : vb;
     double* cur = zA; double* other = zB;    // z_j, and the buffer of z_{j-1} that receives z_{j+1}
     for (int j = 1; j < k; ++j) {
@@ -448,13 +448,13 @@ int ps_context::chebyshevApply(const double* rvec, double* zA, double* zB, doubl
         L.spmvS(0, cur, ts.p);
         L.tiles(0, ts.p);
         if (L.stOnPipe()) {
-            const ChebArgs ca{rvec, dinv.p, zprev, c1, c2};
+            const ChebArgs ca{rvec, dinvF.p, zprev, c1, c2};
             L.spmvSt(2, ts.p, cur, nullptr, other, rzPartial, &ca);
             count = L.stBlocks();
         } else {
             tmp5.alloc((size_t)n);
             L.spmvSt(0, ts.p, cur, nullptr, tmp5.p, dotPartials2.p);
-            hipLaunchKernelGGL(k_cheb_step, dim3(vb), dim3(BS), 0, stream, sc, rvec, dinv.p, (const double*)tmp5.p, c1, c2, (const double*)cur, zprev, other, n, rzPartial);
+            hipLaunchKernelGGL(k_cheb_step, dim3(vb), dim3(BS), 0, stream, sc, rvec, (const diag_t*)dinvF.p, (const double*)tmp5.p, c1, c2, (const double*)cur, zprev, other, n, rzPartial);
             count = vb;
         }
         std::swap(cur, other);
@@ -474,7 +474,7 @@ void ps_context::applyPreconditionerDevice(const double* rvec, double* z, double
         chebyshevApply(rvec, z, scratch, chebPartials.p, nullptr, false, &zfin);
         if (zfin != z) HIP_CHECK(hipMemcpyAsync(z, zfin, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     } else if (P.preconditioner == PS_PRE_DIAGONAL) {
-        hipLaunchKernelGGL(k_mulv, dim3(vb), dim3(BS), 0, stream, z, dinv.p, rvec, n);   // the fp64 diagonal (the PCG kernels read its fp32 copy)
+        hipLaunchKernelGGL(k_mul_diag, dim3(vb), dim3(BS), 0, stream, z, (const diag_t*)dinvF.p, rvec, n);   // the diagonal as the PCG kernels read it
     } else {
         HIP_CHECK(hipMemcpyAsync(z, rvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     }
@@ -559,7 +559,7 @@ int ps_context::solve() {
             L.spmvS(0, pvec.p, ts.p);
             L.tiles(0, ts.p);
             if (fused && cheb) {   // St kernel: r -= alpha A p and the polynomial's first term on the new r; then terms 2..k; then x, p
-                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, nullptr, fR, dinv.p, 1. / chebTheta(), zvec, nullptr, 0, (int)n, nullptr};
+                const FusedR fr{sc, fS, sBlocks, fT, (int)regionCount, fU, vb, dotPartials3.p, vb, it, r.p, nullptr, fR, dinvF.p, 1. / chebTheta(), zvec, nullptr, 0, (int)n, nullptr};
                 L.spmvSt(3, ts.p, pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
                 double* zfin = zvec;
                 const int c2 = chebyshevApply(r.p, zvec, dvec, rzPart, sc, true, &zfin);
