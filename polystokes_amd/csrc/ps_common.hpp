@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -278,6 +279,26 @@ inline bool debugPoisonOn() {
     static const bool on = [] { const char* e = PS_ENV_LOUD("PS_DEBUG_POISON"); return e && atoi(e) != 0; }();
     return on;
 }
+// hipFree synchronises the WHOLE device — every stream of the process, other contexts' included.  Inside a step that is a stall (the setup
+// grows scratch buffers while kernels are in flight), and with two ranks of one communicator in one process (tests/mp_rank.py: ranks as
+// threads over the asynchronous transport) it is a deadlock: rank A blocks in hipFree behind rank B's stream, which waits for a message
+// A has not enqueued yet.  A step therefore never frees: a buffer that is grown or dropped goes on this list, and the list is emptied
+// where the caller's stream has just been synchronised anyway — at the end of a step once more than DEFERRED_FREE_LIMIT bytes wait
+// (trimDeferredFrees), and when a context is destroyed.
+struct DeferredFrees { std::mutex m; std::vector<void*> v; size_t bytes = 0; };
+inline DeferredFrees& deferredFrees() { static DeferredFrees d; return d; }
+constexpr size_t DEFERRED_FREE_LIMIT = (size_t)1 << 30;
+inline void trimDeferredFrees(size_t ifAbove = DEFERRED_FREE_LIMIT) {
+    std::vector<void*> v;
+    {
+        DeferredFrees& d = deferredFrees();
+        std::lock_guard<std::mutex> lk(d.m);
+        if (d.bytes <= ifAbove) return;
+        v.swap(d.v);
+        d.bytes = 0;
+    }
+    for (void* q : v) (void)hipFree(q);
+}
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -298,12 +319,21 @@ struct DevBuf {
         HIP_CHECK(hipMemset((void*)p, 0xff, n * sizeof(T)));
         HIP_CHECK(hipDeviceSynchronize());
     }
-    void free() {
+    void free() {                       // (deferred: see DeferredFrees above)
+        if (p) {
+            DeferredFrees& d = deferredFrees();
+            std::lock_guard<std::mutex> lk(d.m);
+            d.v.push_back((void*)p);
+            d.bytes += n * sizeof(T);
+        }
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() {                         // the context goes away: its stream has been synchronised (ps_context_destroy)
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
     }
-    ~DevBuf() { free(); }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;

@@ -531,6 +531,7 @@ void ps_context_destroy(ps_context* c) {
     hipStream_t s = c->ownsStream ? c->stream : nullptr;
     if (c->pinnedCounters) (void)hipHostFree(c->pinnedCounters);
     delete c;
+    ps::trimDeferredFrees(0);
     if (s) (void)hipStreamDestroy(s);
 }
 
@@ -570,11 +571,15 @@ int32_t ps_step_device(ps_context* c, ps_stats* st) {
     PS_TRY(c, {
         if (c->slabEnabled) {
             if (!c->rcclComm && !c->hostComm) throw Error("a slab is set but no communicator: call ps_comm_init_rccl / ps_comm_init_tcp (or use ps_group_step)");
-            return ps_dist_step_single(c, st);
+            const int result = ps_dist_step_single(c, st);
+            ps::trimDeferredFrees();
+            return result;
         }
         const int rc = c->setup(nullptr);
         if (rc != PS_SUCCESS) return rc;
-        return c->solveStage(st);
+        const int result = c->solveStage(st);
+        ps::trimDeferredFrees();            // (the solve stage ends with the stream synchronised)
+        return result;
     })
 }
 int32_t ps_set_interrupt(ps_context* c, ps_interrupt_fn cb, void* user) {
@@ -603,6 +608,7 @@ int32_t polystokes_step(ps_context* c, const ps_params* p, const ps_fields_in* i
         const int rc = c->setup(nullptr);
         if (rc != PS_SUCCESS) return rc;
         const int result = c->solveStage(st);
+        ps::trimDeferredFrees();
         if (out) {
             const int rc2 = ps_download_fields(c, out);
             if (rc2 != PS_SUCCESS) return rc2;

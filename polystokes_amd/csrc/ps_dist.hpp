@@ -235,8 +235,10 @@ struct Rccl {
     int (*CommDestroy)(void*) = nullptr;
 };
 Rccl& rccl() {
-    static Rccl R;
-    if (!R.h) {
+    // loaded once, by the first caller, under the compiler's guard of a function-local static: several contexts of one process may reach
+    // this from different threads at the same time (a throwing first attempt is retried by the next caller)
+    static Rccl loaded = [] {
+        Rccl R;
         // PS_RCCL_LIB (tests only): another library exporting the same eight entry points — tests/stub_rccl, the stand-in that lets
         // this asynchronous branch run with several ranks on ONE GPU (real RCCL refuses duplicate devices)
         if (const char* alt = PS_ENV_LOUD("PS_RCCL_LIB")) {
@@ -258,8 +260,9 @@ Rccl& rccl() {
         R.GroupStart = (int (*)())sym("ncclGroupStart");
         R.GroupEnd = (int (*)())sym("ncclGroupEnd");
         R.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
-    }
-    return R;
+        return R;
+    }();
+    return loaded;
 }
 // ---- host-staged transport: TCP sockets between the ranks' processes (pack -> D2H -> socket -> H2D -> unpack) ----
 // The same distributed algorithm without RCCL: for boxes where RCCL cannot run (several ranks on one GPU: RCCL refuses
@@ -1616,7 +1619,9 @@ int32_t ps_group_step(ps_group* g, ps_stats* stats) {
         Dist D;
         D.R = g->ranks;
         D.useRccl = false;
-        return distStep(D, stats);
+        const int result = distStep(D, stats);
+        ps::trimDeferredFrees();
+        return result;
     } PS_CATCH_ALL(g->ranks[0])
 }
 

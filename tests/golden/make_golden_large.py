@@ -41,7 +41,7 @@ CASES = {
 # four-kernel PCG step from 2 M rows, the non-temporal cache policy from 4 M rows) engage here by size, unforced.  Same digest form;
 # consumed by the GPU test only (the oracle needs minutes per case: the CPU suite does not re-run them — `make_golden_large.py huge`).
 HUGE = {
-    "cavity128_t16p2_jacobi": lambda: scenes.cavity(128, tile=16, pad=2),      # 5.9 M system DOFs, BASELINE config 3 at half resolution
+    "cavity128_t16p2_jacobi": lambda: scenes.cavity(128, tile=16, pad=2, precond=abi.PRE_DIAGONAL),      # 5.9 M system DOFs, BASELINE config 3 (Jacobi-PCG) at half resolution
     "coil128": lambda: scenes.coil(128, tile=16, pad=2),                        # BASELINE config 2 at its stated size
     "spheres128": lambda: scenes.spheres(128, tile=16, pad=2),                  # BASELINE config 5's geometry (moving solids, mu = 1e4) at 128^3
 }

@@ -2,7 +2,9 @@
 """One rank of a real multi-process distributed step (one process per rank, ps_step_device on a slab context) with the
 host-staged TCP transport — several ranks may share one GPU.  Started by tests/test_gpu_multiprocess.py:
     mp_rank.py <case> <world> <rank> <base_port> <out.npz> [device]
-Writes the rank's owned faces (local layout), masks, result code and iteration count."""
+Writes the rank's owned faces (local layout), masks, result code and iteration count.
+<rank> may be a list "r0,r1" (with <out.npz> a matching list): the process then holds SEVERAL ranks, one thread and one ps_context each
+(the box admits six GPU processes: eight ranks run as four processes of two; the library calls release the GIL)."""
 import os
 import sys
 
@@ -14,8 +16,41 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    case, world, rank, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    case, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[4])
+    ranks, outs = [int(r) for r in sys.argv[3].split(",")], sys.argv[5].split(",")
     device = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    if len(ranks) == 1:
+        run_rank(case, world, ranks[0], port, outs[0], device, None)
+        return
+    import threading
+    if os.environ.get("PS_DBG_DUMP"):           # debugging aid: where every thread stands after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PS_DBG_DUMP"]), exit=False)
+        if os.environ.get("PS_DBG_BT"):         # native stacks too (scripts/dbg/btdump.c)
+            import ctypes
+            bt = ctypes.CDLL(os.environ["PS_DBG_BT"])
+            threading.Timer(int(os.environ["PS_DBG_DUMP"]) + 2, bt.bt_dump_all).start()
+    import polystokes_amd  # noqa: F401  (loaded once, before the threads)
+    done = threading.Barrier(len(ranks))        # no rank of this process frees its buffers while another still enqueues work
+    errs = []
+
+    def body(r, o):
+        try:
+            run_rank(case, world, r, port, o, device, done)
+        except BaseException as e:              # noqa: BLE001 — reported by the process' exit code
+            errs.append((r, repr(e)))
+            done.abort()
+
+    th = [threading.Thread(target=body, args=(r, o)) for r, o in zip(ranks, outs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise SystemExit("ranks failed: %s" % errs)
+
+
+def run_rank(case, world, rank, port, out, device, done):
     import polystokes_amd
     from polystokes_amd import partition
     import mp_cases
@@ -72,6 +107,8 @@ def main():
         res["fused"] = int(s.array("fusedStep")[0])
         res["overlap"] = int(bool(s.dist_stats()["overlap"]))
     np.savez(out, **res)
+    if done is not None:
+        done.wait()
     s.close()
 
 

@@ -3,7 +3,9 @@
 // ranks on a box with ONE GPU: real RCCL refuses several ranks on one device, the TCP transport synchronises the host with the device
 // twice per exchange and the in-process group shares one stream — both hide a missing ordering between the solver and the comm stream.
 //
-// Ranks = processes sharing GPU 0.  Every message is stream-ordered on the caller's stream, as in RCCL, and NOTHING in it involves the
+// Ranks = processes sharing GPU 0 — or several ranks per process, one THREAD each (r05: eight ranks as four processes of two, the box
+// admits six GPU processes): a peer of the same process is reached through its plain device pointer instead of an IPC mapping, nothing
+// else differs.  Every message is stream-ordered on the caller's stream, as in RCCL, and NOTHING in it involves the
 // host after the communicator is built (no hipStreamSynchronize / hipEventSynchronize / hipDeviceSynchronize, no host-side handshake):
 //   send k:  [stream waits until the receiver has taken message k - 2, whose mailbox slot this one reuses]
 //            device copy into the receiver's mailbox (its device memory, mapped with hipIpcOpenMemHandle)
@@ -45,6 +47,8 @@ constexpr int ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, 
 struct RankCtl {
     std::atomic<int> ready;                          // 1: the handle below is valid; 3: this rank has left
     hipIpcMemHandle_t mailbox;                       // this rank's mailbox allocation (flags page + message slots)
+    int pid;                                         // the process holding it, and its address there: a rank of the SAME process cannot
+    char* base;                                      // open its own process' handle — it uses the pointer
 };
 struct Shm { RankCtl rank[MAXW]; };                  // only the start-up handshake goes through the host
 
@@ -62,6 +66,7 @@ struct Comm {
     size_t slotBytes = 0;
     char* mailbox = nullptr;
     char* peerMailbox[MAXW] = {nullptr};
+    bool peerLocal[MAXW] = {};                       // peerMailbox[q] is a pointer of this process, not an IPC mapping
     uint32_t sendSeq[MAXW][CH] = {}, recvSeq[MAXW][CH] = {};
     double* arStage = nullptr;                       // world x 64 doubles: the contributions lined up for the sum kernel
     size_t chBytes(int ch) const { return ch == 0 ? slotBytes : AR_BYTES; }
@@ -80,6 +85,21 @@ thread_local Comm* g_groupComm = nullptr;
 #define STUB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "[stub rccl] %s -> %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return ncclUnhandledCudaError; } } while (0)
 
 const bool g_dbg = getenv("PS_STUB_DEBUG") != nullptr;
+// Payloads move by a KERNEL on the caller's stream, not by hipMemcpyAsync: a device-to-device copy goes through the HSA runtime's copy
+// queue (SDMA ring or blit queue), ONE per process and agent, filled under a mutex by every stream of the process.  With two ranks of a
+// communicator in one process (threads) a copy of rank A that waits for A's value-wait sits at the head of that queue, the ring fills
+// with the 25 iterations A's host enqueues ahead, A's thread spins for space holding the mutex — and rank B's thread, whose copy would
+// release A, blocks on the mutex (native stacks: scripts/dbg/btdump.c).  A kernel uses the stream's own queue.  (All messages are doubles.)
+__global__ void k_copy_words(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int copyOn(hipStream_t st, void* dst, const void* src, size_t bytes) {
+    if ((bytes & 7) || ((uintptr_t)dst & 7) || ((uintptr_t)src & 7)) return ncclInvalidArgument;
+    const size_t n = bytes / 8;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_copy_words, dim3(grid ? grid : 1), dim3(256), 0, st, (unsigned long long*)dst, (const unsigned long long*)src, n);
+    return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+}
 int doSend(Comm* c, int ch, const void* buf, size_t bytes, int peer, hipStream_t st) {
     if (bytes > c->chBytes(ch)) { std::fprintf(stderr, "[stub rccl] message of %zu bytes exceeds the mailbox slot (%zu): raise PS_STUB_MAILBOX_MB\n", bytes, c->chBytes(ch)); return ncclInvalidArgument; }
     const uint32_t k = c->sendSeq[peer][ch]++;
@@ -87,7 +107,7 @@ int doSend(Comm* c, int ch, const void* buf, size_t bytes, int peer, hipStream_t
     if (g_dbg) std::fprintf(stderr, "[stub %d] send ch %d -> %d, %zu B, k %u, stream %p\n", c->rank, ch, peer, bytes, k, (void*)st);
     if (k >= (uint32_t)SLOTS)   // the slot's previous message (k - SLOTS) must have been copied out by the receiver
         STUB_HIP(hipStreamWaitValue32(st, Comm::consFlag(c->mailbox, peer, ch), k - SLOTS + 1, hipStreamWaitValueGte, 0xffffffffu));
-    if (bytes) STUB_HIP(hipMemcpyAsync(c->peerMailbox[peer] + c->regionOff(c->rank, ch, slot), buf, bytes, hipMemcpyDeviceToDevice, st));
+    if (bytes) { const int rc = copyOn(st, c->peerMailbox[peer] + c->regionOff(c->rank, ch, slot), buf, bytes); if (rc) return rc; }
     STUB_HIP(hipStreamWriteValue32(st, Comm::readyFlag(c->peerMailbox[peer], c->rank, ch), k + 1, 0));
     return ncclSuccess;
 }
@@ -97,7 +117,7 @@ int doRecv(Comm* c, int ch, void* buf, size_t bytes, int peer, hipStream_t st) {
     const int slot = (int)(k % SLOTS);
     if (g_dbg) std::fprintf(stderr, "[stub %d] recv ch %d <- %d, %zu B, k %u, stream %p\n", c->rank, ch, peer, bytes, k, (void*)st);
     STUB_HIP(hipStreamWaitValue32(st, Comm::readyFlag(c->mailbox, peer, ch), k + 1, hipStreamWaitValueGte, 0xffffffffu));
-    if (bytes) STUB_HIP(hipMemcpyAsync(buf, c->mailbox + c->regionOff(peer, ch, slot), bytes, hipMemcpyDeviceToDevice, st));
+    if (bytes) { const int rc = copyOn(st, buf, c->mailbox + c->regionOff(peer, ch, slot), bytes); if (rc) return rc; }
     STUB_HIP(hipStreamWriteValue32(st, Comm::consFlag(c->peerMailbox[peer], c->rank, ch), k + 1, 0));
     return ncclSuccess;
 }
@@ -110,7 +130,7 @@ int flush(Comm* c, std::vector<Op>& ops) {
         if (ss.size() != rr.size()) return ncclInvalidUsage;
         for (size_t k = 0; k < ss.size(); ++k) {
             if (ss[k]->bytes != rr[k]->bytes) return ncclInvalidArgument;
-            if (ss[k]->bytes) STUB_HIP(hipMemcpyAsync(rr[k]->rbuf, ss[k]->sbuf, ss[k]->bytes, hipMemcpyDeviceToDevice, rr[k]->stream));
+            if (ss[k]->bytes) { const int rc = copyOn(rr[k]->stream, rr[k]->rbuf, ss[k]->sbuf, ss[k]->bytes); if (rc) return rc; }
         }
         std::vector<Op> rest;
         for (const Op& o : ops) if (o.peer != c->rank) rest.push_back(o);
@@ -162,6 +182,7 @@ int ncclCommInitRank(void** comm, int world, StubUid id, int rank) {
     STUB_HIP(hipDeviceSynchronize());                                                 // (start-up only: the zeros are there before a peer can write)
     RankCtl& me = c->shm->rank[rank];
     if (world > 1) STUB_HIP(hipIpcGetMemHandle(&me.mailbox, c->mailbox));
+    me.pid = (int)getpid(); me.base = c->mailbox;
     me.ready.store(1, std::memory_order_release);
     for (int q = 0; q < world; ++q) {
         if (q == rank) continue;
@@ -171,7 +192,8 @@ int ncclCommInitRank(void** comm, int world, StubUid id, int rank) {
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { std::fprintf(stderr, "[stub rccl] rank %d never arrived\n", q); return ncclSystemError; }
         }
-        STUB_HIP(hipIpcOpenMemHandle((void**)&c->peerMailbox[q], pr.mailbox, hipIpcMemLazyEnablePeerAccess));
+        if (pr.pid == (int)getpid()) { c->peerMailbox[q] = pr.base; c->peerLocal[q] = true; }
+        else STUB_HIP(hipIpcOpenMemHandle((void**)&c->peerMailbox[q], pr.mailbox, hipIpcMemLazyEnablePeerAccess));
     }
     *comm = c;
     return ncclSuccess;
@@ -204,7 +226,7 @@ int ncclRecv(void* buf, size_t count, int dtype, int peer, void* comm, hipStream
 int ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm, hipStream_t st) {
     Comm* c = (Comm*)comm;
     if (!c || dtype != 8 || op != 0 || count > 64) return ncclInvalidArgument;
-    STUB_HIP(hipMemcpyAsync(c->arStage + (size_t)c->rank * 64, sendbuf, count * 8, hipMemcpyDeviceToDevice, st));
+    { const int rc = copyOn(st, c->arStage + (size_t)c->rank * 64, sendbuf, count * 8); if (rc) return rc; }
     for (int q = 0; q < c->world; ++q) if (q != c->rank) { const int rc = doSend(c, 1, sendbuf, count * 8, q, st); if (rc) return rc; }
     for (int q = 0; q < c->world; ++q) if (q != c->rank) { const int rc = doRecv(c, 1, c->arStage + (size_t)q * 64, count * 8, q, st); if (rc) return rc; }
     hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(64), 0, st, (const double*)c->arStage, c->world, (int)count, (double*)recvbuf);
@@ -215,7 +237,7 @@ int ncclCommDestroy(void* comm) {
     Comm* c = (Comm*)comm;
     if (!c) return ncclSuccess;
     (void)hipDeviceSynchronize();                    // teardown only: the mailboxes go away
-    for (int q = 0; q < c->world; ++q) if (q != c->rank && c->peerMailbox[q]) (void)hipIpcCloseMemHandle(c->peerMailbox[q]);
+    for (int q = 0; q < c->world; ++q) if (q != c->rank && c->peerMailbox[q] && !c->peerLocal[q]) (void)hipIpcCloseMemHandle(c->peerMailbox[q]);
     // the last rank out removes the shared-memory name (the others may still hold their mappings)
     c->shm->rank[c->rank].ready.store(3, std::memory_order_release);
     bool last = true;
