@@ -258,7 +258,8 @@ __host__ __device__ inline void unpackFace(uint32_t q, int& i, int& j, int& k, i
 }
 
 // The Jacobi diagonal as the PCG kernels read it (ps_context::dinvF): 16 bits per DOF — the upper half of the fp32 value of 1 / A_jj, rounded
-// to nearest even (sign, 8 exponent bits, 7 mantissa bits: 0.4 % relative).  The preconditioner is ANY fixed positive diagonal: the
+// to nearest even (sign — the system is assembled negative definite, with the reference's signs — 8 exponent bits, 7 mantissa bits: 0.4 %
+// relative).  The preconditioner is ANY fixed diagonal of one sign: the
 // recurrences, the stop test and every sum stay fp64, x converges to the same tolerance; what changes is the operator D^-1 A whose
 // spectrum sets the iteration count — by the rounding of D (r05: 987 iterations at 256^3 either way).  It is read by both step kernels
 // of every iteration: 8 B/DOF as fp32 — the 6 % a Jacobi iteration cost over an identity one — 4 B/DOF now.  -DPS_DIAG_FP32: the fp32 copy of r02-r05.

@@ -336,6 +336,34 @@ def test_chebyshev_preconditioner_matches_oracle(gpu, oracle_mod, scene):
         assert int(gpu.stats.solveData[1]) >= 2.5 * itg, (int(gpu.stats.solveData[1]), itg)
 
 
+@pytest.mark.parametrize("scene", ["cavity32", "blob6_variable_viscosity"])
+def test_jacobi_on_the_stored_diagonal_matches_oracle(gpu, oracle_mod, scene):
+    """The Jacobi extension reads 1 / A_jj as the upper 16 bits of its fp32 value, rounded to nearest even (ps_common.hpp: diag_t);
+    the oracle restates the rounding (ps_oracle_solve.cpp: storedDinv).  The stored values are EQUAL bit for bit (the rounding itself is
+    0.4 %: a restatement without it would miss by that much), every one within 2^-8 of the fp64 reciprocal, z = M^-1 r equal, the
+    iteration counts equal (± 1) and x within the tolerance."""
+    sc, p = scenes.cavity(32) if scene == "cavity32" else scenes.blob(seed=6)
+    p.preconditioner = abi.PRE_DIAGONAL
+    p.tolerance = 1e-6
+    o = oracle_mod.Oracle()
+    o.run(sc, p)
+    assert gpu.step(sc, p) == o.result == abi.SUCCESS
+    n = gpu.nP + gpu.nT
+    one = np.ones(n)
+    zo, zg = o.precondition(one), gpu.precondition(one)          # the stored diagonal itself
+    same = zo == zg                                               # (the two diagonals differ by 1e-9 before the rounding: an entry next to a
+    assert same.mean() >= 0.9999                                  #  rounding midpoint may land on the other neighbour — one step of 2^-8)
+    assert np.abs(zg / zo - 1.0).max() <= 2.0 ** -7
+    dg = o.array("diagA")                                         # (negative: the system is assembled with the reference's signs; 0 -> 1 where a row is empty)
+    exact = np.where(dg != 0., 1.0 / np.where(dg != 0., dg, 1.), 1.0)
+    assert 1e-5 < np.abs(zg / exact - 1.0).max() <= 2.0 ** -8 * (1 + 1e-6)
+    r = np.random.RandomState(5).standard_normal(n)
+    assert np.array_equal(o.precondition(r)[same], gpu.precondition(r)[same])
+    assert abs(int(gpu.stats.solveData[1]) - int(o.stats.solveData[1])) <= 1, (int(gpu.stats.solveData[1]), int(o.stats.solveData[1]))
+    xo, xg = o.array("solutionVector"), gpu.array("solutionVector")
+    assert np.linalg.norm(xg - xo) <= 10 * p.tolerance * np.linalg.norm(xo)
+
+
 def test_export_component_matrices_roundtrip(gpu, oracle_mod, tmp_path):
     """exportComponentMatrices / exportStats (Solver.cpp:543-606): MatrixMarket files with the reference's names,
     read back with scipy and compared with the oracle's blocks (reference numbering)."""
