@@ -564,7 +564,7 @@ int32_t ps_setup_device(ps_context* c, ps_stats* st) {
 }
 int32_t ps_solve_device(ps_context* c, ps_stats* st) {
     if (!c) return PS_FAILED;
-    PS_TRY(c, { refuseSlab(c, "ps_solve_device"); return c->solveStage(st); })
+    PS_TRY(c, { refuseSlab(c, "ps_solve_device"); const int result = c->solveStage(st); ps::trimDeferredFrees(); return result; })
 }
 int32_t ps_step_device(ps_context* c, ps_stats* st) {
     if (!c) return PS_FAILED;
