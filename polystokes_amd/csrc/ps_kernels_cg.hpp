@@ -24,6 +24,9 @@
 #ifndef PS_VEC_NT_PL
 #define PS_VEC_NT_PL 0     // p as read by k_cg_update_xp
 #endif
+#ifndef PS_VEC_NT_U
+#define PS_VEC_NT_U 1      // the uInv codes as read by k_cg_update_xp_u
+#endif
 #ifndef PS_VEC_NT_D
 #define PS_VEC_NT_D 1      // the stored Jacobi diagonal (read by both step kernels, half an iteration apart)
 #endif
@@ -291,7 +294,7 @@ __device__ inline void cgUpdateXp(CGScalars* sc, const double* __restrict__ red,
         axx += xv.x * xv.x; axx += xv.y * xv.y;
         if (UPP) {
             double u0, u1;
-            if (uCode) { const uint16_t cc = nt ? __builtin_nontemporal_load((const uint16_t*)uCode + i) : ((const uint16_t*)uCode)[i]; u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
+            if (uCode) { const uint16_t cc = (nt && PS_VEC_NT_U) ? __builtin_nontemporal_load((const uint16_t*)uCode + i) : ((const uint16_t*)uCode)[i]; u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
             else { const double2 uv = ldD2((const double2*)uInv + i, nt); u0 = uv.x; u1 = uv.y; }
             aup += u0 * (pv.x * pv.x); aup += u1 * (pv.y * pv.y);
         }
@@ -497,7 +500,7 @@ __device__ inline void cgUpdateXpZ(CGScalars* sc, const double* __restrict__ rrP
         axx += xv.x * xv.x; axx += xv.y * xv.y;
         if (UPP) {
             double u0, u1;
-            if (uCode) { const uint16_t cc = nt ? __builtin_nontemporal_load((const uint16_t*)uCode + i) : ((const uint16_t*)uCode)[i]; u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
+            if (uCode) { const uint16_t cc = (nt && PS_VEC_NT_U) ? __builtin_nontemporal_load((const uint16_t*)uCode + i) : ((const uint16_t*)uCode)[i]; u0 = dict[cc & 255]; u1 = dict[cc >> 8]; }
             else { const double2 uv = ldD2((const double2*)uInv + i, nt); u0 = uv.x; u1 = uv.y; }
             aup += u0 * (pv.x * pv.x); aup += u1 * (pv.y * pv.y);
         }

@@ -250,6 +250,12 @@ __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, d
 #ifndef PS_EPI_AUX
 #define PS_EPI_AUX 2       // the per-row streams of the epilogues (row length, x, uInv / codes): read once per launch -> nt (St -3 %)
 #endif
+#ifndef PS_DIAG_AUX
+#define PS_DIAG_AUX PS_EPI_AUX   // the stored Jacobi diagonal in the residual-update epilogue (read again by the x/p update half an iteration later)
+#endif
+#ifndef PS_UC_AUX
+#define PS_UC_AUX PS_EPI_AUX     // the uInv codes in the two-unit St kernels (read again by the x/p update)
+#endif
 // POL (template parameter of the pipelined kernels), bit 0: the non-temporal policies above for the result stores and the per-row
 // epilogue streams; bit 1: for the matrix stream (col16 / code4 / val4).  Chosen per system (Launch::policy): streams that are
 // touched once per launch should not sweep the caches of a 45 M-row system, but a system that fits in the 256 MB memory-side
@@ -258,9 +264,9 @@ __device__ inline void bufStoreF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff, d
 // entry `row` of the stored Jacobi diagonal (diag_t: 16 bits, the upper half of an fp32 value; fp32 under -DPS_DIAG_FP32) as a float — 0 past the buffer
 template <bool NT> __device__ inline float bufLoadDiag(__amdgpu_buffer_rsrc_t r, unsigned row) {
 #ifdef PS_DIAG_FP32
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(row * 4u), 0, NT ? PS_EPI_AUX : 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(row * 4u), 0, NT ? PS_DIAG_AUX : 0));
 #else
-    const uint32_t h = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)(row * 2u), 0, NT ? PS_EPI_AUX : 0);
+    const uint32_t h = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)(row * 2u), 0, NT ? PS_DIAG_AUX : 0);
     return __builtin_bit_cast(float, h << 16);
 #endif
 }
@@ -1038,8 +1044,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const bool liveA = (int)lane < ua.rows, liveB = (int)lane < ub.rows;
             const unsigned rowA = liveA ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = liveB ? (unsigned)ub.row0 + lane : ROW_NONE;
             const double eA = bufLoadF64epi<NT>(rE0, rowA * 8u), eB = bufLoadF64epi<NT>(rE0, rowB * 8u);
-            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_EPI_AUX : 0);
-            const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_EPI_AUX : 0);
+            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_UC_AUX : 0);
+            const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_UC_AUX : 0);
             const double crA = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(rowA * 8u), 0, NT ? PS_EPI_AUX : 0));
             const double crB = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(rowB * 8u), 0, NT ? PS_EPI_AUX : 0));
             float fdA = 1.f, fdB = 1.f;
@@ -1114,8 +1120,8 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell2c(const uint16_t* __restrict
             if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
             const unsigned rowA = (int)lane < ua.rows ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = (int)lane < ub.rows ? (unsigned)ub.row0 + lane : ROW_NONE;
             const double eA = bufLoadF64epi<NT>(rE0, rowA * 8u), eB = bufLoadF64epi<NT>(rE0, rowB * 8u);
-            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_EPI_AUX : 0);
-            const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_EPI_AUX : 0);
+            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_UC_AUX : 0);
+            const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_UC_AUX : 0);
             const double crA = bufLoadF64(rCr, rowA * 8u), crB = bufLoadF64(rCr, rowB * 8u);
             const double ciA = (double)bufLoadDiag<false>(rCi, rowA), ciB = (double)bufLoadDiag<false>(rCi, rowB);
             const double cdA = bufLoadF64(rCd, rowA * 8u), cdB = bufLoadF64(rCd, rowB * 8u);     // z_{j-1} (0: no buffer)
