@@ -287,7 +287,7 @@ inline bool debugPoisonOn() {
 // where the caller's stream has just been synchronised anyway — at the end of a step once more than DEFERRED_FREE_LIMIT bytes wait
 // (trimDeferredFrees), and when a context is destroyed.
 struct DeferredFrees { std::mutex m; std::vector<void*> v; size_t bytes = 0; };
-inline DeferredFrees& deferredFrees() { static DeferredFrees d; return d; }
+inline DeferredFrees& deferredFrees() { static DeferredFrees* d = new DeferredFrees; return *d; }   // never destroyed: a context may outlive the statics at process exit
 constexpr size_t DEFERRED_FREE_LIMIT = (size_t)1 << 30;
 inline void trimDeferredFrees(size_t ifAbove = DEFERRED_FREE_LIMIT) {
     std::vector<void*> v;
