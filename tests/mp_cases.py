@@ -41,10 +41,12 @@ def make(case):
         return sc, p
     if base in ("cavity64_b2x2x1", "cavity64_b2x2x2"):          # bricks: cuts along x and y, four processes; along all three axes, eight ranks
         return scenes.cavity(64, tile=16, precond=abi.PRE_DIAGONAL)
+    if base == "cavity32_b2x2x2":          # the small eight-rank case (tile 8: bricks of 16^3 cells)
+        return scenes.cavity(32, tile=8, precond=abi.PRE_DIAGONAL)
     if base == "cavity_b2x1x2":
         return tall_cavity(32, 64)
     raise KeyError(case)
 
 
-DIMS = {"cavity64_b2x2x1": (2, 2, 1), "cavity_b2x1x2": (2, 1, 2), "cavity64_b2x2x2": (2, 2, 2)}      # brick cases: ranks per axis
-WORLD = {"cavity64_b2x2x2": 8, "cavity64_b2x2x1": 4, "cavity_b2x1x2": 4, "cavity_w2": 2, "cavity_w3_jacobi": 3, "coil_w2": 2, "cavity_w2_bicgstab": 2, "cavity_w2_chebyshev": 2}
+DIMS = {"cavity64_b2x2x1": (2, 2, 1), "cavity_b2x1x2": (2, 1, 2), "cavity64_b2x2x2": (2, 2, 2), "cavity32_b2x2x2": (2, 2, 2)}      # brick cases: ranks per axis
+WORLD = {"cavity64_b2x2x2": 8, "cavity32_b2x2x2": 8, "cavity64_b2x2x1": 4, "cavity_b2x1x2": 4, "cavity_w2": 2, "cavity_w3_jacobi": 3, "coil_w2": 2, "cavity_w2_bicgstab": 2, "cavity_w2_chebyshev": 2}
