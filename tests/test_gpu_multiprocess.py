@@ -109,21 +109,21 @@ def test_multiprocess_async_transport_matches_tcp_and_single_domain(case, tmp_pa
 
 
 def test_eight_asynchronous_ranks_as_bricks(tmp_path):
-    """2 x 2 x 2 bricks of the 64^3 cavity over the asynchronous transport: EIGHT ranks, every one with its own ps_context, solver stream and comm
+    """2 x 2 x 2 bricks of a 32^3 cavity (tile 8) over the asynchronous transport: EIGHT ranks, every one with its own ps_context, solver stream and comm
     stream, exchanging with three face neighbours and three diagonal ones in one grouped round (Dist::valuesOut / contributionsBack) and
     all-reducing among eight — as four processes of two ranks (one thread each; tests/stub_rccl reaches a rank of the same process through
     its device pointer).  The overlapped four-kernel step, Jacobi-PCG; compared with the single domain.  (VERDICT r04 missing #3: eight
     asynchronous ranks had never run; the in-process group of eight shares one stream.)"""
     if not os.path.exists(STUB_LIB):
         pytest.fail("tests/stub_rccl/libps_stub_rccl.so is missing: __graft_entry__.build() compiles it")
-    case, world = "cavity64_b2x2x2", 8
+    case, world = "cavity32_b2x2x2", 8           # tile 8, bricks of 16^3 owned cells (eight ranks share one GPU: the 64^3 case takes 50 s per run, this one 10)
     env = {"PS_TEST_TRANSPORT": "stub", "PS_RCCL_LIB": STUB_LIB, "PS_DIST_OVERLAP": "1", "PS_FUSED_R": "1"}
     res = _run_ranks(case, world, tmp_path, env, per_process=2)
     assert all(int(r["fused"]) == 1 and int(r["overlap"]) == 1 for r in res)
     _compare_with_single_domain(case, world, res)
-    (tmp_path / "fwd").mkdir()                   # the three forwarding rounds of r03 / r04, on the small case (eight ranks share one GPU: 50 s per run at 64^3)
-    res_fwd = _run_ranks("cavity32_b2x2x2", world, tmp_path / "fwd", dict(env, PS_DIST_FORWARD="1"), per_process=2)
-    _compare_with_single_domain("cavity32_b2x2x2", world, res_fwd)
+    (tmp_path / "fwd").mkdir()                   # the three forwarding rounds of r03 / r04
+    res_fwd = _run_ranks(case, world, tmp_path / "fwd", dict(env, PS_DIST_FORWARD="1"), per_process=2)
+    _compare_with_single_domain(case, world, res_fwd)
 
 
 def test_async_transport_exposes_a_missing_stream_order(tmp_path):
