@@ -2,6 +2,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from polystokes_amd import _abi as abi
+from polystokes_amd import scenes
 
 
 def basis_rows(off, axis):
@@ -136,3 +137,23 @@ def fuzz_brick_case(seed, tol=1e-6):
     p.tolerance = float(tol)
     p.maxSolverIterations = 20000
     return sc, p, dims, n, tile
+
+
+def rigid_rotation_scene(n=24, w=(0.3, -0.2, 0.5)):
+    """the droplet scene with u = w x (x - centre) sampled on its faces; returns (scene, params, the three face arrays flattened)"""
+    sc, p = scenes.droplet(n)
+    dx = sc.dx
+    w = np.array(w)
+    c = np.array([0.5, 0.5, 0.5])
+    ref = []
+    for a in range(3):
+        shp = [n, n, n]
+        shp[a] += 1
+        i, j, k = np.meshgrid(np.arange(shp[0]), np.arange(shp[1]), np.arange(shp[2]), indexing="ij")      # (x, y, z) index order
+        pos = [(i + (0.0 if a == 0 else 0.5)) * dx - c[0], (j + (0.0 if a == 1 else 0.5)) * dx - c[1], (k + (0.0 if a == 2 else 0.5)) * dx - c[2]]
+        u = np.cross(w, np.stack(pos, axis=-1))[..., a]
+        ua = np.ascontiguousarray(u.transpose(2, 1, 0)).astype(np.float32)                                 # stored z-major, x fastest
+        assert ua.shape == np.asarray(sc.vel[a]).shape
+        sc.vel[a][:] = ua
+        ref.append(ua.ravel())
+    return sc, p, ref

@@ -526,6 +526,21 @@ def test_exported_system_solved_independently(gpu, tmp_path):
     assert np.linalg.norm(A @ x - b) <= 1e-7 * np.linalg.norm(b)
 
 
+def test_rigid_rotation_is_preserved_on_the_gpu(gpu):
+    """Known answer, no oracle involved (tests/test_oracle_kat.py holds the same for the oracle): a liquid ball spinning rigidly about a tilted
+    axis has zero strain rate — b = 0 and the velocity comes back unchanged, on the active faces and through the 26-DOF fit of the reduced
+    tile (whose basis contains the rigid modes)."""
+    from helpers import rigid_rotation_scene
+    sc, p, ref = rigid_rotation_scene()
+    assert gpu.step(sc, p) == abi.SUCCESS and gpu.nRegions >= 1
+    assert np.abs(gpu.array("b")).max() < 1e-9 * (np.abs(gpu.array("activeRHSVector")).max() / sc.dx)
+    vmax = max(np.abs(r).max() for r in ref)
+    for a in range(3):
+        ok = gpu.valid[a].ravel() > 0
+        assert ok.sum() > 100
+        assert np.abs(gpu.vel[a].ravel()[ok] - ref[a][ok]).max() <= 1e-6 * vmax
+
+
 def test_interrupt_callback_stops_the_solve(gpu):
     sc, p = scenes.cavity(32)
     calls = []

@@ -211,6 +211,23 @@ def test_rigid_translation_is_preserved(oracle_mod):
         np.testing.assert_allclose(out[ok], v, rtol=1e-6)
 
 
+def test_rigid_rotation_is_preserved(oracle_mod):
+    # the same ball spinning rigidly about a tilted axis through its centre: u = w x (x - c) is linear, its strain rate vanishes exactly
+    # on the staggered grid (every stencil of S differences a linear field) -> b == 0, velocity unchanged, on active faces AND on the
+    # reduced tiles (the 26 basis functions contain the rigid modes: K times a rotation is zero)
+    from helpers import rigid_rotation_scene
+    sc, p, ref = rigid_rotation_scene()
+    o = _run(oracle_mod, sc, p)
+    assert o.result == abi.SUCCESS and o.nRegions >= 1
+    assert np.abs(o.array("b")).max() < 1e-9 * (np.abs(o.array("activeRHSVector")).max() / sc.dx)      # (measured: 8e-11)
+    vmax = max(np.abs(r).max() for r in ref)
+    for a in range(3):
+        out = o.array("vel" + "XYZ"[a])
+        ok = o.array("valid" + "XYZ"[a]) > 0
+        assert ok.sum() > 100
+        assert np.abs(out[ok] - ref[a][ok]).max() <= 1e-6 * vmax                                          # (measured: 2e-8, the fp32 output)
+
+
 def test_eigen_cg_config1(oracle_mod):
     # BASELINE config 1: 32^3-class uniform beam, explicit A + Eigen CG (Jacobi, ||r|| <= tol ||b||)
     sc, p = scenes.beam(16)
