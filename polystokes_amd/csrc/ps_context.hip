@@ -513,7 +513,9 @@ ps_context* ps_context_create(int32_t device) {
     }
     ps_context* c = new ps_context();
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    // a NON-BLOCKING stream: the host application's work on the legacy default stream neither waits for ours nor makes ours wait (every input
+    // and output of the ABI is a host pointer; the entry points synchronise this stream themselves before they return results)
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         g_createError = "polystokes: cannot initialise HIP device";
         std::fprintf(stderr, "%s\n", g_createError.c_str());
