@@ -308,7 +308,12 @@ struct DevBuf {
         if (count <= n && p) { poison(); return; }
         free();
         if (count == 0) count = 1;
-        HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+        if (hipMalloc((void**)&p, count * sizeof(T)) != hipSuccess) {      // out of memory with buffers waiting on the deferred list: release them and try once more
+            (void)hipGetLastError();
+            p = nullptr;
+            trimDeferredFrees(0);
+            HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+        }
         n = count;
         poison();
     }
