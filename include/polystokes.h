@@ -228,6 +228,13 @@ int32_t ps_solve_exported_system(ps_context* ctx, const char* prefix, const ps_p
 int32_t ps_bench_kernel(ps_context* ctx, const char* kernel, int32_t iters, double* avg_ms,
                         double* algorithmic_bytes);
 
+/* Device memory held through this library, for a host application's bookkeeping and for the tests that check a context does not grow
+ * across steps: out4 = { bytes allocated by all contexts of this process (buffers waiting for release included), their peak,
+ * bytes of buffers THIS context dropped that still wait for release (0 after every successful or failed setup / solve / step: they are
+ * released where the context's stream has just been synchronised), live contexts }.  ctx may be null (entry 2 is then 0).
+ * Replaces nothing in the reference (its Solver owns host temporaries for the duration of the call, exec/HDK_PolyStokesSolver.h:272-375). */
+int32_t ps_memory_stats(const ps_context* ctx, int64_t* out4);
+
 /* ---- Multi-GPU (not in the reference, which is single-process) -------------------------
  * Slab decomposition along z, cut at multiples of lcm(16, tileSize).  Each rank is given (as an ordinary
  * ps_fields_in) its slab plus one halo tile per interior side, and is told which local cell layers it owns.

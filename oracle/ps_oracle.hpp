@@ -114,6 +114,7 @@ struct Oracle {
     CSR Gt, D;  // explicit transposes (ApplyPressureStressMatrix.h:42-45)
     CSR A;      // explicit operator (AssembleSystem.cpp:351-430), optional
     std::vector<double> diagA; // Jacobi extension
+    bool exactDiagonal = false; // Jacobi / Chebyshev extensions on 1 / A_jj in fp64 instead of the product's 16-bit storage form (ps_oracle_solve.cpp: storedDinv)
     std::vector<double> b, solution, recovered, guess;
     Field<float> velOut[3], valid[3];
 

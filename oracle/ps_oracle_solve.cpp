@@ -147,7 +147,11 @@ void Oracle::applyOperatorFair(const double* x, double* y) const {
 // product stores it in (polystokes_amd/csrc/ps_common.hpp: diag_t).  Any fixed positive diagonal preconditions; restating the
 // rounding here keeps z = M^-1 r and the iteration counts comparable to the last digits instead of to 0.4 %.  The interval
 // estimate below and Eigen's own diagonal preconditioner (eigenCG, reference behaviour) use the unrounded diagonal.
-static inline double storedDinv(double diag) {
+// exactDiagonal (po_set_exact_diagonal; default off): the textbook Jacobi diagonal 1 / A_jj in fp64 instead — what "Jacobi-PCG" means without
+// the product's storage format.  tests/test_gpu_parity.py::test_stored_diagonal_jacobi_is_equivalent_to_exact_jacobi compares the product
+// (16-bit diagonal) with THAT solve: iterations within 2 %, x within 10 tol.
+static inline double storedDinv(double diag, bool exact) {
+    if (exact) return diag != 0. ? 1. / diag : 1.;
     const float f = (float)(diag != 0. ? 1. / diag : 1.);
     uint32_t b;
     std::memcpy(&b, &f, 4);
@@ -162,7 +166,7 @@ void Oracle::precondition(const std::vector<double>& in, std::vector<double>& ou
     if (P.preconditioner == PS_PRE_CHEBYSHEV) { chebyshev(in, out); return; }
     if (P.preconditioner != PS_PRE_DIAGONAL) { out = in; return; }
     out.resize(n);
-    for (size_t i = 0; i < n; ++i) out[i] = storedDinv(diagA[i]) * in[i];
+    for (size_t i = 0; i < n; ++i) out[i] = storedDinv(diagA[i], exactDiagonal) * in[i];
 }
 // Largest eigenvalue of D^-1 A by 10 power iterations from the all-ones vector (Rayleigh quotient of the last iterate), with
 // the safety margin the polynomial needs: an UNDER-estimate would make it negative beyond the interval.  A = sum over faces of
@@ -192,7 +196,7 @@ void Oracle::chebyshev(const std::vector<double>& r, std::vector<double>& z) con
     double rho = 1. / sigma;
     std::vector<double> d(n), Az(n);
     z.resize(n);
-    auto dinv = [&](size_t i) { return storedDinv(diagA[i]); };
+    auto dinv = [&](size_t i) { return storedDinv(diagA[i], exactDiagonal); };
     for (size_t i = 0; i < n; ++i) { d[i] = dinv(i) * r[i] / theta; z[i] = d[i]; }
     for (int j = 1; j < k; ++j) {
         const double rhoN = 1. / (2. * sigma - rho);
@@ -642,6 +646,7 @@ void po_precondition(void* h, const double* r, double* z) {
     std::copy(out.begin(), out.end(), z);
 }
 double po_cheb_lmax(void* h) { return ((Oracle*)h)->chebLmax; }
+void po_set_exact_diagonal(void* h, int32_t on) { ((Oracle*)h)->exactDiagonal = on != 0; }
 int32_t po_reduced_dof(void) { return psoracle::RD; }
 void po_basis(const double* off, int32_t axis, double* out) { psoracle::buildConversionCoefficients(off, axis, out); }
 int32_t po_fullpivlu_solve(const double* N, const double* rhs, double* x) { return psoracle::fullPivLuSolve(N, rhs, x) ? 1 : 0; }

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "ps_abi_version", "ps_reduced_dof", "ps_context_create", "ps_context_destroy", "ps_last_error", "ps_params_default",
     "ps_upload_fields", "ps_step_device", "ps_setup_device", "ps_solve_device", "ps_download_fields",
     "polystokes_step", "ps_apply_operator", "ps_apply_preconditioner", "ps_query_array", "ps_read_array",
-    "ps_export_component_matrices", "ps_export_matrices", "ps_export_stats", "ps_bench_kernel", "ps_set_interrupt", "ps_solve_exported_system",
+    "ps_export_component_matrices", "ps_export_matrices", "ps_export_stats", "ps_bench_kernel", "ps_memory_stats", "ps_set_interrupt", "ps_solve_exported_system",
     "ps_set_slab", "ps_set_brick", "ps_comm_unique_id", "ps_comm_init_rccl", "ps_comm_selftest", "ps_comm_init_tcp", "ps_dist_stats",
     "ps_group_create", "ps_group_destroy", "ps_group_rank", "ps_group_step",
 ]
@@ -79,6 +79,8 @@ def lib():
         L.ps_export_stats.restype = C.c_int32
         L.ps_bench_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ps_bench_kernel.restype = C.c_int32
+        L.ps_memory_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.ps_memory_stats.restype = C.c_int32
         L.ps_solve_exported_system.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Params), C.c_double, C.c_void_p, C.c_int64, C.POINTER(Stats)]
         L.ps_solve_exported_system.restype = C.c_int32
         L.ps_set_interrupt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -123,6 +125,13 @@ def _kind(name):
     if name == "reducedRowFace":
         return "u"
     return "f"
+
+
+def process_memory_stats():
+    """ps_memory_stats without a context: device bytes held through the library in this process, their peak, live contexts"""
+    v = (C.c_int64 * 4)()
+    lib().ps_memory_stats(None, v)
+    return {"live_bytes": int(v[0]), "peak_bytes": int(v[1]), "contexts": int(v[3])}
 
 
 class PolyStokesError(RuntimeError):
@@ -179,6 +188,13 @@ class Solver:
         return {"halo_bytes_per_iter": v[0], "owned_dofs": v[1], "overlap": bool(v[2]),
                 "exchange_ms_per_transport": (v[3] / v[4]) if v[4] else None, "exchange_samples": int(v[4]),
                 "allreduce_ms": (v[5] / v[6]) if v[6] else None, "allreduce_samples": int(v[6]), "halo_label_changes": int(v[7])}
+
+    def memory_stats(self):
+        """ps_memory_stats: device bytes held through the library in this process, their peak, bytes this context dropped that still wait for
+        release, live contexts"""
+        v = (C.c_int64 * 4)()
+        self.L.ps_memory_stats(self.h, v)
+        return {"live_bytes": int(v[0]), "peak_bytes": int(v[1]), "deferred_bytes": int(v[2]), "contexts": int(v[3])}
 
     def comm_init(self, uid_bytes, rank, world):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)

@@ -283,22 +283,69 @@ inline bool debugPoisonOn() {
 // hipFree synchronises the WHOLE device — every stream of the process, other contexts' included.  Inside a step that is a stall (the setup
 // grows scratch buffers while kernels are in flight), and with two ranks of one communicator in one process (tests/mp_rank.py: ranks as
 // threads over the asynchronous transport) it is a deadlock: rank A blocks in hipFree behind rank B's stream, which waits for a message
-// A has not enqueued yet.  A step therefore never frees: a buffer that is grown or dropped goes on this list, and the list is emptied
-// where the caller's stream has just been synchronised anyway — at the end of a step once more than DEFERRED_FREE_LIMIT bytes wait
-// (trimDeferredFrees), and when a context is destroyed.
-struct DeferredFrees { std::mutex m; std::vector<void*> v; size_t bytes = 0; };
-inline DeferredFrees& deferredFrees() { static DeferredFrees* d = new DeferredFrees; return *d; }   // never destroyed: a context may outlive the statics at process exit
-constexpr size_t DEFERRED_FREE_LIMIT = (size_t)1 << 30;
-inline void trimDeferredFrees(size_t ifAbove = DEFERRED_FREE_LIMIT) {
-    std::vector<void*> v;
+// A has not enqueued yet.  A step therefore never frees: a buffer that is grown or dropped goes on the list of the context whose entry
+// point the calling thread is in (ps_context::deferred, made current by SinkScope in every ABI entry; buffers freed outside any entry go
+// to a process-wide orphan list), and that list is released where the context's stream has just been synchronised — at the END of every
+// setup / solve / step, error paths included (ps_context::drainDeferred; r06: unconditionally — r05 kept up to 1 GiB of dead buffers on a
+// process-wide list across steps of the host application) — and when the context is destroyed.
+// The one case that must not release inside a step is the test arrangement above (asyncRanks > 1: several ranks with their own
+// asynchronous communicator in ONE process): rank B may already wait, in its NEXT step, for a message rank A sends only after its
+// hipFree returns.  There the lists wait for ps_context_destroy, and running out of memory is an error (ps_last_error), not a retry.
+struct DeferredFrees { std::mutex m; std::vector<std::pair<void*, size_t>> v; size_t bytes = 0; };
+struct MemState {
+    std::mutex m;
+    long long liveBytes = 0, peakBytes = 0;     // bytes hipMalloc'ed through DevBuf and not yet hipFree'd (deferred buffers included)
+    int asyncRanks = 0;                         // live contexts that own an asynchronous communicator (ps_comm_init_rccl)
+    int contexts = 0;                           // live contexts
+    std::vector<DeferredFrees*> lists;          // every live context's list (+ the orphan list): the out-of-memory path releases them all
+};
+inline MemState& memState() { static MemState* s = new MemState; return *s; }   // never destroyed: a context may outlive the statics at process exit
+inline DeferredFrees& orphanFrees() {
+    static DeferredFrees* d = [] { DeferredFrees* q = new DeferredFrees; std::lock_guard<std::mutex> lk(memState().m); memState().lists.push_back(q); return q; }();
+    return *d;
+}
+inline DeferredFrees*& currentSink() { static thread_local DeferredFrees* s = nullptr; return s; }
+struct SinkScope {
+    DeferredFrees* prev;
+    explicit SinkScope(DeferredFrees* d) : prev(currentSink()) { if (d) currentSink() = d; }
+    ~SinkScope() { currentSink() = prev; }
+};
+inline void memAccount(long long delta) {
+    MemState& M = memState();
+    std::lock_guard<std::mutex> lk(M.m);
+    M.liveBytes += delta;
+    if (M.liveBytes > M.peakBytes) M.peakBytes = M.liveBytes;
+}
+// hipFree everything on the list.  The caller has synchronised every stream that used the buffers (the context's own).
+inline size_t releaseDeferred(DeferredFrees& d) {
+    std::vector<std::pair<void*, size_t>> v;
     {
-        DeferredFrees& d = deferredFrees();
         std::lock_guard<std::mutex> lk(d.m);
-        if (d.bytes <= ifAbove) return;
         v.swap(d.v);
         d.bytes = 0;
     }
-    for (void* q : v) (void)hipFree(q);
+    size_t bytes = 0;
+    for (auto& q : v) { (void)hipFree(q.first); bytes += q.second; }
+    if (bytes) memAccount(-(long long)bytes);
+    return bytes;
+}
+inline bool threadedRanks() { MemState& M = memState(); std::lock_guard<std::mutex> lk(M.m); return M.asyncRanks > 1; }
+// PS_DEBUG_ALLOC_LIMIT=<bytes> (lab build, tests): an allocation that would take the bytes held through DevBuf above the limit fails as if
+// the device were full — the out-of-memory paths below run without filling 288 GB
+inline long long debugAllocLimit() {
+    static const long long lim = [] { const char* e = PS_ENV_LOUD("PS_DEBUG_ALLOC_LIMIT"); return e ? atoll(e) : 0LL; }();
+    return lim;
+}
+inline hipError_t mallocCounted(void** out, size_t bytes) {
+    const long long lim = debugAllocLimit();
+    if (lim > 0) {
+        MemState& M = memState();
+        std::lock_guard<std::mutex> lk(M.m);
+        if (M.liveBytes + (long long)bytes > lim) { *out = nullptr; return hipErrorOutOfMemory; }
+    }
+    const hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) memAccount((long long)bytes); else { (void)hipGetLastError(); *out = nullptr; }
+    return e;
 }
 template <class T>
 struct DevBuf {
@@ -308,11 +355,29 @@ struct DevBuf {
         if (count <= n && p) { poison(); return; }
         free();
         if (count == 0) count = 1;
-        if (hipMalloc((void**)&p, count * sizeof(T)) != hipSuccess) {      // out of memory with buffers waiting on the deferred list: release them and try once more
-            (void)hipGetLastError();
-            p = nullptr;
-            trimDeferredFrees(0);
-            HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+        const size_t bytes = count * sizeof(T);
+        if (mallocCounted((void**)&p, bytes) != hipSuccess) {
+            // Out of memory.  Buffers may be waiting on the deferred lists: releasing them means hipFree, i.e. a device-wide synchronisation
+            // in the middle of a step.  With one asynchronous rank per process (production: one process per GPU; single domain; in-process
+            // groups on one stream) that is only a stall: synchronise, release every list, try once more.  With several asynchronous ranks
+            // in this process it can deadlock them (see above): fail THIS rank with a message instead of hanging two.
+            size_t waiting = 0;
+            { MemState& M = memState(); std::lock_guard<std::mutex> lk(M.m); for (DeferredFrees* d : M.lists) { std::lock_guard<std::mutex> l2(d->m); waiting += d->bytes; } }
+            if (threadedRanks())
+                throw Error("out of device memory: " + std::to_string(bytes) + " bytes requested, " + std::to_string(waiting) +
+                            " bytes of dropped buffers wait for release, which cannot happen inside a step while several ranks of one communicator share this process");
+            if (waiting > 0) {
+                (void)hipDeviceSynchronize();
+                std::vector<DeferredFrees*> lists;
+                { MemState& M = memState(); std::lock_guard<std::mutex> lk(M.m); lists = M.lists; }
+                for (DeferredFrees* d : lists) releaseDeferred(*d);
+            }
+            if (mallocCounted((void**)&p, bytes) != hipSuccess) {
+                p = nullptr;
+                long long live; { MemState& M = memState(); std::lock_guard<std::mutex> lk(M.m); live = M.liveBytes; }
+                throw Error("out of device memory: " + std::to_string(bytes) + " bytes requested with " + std::to_string(live) + " bytes held by this library" +
+                            (waiting ? " (after releasing " + std::to_string(waiting) + " bytes of dropped buffers)" : std::string()));
+            }
         }
         n = count;
         poison();
@@ -327,16 +392,16 @@ struct DevBuf {
     }
     void free() {                       // (deferred: see DeferredFrees above)
         if (p) {
-            DeferredFrees& d = deferredFrees();
+            DeferredFrees& d = currentSink() ? *currentSink() : orphanFrees();
             std::lock_guard<std::mutex> lk(d.m);
-            d.v.push_back((void*)p);
+            d.v.emplace_back((void*)p, n * sizeof(T));
             d.bytes += n * sizeof(T);
         }
         p = nullptr;
         n = 0;
     }
     ~DevBuf() {                         // the context goes away: its stream has been synchronised (ps_context_destroy)
-        if (p) (void)hipFree(p);
+        if (p) { (void)hipFree(p); memAccount(-(long long)(n * sizeof(T))); }
         p = nullptr;
         n = 0;
     }

@@ -361,12 +361,15 @@ void ps_context::registerArrays() {
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
+// Every entry point makes the context's deferred-free list current for the calling thread (ps_common.hpp: SinkScope) and, on an error
+// path, releases what the failed call dropped if the stream is idle (the successful paths release at their end: drainDeferred(true)).
 #define PS_TRY(ctx, ...)                                                     \
+    ps::SinkScope sinkScope_((ctx) ? &(ctx)->deferred : nullptr);            \
     try { __VA_ARGS__ } catch (const ps::Error& e) {                         \
-        if (ctx) (ctx)->err = e.msg;                                         \
+        if (ctx) { (ctx)->err = e.msg; (ctx)->drainDeferred(false); }        \
         return PS_FAILED;                                                    \
     } catch (const std::exception& e) {                                      \
-        if (ctx) (ctx)->err = e.what();                                      \
+        if (ctx) { (ctx)->err = e.what(); (ctx)->drainDeferred(false); }     \
         return PS_FAILED;                                                    \
     }
 
@@ -532,8 +535,8 @@ void ps_context_destroy(ps_context* c) {
     ps_dist_release(c);   // communicator / sockets first, then the stream they use
     hipStream_t s = c->ownsStream ? c->stream : nullptr;
     if (c->pinnedCounters) (void)hipHostFree(c->pinnedCounters);
-    delete c;
-    ps::trimDeferredFrees(0);
+    delete c;                              // (releases the context's deferred list, then its buffers)
+    ps::releaseDeferred(ps::orphanFrees());
     if (s) (void)hipStreamDestroy(s);
 }
 
@@ -562,11 +565,11 @@ static void refuseSlab(const ps_context* c, const char* fn) {
 }
 int32_t ps_setup_device(ps_context* c, ps_stats* st) {
     if (!c) return PS_FAILED;
-    PS_TRY(c, { refuseSlab(c, "ps_setup_device"); return c->setup(st); })
+    PS_TRY(c, { refuseSlab(c, "ps_setup_device"); const int rc = c->setup(st); c->drainDeferred(true); return rc; })   // (setup ends with the stream synchronised)
 }
 int32_t ps_solve_device(ps_context* c, ps_stats* st) {
     if (!c) return PS_FAILED;
-    PS_TRY(c, { refuseSlab(c, "ps_solve_device"); const int result = c->solveStage(st); ps::trimDeferredFrees(); return result; })
+    PS_TRY(c, { refuseSlab(c, "ps_solve_device"); const int result = c->solveStage(st); c->drainDeferred(true); return result; })
 }
 int32_t ps_step_device(ps_context* c, ps_stats* st) {
     if (!c) return PS_FAILED;
@@ -574,15 +577,24 @@ int32_t ps_step_device(ps_context* c, ps_stats* st) {
         if (c->slabEnabled) {
             if (!c->rcclComm && !c->hostComm) throw Error("a slab is set but no communicator: call ps_comm_init_rccl / ps_comm_init_tcp (or use ps_group_step)");
             const int result = ps_dist_step_single(c, st);
-            ps::trimDeferredFrees();
+            c->drainDeferred(true);
             return result;
         }
         const int rc = c->setup(nullptr);
-        if (rc != PS_SUCCESS) return rc;
+        if (rc != PS_SUCCESS) { c->drainDeferred(true); return rc; }
         const int result = c->solveStage(st);
-        ps::trimDeferredFrees();            // (the solve stage ends with the stream synchronised)
+        c->drainDeferred(true);             // (the solve stage ends with the stream synchronised)
         return result;
     })
+}
+int32_t ps_memory_stats(const ps_context* c, int64_t* out4) {
+    if (!out4) return PS_FAILED;
+    ps::MemState& M = ps::memState();
+    std::lock_guard<std::mutex> lk(M.m);
+    out4[0] = M.liveBytes; out4[1] = M.peakBytes; out4[2] = 0;
+    if (c) { ps::DeferredFrees& d = const_cast<ps_context*>(c)->deferred; std::lock_guard<std::mutex> l2(d.m); out4[2] = (int64_t)d.bytes; }
+    out4[3] = M.contexts;
+    return PS_SUCCESS;
 }
 int32_t ps_set_interrupt(ps_context* c, ps_interrupt_fn cb, void* user) {
     if (!c) return PS_FAILED;
@@ -608,9 +620,9 @@ int32_t polystokes_step(ps_context* c, const ps_params* p, const ps_fields_in* i
     PS_TRY(c, {
         c->upload(p, in);
         const int rc = c->setup(nullptr);
-        if (rc != PS_SUCCESS) return rc;
+        if (rc != PS_SUCCESS) { c->drainDeferred(true); return rc; }
         const int result = c->solveStage(st);
-        ps::trimDeferredFrees();
+        c->drainDeferred(true);
         if (out) {
             const int rc2 = ps_download_fields(c, out);
             if (rc2 != PS_SUCCESS) return rc2;

@@ -76,6 +76,24 @@ struct ArrayInfo {
 }  // namespace ps
 
 struct ps_context {
+    // buffers this context dropped or grew inside a step, waiting for hipFree (ps_common.hpp: DeferredFrees).  First member: alive until the
+    // last DevBuf below has gone.
+    ps::DeferredFrees deferred;
+    ps_context() { ps::MemState& M = ps::memState(); std::lock_guard<std::mutex> lk(M.m); M.lists.push_back(&deferred); ++M.contexts; }
+    ~ps_context() {
+        { ps::MemState& M = ps::memState(); std::lock_guard<std::mutex> lk(M.m); --M.contexts; for (size_t q = 0; q < M.lists.size(); ++q) if (M.lists[q] == &deferred) { M.lists.erase(M.lists.begin() + (long)q); break; } }
+        ps::releaseDeferred(deferred);      // (ps_context_destroy has synchronised the stream)
+    }
+    ps_context(const ps_context&) = delete;
+    ps_context& operator=(const ps_context&) = delete;
+    // Release the dropped buffers: called where the stream has just been synchronised (end of setup / solve / step: streamIsIdle) and on
+    // error paths (then only if the stream really is idle).  Never inside a step of threaded ranks (ps_common.hpp).
+    void drainDeferred(bool streamIsIdle) {
+        if (ps::threadedRanks()) return;
+        if (!streamIsIdle && (!stream || hipStreamQuery(stream) != hipSuccess)) { (void)hipGetLastError(); return; }
+        ps::releaseDeferred(deferred);
+        ps::releaseDeferred(ps::orphanFrees());
+    }
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;

@@ -1446,15 +1446,19 @@ int ps_dist_step_single(ps_context* c, ps_stats* stats) {   // one process per r
     return distStep(D, stats);
 }
 void ps_dist_release(ps_context* c) {
-    if (c->rcclComm) { try { (void)rccl().CommDestroy(c->rcclComm); } catch (...) {} c->rcclComm = nullptr; }
+    if (c->rcclComm) {
+        try { (void)rccl().CommDestroy(c->rcclComm); } catch (...) {}
+        c->rcclComm = nullptr;
+        ps::MemState& M = ps::memState(); std::lock_guard<std::mutex> lk(M.m); --M.asyncRanks;
+    }
     if (c->hostComm) { delete (HostComm*)c->hostComm; c->hostComm = nullptr; }
     if (c->commStream && c->commStream != c->stream) (void)hipStreamDestroy(c->commStream);
     c->commStream = nullptr;
     for (int e = 0; e < 8; ++e) if (c->distEv[e]) { (void)hipEventDestroy(c->distEv[e]); c->distEv[e] = nullptr; }
 }
 #define PS_CATCH_ALL(ctx)                                                                    \
-    catch (const ps::Error& e) { if (ctx) (ctx)->err = e.msg; return PS_FAILED; }            \
-    catch (const std::exception& e) { if (ctx) (ctx)->err = e.what(); return PS_FAILED; }
+    catch (const ps::Error& e) { if (ctx) { (ctx)->err = e.msg; (ctx)->drainDeferred(false); } return PS_FAILED; }            \
+    catch (const std::exception& e) { if (ctx) { (ctx)->err = e.what(); (ctx)->drainDeferred(false); } return PS_FAILED; }
 
 extern "C" {
 
@@ -1536,6 +1540,7 @@ int32_t ps_comm_init_rccl(ps_context* c, const void* id128, int32_t rank, int32_
         ncclCheck(rccl().CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
         ps_dist_release(c);
         c->rcclComm = comm;
+        { ps::MemState& M = ps::memState(); std::lock_guard<std::mutex> lk(M.m); ++M.asyncRanks; }   // (ps_common.hpp: several of these in one process = threaded ranks)
         return PS_SUCCESS;
     } PS_CATCH_ALL(c)
 }
@@ -1557,6 +1562,7 @@ int32_t ps_comm_init_tcp(ps_context* c, int32_t rank, int32_t world, const char*
 // rank's communicator; returns PS_SUCCESS when the values come back right.
 int32_t ps_comm_selftest(ps_context* c) {
     if (!c) return PS_FAILED;
+    ps::SinkScope sinkScope_(&c->deferred);
     try {
         if (!c->rcclComm) throw Error("no communicator");
         HIP_CHECK(hipSetDevice(c->device));
@@ -1619,8 +1625,9 @@ int32_t ps_group_step(ps_group* g, ps_stats* stats) {
         Dist D;
         D.R = g->ranks;
         D.useRccl = false;
+        ps::SinkScope sinkScope_(&g->ranks[0]->deferred);   // (the ranks of a group share one stream and one host thread: one list)
         const int result = distStep(D, stats);
-        ps::trimDeferredFrees();
+        for (ps_context* c : g->ranks) c->drainDeferred(true);
         return result;
     } PS_CATCH_ALL(g->ranks[0])
 }

@@ -1139,6 +1139,7 @@ void ps_context::constructCenterReducedIndices(int part) {
             compact.alloc((size_t)std::max<int64_t>(newR, 1) * 6);
             hipLaunchKernelGGL(k_bbox_compact, dim3(gridFor(R, BS)), bl, 0, stream, bbox.p, keep.p, remap.p, R, compact.p);
             HIP_CHECK(hipMemcpyAsync(bbox.p, compact.p, (size_t)newR * 6 * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+            compact.free();   // deferred (a DevBuf going out of scope calls hipFree: a device-wide synchronisation inside a step)
             regionCount = newR;
         }
         bboxValid = true;   // the boxes of the final regions are already on the device (computeRegionBoxes only downloads them)

@@ -200,6 +200,7 @@ __global__ void k_gen_jacobi(const int32_t* __restrict__ ctp, const int32_t* __r
 extern "C" int32_t ps_solve_exported_system(ps_context* c, const char* prefix, const ps_params* params, double dt, double* x_out,
                                             int64_t x_len, ps_stats* stats) {
     if (!c || !prefix || !params) return PS_FAILED;
+    ps::SinkScope sinkScope_(&c->deferred);
     try {
         HIP_CHECK(hipSetDevice(c->device));
         const std::string pre(prefix);

@@ -234,6 +234,10 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
     __shared__ double msum[TB / 64][30];
     __shared__ double redScratch[MODE != 2 ? TB / 64 : 1][MODE != 2 ? TILE_RED_SCRATCH : 1];
     __shared__ double Ms[30], wv[PS_RD], vv[PS_RD], Vs[30];
+    // 8.3 KB of reduction scratch per wave: the instantiations that ship (TB <= 256: 33 KB) stay inside the 64 KB a workgroup may take on any
+    // CDNA target; TB = 512 / 1024 (PS_TILE_TB experiments, lab build only) need gfx950's 160 KB
+    static_assert(TB > 256 || sizeof(msum) + sizeof(redScratch) + sizeof(Ms) + sizeof(wv) + sizeof(vv) + sizeof(Vs) <= 64 * 1024, "k_tile_apply: static LDS of a default instantiation above 64 KB");
+    static_assert(sizeof(msum) + sizeof(redScratch) + sizeof(Ms) + sizeof(wv) + sizeof(vv) + sizeof(Vs) <= 160 * 1024, "k_tile_apply: static LDS above the 160 KB of gfx950");
     const int r = blockIdx.x;
     const int r0 = regionRowPtr[r], r1 = regionRowPtr[r + 1];
     const double cx = COM[(int64_t)r * 3], cy = COM[(int64_t)r * 3 + 1], cz = COM[(int64_t)r * 3 + 2];

@@ -368,8 +368,11 @@ void ps_context::constructPreconditioner() {
                        (int)nPressures, (int)nActiveVs, dt, McInv.p, uInv.p, rrowFace.p, rrowRegion.p, COM.p, dx, make_int3(gOff[0], gOff[1], gOff[2]), Binv.p, dinv.p,
                        slabEnabled ? 0 : 1);
     // The PCG kernels read the diagonal in 16 bits (ps_common.hpp: diag_t — 2 instead of 8 bytes per DOF in both step kernels; fp32 until
-    // r05).  Any positive diagonal is a valid preconditioner; the Jacobi option itself is an extension (the reference's is a stub,
-    // Preconditioners.cpp:37-41).  The fp64 array stays for export / tests / the Chebyshev polynomial; with a slab the conversion
+    // r05).  Any diagonal of the operator's sign is a valid preconditioner; the Jacobi option itself is an extension (the reference's is a stub,
+    // Preconditioners.cpp:37-41).  The fp64 array stays for export / tests / Eigen's CG / the interval estimate of the Chebyshev polynomial
+    // (estimateLambdaMax: the power iteration runs on D64^-1 A while the polynomial applies D16^-1 A, whose entries differ by <= 2^-8: the
+    // spectrum of D16^-1 A lies within (1 +- 0.004) of the other's, an order of magnitude inside the 1.25 x margin and the 8.4 floor of the
+    // estimate — the oracle's estimate is on the fp64 diagonal too, so the two intervals agree to rounding); with a slab the conversion
     // follows the cross-rank completion of the diagonal (Dist::finishSetup).
     dinvF.alloc((size_t)nSystem);
     if (!slabEnabled) hipLaunchKernelGGL(k_to_diag, dim3(dotBlocks(nSystem)), dim3(BS), 0, stream, dinv.p, dinvF.p, nSystem);
@@ -792,10 +795,11 @@ void ps_bench_launch(ps_context* c, const std::string& k, const double* x, doubl
         if (ones.n < (size_t)2 * VGRID) {
             ones.alloc((size_t)2 * VGRID);
             std::vector<double> hv((size_t)2 * VGRID, 1.);
-            HIP_CHECK(hipMemcpy(ones.p, hv.data(), hv.size() * 8, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpyAsync(ones.p, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, c->stream));   // (the context's stream is non-blocking: nothing
+            HIP_CHECK(hipStreamSynchronize(c->stream));                                                      //  orders it behind the legacy stream; hv dies here)
         }
         ps::DevBuf<double>& zeros = c->benchZeros;
-        if (zeros.n < (size_t)2 * VGRID) { zeros.alloc((size_t)2 * VGRID); HIP_CHECK(hipMemset(zeros.p, 0, (size_t)2 * VGRID * 8)); }
+        if (zeros.n < (size_t)2 * VGRID) { zeros.alloc((size_t)2 * VGRID); HIP_CHECK(hipMemsetAsync(zeros.p, 0, (size_t)2 * VGRID * 8, c->stream)); }
         const int64_t n = c->nSystem;
         const int vb = dotBlocks(n);
         const double* dv = c->P.preconditioner == PS_PRE_DIAGONAL ? c->dinv.p : nullptr;

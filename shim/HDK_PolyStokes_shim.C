@@ -190,10 +190,12 @@ bool HDK_PolyStokes::solveGasSubclass(SIM_Engine& engine, SIM_Object* obj, SIM_T
     ps_params p;
     ps_params_default(&p);
     p.mindensity = getMinDensity();                 p.maxdensity = getMaxDensity();
-    // the menus have one entry each; the template default ordinal (1) is off their end and old scenes store index 0:
-    // anything but an explicit EIGEN request maps to the live path
-    p.matrixSetup = PS_PRESSURE_STRESS;
-    p.solverType = PS_PCG_MATRIX_VECTOR_PRODUCTS;
+    // The two menus are read as the reference reads them (HDK_PolyStokes.h:23-24 -> units.h:76-94: the stored ordinal IS the enum value).  Each
+    // menu has ONE entry (HDK_PolyStokes.C:150-168), so the UI — and every shipped scene — stores 0 = pressurestress / pcg_matrix_vector_products;
+    // a hand-set ordinal 1 selects SolverType::EIGEN as it does in the reference (Solver.cpp:646-668) and the library runs it; any other matrix
+    // scheme or solver comes back through ps_last_error as "Unsupported matrix setup." / "Unsupported Solver." (HDK_PolyStokes.C:530-535).
+    p.matrixSetup = (int32_t)getMatrixSetup();
+    p.solverType = (int32_t)getSolverType();
     p.doSolve = getDoSolve();                       p.keepNonConvergedResults = getKeepNonConvergedResults();
     p.exportMatrices = getExportMatrices();         p.exportComponentMatrices = getExportComponentMatrices();
     p.exportStats = getExportStats();               p.useWarmStart = getUseWarmStart();

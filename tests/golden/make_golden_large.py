@@ -74,10 +74,14 @@ def digest(get, stats, apply):
     return out
 
 
-def build(name):
+def build(name, exact_diagonal=False):
+    """exact_diagonal: the oracle's Jacobi on 1 / A_jj in fp64 (ps_oracle.Oracle.set_exact_diagonal) instead of the product's 16-bit
+    storage form — the fixture large_<name>_exactdiag.npz pins 'Jacobi-PCG on the stored diagonal == Jacobi-PCG' (VERDICT r05 item 2)."""
     from oracle import ps_oracle
     sc, p = (CASES.get(name) or HUGE[name])()
     o = ps_oracle.Oracle()
+    if exact_diagonal:
+        o.set_exact_diagonal(True)
     rc = o.run(sc, p)
     d = digest(o.array, o.stats, o.apply)
     d["result"] = np.int32(rc)
@@ -127,6 +131,15 @@ if __name__ == "__main__":
             t0 = time.time()
             np.savez_compressed(os.path.join(here, "large_" + name + ".npz"), **build(name))
             print("wrote", name, "in %.0f s" % (time.time() - t0), flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "exactdiag":    # python tests/golden/make_golden_large.py exactdiag [case]: the Jacobi cases once more on the fp64 diagonal
+        import time
+        for name in (sys.argv[2:] or [n for n in HUGE if n.endswith("_jacobi")]):
+            t0 = time.time()
+            d = build(name, exact_diagonal=True)
+            keep = {k: d[k] for k in ("result", "iterations", "solveError", "x32_stride5", "x_norm", "x_dot_w", "dimData")}
+            np.savez_compressed(os.path.join(here, "large_" + name + "_exactdiag.npz"), **keep)
+            print("wrote", name, "(exact diagonal) in %.0f s, %d iterations" % (time.time() - t0, int(d["iterations"])), flush=True)
         sys.exit(0)
     for name in CASES:
         np.savez_compressed(os.path.join(here, "large_" + name + ".npz"), **build(name))

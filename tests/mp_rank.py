@@ -90,6 +90,7 @@ def run_rank(case, world, rank, port, out, device, done):
         s.comm_selftest()
     else:
         s.comm_init_tcp(rank, world, "127.0.0.1", port)
+    mem_after_upload = s.memory_stats()["live_bytes"]      # (process-wide: all ranks of this process)
     if case.endswith("_interrupt") and rank == world - 1:
         s.set_interrupt(lambda: True)     # ONE rank asks to stop: every rank must return PS_INCOMPLETE at the same batch
     try:
@@ -97,7 +98,8 @@ def run_rank(case, world, rank, port, out, device, done):
         err = ""
     except polystokes_amd.PolyStokesError as e:
         rc, err = -1, str(e)
-    res = dict(rc=rc, err=err, iters=int(s.stats.solveData[1]), used_bicgstab=int(s.stats.usedBiCGStab))
+    res = dict(rc=rc, err=err, iters=int(s.stats.solveData[1]), used_bicgstab=int(s.stats.usedBiCGStab), mem_after_upload=mem_after_upload,
+               mem_peak=s.memory_stats()["peak_bytes"], mem_deferred=s.memory_stats()["deferred_bytes"])
     if rc in (0, 1):
         lv, lval = s.download()
         for a in range(3):

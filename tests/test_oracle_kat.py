@@ -242,3 +242,24 @@ def test_eigen_cg_config1(oracle_mod):
     o2 = _run(oracle_mod, sc, p)
     x2 = o2.array("solutionVector")
     assert np.linalg.norm(x - x2) <= 1e-5 * np.linalg.norm(x2)
+
+
+@pytest.mark.parametrize("mk", [lambda: scenes.cavity(24, tile=12, pad=2), lambda: scenes.blob(seed=6)])
+def test_jacobi_on_the_stored_diagonal_equals_exact_jacobi_on_the_cpu(oracle_mod, mk):
+    """The Jacobi extension with the 16-bit storage form of 1 / A_jj (the default restatement of the product) against the textbook
+    fp64 diagonal (set_exact_diagonal): any fixed diagonal of the operator's sign preconditions — the counts agree within 2 % (or 2)
+    and both solves reach the same x within the tolerance.  (GPU side: tests/test_gpu_parity.py::
+    test_stored_diagonal_jacobi_is_equivalent_to_exact_jacobi, against the exact-diagonal solve.)"""
+    out = []
+    for exact in (False, True):
+        sc, p = mk()
+        p.preconditioner = abi.PRE_DIAGONAL
+        p.tolerance = 1e-6
+        o = oracle_mod.Oracle()
+        o.set_exact_diagonal(exact)
+        assert o.run(sc, p) == abi.SUCCESS
+        out.append((int(o.stats.solveData[1]), o.array("solutionVector").copy(), o.precondition(np.ones(o.nP + o.nT))))
+    (it16, x16, d16), (itex, xex, dex) = out
+    assert 0 < np.abs(d16 / dex - 1.0).max() <= 2.0 ** -8 * (1 + 1e-12)
+    assert abs(it16 - itex) <= max(2, 0.02 * itex), (it16, itex)
+    assert np.linalg.norm(x16 - xex) <= 10 * 1e-6 * np.linalg.norm(xex)
