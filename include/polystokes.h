@@ -65,8 +65,14 @@ enum ps_solver_type { PS_PCG_MATRIX_VECTOR_PRODUCTS = 0, PS_EIGEN = 1 };
 /* PS_PRE_CHEBYSHEV (extension): z = q(D^-1 A) D^-1 r with q the degree-(k-1) Chebyshev polynomial
  * of the interval [lmax/PS_CHEB_INTERVAL_RATIO, lmax], D = diag(A), k = ps_params.preconditionerDegree (default 4): k-1 operator applies per
  * CG iteration, the same smoother-as-preconditioner idea as the reference's abandoned GS designs
- * (lib/src/Preconditioner.cpp:30-158) on the live pressure-stress operator.  lmax = max(8.4, 1.25 x the estimate of 10 power iterations at setup). */
-enum ps_preconditioner { PS_PRE_IDENTITY = 1, PS_PRE_DIAGONAL = 5, PS_PRE_CHEBYSHEV = 6 };
+ * (lib/src/Preconditioner.cpp:30-158) on the live pressure-stress operator.  lmax = max(8.4, 1.25 x the estimate of 10 power iterations at setup).
+ * PS_PRE_CHEBYSHEV_F32 (r06): the same polynomial with its INNER vectors — the iterates z_j and the face-row vector of the k-1 inner operator
+ * applies — stored in single precision (half the bytes of those applies; every product, sum and recurrence, the residual r, the outer PCG
+ * and its stop rule stay fp64).  The preconditioner only approximates an inverse, so its storage rounding (6e-8 relative per stored value)
+ * perturbs the iteration count (<= +5 % accepted; equal on the scenes measured), not the solution: x converges to the same tolerance.  It runs
+ * where the row-per-lane two-unit kernels run (coded stencil values and diagonals, single domain, >= 8 chunks); elsewhere — fallback
+ * formats, decompositions — the fp64 form above runs (array "chebInner32" says which). */
+enum ps_preconditioner { PS_PRE_IDENTITY = 1, PS_PRE_DIAGONAL = 5, PS_PRE_CHEBYSHEV = 6, PS_PRE_CHEBYSHEV_F32 = 7 };
 #define PS_CHEB_INTERVAL_RATIO 250.0   /* lmax / lmin of the Chebyshev interval: flat optimum 120..1000 on the 256^3 scenes (30: 5 % slower) */
 /* order in which serialAssignFieldIndices walks a field (Classifier.cpp:1738-1770):
  * 0 = UT_VoxelArray order (16^3 voxel tiles, tile-linear, x-fastest inside), 1 = plain x-fastest. */

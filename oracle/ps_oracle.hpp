@@ -159,6 +159,8 @@ struct Oracle {
     double chebLmax = 0;
     void estimateLambdaMax();
     void chebyshev(const std::vector<double>& r, std::vector<double>& z) const;
+    void chebyshev32(const std::vector<double>& r, std::vector<double>& z) const;   // PS_PRE_CHEBYSHEV_F32: inner vectors stored as fp32
+    void applyOperatorInner32(const double* x, double* y) const;
     void precondition(const std::vector<double>& r, std::vector<double>& z) const;   // z = M^-1 r of the configured preconditioner
     void applySection1(const double* x, std::vector<double>& A11_1, std::vector<double>& A21_1) const;
     void applySection2(const double* x, std::vector<double>& tp, std::vector<double>& tt) const;

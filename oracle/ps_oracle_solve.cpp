@@ -164,6 +164,7 @@ static inline double storedDinv(double diag, bool exact) {
 void Oracle::precondition(const std::vector<double>& in, std::vector<double>& out) const {
     const size_t n = in.size();
     if (P.preconditioner == PS_PRE_CHEBYSHEV) { chebyshev(in, out); return; }
+    if (P.preconditioner == PS_PRE_CHEBYSHEV_F32) { chebyshev32(in, out); return; }
     if (P.preconditioner != PS_PRE_DIAGONAL) { out = in; return; }
     out.resize(n);
     for (size_t i = 0; i < n; ++i) out[i] = storedDinv(diagA[i], exactDiagonal) * in[i];
@@ -207,6 +208,56 @@ void Oracle::chebyshev(const std::vector<double>& r, std::vector<double>& z) con
             d[i] = c1 * d[i] + c2 * res;
             z[i] = z[i] + d[i];
         }
+        rho = rhoN;
+    }
+}
+
+// PS_PRE_CHEBYSHEV_F32 (include/polystokes.h; an extension like the polynomial itself — there is no reference algorithm to depart from): the
+// polynomial above with its INNER vectors stored in single precision, restated BEFORE the kernels were written to bound
+// what the storage rounding does to the iteration count.  Rounded to fp32 here, at the points where the product stores a value: every iterate
+// z_j (three-term form: z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 dinv (r - A z_j), the form the product's St epilogue evaluates) and the
+// ACTIVE rows of the face-row vector t = dt McInv [G Dt] z of each inner apply.  NOT restated: the product also stores the tile rows' share of
+// that vector (s = [Ghat Dhat] z before the 26x26 block, t = J v after it) as fp32 — this oracle holds JG = J^T Ghat, not the per-row products,
+// so its tile part stays fp64.  The two therefore agree to the rounding LEVEL (z within ~1e-6 of its norm), not to the bit: the tests say so.
+// r, the stored diagonal, every product and sum, and the outer PCG with its stop rule are fp64 in both.
+static inline double f32r(double v) { return (double)(float)v; }
+void Oracle::applyOperatorInner32(const double* x, double* y) const {
+    const int64_t nP = nPressures, nT = nStresses, nA = nActiveVs, nR = nReducedVs;
+    std::vector<double> t((size_t)nA), t2((size_t)nA), w((size_t)nR), w2((size_t)nR), v((size_t)nR);
+    G.mul(x, t.data());
+    Dt.mul(x + nP, t2.data());
+    for (int64_t f = 0; f < nA; ++f) t[(size_t)f] = -f32r((t[(size_t)f] + t2[(size_t)f]) * (dt * McInv[(size_t)f]));   // the stored fp32 value, sign folded in
+    Gt.mul(t.data(), y);
+    D.mul(t.data(), y + nP);
+    JG.mul(x, w.data());
+    JDt.mul(x + nP, w2.data());
+    for (int64_t r = 0; r < regionCount; ++r)
+        for (int m = 0; m < RD; ++m) {
+            double s = 0;
+            for (int n = 0; n < RD; ++n) s += Binv[(size_t)r * RD * RD + m * RD + n] * (w[(size_t)r * RD + n] + w2[(size_t)r * RD + n]);
+            v[(size_t)r * RD + m] = -s;
+        }
+    JG.mulT_add(v.data(), y);
+    JDt.mulT_add(v.data(), y + nP);
+    for (int64_t i = 0; i < nT; ++i) y[nP + i] += -0.5 * uInv[(size_t)i] * x[nP + i];
+}
+void Oracle::chebyshev32(const std::vector<double>& r, std::vector<double>& z) const {
+    const size_t n = r.size();
+    const int k = P.preconditionerDegree > 0 ? P.preconditionerDegree : 4;
+    const double lmax = chebLmax, lmin = lmax / PS_CHEB_INTERVAL_RATIO;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1. / sigma;
+    std::vector<double> zprev(n, 0.), Az(n), znext(n);
+    z.resize(n);
+    auto dinv = [&](size_t i) { return storedDinv(diagA[i], exactDiagonal); };
+    for (size_t i = 0; i < n; ++i) z[i] = f32r(dinv(i) * r[i] * (1. / theta));
+    for (int j = 1; j < k; ++j) {
+        const double rhoN = 1. / (2. * sigma - rho);
+        const double c1 = rhoN * rho, c2 = 2. * rhoN / delta;
+        applyOperatorInner32(z.data(), Az.data());
+        for (size_t i = 0; i < n; ++i) znext[i] = f32r(z[i] + (c1 * (z[i] - zprev[i]) + c2 * (dinv(i) * (r[i] - Az[i]))));
+        zprev.swap(z);
+        z.swap(znext);
         rho = rhoN;
     }
 }
@@ -483,8 +534,8 @@ int Oracle::setup(const ps_params* p, const ps_fields_in* in) {
     // HDK_PolyStokes.C:462-467: initializeGuessVectors(); if (getUseWarmStart()) constructGuessVectors();
     constructGuessVectors();
     assembleSystemPressureStressFactored();
-    if (P.preconditioner == PS_PRE_DIAGONAL || P.preconditioner == PS_PRE_CHEBYSHEV) buildJacobiDiagonal();
-    if (P.preconditioner == PS_PRE_CHEBYSHEV) estimateLambdaMax();
+    if (P.preconditioner == PS_PRE_DIAGONAL || P.preconditioner == PS_PRE_CHEBYSHEV || P.preconditioner == PS_PRE_CHEBYSHEV_F32) buildJacobiDiagonal();
+    if (P.preconditioner == PS_PRE_CHEBYSHEV || P.preconditioner == PS_PRE_CHEBYSHEV_F32) estimateLambdaMax();
     const auto w1 = std::chrono::high_resolution_clock::now();
     stats.solveData[4] = 1000.0 * (double)(std::clock() - c0) / CLOCKS_PER_SEC;
     stats.solveData[5] = std::chrono::duration<double, std::milli>(w1 - w0).count();

@@ -116,7 +116,7 @@ _DT = {(1, "i"): np.int8, (4, "i"): np.int32, (4, "f"): np.float32, (8, "f"): np
 def _kind(name):
     if name.endswith(("Labels", "Indices", ".col", ".ptr", "Region", "Perm", ".chunkInfo", ".chunkRep", ".code")) or name.startswith("faceRow"):
         return "i"
-    if name in ("valuesCoded", "columns16", "diagonalsCoded", "fusedStep", "streamRuns", "rowPerLane"):
+    if name in ("valuesCoded", "columns16", "diagonalsCoded", "fusedStep", "streamRuns", "rowPerLane", "chebInner32"):
         return "i"
     if name in ("ownedX", "ownedY", "ownedZ"):
         return "f"

@@ -14,7 +14,7 @@ UNSUPPORTED_SOLVER, INCOMPLETE, INVALID, FAILED, NOCONVERGE, SUCCESS, NOCHANGE =
 UNASSIGNED, UNSOLVED, GENERICFLUID, ACTIVEFLUID, SOLID, REDUCED, UNVISITED, VISITED, BOUNDARY = (
     -1, -2, -3, -4, -5, -6, -7, -8, -9)
 PCG_MATRIX_VECTOR_PRODUCTS, EIGEN = 0, 1
-PRE_IDENTITY, PRE_DIAGONAL, PRE_CHEBYSHEV = 1, 5, 6
+PRE_IDENTITY, PRE_DIAGONAL, PRE_CHEBYSHEV, PRE_CHEBYSHEV_F32 = 1, 5, 6, 7
 ORDER_VOXEL_TILES, ORDER_LINEAR = 0, 1
 
 STAGE_NAMES = ["weights", "classify", "regions", "indices", "tile_matrices", "blocks", "assemble",

@@ -66,9 +66,14 @@ void ps_context::upload(const ps_params* p, const ps_fields_in* in) {
     if (p->doReducedRegions && p->doTile && p->tileSize < 1) throw Error("tileSize must be at least 1");
     if (p->tilePadding < 0 || p->activeLiquidBoundaryLayerSize < 0 || p->activeSolidBoundaryLayerSize < 0) throw Error("layer sizes and tilePadding must not be negative");
     if (!(p->tolerance >= 0.) || p->maxSolverIterations < 0) throw Error("tolerance and maxSolverIterations must not be negative");
-    if (p->preconditioner != PS_PRE_IDENTITY && p->preconditioner != PS_PRE_DIAGONAL && p->preconditioner != PS_PRE_CHEBYSHEV) throw Error("Unsupported preconditioner.");
+    if (p->preconditioner != PS_PRE_IDENTITY && p->preconditioner != PS_PRE_DIAGONAL && p->preconditioner != PS_PRE_CHEBYSHEV && p->preconditioner != PS_PRE_CHEBYSHEV_F32)
+        throw Error("Unsupported preconditioner.");
     if (p->preconditionerDegree < 0 || p->preconditionerDegree > 64) throw Error("preconditionerDegree must lie in 0..64");
     P = *p;
+    // PS_PRE_CHEBYSHEV_F32 is PS_PRE_CHEBYSHEV with permission to keep the polynomial's inner vectors in fp32 where the kernels for it run
+    chebInner32Req = p->preconditioner == PS_PRE_CHEBYSHEV_F32;
+    if (chebInner32Req) P.preconditioner = PS_PRE_CHEBYSHEV;
+    chebInner32 = false;
     g.nx = in->nx; g.ny = in->ny; g.nz = in->nz; g.order = p->indexOrder;
     dx = in->dx; invDx = 1. / dx; dt = in->dt; invDt = 1. / dt; rho = (double)in->density;
     HIP_CHECK(hipSetDevice(device));
@@ -328,6 +333,10 @@ void ps_context::registerArrays() {
     // 1: the last PCG solve ran the four-kernel step (residual update inside the St kernel, ps_solve.hip)
     HIP_CHECK(hipMemcpyAsync(counters.p + 28, &fusedStepHost, sizeof(int32_t), hipMemcpyHostToDevice, stream));
     reg("fusedStep", counters.p + 28, 1, 4);
+    // 1: the last solve / preconditioner apply kept the Chebyshev polynomial's inner vectors in fp32 (PS_PRE_CHEBYSHEV_F32 where its kernels run)
+    chebInner32Host = chebInner32 ? 1 : 0;
+    HIP_CHECK(hipMemcpyAsync(counters.p + 36, &chebInner32Host, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    reg("chebInner32", counters.p + 36, 1, 4);
     // entries of the distinct runs of the compressed streams / all entries: S, then St (equal without sharing; 0 without a stream)
     streamRunsHost[0] = S.col16ok ? (int32_t)S.uniqueLen : 0; streamRunsHost[1] = S.col16ok ? (int32_t)S.streamLen : 0;
     streamRunsHost[2] = St.col16ok ? (int32_t)St.uniqueLen : 0; streamRunsHost[3] = St.col16ok ? (int32_t)St.streamLen : 0;

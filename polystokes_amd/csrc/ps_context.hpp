@@ -187,6 +187,9 @@ struct ps_context {
     ps::DevBuf<double> b, x, r, pvec, Ap, dinv, ts, vreg, wreg, recovered, tmp1, tmp2, tmp3, tmp4, tmp5;
     ps::DevBuf<double> chebPartials, chebPartials2;   // r.z partials of the Chebyshev polynomial's last term
     double chebLmax = 8.4;                            // upper end of the Chebyshev interval (estimateLambdaMax)
+    bool chebInner32Req = false;                      // the caller asked for PS_PRE_CHEBYSHEV_F32 (P.preconditioner then holds PS_PRE_CHEBYSHEV)
+    bool chebInner32 = false;                         // ... and this system runs it: the polynomial's z_j and face-row vector are stored as fp32 (ps_solve.hip: chebyshevApply)
+    int32_t chebInner32Host = 0;
     ps::DevBuf<double> guess;   // [pressureGuess; stressGuess] of constructGuessVectors (Solver.cpp:512-531), internal numbering
     // dotPartials: p.Ap partials of the St kernel; dotPartials2: their first-stage sums (one-shot St kernel only);
     // dotPartialsR: r.r / r.z partials of k_cg_update_r; dotPartials3: x.x partials of k_cg_update_xp.  Separate buffers:

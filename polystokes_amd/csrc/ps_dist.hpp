@@ -865,7 +865,7 @@ struct Dist {
         const Vec AZ = &ps_context::tmp5;
         for (ps_context* c : R) {
             const int64_t n = c->ownHi - c->ownLo, lo = c->ownLo;
-            hipLaunchKernelGGL(k_cheb_first, dim3(dotBlocks(std::max<int64_t>(n, 1))), dim3(BS), 0, c->stream, (const CGScalars*)c->scal.p, (const double*)(c->*Rv).p + lo,
+            hipLaunchKernelGGL(k_cheb_first<double>, dim3(dotBlocks(std::max<int64_t>(n, 1))), dim3(BS), 0, c->stream, (const CGScalars*)c->scal.p, (const double*)(c->*Rv).p + lo,
                                (const diag_t*)c->dinvF.p + lo, 1. / theta, c->tmp1.p + lo, n, c->chebPartials.p);
         }
         for (int j = 1; j < k; ++j) {
@@ -1241,7 +1241,7 @@ struct Dist {
                     for (size_t q = 0; q < R.size(); ++q) {
                         ps_context* c = R[q];
                         Loc& l = loc[q];
-                        hipLaunchKernelGGL(k_cg_update_xp_z, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, 1, (const double*)c->redbuf.p + 1, 1, it,
+                        hipLaunchKernelGGL(k_cg_update_xp_z<double>, dim3(l.vb), dim3(BS), 0, c->stream, l.sc, (const double*)c->redbuf.p, 1, (const double*)c->redbuf.p + 1, 1, it,
                                            (const double*)(c->*zf).p + l.lo, c->x.p + l.lo, c->pvec.p + l.lo, l.n, c->dotPartials3.p);
                     }
                     continue;

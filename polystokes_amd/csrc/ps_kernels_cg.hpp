@@ -442,14 +442,17 @@ __global__ void __launch_bounds__(BS) k_sum1(const double* __restrict__ partial,
 }
 // ---- Chebyshev-Jacobi polynomial preconditioner (PS_PRE_CHEBYSHEV) -------------------------------------------------
 // first term: z_1 = dinv r / theta ; partial of r.z (used when the polynomial has this one term only)
+// TZ: element type z is stored in (float: PS_PRE_CHEBYSHEV_F32; r.z is formed with the value as stored)
+template <class TZ>
 __global__ void __launch_bounds__(BS) k_cheb_first(const CGScalars* __restrict__ sc, const double* __restrict__ r, const diag_t* __restrict__ dinv,
-                                                   double invTheta, double* __restrict__ z, int64_t n, double* __restrict__ partial) {
+                                                   double invTheta, TZ* __restrict__ z, int64_t n, double* __restrict__ partial) {
     if (sc && sc->done) return;
     double acc = 0.;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double rv = r[i];
-        const double v = diagValue(dinv[i]) * rv * invTheta;
-        z[i] = v;
+        const TZ vs = (TZ)(diagValue(dinv[i]) * rv * invTheta);
+        z[i] = vs;
+        const double v = (double)vs;
         acc += rv * v;
     }
     const double s = blockReduceSum(acc);
@@ -473,9 +476,17 @@ __global__ void __launch_bounds__(BS) k_cheb_step(const CGScalars* __restrict__ 
 }
 // beta = r.z / rsold ; x += alpha p ; p = z + beta p with z a VECTOR (polynomial preconditioner) ; partials of x.x
 // UPP: also the partials of sum uInv p^2 of the new p (four-kernel step, see cgUpdateXp)
-template <bool UPP>
+// TZ: element type of z (float: the single-precision Chebyshev polynomial)
+__device__ inline double2 ldZ2(const double* z, int64_t i2, bool nt) { return ldD2((const double2*)z + i2, nt); }
+__device__ inline double2 ldZ2(const float* z, int64_t i2, bool nt) {
+    typedef float psf2z __attribute__((ext_vector_type(2)));
+    const psf2z* q = reinterpret_cast<const psf2z*>(z) + i2;
+    const psf2z v = nt ? __builtin_nontemporal_load(q) : *q;
+    return make_double2((double)v.x, (double)v.y);
+}
+template <bool UPP, class TZ>
 __device__ inline void cgUpdateXpZ(CGScalars* sc, const double* __restrict__ rrPartial, int rrCount, const double* __restrict__ rzPartial,
-                                   int rzCount, int it, const double* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
+                                   int rzCount, int it, const TZ* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
                                    int64_t n, double* __restrict__ partial,
                                    const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
     if (sc->done) return;
@@ -489,10 +500,9 @@ __device__ inline void cgUpdateXpZ(CGScalars* sc, const double* __restrict__ rrP
     double axx = 0., aup = 0.;
     const bool vec = ((((uintptr_t)p | (uintptr_t)z | (uintptr_t)x) & 15) == 0) && (!UPP || ((((uintptr_t)uCode & 1) == 0) && (((uintptr_t)uInv & 15) == 0)));
     const int64_t n2 = vec ? n / 2 : 0;
-    const double2* z2 = (const double2*)z;
     double2* p2 = (double2*)p; double2* x2 = (double2*)x;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        const double2 zv = ldD2(z2 + i, nt);
+        const double2 zv = ldZ2(z, i, nt);
         double2 pv = ldD2(p2 + i, nt && PS_VEC_NT_PL), xv = ldD2(x2 + i, nt && PS_VEC_NT_X);
         xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
         pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y;
@@ -508,7 +518,7 @@ __device__ inline void cgUpdateXpZ(CGScalars* sc, const double* __restrict__ rrP
     for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const double pv = p[i];
         const double xv = x[i] + alpha * pv;
-        const double pn = z[i] + beta * pv;
+        const double pn = (double)z[i] + beta * pv;
         x[i] = xv; p[i] = pn;
         axx += xv * xv;
         if (UPP) aup += (uCode ? dict[uCode[i]] : uInv[i]) * (pn * pn);
@@ -520,16 +530,18 @@ __device__ inline void cgUpdateXpZ(CGScalars* sc, const double* __restrict__ rrP
         if (threadIdx.x == 0) uPart[blockIdx.x] = s2;
     }
 }
+template <class TZ>
 __global__ void __launch_bounds__(BS) k_cg_update_xp_z(CGScalars* sc, const double* __restrict__ rrPartial, int rrCount, const double* __restrict__ rzPartial,
-                                                       int rzCount, int it, const double* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
+                                                       int rzCount, int it, const TZ* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
                                                        int64_t n, double* __restrict__ partial) {
-    cgUpdateXpZ<false>(sc, rrPartial, rrCount, rzPartial, rzCount, it, z, x, p, n, partial, nullptr, nullptr, nullptr, nullptr);
+    cgUpdateXpZ<false, TZ>(sc, rrPartial, rrCount, rzPartial, rzCount, it, z, x, p, n, partial, nullptr, nullptr, nullptr, nullptr);
 }
+template <class TZ>
 __global__ void __launch_bounds__(BS) k_cg_update_xp_z_u(CGScalars* sc, const double* __restrict__ rrPartial, int rrCount, const double* __restrict__ rzPartial,
-                                                         int rzCount, int it, const double* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
+                                                         int rzCount, int it, const TZ* __restrict__ z, double* __restrict__ x, double* __restrict__ p,
                                                          int64_t n, double* __restrict__ partial,
                                                          const uint8_t* __restrict__ uCode, const double* __restrict__ uDict, const double* __restrict__ uInv, double* __restrict__ uPart) {
-    cgUpdateXpZ<true>(sc, rrPartial, rrCount, rzPartial, rzCount, it, z, x, p, n, partial, uCode, uDict, uInv, uPart);
+    cgUpdateXpZ<true, TZ>(sc, rrPartial, rrCount, rzPartial, rzCount, it, z, x, p, n, partial, uCode, uDict, uInv, uPart);
 }
 // one step of the power iteration on D^-1 A (ps_context::estimateLambdaMax): w = dinv .* Av ; partials of v.v and v.w
 __global__ void __launch_bounds__(BS) k_power_step(const double* __restrict__ v, const double* __restrict__ Av, const double* __restrict__ dinv,
@@ -542,6 +554,9 @@ __global__ void __launch_bounds__(BS) k_power_step(const double* __restrict__ v,
     }
     const double s0 = blockReduceSum(avv), s1 = blockReduceSum(avw);
     if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
+}
+__global__ void k_widen_f32(double* __restrict__ out, const float* __restrict__ a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (double)a[i];
 }
 __global__ void k_fill_f64(double* __restrict__ a, double v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = v;

@@ -279,6 +279,29 @@ template <bool NT> __device__ inline void bufStoreF64nt(__amdgpu_buffer_rsrc_t r
 __device__ inline double bufGatherF64(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byteOff, 0, PS_GATHER_AUX));
 }
+// Element type of a vector a kernel gathers from / streams: double everywhere except the INNER vectors of the Chebyshev polynomial in its
+// single-precision form (PS_PRE_CHEBYSHEV_F32: z_j and the face-row vector t of the polynomial's operator applies are STORED as fp32 — half the
+// bytes of every gather and epilogue stream, half the lines a unit's gathers touch; every product, sum and recurrence stays fp64 in registers).
+// Index = element index (the byte offset is formed here); loads past the buffer return 0, stores are dropped (buffer descriptors).
+template <class T> struct VecIO;
+template <> struct VecIO<double> {
+    static constexpr unsigned BYTES = 8;
+    __device__ static inline double gather(__amdgpu_buffer_rsrc_t r, unsigned i) { return bufGatherF64(r, i * 8u); }
+    template <bool NT> __device__ static inline double loadEpi(__amdgpu_buffer_rsrc_t r, unsigned i) { return bufLoadF64epi<NT>(r, i * 8u); }
+    __device__ static inline double load(__amdgpu_buffer_rsrc_t r, unsigned i) { return bufLoadF64(r, i * 8u); }
+    template <bool NT> __device__ static inline void store(__amdgpu_buffer_rsrc_t r, unsigned i, double v) { bufStoreF64nt<NT>(r, i * 8u, v); }
+    __device__ static inline double stored(double v) { return v; }              // the value a later kernel reads back
+};
+template <> struct VecIO<float> {
+    static constexpr unsigned BYTES = 4;
+    __device__ static inline double gather(__amdgpu_buffer_rsrc_t r, unsigned i) { return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4u), 0, PS_GATHER_AUX)); }
+    template <bool NT> __device__ static inline double loadEpi(__amdgpu_buffer_rsrc_t r, unsigned i) { return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4u), 0, NT ? PS_EPI_AUX : 0)); }
+    __device__ static inline double load(__amdgpu_buffer_rsrc_t r, unsigned i) { return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4u), 0, 0)); }
+    template <bool NT> __device__ static inline void store(__amdgpu_buffer_rsrc_t r, unsigned i, double v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r, (int)(i * 4u), 0, NT ? PS_STORE_AUX : 0);
+    }
+    __device__ static inline double stored(double v) { return (double)(float)v; }
+};
 // one lane's share of a chunk's stream: NV groups of 4 consecutive entries (non-temporal: read once)
 // F64 = false: int8 value codes (3 B per entry with the column);  F64 = true: the fp64 values themselves in the same 4-aligned
 // chunk layout (10 B per entry) — the form that runs when the stencil values are not code * scale (user-supplied weights)
@@ -670,7 +693,7 @@ template <int K> __device__ inline unsigned ellColWord(const EllRegs& r) { retur
 // the row's W gathers (all in flight together), and — after the caller has issued its prefetches behind them — the products in
 // entry order (CSR order)
 struct EllX { double x0, x1, x2, x3, x4, x5, x6, x7; };
-template <int W>
+template <int W, class T = double>
 __device__ inline EllX ellGather(const EllRegs& r, int myBase, __amdgpu_buffer_rsrc_t rX) {
     const unsigned cw[4] = {r.c0, r.c1, r.c2, r.c3};
     double xv[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
@@ -678,15 +701,16 @@ __device__ inline EllX ellGather(const EllRegs& r, int myBase, __amdgpu_buffer_r
     for (int k = 0; k < W; ++k) {
         const unsigned raw = (cw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
         const unsigned col = (unsigned)__shfl(myBase, (int)(raw >> 12), 16) + (raw & 4095u);
-        xv[k] = bufGatherF64(rX, col * 8u);
+        xv[k] = VecIO<T>::gather(rX, col);
     }
     return EllX{xv[0], xv[1], xv[2], xv[3], xv[4], xv[5], xv[6], xv[7]};
 }
+template <class T = double>
 __device__ inline EllX ellGatherW(int W, const EllRegs& r, int myBase, __amdgpu_buffer_rsrc_t rX) {
-    if (W == 8) return ellGather<8>(r, myBase, rX);
-    if (W == 6) return ellGather<6>(r, myBase, rX);
-    if (W == 4) return ellGather<4>(r, myBase, rX);
-    if (W == 2) return ellGather<2>(r, myBase, rX);
+    if (W == 8) return ellGather<8, T>(r, myBase, rX);
+    if (W == 6) return ellGather<6, T>(r, myBase, rX);
+    if (W == 4) return ellGather<4, T>(r, myBase, rX);
+    if (W == 2) return ellGather<2, T>(r, myBase, rX);
     return EllX{0., 0., 0., 0., 0., 0., 0., 0.};
 }
 template <int W>
@@ -915,10 +939,11 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell(const uint16_t* __restrict__
 // k_spmv_S_ell with twice the memory-level parallelism per wave: a workgroup takes TWO chunks per step, waves 0-1 the first, waves 2-3 the
 // second; a wave owns units 2 (w & 1) and 2 (w & 1) + 1 of its chunk and has the streams, the gathers and the epilogue loads of both in
 // flight before it sums either.  Same products, same order per row: bit-identical t; the per-workgroup partials of sum s.t group differently.
-template <int POL, bool LIST>
+// TV: element type of x and of the output (double; float = the inner applies of the single-precision Chebyshev polynomial, VecIO)
+template <int POL, bool LIST, class TV = double>
 __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                     const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
-                                                    const double* __restrict__ x, int cols, int rows, int nA, double dt, double* __restrict__ out,
+                                                    const TV* __restrict__ x, int cols, int rows, int nA, double dt, TV* __restrict__ out,
                                                     const int* __restrict__ done, int nChunks, const uint8_t* __restrict__ mcCode, const double* __restrict__ mcDict,
                                                     double* __restrict__ stPart, const int32_t* __restrict__ list) {   // LIST: as k_spmv_S_ell (nChunks = entries of the list)
     if (done && *done) return;
@@ -926,8 +951,8 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__
     __shared__ double dict[256];
     dict[threadIdx.x] = mcDict[threadIdx.x];
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rX = bufRsrc(x, (size_t)cols * 8),
-                                 rMcc = bufRsrc(mcCode, (size_t)nA), rOut = bufRsrc(out, (size_t)rows * 8);
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rX = bufRsrc(x, (size_t)cols * sizeof(TV)),
+                                 rMcc = bufRsrc(mcCode, (size_t)nA), rOut = bufRsrc(out, (size_t)rows * sizeof(TV));
     const unsigned lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int half = wv >> 1, u0 = 2 * (wv & 1);
@@ -959,14 +984,14 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__
             const unsigned rowA = (int)lane < ua.rows ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = (int)lane < ub.rows ? (unsigned)ub.row0 + lane : ROW_NONE;
             const int mA = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)rowA, 0, NT ? PS_EPI_AUX : 0);
             const int mB = (int)__builtin_amdgcn_raw_buffer_load_b8(rMcc, (int)rowB, 0, NT ? PS_EPI_AUX : 0);
-            const EllX XA = ellGatherW(ua.W, sa, myBase, rX);
-            const EllX XB = ellGatherW(ub.W, sb, myBase, rX);
+            const EllX XA = ellGatherW<TV>(ua.W, sa, myBase, rX);
+            const EllX XB = ellGatherW<TV>(ub.W, sb, myBase, rX);
             const double a = ellSumW(ua.W, sa, XA, scale), b = ellSumW(ub.W, sb, XB, scale);
             const double scA = (int)rowA < nA ? dt * dict[mA] : 1., scB = (int)rowB < nA ? dt * dict[mB] : 1.;
             stAcc += (int)rowA < nA ? a * (a * scA) : 0.;
             stAcc += (int)rowB < nA ? b * (b * scB) : 0.;
-            bufStoreF64nt<NT>(rOut, rowA * 8u, a * scA);
-            bufStoreF64nt<NT>(rOut, rowB * 8u, b * scB);
+            VecIO<TV>::template store<NT>(rOut, rowA, a * scA);
+            VecIO<TV>::template store<NT>(rOut, rowB, b * scB);
         } else if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
         q = qn; chunk = nchunk; ci = nci; myBase = nBase;
     }
@@ -982,7 +1007,9 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__
 // CZ: the Chebyshev polynomial's first term on the new r in the epilogue (z_1 = dinv r / theta -> fr.cz, r.z partials from it; fr.dinvF unused)
 // DIST: a rank of a decomposition — alpha and ||x||^2 from the all-reduced sums (fr.red), partials at fr.rStride; with LIST the launch over
 // the chunks of OWNED rows only that runs under the exchange (ps_dist.hpp; k_spmv_St_ell's FX bit 2)
-template <int POL, bool CZ, bool DIST, bool LIST>
+// TZ: element type of fr.cz (CZ only; float: the single-precision Chebyshev polynomial — fr.cz then points at floats and r.z is formed
+// with the value as stored)
+template <int POL, bool CZ, bool DIST, bool LIST, class TZ = double>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_spmv_St_ell2(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                      const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                      const double* __restrict__ t, int cols, int rows, const double* __restrict__ xin,
@@ -1014,7 +1041,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows),
                                  rFr = bufRsrc(fr.r, (size_t)rows * 8), rFd = bufRsrc(fr.dinvF, (!CZ && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
-                                 rF64 = bufRsrc(fr.dinvC, CZ ? (size_t)rows * sizeof(diag_t) : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * 8 : 0);
+                                 rF64 = bufRsrc(fr.dinvC, CZ ? (size_t)rows * sizeof(diag_t) : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * sizeof(TZ) : 0);
     const unsigned lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int half = wv >> 1, u0 = 2 * (wv & 1);
@@ -1063,8 +1090,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const double rvA = liveA ? crA - alpha * yA : 0., rvB = liveB ? crB - alpha * yB : 0.;   // pcg.h:316
             dacc += rvA * rvA; dacc += rvB * rvB;
             if (CZ) {                                                        // k_cheb_first on these rows
-                const double vA = ciA * rvA * fr.invTheta, vB = ciB * rvB * fr.invTheta;
-                bufStoreF64nt<NT>(rFcz, rowA * 8u, vA); bufStoreF64nt<NT>(rFcz, rowB * 8u, vB);
+                const double vA = VecIO<TZ>::stored(ciA * rvA * fr.invTheta), vB = VecIO<TZ>::stored(ciB * rvB * fr.invTheta);
+                VecIO<TZ>::template store<NT>(rFcz, rowA, vA); VecIO<TZ>::template store<NT>(rFcz, rowB, vB);
                 dacc2 += rvA * vA; dacc2 += rvB * vB;
             } else if (fr.dinvF) { dacc2 += rvA * ((double)fdA * rvA); dacc2 += rvB * ((double)fdB * rvB); }
             bufStoreF64nt<NT>(rFr, rowA * 8u, rvA);
@@ -1077,10 +1104,11 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 }
 
 // ... and for MODE 2 (one term of the Chebyshev preconditioner in the epilogue; coded uInv): two units in flight per wave.
-template <int POL>
+// TV: element type of t, xin (z_j), cheb.zprev (z_{j-1}) and out (z_{j+1}); r and every sum stay fp64
+template <int POL, class TV = double>
 __global__ void __launch_bounds__(BS) k_spmv_St_ell2c(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                       const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
-                                                      const double* __restrict__ t, int cols, int rows, const double* __restrict__ xin, double* __restrict__ out,
+                                                      const TV* __restrict__ t, int cols, int rows, const TV* __restrict__ xin, TV* __restrict__ out,
                                                       double* __restrict__ partial, const int* __restrict__ done, int nChunks, ChebArgs cheb,
                                                       const uint8_t* __restrict__ uCode, const double* __restrict__ uDict) {
     if (done && *done) return;
@@ -1088,10 +1116,10 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell2c(const uint16_t* __restrict
     __shared__ double dict[256];
     dict[threadIdx.x] = uDict[threadIdx.x];
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
-                                 rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows), rOut = bufRsrc(out, (size_t)rows * 8),
+    const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * sizeof(TV)),
+                                 rE0 = bufRsrc(xin, (size_t)rows * sizeof(TV)), rUc = bufRsrc(uCode, (size_t)rows), rOut = bufRsrc(out, (size_t)rows * sizeof(TV)),
                                  rCr = bufRsrc(cheb.r, (size_t)rows * 8), rCi = bufRsrc(cheb.dinv, (size_t)rows * sizeof(diag_t)),
-                                 rCd = bufRsrc(cheb.zprev, cheb.zprev ? (size_t)rows * 8 : 0);
+                                 rCd = bufRsrc(cheb.zprev, cheb.zprev ? (size_t)rows * sizeof(TV) : 0);   // (cheb.zprev points at TV elements)
     const unsigned lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int half = wv >> 1, u0 = 2 * (wv & 1);
@@ -1119,22 +1147,22 @@ __global__ void __launch_bounds__(BS) k_spmv_St_ell2c(const uint16_t* __restrict
             const EllRegs sa = ellLoad<SNT>(rCol, rCode, ua, lane), sb = ellLoad<SNT>(rCol, rCode, ub, lane);
             if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
             const unsigned rowA = (int)lane < ua.rows ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = (int)lane < ub.rows ? (unsigned)ub.row0 + lane : ROW_NONE;
-            const double eA = bufLoadF64epi<NT>(rE0, rowA * 8u), eB = bufLoadF64epi<NT>(rE0, rowB * 8u);
+            const double eA = VecIO<TV>::template loadEpi<NT>(rE0, rowA), eB = VecIO<TV>::template loadEpi<NT>(rE0, rowB);
             const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_UC_AUX : 0);
             const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_UC_AUX : 0);
             const double crA = bufLoadF64(rCr, rowA * 8u), crB = bufLoadF64(rCr, rowB * 8u);
             const double ciA = (double)bufLoadDiag<false>(rCi, rowA), ciB = (double)bufLoadDiag<false>(rCi, rowB);
-            const double cdA = bufLoadF64(rCd, rowA * 8u), cdB = bufLoadF64(rCd, rowB * 8u);     // z_{j-1} (0: no buffer)
-            const EllX XA = ellGatherW(ua.W, sa, myBase, rT);
-            const EllX XB = ellGatherW(ub.W, sb, myBase, rT);
+            const double cdA = VecIO<TV>::load(rCd, rowA), cdB = VecIO<TV>::load(rCd, rowB);     // z_{j-1} (0: no buffer)
+            const EllX XA = ellGatherW<TV>(ua.W, sa, myBase, rT);
+            const EllX XB = ellGatherW<TV>(ub.W, sb, myBase, rT);
             const double a = ellSumW(ua.W, sa, XA, scale), b = ellSumW(ub.W, sb, XB, scale);
             double azA = -a; azA -= 0.5 * dict[ucA] * eA;
             double azB = -b; azB -= 0.5 * dict[ucB] * eB;
-            const double yA = eA + (cheb.c1 * (eA - cdA) + cheb.c2 * (ciA * (crA - azA)));
-            const double yB = eB + (cheb.c1 * (eB - cdB) + cheb.c2 * (ciB * (crB - azB)));
-            dacc += crA * yA; dacc += crB * yB;                          // r.z of the updated z (0 past the last row: every load returned 0)
-            bufStoreF64nt<NT>(rOut, rowA * 8u, yA);
-            bufStoreF64nt<NT>(rOut, rowB * 8u, yB);
+            const double yA = VecIO<TV>::stored(eA + (cheb.c1 * (eA - cdA) + cheb.c2 * (ciA * (crA - azA))));
+            const double yB = VecIO<TV>::stored(eB + (cheb.c1 * (eB - cdB) + cheb.c2 * (ciB * (crB - azB))));
+            dacc += crA * yA; dacc += crB * yB;                          // r.z of the updated z AS STORED (0 past the last row: every load returned 0)
+            VecIO<TV>::template store<NT>(rOut, rowA, yA);
+            VecIO<TV>::template store<NT>(rOut, rowB, yB);
         } else if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
         q = qn; chunk = nchunk; ci = nci; myBase = nBase;
     }

@@ -142,8 +142,8 @@ __device__ inline void waveSum30(const double* M, double* __restrict__ scratch, 
 // packed faces a lane keeps in registers between the gather and the expand of k_tile_apply: all of a lane's rows in the 256-thread form (few tiles:
 // latency bound), 12 in the one-wave-per-tile form (126 VGPRs: the fourth wave per SIMD, i.e. all 4096 tiles of the 256^3 cavity resident at once)
 template <int TB> struct TileFaceCache { static constexpr int N = TB >= 256 ? 16 : 12; };
-template <bool CACHE, int U, int FC>
-__device__ inline void tileAccumulate(int first, int stride, int end, const uint32_t* __restrict__ rrowFace, const double* __restrict__ sred, double dx, int3 off,
+template <bool CACHE, int U, int FC, class TS = double>
+__device__ inline void tileAccumulate(int first, int stride, int end, const uint32_t* __restrict__ rrowFace, const TS* __restrict__ sred, double dx, int3 off,
                                       double cx, double cy, double cz, double* __restrict__ M, uint32_t* __restrict__ fcache) {
     // U (face, s) pairs are requested together: independent loads in flight, then the arithmetic
     int it = 0;
@@ -155,7 +155,7 @@ __device__ inline void tileAccumulate(int first, int stride, int end, const uint
             const int rr = base + u * stride;
             const bool ok = rr < end;
             f[u] = ok ? __builtin_nontemporal_load(rrowFace + rr) : 0u;
-            s[u] = ok ? __builtin_nontemporal_load(sred + rr) : 0.;   // 0 past the end: contributes nothing
+            s[u] = ok ? (double)__builtin_nontemporal_load(sred + rr) : 0.;   // 0 past the end: contributes nothing
         }
         if (CACHE && it < FC / U) {
 #pragma unroll
@@ -225,10 +225,11 @@ __global__ void __launch_bounds__(64) k_tile_gather(const int32_t* __restrict__ 
 //   MODE 0: v = BInv w, t = J v                         (operator apply)
 //   MODE 1: v = BInv (invDt rhsR - w) -> vreg, no expand (velocity recovery, Solver.cpp:509)
 //   MODE 2: v = invDt BInv rhsR, t = J v, no gather      (right-hand side, AssembleSystem.cpp:448-452)
-template <int MODE, int TB>
+// TS: element type of the face-row vector (float: the inner applies of the single-precision Chebyshev polynomial, ps_kernels_spmv.hpp: VecIO)
+template <int MODE, int TB, class TS = double>
 __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ regionRowPtr, const uint32_t* __restrict__ rrowFace,
                                                    const double* __restrict__ COM, double dx, int3 off, const double* __restrict__ Binv,
-                                                   const double* __restrict__ rhsR, double invDt, double* __restrict__ sred,
+                                                   const double* __restrict__ rhsR, double invDt, TS* __restrict__ sred,
                                                    double* __restrict__ vreg, const int* __restrict__ done, double* __restrict__ wvPart) {
     if (done && *done) return;
     __shared__ double msum[TB / 64][30];
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
         double M[30];
 #pragma unroll
         for (int n = 0; n < 30; ++n) M[n] = 0.;
-        tileAccumulate<MODE == 0, U, FC>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, off, cx, cy, cz, M, fcache);
+        tileAccumulate<MODE == 0, U, FC, TS>(r0 + (int)threadIdx.x, TB, r1, rrowFace, sred, dx, off, cx, cy, cz, M, fcache);
 #ifdef PS_TILE_DPP_REDUCE   // A/B build: the DPP ladder per moment of r01 - r04
 #pragma unroll
         for (int n = 0; n < 30; ++n) {
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(TB) k_tile_apply(const int32_t* __restrict__ r
             double t = 0.;
 #pragma unroll
             for (int m = 0; m < 10; ++m) t = PS_TILE_FMA(mu[m], V[m], t);
-            sred[base + u * TB] = t;
+            sred[base + u * TB] = (TS)t;
         }
     }
 }

@@ -153,6 +153,47 @@ struct Launch {
             hipLaunchKernelGGL(k_tile_expand, dim3((unsigned)c->nRChunks), dim3(BS), 0, c->stream, c->rchunkRegion.p, c->rchunkStart.p,
                                c->rchunkEnd.p, c->rrowFace.p, c->COM.p, c->dx, make_int3(c->gOff[0], c->gOff[1], c->gOff[2]), c->vreg.p, sred, done);
     }
+    // ---- the inner operator applies of the single-precision Chebyshev polynomial (PS_PRE_CHEBYSHEV_F32): z_j and the face-row vector are stored
+    // as fp32 (ps_kernels_spmv.hpp: VecIO), on the two-units-per-wave kernels only — cheb32Ok() says whether this system runs them
+    bool cheb32Ok() const {
+        static const bool dualS = !(PS_ENV("PS_S_DUAL") && atoi(PS_ENV("PS_S_DUAL")) == 0), dualT = !(PS_ENV("PS_ST_DUAL") && atoi(PS_ENV("PS_ST_DUAL")) == 0);
+        static const bool noFuse = PS_ENV("PS_TILE_SPLIT") && atoi(PS_ENV("PS_TILE_SPLIT")) != 0;
+        return dualS && dualT && listsOk() && c->mcCoded && c->uCoded && !c->slabEnabled && !sList && !stList && xcdAware > 0 && c->S.nChunks >= 8 && c->St.nChunks >= 8 &&
+               rowsS > 0 && rowsSt > 0 && (c->regionCount == 0 || (c->maxRegionRows <= TILE_FUSED_MAX_ROWS && !noFuse));
+    }
+    void spmvS32(const float* x, float* out) const {
+        const ps::DevCSR& M = c->S;
+        int xcd = xcdAware;
+        const dim3 gr(pipeBlocks(M.nChunks, xcd, true, sCap())), bl(BS);
+        const int pol = policy(M);
+#define PS_LAUNCH_S2F(POL_) hipLaunchKernelGGL((k_spmv_S_ell2<POL_, false, float>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, x, (int)M.cols, rowsS, nA, c->dt, out, done, M.nChunks, (const uint8_t*)c->mcCode.p, c->mcDict.p, (double*)nullptr, (const int32_t*)nullptr)
+        if (pol == 3) PS_LAUNCH_S2F(3); else if (pol == 1) PS_LAUNCH_S2F(1); else PS_LAUNCH_S2F(0);
+#undef PS_LAUNCH_S2F
+    }
+    void tiles32(float* ts) const {
+        if (c->regionCount == 0) return;
+        float* sred = ts + nA;
+        const dim3 gr((unsigned)c->regionCount);
+        int tb = 64;
+        while (tb < 256 && (int64_t)tb * c->regionCount < 262144 && (int64_t)tb * 2 < c->maxRegionRows) tb *= 2;
+#define PS_TILE_APPLY_F(TB_) hipLaunchKernelGGL((k_tile_apply<0, TB_, float>), gr, dim3(TB_), 0, c->stream, c->regionRowPtr.p, c->rrowFace.p, c->COM.p, c->dx, make_int3(c->gOff[0], c->gOff[1], c->gOff[2]), c->Binv.p, \
+                                                c->rhsR.p, c->invDt, sred, c->vreg.p, done, (double*)nullptr)
+        if (tb >= 256) PS_TILE_APPLY_F(256); else if (tb >= 128) PS_TILE_APPLY_F(128); else PS_TILE_APPLY_F(64);
+#undef PS_TILE_APPLY_F
+    }
+    int spmvSt2c32(const float* t, const float* xin, float* out, double* partial, const ChebArgs& ca) const {   // returns the number of partials written
+        const ps::DevCSR& M = c->St;
+        int xcd = xcdAware;
+        const dim3 gr(pipeBlocks(M.nChunks, xcd, true, stGridFor(2))), bl(BS);
+        const int pol = policy(M);
+#define PS_LAUNCH_T2CF(POL_) hipLaunchKernelGGL((k_spmv_St_ell2c<POL_, float>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                                M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, out, partial, done, M.nChunks, ca, (const uint8_t*)c->uCode.p, c->uDict.p)
+        if (pol == 3) PS_LAUNCH_T2CF(3); else if (pol == 1) PS_LAUNCH_T2CF(1); else PS_LAUNCH_T2CF(0);
+#undef PS_LAUNCH_T2CF
+        return (int)gr.x;
+    }
+    bool cz32 = false;   // MODE 3 with the polynomial's first term: fr.cz points at floats (k_spmv_St_ell2<.., float>)
     void spmvSt_(int mode, const double* t, const double* xin, const double* add, double* out, double* partial) const {
         const dim3 gr(gridFor(rowsSt, BS)), bl(BS);
         const ps::DevCSR& M = c->St;
@@ -199,12 +240,14 @@ struct Launch {
             }
             if (mode == 3 && dualC && plain3Hint2 && c->uCoded && fr.cz && !fr.dinvF && !fr.yOut && !fr.red && fr.rStride == 0 && !stList && (gr.x & 7) == 0) {
                 const int pol = policy(M);   // the Chebyshev step's St launch (first term of the polynomial in the epilogue), two units in flight per wave
-#define PS_LAUNCH_T2Z(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, true, false, false>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+#define PS_LAUNCH_T2Z(POL_, TZ_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, true, false, false, TZ_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
                                                M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, (const int32_t*)nullptr)
-                if (pol == 3) PS_LAUNCH_T2Z(3); else if (pol == 1) PS_LAUNCH_T2Z(1); else PS_LAUNCH_T2Z(0);
+                if (cz32) { if (pol == 3) PS_LAUNCH_T2Z(3, float); else if (pol == 1) PS_LAUNCH_T2Z(1, float); else PS_LAUNCH_T2Z(0, float); }
+                else { if (pol == 3) PS_LAUNCH_T2Z(3, double); else if (pol == 1) PS_LAUNCH_T2Z(1, double); else PS_LAUNCH_T2Z(0, double); }
 #undef PS_LAUNCH_T2Z
                 return;
             }
+            if (cz32 && mode == 3 && fr.cz) throw Error("internal: single-precision Chebyshev vectors without the two-unit St kernel");
             if (single3 && stDual() && !stList && (gr.x & 7) == 0) {
                 const int pol = policy(M);
 #define PS_LAUNCH_T2(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, false, false>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
@@ -441,7 +484,26 @@ int ps_context::chebyshevApply(const double* rvec, double* zA, double* zB, doubl
     const int vb = dotBlocks(n);
     const int* done = sc ? &sc->done : nullptr;
     Launch L = mk(this, done);
-    if (!firstDone) hipLaunchKernelGGL(k_cheb_first, dim3(vb), dim3(BS), 0, stream, sc, rvec, (const diag_t*)dinvF.p, 1. / theta, zA, n, rzPartial);
+    if (chebInner32) {
+        // PS_PRE_CHEBYSHEV_F32: the same recurrence with z_j (zA / zB) and the face-row vector of the inner applies (the first half of ts) STORED as
+        // fp32; r, the diagonal, every product and sum fp64.  The two-units-per-wave kernels only (Launch::cheb32Ok decided chebInner32).
+        float* cur = (float*)zA; float* other = (float*)zB; float* tsF = (float*)ts.p;
+        if (!firstDone) hipLaunchKernelGGL(k_cheb_first<float>, dim3(vb), dim3(BS), 0, stream, sc, rvec, (const diag_t*)dinvF.p, 1. / theta, cur, n, rzPartial);
+        int count = firstDone ? 0 : vb;
+        for (int j = 1; j < k; ++j) {
+            const double rhoN = 1. / (2. * sigma - rho);
+            const double c1 = rhoN * rho, c2 = 2. * rhoN / delta;
+            const ChebArgs ca{rvec, dinvF.p, j == 1 ? (const double*)nullptr : (const double*)other, c1, c2};   // (zprev points at floats: k_spmv_St_ell2c<.., float>)
+            L.spmvS32(cur, tsF);
+            L.tiles32(tsF);
+            count = L.spmvSt2c32(tsF, cur, other, rzPartial, ca);
+            std::swap(cur, other);
+            rho = rhoN;
+        }
+        if (zOut) *zOut = (double*)cur;
+        return count;
+    }
+    if (!firstDone) hipLaunchKernelGGL(k_cheb_first<double>, dim3(vb), dim3(BS), 0, stream, sc, rvec, (const diag_t*)dinvF.p, 1. / theta, zA, n, rzPartial);
     int count = firstDone ? 0 : vb;
     double* cur = zA; double* other = zB;    // z_j, and the buffer of z_{j-1} that receives z_{j+1}
     for (int j = 1; j < k; ++j) {
@@ -474,7 +536,15 @@ void ps_context::applyPreconditionerDevice(const double* rvec, double* z, double
     if (P.preconditioner == PS_PRE_CHEBYSHEV) {
         chebPartials.alloc((size_t)std::max<int64_t>(3 * VGRID, gridFor(n, BS)) + 16);
         double* zfin = z;
+        chebInner32 = chebInner32Req && mk(this, nullptr).cheb32Ok();
+        chebInner32Host = chebInner32 ? 1 : 0;
+        HIP_CHECK(hipMemcpyAsync(counters.p + 36, &chebInner32Host, sizeof(int32_t), hipMemcpyHostToDevice, stream));   // (array "chebInner32")
         chebyshevApply(rvec, z, scratch, chebPartials.p, nullptr, false, &zfin);
+        if (chebInner32) {      // the result is an fp32 vector in one of the two buffers: widen it through a third
+            tmp5.alloc((size_t)n);
+            hipLaunchKernelGGL(k_widen_f32, dim3(vb), dim3(BS), 0, stream, tmp5.p, (const float*)zfin, n);
+            HIP_CHECK(hipMemcpyAsync(z, tmp5.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        } else
         if (zfin != z) HIP_CHECK(hipMemcpyAsync(z, zfin, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     } else if (P.preconditioner == PS_PRE_DIAGONAL) {
         hipLaunchKernelGGL(k_mul_diag, dim3(vb), dim3(BS), 0, stream, z, (const diag_t*)dinvF.p, rvec, n);   // the diagonal as the PCG kernels read it
@@ -501,6 +571,8 @@ int ps_context::solve() {
     Launch L = mk(this, done);
     const int stBlocks = L.stBlocks(0), stBF = L.stBlocks(3);   // workgroups of the St kernel: plain / with the residual update
     double* zvec = nullptr; double* dvec = nullptr; double* rzPart = nullptr;
+    chebInner32 = cheb && chebInner32Req && L.cheb32Ok();     // PS_PRE_CHEBYSHEV_F32 where the two-unit kernels run; fp64 inner vectors otherwise
+    L.cz32 = chebInner32;
     if (cheb) {
         tmp1.alloc((size_t)n); tmp2.alloc((size_t)n);
         zvec = tmp1.p; dvec = tmp2.p;
@@ -545,6 +617,8 @@ int ps_context::solve() {
         HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(CGScalars), stream));   // `done` must read 0 inside the polynomial's kernels
         double* z0 = zvec;
         const int cnt0 = chebyshevApply(r.p, zvec, dvec, rzPart, nullptr, false, &z0);
+        if (chebInner32) hipLaunchKernelGGL(k_widen_f32, dim3(vb), dim3(BS), 0, stream, pvec.p, (const float*)z0, n);
+        else
         HIP_CHECK(hipMemcpyAsync(pvec.p, z0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(BS), 0, stream, rzPart, cnt0, dotPartials.p);
         hipLaunchKernelGGL(k_cg_scal0, dim3(1), dim3(BS), 0, stream, sc, dotPartials.p, 1, tol, maxit, ntLevel() >= 2 ? 1 : 0);
@@ -568,7 +642,11 @@ int ps_context::solve() {
                 const int c2 = chebyshevApply(r.p, zvec, dvec, rzPart, sc, true, &zfin);
                 const double* part; int cnt;
                 if (c2 > 0) rzReduce(rzPart, c2, part, cnt); else { part = fR + stBF; cnt = stBF; }
-                hipLaunchKernelGGL(k_cg_update_xp_z_u, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, part, cnt, it, (const double*)zfin,
+                if (chebInner32)
+                hipLaunchKernelGGL(k_cg_update_xp_z_u<float>, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, part, cnt, it, (const float*)zfin,
+                                   x.p, pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
+                else
+                hipLaunchKernelGGL(k_cg_update_xp_z_u<double>, dim3(vb), dim3(BS), 0, stream, sc, (const double*)fR, stBF, part, cnt, it, (const double*)zfin,
                                    x.p, pvec.p, n, dotPartials3.p, ucode, (const double*)uDict.p, (const double*)uInv.p, fU);
                 continue;
             }
@@ -592,7 +670,11 @@ int ps_context::solve() {
                 const double* part; int cnt;
                 double* zfin = zvec;
                 rzReduce(rzPart, chebyshevApply(r.p, zvec, dvec, rzPart, sc, false, &zfin), part, cnt);
-                hipLaunchKernelGGL(k_cg_update_xp_z, dim3(vb), dim3(BS), 0, stream, sc, (const double*)dotPartialsR.p, vb, part, cnt, it, (const double*)zfin,
+                if (chebInner32)
+                hipLaunchKernelGGL(k_cg_update_xp_z<float>, dim3(vb), dim3(BS), 0, stream, sc, (const double*)dotPartialsR.p, vb, part, cnt, it, (const float*)zfin,
+                                   x.p, pvec.p, n, dotPartials3.p);
+                else
+                hipLaunchKernelGGL(k_cg_update_xp_z<double>, dim3(vb), dim3(BS), 0, stream, sc, (const double*)dotPartialsR.p, vb, part, cnt, it, (const double*)zfin,
                                    x.p, pvec.p, n, dotPartials3.p);
             } else
             hipLaunchKernelGGL(k_cg_update_xp, dim3(vb), dim3(BS), 0, stream, sc, (const double*)nullptr, dotPartialsR.p, vb, dv ? 1 : 0, it, r.p, dv, x.p,

@@ -112,6 +112,21 @@ def test_large_system_paths_and_chebyshev_at_full_size(big):
     rre = min(res @ res, (res @ res) / (x @ x))
     assert rre < p.tolerance ** 2 * 1.001
     assert 0 < s.stats.solveData[1] * 3.5 <= it_jacobi, (s.stats.solveData[1], it_jacobi)
+    it_cheb64, x64 = int(s.stats.solveData[1]), x
+    assert int(s.array("chebInner32")[0]) == 0
+    # ... and with the polynomial's inner vectors stored as fp32 (PS_PRE_CHEBYSHEV_F32, r06): the kernels for it run at this size, the stop
+    # rule holds on the TRUE fp64 residual, the count grows by at most 5 %, x agrees with the fp64 polynomial's within 10 tol
+    p3 = type(p).from_buffer_copy(p)
+    p3.preconditioner = abi.PRE_CHEBYSHEV_F32
+    s.upload(sc, p3)
+    s.setup()
+    assert s.solve() == abi.SUCCESS
+    assert int(s.array("chebInner32")[0]) == 1 and int(s.array("fusedStep")[0]) == 1
+    x32 = s.array("solutionVector")
+    res = b - s.apply(x32)
+    assert min(res @ res, (res @ res) / (x32 @ x32)) < p.tolerance ** 2 * 1.001
+    assert it_cheb64 - 2 <= s.stats.solveData[1] <= 1.05 * it_cheb64 + 2, (s.stats.solveData[1], it_cheb64)
+    assert np.linalg.norm(x32 - x64) <= 10 * p.tolerance * np.linalg.norm(x64)
     s.upload(sc, p)      # leave the module's context as the other tests expect it
     s.setup()
 

@@ -336,6 +336,56 @@ def test_chebyshev_preconditioner_matches_oracle(gpu, oracle_mod, scene):
         assert int(gpu.stats.solveData[1]) >= 2.5 * itg, (int(gpu.stats.solveData[1]), itg)
 
 
+@pytest.mark.parametrize("scene", ["cavity32", "coil32", "spheres32", "blob6", "cavity24_k2", "cavity48_k6"])
+def test_chebyshev_f32_inner_vectors_match_oracle(gpu, oracle_mod, scene):
+    """PS_PRE_CHEBYSHEV_F32 (r06): the polynomial with its inner vectors STORED as fp32, restated in the oracle first
+    (ps_oracle_solve.cpp: chebyshev32 — rounding at the iterates and the active face rows; the tile rows' storage is not restatable there, so
+    the comparison is to the rounding LEVEL).  z = M^-1 r within 5e-6 of max |z| (fp64 form: 1e-10), the iteration count within 2 % (or 2) of the
+    oracle's AND of the product's own fp64 polynomial (growth <= 5 % accepted, none seen), x within 10 tol.  Scenes whose diagonals are not
+    value-set coded (blob6: variable viscosity) fall back to the fp64 form: array chebInner32 says which ran."""
+    deg = 0
+    if scene == "cavity32":
+        sc, p = scenes.cavity(32)
+    elif scene == "coil32":
+        sc, p = scenes.coil(32, tile=8)
+    elif scene == "spheres32":
+        sc, p = scenes.spheres(32, tile=8)
+    elif scene == "blob6":
+        sc, p = scenes.blob(seed=6)
+    elif scene == "cavity24_k2":
+        (sc, p), deg = scenes.cavity(24, tile=12), 2
+    else:
+        (sc, p), deg = scenes.cavity(48), 6
+    p.preconditionerDegree = deg
+    p.tolerance = 1e-6
+    p.preconditioner = abi.PRE_CHEBYSHEV
+    assert gpu.step(sc, p) == abi.SUCCESS
+    it64 = int(gpu.stats.solveData[1])
+    assert int(gpu.array("chebInner32")[0]) == 0
+    p.preconditioner = abi.PRE_CHEBYSHEV_F32
+    o = oracle_mod.Oracle()
+    o.run(sc, p)
+    assert gpu.step(sc, p) == o.result == abi.SUCCESS
+    ran32 = int(gpu.array("chebInner32")[0])
+    assert ran32 == (0 if scene == "blob6" else 1), scene
+    r = np.random.RandomState(11).standard_normal(gpu.nP + gpu.nT)
+    zo, zg = o.precondition(r), gpu.precondition(r)
+    assert int(gpu.array("chebInner32")[0]) == ran32
+    assert np.abs(zo - zg).max() <= 5e-6 * np.abs(zo).max()
+    if ran32:
+        assert np.array_equal(zg, zg.astype(np.float32).astype(np.float64))          # the result IS an fp32 vector
+        assert np.abs(zo - zg).max() > 1e-12 * np.abs(zo).max()                     # ... and not the fp64 polynomial's
+    ito, itg = int(o.stats.solveData[1]), int(gpu.stats.solveData[1])
+    assert abs(itg - ito) <= max(2, 0.02 * ito), (itg, ito)
+    assert itg <= max(it64 + 2, 1.05 * it64), (itg, it64)
+    xo, xg = o.array("solutionVector"), gpu.array("solutionVector")
+    assert np.linalg.norm(xg - xo) <= 10 * p.tolerance * np.linalg.norm(xo)
+    # the stop rule holds on the TRUE fp64 residual (the recurrence residual does not drift away from it under an inexact preconditioner)
+    b = gpu.array("b")
+    res = b - gpu.apply(xg)
+    assert min(res @ res, (res @ res) / (xg @ xg)) < p.tolerance ** 2 * 1.01
+
+
 @pytest.mark.parametrize("scene", ["cavity32", "blob6_variable_viscosity"])
 def test_jacobi_on_the_stored_diagonal_matches_oracle(gpu, oracle_mod, scene):
     """The Jacobi extension reads 1 / A_jj as the upper 16 bits of its fp32 value, rounded to nearest even (ps_common.hpp: diag_t);
