@@ -113,6 +113,7 @@ void ps_context::upload(const ps_params* p, const ps_fields_in* in) {
     uploaded = true; isSetup = false; isSolved = false;
     arrays.clear();          // the registered device pointers may have been re-allocated above
     slabEnabled = false;     // a decomposition describes ONE grid: set it again after every upload (ps_set_slab / ps_set_brick)
+    deviceShareRows = 0; nXseg[0] = nXseg[1] = 0;
     blockMapOwned = -1;
     gOff[0] = gOff[1] = gOff[2] = 0;
 }

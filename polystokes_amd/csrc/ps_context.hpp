@@ -240,6 +240,12 @@ struct ps_context {
     ps::DevBuf<const double*> fixBufs;       // ... and the table of the twelve receive buffers
     int64_t nFix = 0;
     ps::DevBuf<unsigned char> scrMark;       // setup scratch of Dist::decideExchangeMode
+    // in-process groups (all ranks of the group on one device and one stream): the rows of ALL ranks — what passes through the device's caches per
+    // iteration — decide the cache policy (ntLevel), not this rank's share; and an exchange is ONE kernel for all ranks and links that gathers from
+    // the senders' vectors and scatters into the receivers' (Dist::buildDirectExchange; table on rank 0: [0] values of p out, [1] contributions of A p back)
+    int64_t deviceShareRows = 0;
+    ps::DevBuf<unsigned char> xsegTab[2];
+    int nXseg[2] = {0, 0}, xsegBlocks[2] = {0, 0};
     bool haloForward = false;                // the exchange lists carry the copies of an earlier axis's exchange (three forwarding rounds x -> y -> z); false: every
                                              // list holds the sender's OWN samples only and the three axes travel in ONE round (ps_dist.hpp: Dist::decideExchangeMode)
     int64_t haloLabelChanges = 0;            // halo cells whose label the owners' exchange changed in the last setup (both passes)

@@ -64,6 +64,23 @@ __global__ void k_unpack6(Lists6 L, double* __restrict__ v) {
     const int64_t j = i - (q > 0 ? L.end[q - 1] : 0);
     v[L.list[q][j]] = L.buf[q][j];
 }
+// In-process groups: one exchange = ONE launch for all ranks and links.  Segment k moves n entries: dst[dstList[i]] (dstList null: dst[i]) = src[srcList[i]];
+// the two lists of a cut hold the same samples in the same order (Dist::checkLists).  blk0 = the segment's first workgroup.
+struct XSeg { const double* src; const int32_t* srcList; double* dst; const int32_t* dstList; int32_t n, blk0; };
+__global__ void __launch_bounds__(BS) k_xchg_direct(const XSeg* __restrict__ segs, int nSeg) {
+    __shared__ int sIdx;
+    if ((int)threadIdx.x < nSeg) {
+        const int b0 = segs[threadIdx.x].blk0, b1 = (int)threadIdx.x + 1 < nSeg ? segs[threadIdx.x + 1].blk0 : 0x7fffffff;
+        if (b0 <= (int)blockIdx.x && (int)blockIdx.x < b1) sIdx = (int)threadIdx.x;
+    }
+    __syncthreads();
+    const XSeg s = segs[sIdx];
+    const int i = ((int)blockIdx.x - s.blk0) * BS + (int)threadIdx.x;
+    if (i < s.n) {
+        const double v = s.src[s.srcList[i]];
+        if (s.dstList) s.dst[s.dstList[i]] = v; else s.dst[i] = v;
+    }
+}
 // the received contributions whose DOF is not this rank's own (it sits on an earlier axis's upper halo plane: see buildHaloLists) are added
 // to the rank's copy, which the exchange along that earlier axis passes on
 __global__ void k_relay2(const int32_t* __restrict__ listA, int64_t nA, const double* __restrict__ bufA, const int32_t* __restrict__ listB, int64_t nB,
@@ -517,8 +534,50 @@ struct Dist {
     // rank reaches a sample of a DIAGONAL neighbour (decideExchangeMode checks it on the matrices; it happens only when a tile's skin rows lie on a
     // cut plane, i.e. with tilePadding 1): then the forwarding rounds below run as before.
     bool forwarding() const { return R[0]->haloForward; }
+    // in-process group, one-round mode: the tables of k_xchg_direct for the two exchanges of the PCG iteration (values of p out, contributions of A p
+    // back into the receive buffers the fix-up reads).  Rebuilt per setup (buildLists): the lists and the vectors may have been re-allocated.
+    bool inProcess() const { return !useRccl && !useTcp && R.size() > 1; }
+    void buildDirectExchange() {
+        ps_context* c0 = R[0];
+        c0->nXseg[0] = c0->nXseg[1] = 0;
+        if (!inProcess() || forwarding() || R.size() * 2 * ps_context::NLINK > (size_t)BS) return;
+        for (int kind = 0; kind < 2; ++kind) {
+            std::vector<XSeg> segs;
+            int blk = 0;
+            auto add = [&](const double* src, const int32_t* sl, double* dst, const int32_t* dl, int64_t n) {
+                if (n <= 0) return;
+                segs.push_back(XSeg{src, sl, dst, dl, (int32_t)n, blk});
+                blk += gridFor(n, BS);
+            };
+            for (ps_context* c : R)
+                for (int a = 0; a < ps_context::NLINK; ++a) {
+                    if (c->linkLower(a)) {
+                        ps_context* nb = R[(size_t)c->nbrLo(a)];
+                        if (kind == 0) add(c->pvec.p, c->listLowOwn[a].p, nb->pvec.p, nb->listUpHalo[a].p, c->nLowOwn[a]);
+                        else add(c->Ap.p, c->listLowHalo[a].p, nb->recvUp[a].p, nullptr, c->nLowHalo[a]);
+                    }
+                    if (c->linkUpper(a)) {
+                        ps_context* nb = R[(size_t)c->nbrUp(a)];
+                        if (kind == 0) add(c->pvec.p, c->listUpOwn[a].p, nb->pvec.p, nb->listLowHalo[a].p, c->nUpOwn[a]);
+                        else add(c->Ap.p, c->listUpHalo[a].p, nb->recvLo[a].p, nullptr, c->nUpHalo[a]);
+                    }
+                }
+            if (segs.empty() || segs.size() > (size_t)BS) continue;
+            c0->xsegTab[kind].alloc(segs.size() * sizeof(XSeg));
+            HIP_CHECK(hipMemcpyAsync(c0->xsegTab[kind].p, segs.data(), segs.size() * sizeof(XSeg), hipMemcpyHostToDevice, c0->stream));
+            HIP_CHECK(hipStreamSynchronize(c0->stream));     // (the host vector goes out of scope)
+            c0->nXseg[kind] = (int)segs.size(); c0->xsegBlocks[kind] = blk;
+        }
+    }
+    bool directExchange(int kind) {
+        ps_context* c0 = R[0];
+        if (c0->nXseg[kind] <= 0) return false;
+        hipLaunchKernelGGL(k_xchg_direct, dim3((unsigned)c0->xsegBlocks[kind]), dim3(BS), 0, c0->stream, (const XSeg*)c0->xsegTab[kind].p, c0->nXseg[kind]);
+        return true;
+    }
     void valuesOut(DevBuf<double> ps_context::*vec, bool onComm) {
         if (!forwarding()) {
+            if (inProcess() && vec == &ps_context::pvec && directExchange(0)) return;
             for (ps_context* c : R) packAll(c, true, (c->*vec).p, cs(c, onComm));
             transport(0, onComm);
             for (ps_context* c : R) unpackAllValues(c, (c->*vec).p, cs(c, onComm));
@@ -535,6 +594,7 @@ struct Dist {
     // else only the copies on the way are updated (the owners of the fused step correct r from the receive buffers: fixup)
     void contributionsBack(DevBuf<double> ps_context::*vec, bool onComm, bool addOwned) {
         if (!forwarding()) {   // one round: what arrives is for DOFs of this rank's own (added here in the order z, y, x of the forwarding rounds: the same sums)
+            if (inProcess() && !addOwned && vec == &ps_context::Ap && directExchange(1)) return;
             for (ps_context* c : R) packAll(c, false, (c->*vec).p, cs(c, onComm));
             transport(1, onComm);
             if (addOwned)
@@ -888,6 +948,7 @@ struct Dist {
     // Chunk lists of the row-per-lane kernels (ps_context::distList): which chunks can run before the halo values have arrived /
     // while this rank's contributions to its neighbours travel.  Built from two flag kernels and a host pass per setup.
     void buildLists() {
+        { int64_t all = 0; for (ps_context* c : R) all += c->nSystem; for (ps_context* c : R) c->deviceShareRows = inProcess() ? all : 0; }
         static const bool mergedFix = !(PS_ENV("PS_DIST_FIXUP_MERGED") && atoi(PS_ENV("PS_DIST_FIXUP_MERGED")) == 0);   // A/B: 0 = one k_dist_fixup launch per link
         for (ps_context* c : R) { c->nFix = 0; if (mergedFix) buildFixup(c); }
         for (ps_context* c : R) {
@@ -955,6 +1016,7 @@ struct Dist {
         decideExchangeMode();
         checkLists();
         buildLists();
+        buildDirectExchange();
         exchangeAddY(&ps_context::b);
         const bool jac = R[0]->P.preconditioner == PS_PRE_DIAGONAL, cheb = R[0]->P.preconditioner == PS_PRE_CHEBYSHEV;
         if (jac || cheb) {
@@ -1053,7 +1115,10 @@ struct Dist {
         struct FBuf { double *fS, *fT, *fU, *fR, *fX; int sBlocks, stBF, gFix, sI, tB; };   // sI / tB: workgroups of the first of the two S / St launches
         std::vector<FBuf> fb(R.size());
         // the exchanges overlap with the rows that do not need them when every rank has its chunk lists (row-per-lane kernels)
-        bool overlap = fused;
+        // (the ranks of an in-process group share ONE stream: nothing runs beside anything, and splitting S and St into the chunks next to a cut and
+        // the rest only doubles their launches — one launch each there; PS_DIST_OVERLAP=1 forces the split for the tests that walk that path on one GPU)
+        static const bool forceSplit = PS_ENV("PS_DIST_OVERLAP") && atoi(PS_ENV("PS_DIST_OVERLAP")) == 1;
+        bool overlap = fused && (useRccl || useTcp || forceSplit);
         for (ps_context* c : R) overlap = overlap && c->distListsOk;
         if (useRccl || useTcp) {   // all ranks take the same branch (the kernels differ, not the messages — but keep the ranks alike)
             double mine = overlap ? 0. : 1.;

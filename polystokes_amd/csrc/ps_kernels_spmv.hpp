@@ -1009,7 +1009,10 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__
 // the chunks of OWNED rows only that runs under the exchange (ps_dist.hpp; k_spmv_St_ell's FX bit 2)
 // TZ: element type of fr.cz (CZ only; float: the single-precision Chebyshev polynomial — fr.cz then points at floats and r.z is formed
 // with the value as stored)
-template <int POL, bool CZ, bool DIST, bool LIST, class TZ = double>
+// HALO (DIST only, r06): the launch may hold halo rows — rows outside [fr.ownLo, fr.ownHi) whose y is this rank's share of a neighbour's A p: it goes
+// to fr.yOut and r is left alone there (k_spmv_St_ell's generic MODE 3 did this on one unit per wave; the rank's launch over the chunks next
+// to a cut and the whole-rank launch of the sequential exchange now run two units per wave like the owned-rows launch)
+template <int POL, bool CZ, bool DIST, bool LIST, class TZ = double, bool HALO = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_spmv_St_ell2(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                      const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                      const double* __restrict__ t, int cols, int rows, const double* __restrict__ xin,
@@ -1041,7 +1044,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
                                  rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows),
                                  rFr = bufRsrc(fr.r, (size_t)rows * 8), rFd = bufRsrc(fr.dinvF, (!CZ && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
-                                 rF64 = bufRsrc(fr.dinvC, CZ ? (size_t)rows * sizeof(diag_t) : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * sizeof(TZ) : 0);
+                                 rF64 = bufRsrc(fr.dinvC, CZ ? (size_t)rows * sizeof(diag_t) : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * sizeof(TZ) : 0),
+                                 rFy = bufRsrc(fr.yOut, HALO ? (size_t)rows * 8 : 0);
+    static_assert(!HALO || DIST, "halo rows exist on a rank of a decomposition only");
     const unsigned lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int half = wv >> 1, u0 = 2 * (wv & 1);
@@ -1087,15 +1092,20 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const double a = ellSumW(ua.W, sa, XA, scale), b = ellSumW(ub.W, sb, XB, scale);
             double yA = -a; yA -= 0.5 * dict[ucA] * eA;
             double yB = -b; yB -= 0.5 * dict[ucB] * eB;
-            const double rvA = liveA ? crA - alpha * yA : 0., rvB = liveB ? crB - alpha * yB : 0.;   // pcg.h:316
+            const bool mineA = HALO ? ((int)rowA >= fr.ownLo && (int)rowA < fr.ownHi) : liveA, mineB = HALO ? ((int)rowB >= fr.ownLo && (int)rowB < fr.ownHi) : liveB;   // (idle lanes: ROW_NONE is beyond ownHi)
+            if (HALO) {                                                      // a neighbour's row: its share of A p
+                bufStoreF64nt<NT>(rFy, (!mineA && liveA) ? rowA * 8u : 0xfffffff8u, yA);
+                bufStoreF64nt<NT>(rFy, (!mineB && liveB) ? rowB * 8u : 0xfffffff8u, yB);
+            }
+            const double rvA = mineA ? crA - alpha * yA : 0., rvB = mineB ? crB - alpha * yB : 0.;   // pcg.h:316
             dacc += rvA * rvA; dacc += rvB * rvB;
             if (CZ) {                                                        // k_cheb_first on these rows
                 const double vA = VecIO<TZ>::stored(ciA * rvA * fr.invTheta), vB = VecIO<TZ>::stored(ciB * rvB * fr.invTheta);
                 VecIO<TZ>::template store<NT>(rFcz, rowA, vA); VecIO<TZ>::template store<NT>(rFcz, rowB, vB);
                 dacc2 += rvA * vA; dacc2 += rvB * vB;
             } else if (fr.dinvF) { dacc2 += rvA * ((double)fdA * rvA); dacc2 += rvB * ((double)fdB * rvB); }
-            bufStoreF64nt<NT>(rFr, rowA * 8u, rvA);
-            bufStoreF64nt<NT>(rFr, rowB * 8u, rvB);
+            bufStoreF64nt<NT>(rFr, (!HALO || mineA) ? rowA * 8u : 0xfffffff8u, rvA);
+            bufStoreF64nt<NT>(rFr, (!HALO || mineB) ? rowB * 8u : 0xfffffff8u, rvB);
         } else if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
         q = qn; chunk = nchunk; ci = nci; myBase = nBase;
     }

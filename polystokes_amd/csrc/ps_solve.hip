@@ -264,6 +264,15 @@ struct Launch {
                 if (pol == 3) PS_LAUNCH_T2D(3); else if (pol == 1) PS_LAUNCH_T2D(1); else PS_LAUNCH_T2D(0);
 #undef PS_LAUNCH_T2D
             }
+            else if (coded3 && dualC && fr.red && fr.yOut && !stOwnedOnly && (gr.x & 7) == 0) {   // a rank's launch that holds halo rows (the chunks next to a cut, or the whole rank), two units in flight per wave
+                const int pol = policy(M);
+#define PS_LAUNCH_T2H(POL_, LIST_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, true, LIST_, double, true>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, stList)
+#define PS_LAUNCH_T2H2(POL_) do { if (stList) PS_LAUNCH_T2H(POL_, true); else PS_LAUNCH_T2H(POL_, false); } while (0)
+                if (pol == 3) PS_LAUNCH_T2H2(3); else if (pol == 1) PS_LAUNCH_T2H2(1); else PS_LAUNCH_T2H2(0);
+#undef PS_LAUNCH_T2H2
+#undef PS_LAUNCH_T2H
+            }
             else if (coded3 && stOwnedOnly && stList) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEL(3, 3, 5, true); else if (pol == 1) PS_LAUNCH_TEL(3, 1, 5, true); else PS_LAUNCH_TEL(3, 0, 5, true); }
             else if (coded3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 1); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 1); else PS_LAUNCH_TEX(3, 0, 1); }
             else if (mode == 0) PS_LAUNCH_TE2(0); else if (mode == 1) PS_LAUNCH_TE2(1); else if (mode == 2) PS_LAUNCH_TE2(2); else PS_LAUNCH_TE2(3);
@@ -435,7 +444,8 @@ void ps_context::constructPreconditioner() {
 int ps_context::ntLevel() const {
     static const int env = PS_ENV("PS_NT_LEVEL") ? atoi(PS_ENV("PS_NT_LEVEL")) : -1;
     if (env >= 0) return env;
-    return nSystem < NT_LEVEL1_MIN_ROWS ? 0 : (nSystem < NT_LEVEL2_MIN_ROWS ? 1 : 2);
+    const int64_t rows = std::max(nSystem, deviceShareRows);   // (ranks of an in-process group share the device's caches: ps_context::deviceShareRows)
+    return rows < NT_LEVEL1_MIN_ROWS ? 0 : (rows < NT_LEVEL2_MIN_ROWS ? 1 : 2);
 }
 
 static double chebRatio() { static const double r = PS_ENV("PS_CHEB_RATIO") ? atof(PS_ENV("PS_CHEB_RATIO")) : PS_CHEB_INTERVAL_RATIO; return r; }   // lmax / lmin (PS_CHEB_RATIO: experiments only — the oracle uses the constant)

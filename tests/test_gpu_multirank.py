@@ -119,13 +119,19 @@ def test_bricks_match_single_domain(case):
 
 
 @pytest.mark.skipif(__import__("os").environ.get("PS_TEST_CHILD") == "1", reason="this IS the child run")
-def test_bricks_and_slabs_with_the_four_kernel_step_forced():
+@pytest.mark.parametrize("split", ["", "1"])
+def test_bricks_and_slabs_with_the_four_kernel_step_forced(split):
     """The four-kernel PCG step across the cuts (the St kernel corrects r on owned rows, the halo rows' A p travels back axis after axis,
-    k_relay2 / k_dist_fixup) switches on from 1.2 M owned rows per rank: force it (PS_FUSED_R=1) through the brick and slab cases in a child."""
+    k_relay2 / k_dist_fixup) switches on from 1.2 M owned rows per rank: force it (PS_FUSED_R=1) through the brick and slab cases in a child.
+    r06: the ranks of an in-process group share one stream, so their S and St run as ONE launch each (two units per wave, halo rows included:
+    k_spmv_St_ell2<.., HALO>) and an exchange is one kernel for all ranks (k_xchg_direct) — split "": that path; split "1" (PS_DIST_OVERLAP=1):
+    the launches split into the chunks next to a cut and the rest, pack / transport / unpack, as one process per GPU runs them."""
     import os
     import subprocess
     import sys
     env = dict(os.environ, PS_FUSED_R="1", PS_TEST_CHILD="1")
+    if split:
+        env["PS_DIST_OVERLAP"] = split
     pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                          "-k", "test_bricks_match_single_domain or test_group_matches_single_domain"],
                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
@@ -254,6 +260,8 @@ def test_group_reused_across_scenes_with_the_four_kernel_step(poison):
     import subprocess
     import sys
     env = dict(os.environ, PS_FUSED_R="1", PS_TEST_CHILD="1", PS_TEST_REUSE_CHILD="1", PS_DEBUG_POISON=poison)
+    if poison == "1":
+        env["PS_DIST_OVERLAP"] = "1"      # (r06: an in-process group runs unsplit launches by default; the poisoned run walks the split ones)
     pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                          "-k", "test_reused_group_child"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
     assert pr.returncode == 0, pr.stdout[-3000:]
@@ -392,7 +400,7 @@ def test_bricks_without_reduced_regions_match_single_domain(dims):
     grp = polystokes_amd.Group(dims[0] * dims[1] * dims[2], dims=dims)
     rc2 = grp.solve_scene(sc, p)
     assert rc1 == rc2 == abi.SUCCESS
-    assert int(single.stats.solveData[1]) == int(grp.stats.solveData[1])
+    assert abs(int(single.stats.solveData[1]) - int(grp.stats.solveData[1])) <= 1      # (at tol 1e-8 the partial sums' grouping may move the count by one)
     _views_hold_the_global_cell_labels(single, grp, sc)
     for a in range(3):
         assert np.array_equal(grp.valid[a], single.valid[a])
