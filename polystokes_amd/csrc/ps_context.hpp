@@ -227,8 +227,8 @@ struct ps_context {
     // Overlap of the halo exchanges with the rows that do not need them (ps_dist.hpp: Dist::solve).  Chunk lists of the row-per-lane
     // kernels: [0] S chunks without a halo column, [1] S chunks with one; [2] St chunks holding halo rows with entries (their A p goes
     // to the neighbour), [3] St chunks of owned rows only.  St chunks of halo rows without entries are in neither: never launched.
-    ps::DevBuf<int32_t> distList[4];
-    int nDistList[4] = {0, 0, 0, 0};
+    ps::DevBuf<int32_t> distList[5];          // [4]: the St chunks of [2] and [3] together, in chunk order — the ONE St launch of a rank whose exchanges are not overlapped
+    int nDistList[5] = {0, 0, 0, 0, 0};
     bool distListsOk = false;
     hipStream_t commStream = nullptr;        // transports run here (= stream for in-process ranks: nothing to overlap on one stream)
     hipEvent_t distEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

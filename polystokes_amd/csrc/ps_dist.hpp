@@ -953,14 +953,14 @@ struct Dist {
         for (ps_context* c : R) { c->nFix = 0; if (mergedFix) buildFixup(c); }
         for (ps_context* c : R) {
             c->distListsOk = false;
-            for (int q = 0; q < 4; ++q) c->nDistList[q] = 0;
+            for (int q = 0; q < 5; ++q) c->nDistList[q] = 0;
             Launch L = mk(c, nullptr);
             static const bool off = PS_ENV("PS_DIST_OVERLAP") && atoi(PS_ENV("PS_DIST_OVERLAP")) == 0;   // A/B: the sequential exchange
             if (off || !L.listsOk() || c->S.nChunks == 0 || c->St.nChunks == 0) continue;
             const int nS = c->S.nChunks, nT = c->St.nChunks;
             DevBuf<int32_t>& flags = c->scrVals;               // setup scratch
             flags.alloc((size_t)std::max(nS, nT));
-            std::vector<int32_t> h((size_t)std::max(nS, nT)), lists[4];
+            std::vector<int32_t> h((size_t)std::max(nS, nT)), lists[5];
             hipLaunchKernelGGL(k_chunk_flags_S, dim3((unsigned)nS), dim3(64), 0, c->stream, (const int32_t*)c->S.ptr.p, (const int32_t*)c->S.col.p, (const int4*)c->S.chunkInfo.p,
                                (int)c->ownLo, (int)c->ownHi, flags.p);
             HIP_CHECK(hipMemcpyAsync(h.data(), flags.p, (size_t)nS * 4, hipMemcpyDeviceToHost, c->stream));
@@ -974,8 +974,8 @@ struct Dist {
                                        (const int32_t*)c->listUpOwn[a].p, c->nUpOwn[a], (int)c->ownHi, (const int4*)c->St.chunkInfo.p, nT, flags.p);
             HIP_CHECK(hipMemcpyAsync(h.data(), flags.p, (size_t)nT * 4, hipMemcpyDeviceToHost, c->stream));
             HIP_CHECK(hipStreamSynchronize(c->stream));
-            for (int i = 0; i < nT; ++i) { if (h[(size_t)i] == 2) lists[2].push_back(i); else if (h[(size_t)i] == 1) lists[3].push_back(i); }
-            for (int q = 0; q < 4; ++q) {
+            for (int i = 0; i < nT; ++i) { if (h[(size_t)i] == 2) lists[2].push_back(i); else if (h[(size_t)i] == 1) lists[3].push_back(i); if (h[(size_t)i] != 0) lists[4].push_back(i); }
+            for (int q = 0; q < 5; ++q) {
                 c->nDistList[q] = (int)lists[q].size();
                 c->distList[q].alloc(lists[q].size());
                 if (!lists[q].empty()) HIP_CHECK(hipMemcpyAsync(c->distList[q].p, lists[q].data(), lists[q].size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -1141,14 +1141,15 @@ struct Dist {
                 ps_context* c = R[q];
                 Loc& l = loc[q];
                 FBuf& f = fb[q];
-                f.sBlocks = l.L.sBlocks(); f.stBF = l.L.stBlocks(3); f.sI = 0; f.tB = 0;
+                f.sBlocks = l.L.sBlocks(); f.stBF = (c->distListsOk && !overlap) ? l.L.stBlocksFor(c->nDistList[4], 3) : l.L.stBlocks(3); f.sI = 0; f.tB = 0;
                 if (overlap) {
                     f.sI = l.L.sBlocksFor(c->nDistList[0]); f.sBlocks = f.sI + l.L.sBlocksFor(c->nDistList[1]);
                     f.tB = l.L.stBlocksFor(c->nDistList[2], 3); f.stBF = f.tB + l.L.stBlocksFor(c->nDistList[3], 3);
                 }
                 int64_t mostOwn = 1;
                 for (int a = 0; a < ps_context::NLINK; ++a) mostOwn = std::max(mostOwn, c->nLowOwn[a] + c->nUpOwn[a]);
-                f.gFix = (int)std::min<int64_t>(256, (mostOwn + BS - 1) / BS);   // workgroups of one axis's k_dist_fixup; its partials: [axis][2][gFix]
+                if (c->nFix > 0) mostOwn = std::max<int64_t>(mostOwn, c->nFix);             // the merged fix-up: one thread per receiving DOF, up to 1024 workgroups
+                f.gFix = (int)std::min<int64_t>(c->nFix > 0 ? 1024 : 256, (mostOwn + BS - 1) / BS);   // workgroups of one axis's k_dist_fixup; its partials: [axis][2][gFix]
                 c->fusedPart.alloc((size_t)f.sBlocks + (size_t)c->regionCount + VGRID + 2 * (size_t)f.stBF + 2 * ps_context::NLINK * (size_t)f.gFix + 16);
                 f.fS = c->fusedPart.p; f.fT = f.fS + f.sBlocks; f.fU = f.fT + c->regionCount; f.fR = f.fU + VGRID; f.fX = f.fR + 2 * f.stBF;
                 HIP_CHECK(hipMemsetAsync(f.fX, 0, 2 * ps_context::NLINK * (size_t)f.gFix * sizeof(double), c->stream));
@@ -1216,7 +1217,7 @@ struct Dist {
                         FBuf& f = fb[q];
                         order(c, 5, false);
                         fixup(c, l.sc, jac, f.fX, f.gFix);
-                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, ps_context::NLINK, c->redbuf.p);
+                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(1024), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, c->nFix > 0 ? 1 : ps_context::NLINK, c->redbuf.p);   // (the merged fix-up writes ONE set of partials)
                     }
                     allreduce(2);
                     for (size_t q = 0; q < R.size(); ++q) {
@@ -1247,8 +1248,11 @@ struct Dist {
                         Loc& l = loc[q];
                         FBuf& f = fb[q];
                         const FusedR fr{l.sc, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, it, c->r.p, jac ? c->dinvF.p : (const diag_t*)nullptr, f.fR, nullptr, 0., nullptr,
-                                        (const double*)c->redbuf.p, (int)c->ownLo, (int)c->ownHi, c->Ap.p};
+                                        (const double*)c->redbuf.p, (int)c->ownLo, (int)c->ownHi, c->Ap.p, f.stBF};
+                        // (the chunks that hold work: halo rows without entries — most of a halo block — are in no list; r and A p of those rows stay as the solve's start left them: zero)
+                        if (c->distListsOk) { l.L.stList = c->distList[4].p; l.L.nStList = c->nDistList[4]; }
                         l.L.spmvSt(3, c->ts.p, c->pvec.p, nullptr, nullptr, nullptr, nullptr, &fr);
+                        l.L.stList = nullptr; l.L.nStList = 0;
                     }
                     // the halo rows' share of A p goes to its owners (the packing and transport of exchangeAddY; the owners correct r instead of adding into A p)
                     contributionsBack(&ps_context::Ap, false, false);
@@ -1257,7 +1261,7 @@ struct Dist {
                         Loc& l = loc[q];
                         FBuf& f = fb[q];
                         fixup(c, l.sc, jac, f.fX, f.gFix);
-                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(BS), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, ps_context::NLINK, c->redbuf.p);
+                        hipLaunchKernelGGL(k_sum_rr, dim3(1), dim3(1024), 0, c->stream, (const CGScalars*)l.sc, (const double*)f.fR, f.stBF, (const double*)f.fX, f.gFix, c->nFix > 0 ? 1 : ps_context::NLINK, c->redbuf.p);   // (the merged fix-up writes ONE set of partials)
                     }
                     allreduce(2);
                     for (size_t q = 0; q < R.size(); ++q) {

@@ -388,18 +388,25 @@ __global__ void __launch_bounds__(BS) k_dist_fixup(const CGScalars* __restrict__
 // out = {r.r, r.z} of this rank: the St kernel's partials plus the corrections of the fix-up ([2][fixCount] per set; r05: ONE set — the merged
 // fix-up k_dist_fixup_merged — and the two corrections folded thread by thread before ONE reduction each: this one-block kernel sits on the
 // critical path of every rank-iteration and took 17 us with 2 + 2 x 6 block reductions)   (one block)
-__global__ void __launch_bounds__(BS) k_sum_rr(const CGScalars* __restrict__ sc, const double* __restrict__ rPart, int rCount, const double* __restrict__ fixPart, int fixCount,
+__global__ void __launch_bounds__(1024) k_sum_rr(const CGScalars* __restrict__ sc, const double* __restrict__ rPart, int rCount, const double* __restrict__ fixPart, int fixCount,
                                                int fixSets, double* __restrict__ out) {
+    // (r06: 1024 threads, every load of a thread issued before the sums, ONE round of wave reductions for the four values — as k_fused_local_sum:
+    // 12 us -> a few with 256 threads and four block reductions in a row)
     if (sc->done) return;
-    double a = 0., b = 0., c = 0., d = 0.;
-    for (int i = threadIdx.x; i < rCount; i += BS) { a += rPart[i]; b += rPart[rCount + i]; }
+    __shared__ double red[4][16];
+    double acc[4] = {0., 0., 0., 0.};
+    for (int i = threadIdx.x; i < rCount; i += 1024) { acc[0] += rPart[i]; acc[1] += rPart[rCount + i]; }
     for (int q = 0; q < fixSets; ++q)
-        for (int i = threadIdx.x; i < fixCount; i += BS) { c += fixPart[(size_t)q * 2 * fixCount + i]; d += fixPart[(size_t)q * 2 * fixCount + fixCount + i]; }
-    const double sa = blockReduceSum(a); __syncthreads();
-    const double sb = blockReduceSum(b); __syncthreads();
-    const double sc_ = blockReduceSum(c); __syncthreads();
-    const double sd = blockReduceSum(d);
-    if (threadIdx.x == 0) { out[0] = sa + sc_; out[1] = sb + sd; }
+        for (int i = threadIdx.x; i < fixCount; i += 1024) { acc[2] += fixPart[(size_t)q * 2 * fixCount + i]; acc[3] += fixPart[(size_t)q * 2 * fixCount + fixCount + i]; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const double v = waveReduceSum(acc[q]); if (lane == 0) red[q][w] = v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4];
+        for (int q = 0; q < 4; ++q) { double a = 0.; for (int i = 0; i < 16; ++i) a += red[q][i]; t[q] = a; }
+        out[0] = t[0] + t[2]; out[1] = t[1] + t[3];
+    }
 }
 // The fix-up of the fused step in ONE launch (r05): a thread owns a DOF that receives contributions — from up to MAXSRC links (a DOF next to two or
 // three cuts) — and applies them in link order, each to the r the previous one left: the arithmetic of the per-link launches of k_dist_fixup, DOF by
@@ -409,17 +416,24 @@ constexpr int FIX_MAXSRC = 4;
 __global__ void __launch_bounds__(BS) k_dist_fixup_merged(const CGScalars* __restrict__ sc, const int32_t* __restrict__ dof, const int32_t* __restrict__ src, int64_t n, const double* const* __restrict__ bufs,
                                                           double* __restrict__ r, const diag_t* __restrict__ dinv, double* __restrict__ partial) {
     if (sc->done) return;
+    __shared__ const double* sb[16];                      // the twelve receive buffers: one level less in the dependent chain src -> buffer -> value
+    if (threadIdx.x < 12) sb[threadIdx.x] = bufs[threadIdx.x];
+    __syncthreads();
     const double alpha = sc->alpha;
     double a0 = 0., a1 = 0.;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
         const int j = dof[i];
+        int e[FIX_MAXSRC];
+#pragma unroll
+        for (int k = 0; k < FIX_MAXSRC; ++k) e[k] = src[(size_t)k * (size_t)n + (size_t)i];
+        double cv[FIX_MAXSRC];
+#pragma unroll
+        for (int k = 0; k < FIX_MAXSRC; ++k) cv[k] = e[k] >= 0 ? sb[e[k] & 15][e[k] >> 4] : 0.;   // all loads in flight before the sums
         const double ro = r[j];
         double rn = ro;
 #pragma unroll
-        for (int k = 0; k < FIX_MAXSRC; ++k) {
-            const int e = src[(size_t)k * (size_t)n + (size_t)i];
-            if (e >= 0) rn -= alpha * bufs[e & 15][e >> 4];
-        }
+        for (int k = 0; k < FIX_MAXSRC; ++k)
+            if (e[k] >= 0) rn -= alpha * cv[k];
         r[j] = rn;
         const double d = rn * rn - ro * ro;
         a0 += d;

@@ -311,6 +311,15 @@ struct Launch {
         if (!packed) { xcd = 0; return nChunks; }
         int g = std::min(nChunks, gridCap > 0 ? gridCap : pipeGrid);
         if (xcd > 0) { if (g >= 8) g &= ~7; else xcd = 0; }
+        // Balance (r06).  The two-unit kernels walk PAIRS of chunks, runs of 32 pairs per XCD: workgroup l of an XCD takes steps l, l + per, ... below
+        // qEnd.  With a launch a little larger than its grid cap (a rank's 13.8 k chunks of S on 6144 workgroups) an eighth of the workgroups took
+        // two steps and everybody waited for them: 59 us where two launches of half the chunks took 2 x 20.6.  Shrink the grid to the size at which every
+        // workgroup takes the same number of steps (never above the cap; the 256^3 single domain keeps its 6144 / 1536: 9 / 36 steps each).
+        if (xcd > 0 && g >= 8 && c->S.ellok && c->St.ellok) {
+            const int nPairs = (nChunks + 1) >> 1, qEnd = ((nPairs + 255) >> 8) << 5;
+            const int steps = std::max(1, (qEnd * 8 + g - 1) / g), per = (qEnd + steps - 1) / steps;
+            if (per * 8 <= g) g = per * 8;
+        }
         return g;
     }
     // the fused step needs both products on the persistent coded-stream kernels (their per-workgroup partials)
