@@ -49,84 +49,110 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw, sample_res=128, second_res=96):
-    """CPU restatement (oracle, kind "port") timed on this host's cores on a bounded sample: the same scene at 128^3
-    (5.9 M DOFs; the operator's matrices alone are > 2 GB, far beyond the last-level cache) and, to show how the time scales, at 96^3.
-    Timings of the CG iteration (pcg.h:311-335 around ApplyPressureStressMatrix.h:102-179), >= 10 iterations each:
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) / 1048576.0
+                break
+        else:
+            return 0.0
+        for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            try:
+                v = open(path).read().strip()
+                if v.isdigit():
+                    avail = min(avail, int(v) / 2.0 ** 30)
+            except OSError:
+                pass
+        return avail
+    except OSError:
+        return 0.0
+
+
+def cpu_baseline(n_gpu_cells, gpu_n, gpu_iters, params_kw, sample_res=0, second_res=96, bench_res=256):
+    """CPU restatement (oracle, kind "port") timed on this host's cores.  r06: MEASURED AT THE BENCHMARK SIZE — the oracle builds the 256^3 system
+    with its setup sweeps threaded (ps_oracle.Oracle.set_setup_threads: bit-identical to its serial setup, tests/test_oracle_kat.py; the reference's own
+    setup fans out over all cores, exec/HDK_PolyStokesSolver.cpp:154) and the CG iteration (pcg.h:311-335 around ApplyPressureStressMatrix.h:102-179) is
+    timed THERE — no extrapolation.  (sample_res > 0, or a host with < 100 GB available / < 8 CPUs: the bounded sample of r01-r05 at that resolution,
+    scaled by the DOF ratio and labelled `extrapolated`.)
       A  "reference-shaped": the reference's own pass structure — the three bodies of applyMatrixVectorProducts under
          `omp parallel sections` (so 3 threads at most, McInv*G and McInv*Dt re-formed on every call), Eigen-style
-         single-thread vector updates (BASELINE.md section 2, baseline A); and A on one thread;
-      B  "fair": one pass per block, every row loop split over OpenMP threads — at 16 threads (a 1-GPU share of the host, what
-         r01-r03 reported) AND at min(affinity, 64) and min(affinity, 32): the box is not a 16-core machine, and the baseline must
-         not be pessimistic by a constant in this file.
-    value = the SOLVE stage of one step: the best variant's time per DOF-iteration at the larger sample x the GPU run's DOFs x its
-    iteration count (extrapolated: `linearity` shows the per-DOF time at both sample sizes).  The restatement's single-thread
-    setup is reported apart, not in value: the reference's own setup is multi-threaded (Solver.cpp:154)."""
+         single-thread vector updates (BASELINE.md section 2, baseline A);
+      B  "fair": one pass per block, every row loop split over OpenMP threads — at min(affinity, 16 / 32 / 64) threads.
+    value = the SOLVE stage of one step: the best variant's time per iteration x the GPU run's iteration count.  The restatement's setup
+    (threaded, wall time) is reported apart, not in value."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before libgomp starts: spinning workers starve a shared host
     from oracle import ps_oracle
     from polystokes_amd import scenes
+    from polystokes_amd import _abi as abi
     affinity = _cpu_affinity()
     thread_counts = sorted({min(affinity, t) for t in (16, 32, 64)})
-    iters = 10
+    setup_threads = min(affinity, 64)
+    mem_gb = _mem_available_gb()
+    at_size = sample_res <= 0 and mem_gb >= 100.0 and affinity >= 8
+    if sample_res <= 0:
+        sample_res = bench_res if at_size else 128
+    kw = dict(params_kw)
+    kw["precond"] = abi.PRE_IDENTITY      # (the timed iteration applies no preconditioner: building the Jacobi diagonal would only lengthen the setup)
 
-    def sample(ns, full):
-        sc, p = scenes.cavity(ns, **params_kw)
+    def sample(ns, full, iters_b, iters_a):
+        sc, p = scenes.cavity(ns, **kw)
         o = ps_oracle.Oracle()
+        o.set_setup_threads(setup_threads)
         t0 = time.time()
         o.run(sc, p, solve=False)
         setup_ms = (time.time() - t0) * 1e3
         n_s = o.nP + o.nT
         by = {}
         for t in thread_counts:
-            ms, used = o.time_cg_mt(iters, t)
+            ms, used = o.time_cg_mt(iters_b, t)
             by[str(used)] = ms
         out = {"res": ns, "dofs": n_s, "setup_ms": setup_ms, "B_ms_per_cg_iter_by_threads": by}
         if full:
-            ms_a, used_a = o.time_cg_sections(iters)
-            out["A"] = (ms_a, used_a, o.time_cg(iters, fair=False))
+            ms_a, used_a = o.time_cg_sections(iters_a)
+            out["A"] = (ms_a, used_a)
+        del o
         return out
 
-    big = sample(sample_res, True)
-    small = sample(second_res, False) if second_res and second_res != sample_res else None
+    big = sample(sample_res, True, 10, 3 if sample_res >= 192 else 10)
+    small = sample(second_res, False, 10, 0) if second_res and second_res != sample_res else None
     ns, n_s, setup_ms = big["res"], big["dofs"], big["setup_ms"]
-    ms_it_a, used_a, ms_it_1t = big["A"]
+    ms_it_a, used_a = big["A"]
     by = big["B_ms_per_cg_iter_by_threads"]
     best_threads = min(by, key=lambda k: by[k])
     ms_it_b, used_b = by[best_threads], int(best_threads)
     scale_cells = n_gpu_cells / float(ns ** 3)
     dof_ratio = gpu_n / float(n_s)
+    measured_at_size = abs(dof_ratio - 1.0) < 1e-9
     solve = lambda ms_it: ms_it * dof_ratio * max(gpu_iters, 1)
     best_it = min(ms_it_b, ms_it_a)
-    setup_step = setup_ms * scale_cells
     lin = None
     if small is not None:
         per = lambda smp: {k: v * 1e6 / smp["dofs"] for k, v in smp["B_ms_per_cg_iter_by_threads"].items()}   # ns per DOF-iteration
         lin = {"ns_per_dof_iteration_B": {"%d^3" % small["res"]: per(small), "%d^3" % ns: per(big)},
                "dofs": {"%d^3" % small["res"]: small["dofs"], "%d^3" % ns: n_s},
                "ratio_large_over_small_at_best_threads": per(big)[best_threads] / per(small)[best_threads] if per(small).get(best_threads) else None,
-               "note": "value scales the larger sample's time per DOF-iteration to the benchmark's DOFs; a ratio near 1 means the time per DOF-iteration does not depend on the size (DRAM-bound at both)"}
-    return {
-        # value = the SOLVE of one step only (the iteration count of the GPU run x the best measured CPU iteration time, scaled by the
-        # DOF ratio): the reference's setup fans out over UT_ThreadedAlgorithm / TBB (Solver.cpp:154) and "hugs zero" in its own plots,
-        # while the restatement's setup is literal single-thread code — its time is reported apart (setup_ms_per_step, setup_threads)
-        # and is NOT part of value.  Compare value with the GPU line's stage_ms.solve.
+               "note": "time per DOF-iteration of baseline B at a small sample and at the measured size: what an extrapolation from the small sample would have missed"}
+    out = {
+        # value = the SOLVE of one step only (the iteration count of the GPU run x the best measured CPU iteration time).  Compare with the GPU line's stage_ms.solve.
         "value": solve(best_it), "unit": "ms/step (solve stage only)", "cores": used_b if ms_it_b <= ms_it_a else used_a, "kind": "port",
-        "solve_ms_per_step": solve(best_it), "setup_ms_per_step": setup_step, "setup_threads": 1,
-        "extrapolated": "measured at %d^3 (%d DOFs), scaled to the benchmark size: x%.2f in DOFs for the solve, x%.1f in cells for the setup" % (ns, n_s, dof_ratio, scale_cells),
-        "cpu_model": _cpu_model(), "nproc": os.cpu_count(), "affinity_cpus": affinity, "cpu_share": used_b,
-        "sample": ("oracle (C++ restatement of ApplyPressureStressMatrix + pcg_external_matrix_A) on the same cavity scene at %d^3 "
-                   "(n = %d DOFs, DRAM-resident); per CG iteration over %d iterations: baseline A "
-                   "(reference-shaped, 3 omp sections, per-call McInv*G) %.1f ms on %d threads and %.1f ms on 1 thread; baseline B "
-                   "(fair CSR passes, OpenMP rows) %s ms on %s threads (affinity: %d CPUs); value = best of A / B x the DOF ratio %.2f x the GPU run's %d "
-                   "iterations — EXTRAPOLATED from %d^3, not measured at the benchmark size; setup of the restatement (1 thread, not in "
-                   "value): %.0f ms at %d^3" % (ns, n_s, iters, ms_it_a, used_a, ms_it_1t, " / ".join("%.1f" % by[k] for k in by), " / ".join(by), affinity,
-                                               dof_ratio, gpu_iters, ns, setup_ms, ns)),
-        "sample_res": ns, "sample_dofs": n_s, "sample_setup_ms": setup_ms, "sample_iterations_timed": iters,
-        "baseline_A_reference_shaped": {"ms_per_cg_iter": ms_it_a, "threads": used_a, "ms_per_cg_iter_1_thread": ms_it_1t, "solve_ms_per_step": solve(ms_it_a)},
+        "solve_ms_per_step": solve(best_it), "setup_ms_per_step": setup_ms * scale_cells, "setup_threads": setup_threads,
+        "cpu_model": _cpu_model(), "nproc": os.cpu_count(), "affinity_cpus": affinity, "cpu_share": used_b, "mem_available_gb": mem_gb,
+        "sample": ("oracle (C++ restatement of ApplyPressureStressMatrix + pcg_external_matrix_A) on the same cavity scene at %d^3 (n = %d DOFs%s), setup sweeps on %d threads "
+                   "(%.1f s wall, not in value); per CG iteration: baseline A (reference-shaped, 3 omp sections, per-call McInv*G) %.1f ms on %d threads; baseline B "
+                   "(fair CSR passes, OpenMP rows) %s ms on %s threads (affinity: %d CPUs); value = best of A / B x the GPU run's %d iterations%s"
+                   % (ns, n_s, ": the benchmark's own system" if measured_at_size else "", setup_threads, setup_ms * 1e-3, ms_it_a, used_a,
+                      " / ".join("%.1f" % by[k] for k in by), " / ".join(by), affinity, gpu_iters,
+                      "" if measured_at_size else " x the DOF ratio %.2f — EXTRAPOLATED from %d^3, not measured at the benchmark size" % (dof_ratio, ns))),
+        "sample_res": ns, "sample_dofs": n_s, "sample_setup_ms": setup_ms, "sample_iterations_timed": 10,
+        "baseline_A_reference_shaped": {"ms_per_cg_iter": ms_it_a, "threads": used_a, "solve_ms_per_step": solve(ms_it_a)},
         "baseline_B_fair_openmp": {"ms_per_cg_iter": ms_it_b, "threads": used_b, "solve_ms_per_step": solve(ms_it_b),
                                    "by_threads": {k: {"ms_per_cg_iter": v, "solve_ms_per_step": solve(v)} for k, v in by.items()}},
         "linearity": lin,
     }
+    if not measured_at_size:
+        out["extrapolated"] = "measured at %d^3 (%d DOFs), scaled to the benchmark size: x%.2f in DOFs for the solve, x%.1f in cells for the setup" % (ns, n_s, dof_ratio, scale_cells)
+    return out
 
 
 def _latest_traffic(kernel="k_spmv_St"):
@@ -280,7 +306,7 @@ def main():
     ap.add_argument("--precond", choices=["jacobi", "identity", "chebyshev", "chebyshev64"], default="jacobi",
                     help="jacobi (default: the metric's configuration), identity (the reference's default), chebyshev (this library's polynomial preconditioner, degree 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-res", type=int, default=128)
+    ap.add_argument("--cpu-sample-res", type=int, default=0, help="resolution of the CPU baseline's sample; 0 (default): the benchmark's own resolution — measured, not extrapolated — when the host has the memory")
     ap.add_argument("--bricks", default=os.environ.get("PS_BENCH_BRICKS", ""), help="N > 1: DXxDYxDZ ranks per axis (e.g. 2x2x2) instead of N z-slabs; "
                     "weak: every GPU owns n^3 cells of the (n DX) x (n DY) x (n DZ) cavity; strong: one n^3 scene cut into bricks")
     ap.add_argument("--transport", choices=["rccl", "tcp"], default="rccl",
@@ -621,7 +647,7 @@ def main():
                 blk, ok, why = None, False, "another rank failed"
         out["strong_512"] = blk if ok else {"error": why}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.precond.startswith("chebyshev") and scene_name == "cavity":   # the CPU leg times the reference's own (Jacobi / identity) PCG iteration on the headline scene
-        out["cpu_baseline"] = cpu_baseline(n ** 3, nsys, iters, dict(tile=16, pad=2, precond=kw["precond"]), args.cpu_sample_res)
+        out["cpu_baseline"] = cpu_baseline(n ** 3, nsys, iters, dict(tile=16, pad=2, precond=kw["precond"]), args.cpu_sample_res, second_res=(96 if n > 96 else 0), bench_res=n)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -54,8 +54,8 @@ struct Field {
     }
 };
 
-struct Trip {
-    int64_t r, c;
+struct Trip {          // 16 bytes (r06: int32 indices — the 256^3 system has ~0.9 G of them before duplicates are summed)
+    int32_t r, c;
     double v;
 };
 
@@ -67,7 +67,7 @@ struct CSR {
     int64_t nnz() const { return (int64_t)val.size(); }
     // Eigen setFromTriplets semantics (SparseMatrix.h:1025-1054,1122-1160): duplicates summed,
     // compressed, inner indices sorted.
-    void fromTriplets(int64_t rows_, int64_t cols_, std::vector<Trip>& t);
+    void fromTriplets(int64_t rows_, int64_t cols_, std::vector<Trip>& t, int threads = 1);
     void mul(const double* x, double* y) const;            // y = M x
     void mulT_add(const double* x, double* y) const;       // y += M^T x
     CSR transposed() const;
@@ -114,6 +114,11 @@ struct Oracle {
     CSR Gt, D;  // explicit transposes (ApplyPressureStressMatrix.h:42-45)
     CSR A;      // explicit operator (AssembleSystem.cpp:351-430), optional
     std::vector<double> diagA; // Jacobi extension
+    // Threads of the SETUP sweeps (po_set_setup_threads; default 1 = the literal serial code).  The reference's own setup fans out over all cores
+    // (exec/HDK_PolyStokesSolver.cpp:154); bench.py's CPU leg uses this to build the 256^3 system in seconds instead of minutes.  Every threaded
+    // sweep produces the SAME bits as the serial one (tests/test_oracle_kat.py asserts it): per-tile sums run whole on one thread in the serial
+    // order; triplets are generated per contiguous piece of the serial traversal and concatenated in order; the sort is a stable parallel sort.
+    int setupThreads = 1;
     bool exactDiagonal = false; // Jacobi / Chebyshev extensions on 1 / A_jj in fp64 instead of the product's 16-bit storage form (ps_oracle_solve.cpp: storedDinv)
     std::vector<double> b, solution, recovered, guess;
     Field<float> velOut[3], valid[3];
@@ -182,6 +187,9 @@ struct Oracle {
     void computeSDFWeightsSampled(Field<float>& dst, const Dim& d, const float off[3],
                                   const Field<float>& sdf, bool negate) const;
     template <class F> void forEachOrdered(const Dim& d, F f) const;
+    // the same traversal cut into `pieces` contiguous ranges: f(piece, i, j, k); pieces run concurrently, each in the serial order
+    template <class F> void forEachOrderedPieces(const Dim& d, int pieces, F f) const;
+    void regionCellBoxes(std::vector<int32_t>& box) const;   // per region: min / max cell index (6 ints), from reducedIdx[0]
     int64_t stressDOF(int64_t idx, int type) const;  // Solver.h:586-606 (XX,YY,ZZ,YZ,XZ,XY)
     int64_t faceVelocityDOF(int64_t idx, int axis) const; // Solver.h:628-642
     void connectedComponents();
@@ -212,6 +220,33 @@ void Oracle::forEachOrdered(const Dim& d, F f) const {
                     for (int j = y0; j < y1; ++j)
                         for (int i = x0; i < x1; ++i) f(i, j, k);
             }
+}
+
+template <class F>
+void Oracle::forEachOrderedPieces(const Dim& d, int pieces, F f) const {
+    // blocks of the traversal in order: k-planes (linear order) or 16^3 voxel tiles (tile-linear)
+    struct Blk { int x0, x1, y0, y1, z0, z1; };
+    std::vector<Blk> blocks;
+    if (P.indexOrder == PS_ORDER_LINEAR) {
+        for (int k = 0; k < d.n[2]; ++k) blocks.push_back(Blk{0, d.n[0], 0, d.n[1], k, k + 1});
+    } else {
+        const int T = 16;
+        for (int z0 = 0; z0 < d.n[2]; z0 += T)
+            for (int y0 = 0; y0 < d.n[1]; y0 += T)
+                for (int x0 = 0; x0 < d.n[0]; x0 += T)
+                    blocks.push_back(Blk{x0, (x0 + T < d.n[0] ? x0 + T : d.n[0]), y0, (y0 + T < d.n[1] ? y0 + T : d.n[1]), z0, (z0 + T < d.n[2] ? z0 + T : d.n[2])});
+    }
+    const int64_t nb = (int64_t)blocks.size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(setupThreads > 1 ? setupThreads : 1)
+    for (int pc = 0; pc < pieces; ++pc) {
+        const int64_t b0 = nb * pc / pieces, b1 = nb * (pc + 1) / pieces;
+        for (int64_t b = b0; b < b1; ++b) {
+            const Blk& q = blocks[(size_t)b];
+            for (int k = q.z0; k < q.z1; ++k)
+                for (int j = q.y0; j < q.y1; ++j)
+                    for (int i = q.x0; i < q.x1; ++i) f(pc, i, j, k);
+        }
+    }
 }
 
 void buildConversionCoefficients(const double off[3], int axis, double out[RD]);  // Solver.cpp:2105-2149

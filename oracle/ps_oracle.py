@@ -50,6 +50,7 @@ def lib():
         L.po_time_cg_iterations_sections.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.po_time_cg_iterations_sections.restype = C.c_double
         L.po_set_exact_diagonal.argtypes = [C.c_void_p, C.c_int32]
+        L.po_set_setup_threads.argtypes = [C.c_void_p, C.c_int32]
         L.po_last_error.argtypes = [C.c_void_p]
         L.po_last_error.restype = C.c_char_p
         L.po_basis.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -88,6 +89,10 @@ class Oracle:
     def set_exact_diagonal(self, on=True):
         """Jacobi / Chebyshev extensions with the fp64 diagonal 1 / A_jj instead of the product's 16-bit storage form (default off)"""
         self.L.po_set_exact_diagonal(self.h, 1 if on else 0)
+
+    def set_setup_threads(self, n):
+        """threads of the setup sweeps (default 1: the literal serial code; any n gives the same bits)"""
+        self.L.po_set_setup_threads(self.h, int(n))
 
     def run(self, scene, params, solve=True):
         self.scene = scene

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <parallel/algorithm>   // __gnu_parallel::stable_sort (libstdc++ parallel mode: a stable multiway mergesort, the same result as std::stable_sort)
 
 #include "ps_oracle.hpp"
 
@@ -12,15 +13,19 @@ namespace psoracle {
 static inline bool isActive(int32_t l) { return l == PS_ACTIVEFLUID || l == PS_BOUNDARY; }
 static inline bool isReduced(int32_t l) { return l == PS_REDUCED || l == PS_BOUNDARY; }
 static inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }  // SYSclamp
+static inline Trip mkT(int64_t r, int64_t c, double v) { return Trip{(int32_t)r, (int32_t)c, v}; }
 
 // ---------------------------------------------------------------------------------------------
 // CSR
 // ---------------------------------------------------------------------------------------------
-void CSR::fromTriplets(int64_t rows_, int64_t cols_, std::vector<Trip>& t) {
+void CSR::fromTriplets(int64_t rows_, int64_t cols_, std::vector<Trip>& t, int threads) {
     rows = rows_; cols = cols_;
-    std::stable_sort(t.begin(), t.end(), [](const Trip& a, const Trip& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
+    auto less = [](const Trip& a, const Trip& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; };
+    if (threads > 1) __gnu_parallel::stable_sort(t.begin(), t.end(), less, __gnu_parallel::multiway_mergesort_tag(threads));
+    else std::stable_sort(t.begin(), t.end(), less);
     ptr.assign((size_t)rows + 1, 0);
     col.clear(); val.clear();
+    col.reserve(t.size()); val.reserve(t.size());
     size_t p = 0;
     for (int64_t r = 0; r < rows; ++r) {
         ptr[(size_t)r] = (int64_t)val.size();
@@ -216,35 +221,60 @@ void Oracle::computeCenterOfMasses() {
 }
 
 // Solver.cpp:374-417, 1330-1399
-void Oracle::computeLeastSquaresFits() {
+void Oracle::regionCellBoxes(std::vector<int32_t>& box) const {
     const int64_t R = regionCount;
-    std::vector<double> N((size_t)R * RD * RD, 0.), rhs((size_t)R * RD, 0.);
+    box.assign((size_t)R * 6, 0);
+    for (int64_t r = 0; r < R; ++r) { box[(size_t)r * 6] = box[(size_t)r * 6 + 1] = box[(size_t)r * 6 + 2] = INT32_MAX; box[(size_t)r * 6 + 3] = box[(size_t)r * 6 + 4] = box[(size_t)r * 6 + 5] = -1; }
     for (int k = 0; k < nz; ++k)
         for (int j = 0; j < ny; ++j)
             for (int i = 0; i < nx; ++i) {
                 const int64_t r = reducedIdx[0].at(i, j, k);
                 if (r < 0) continue;
-                for (int axis = 0; axis < 3; ++axis)
-                    for (int dir = 0; dir < 2; ++dir) {
-                        int a[3] = {i, j, k};
-                        a[axis] += dir ? 1 : -1;
-                        if (!isActive(labels[0].getConst(a[0], a[1], a[2], PS_UNASSIGNED))) continue;  // :1375
-                        double off[3] = {(double)i, (double)j, (double)k};
-                        off[axis] += dir == 0 ? -.5 : .5;
-                        for (int q = 0; q < 3; ++q) { off[q] *= dx; off[q] -= COM[(size_t)r * 3 + q]; }
-                        double C[RD];
-                        buildConversionCoefficients(off, axis, C);
-                        int f[3] = {i, j, k};
-                        f[axis] += dir;
-                        const double uval = (double)vel[axis].at(f[0], f[1], f[2]);
-                        double* Nr = &N[(size_t)r * RD * RD];
-                        for (int m = 0; m < RD; ++m) {
-                            for (int n = 0; n < RD; ++n) Nr[m * RD + n] += C[m] * C[n];
-                            rhs[(size_t)r * RD + m] += uval * C[m];
-                        }
-                    }
+                int32_t* b = &box[(size_t)r * 6];
+                b[0] = std::min(b[0], i); b[1] = std::min(b[1], j); b[2] = std::min(b[2], k);
+                b[3] = std::max(b[3], i); b[4] = std::max(b[4], j); b[5] = std::max(b[5], k);
             }
+}
+
+// The per-tile sums below (least-squares systems, Mr, K) visit the grid in the reference's order and add into the tile a sample belongs to.
+// Restricted to ONE tile that is a walk over the tile's box in the same nesting order — so the tiles are independent and each tile's sum
+// sees its terms in the serial order: the loops run tile by tile over the tile's box (threads: Oracle::setupThreads), bit-identical to the
+// single sweep over the whole grid they restate.
+void Oracle::computeLeastSquaresFits() {
+    const int64_t R = regionCount;
+    std::vector<double> N((size_t)R * RD * RD, 0.), rhs((size_t)R * RD, 0.);
+    std::vector<int32_t> box;
+    regionCellBoxes(box);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(setupThreads > 1 ? setupThreads : 1)
+    for (int64_t r = 0; r < R; ++r) {
+        const int32_t* b = &box[(size_t)r * 6];
+        for (int k = b[2]; k <= b[5]; ++k)
+            for (int j = b[1]; j <= b[4]; ++j)
+                for (int i = b[0]; i <= b[3]; ++i) {
+                    if (reducedIdx[0].at(i, j, k) != r) continue;
+                    for (int axis = 0; axis < 3; ++axis)
+                        for (int dir = 0; dir < 2; ++dir) {
+                            int a[3] = {i, j, k};
+                            a[axis] += dir ? 1 : -1;
+                            if (!isActive(labels[0].getConst(a[0], a[1], a[2], PS_UNASSIGNED))) continue;  // :1375
+                            double off[3] = {(double)i, (double)j, (double)k};
+                            off[axis] += dir == 0 ? -.5 : .5;
+                            for (int q = 0; q < 3; ++q) { off[q] *= dx; off[q] -= COM[(size_t)r * 3 + q]; }
+                            double C[RD];
+                            buildConversionCoefficients(off, axis, C);
+                            int f[3] = {i, j, k};
+                            f[axis] += dir;
+                            const double uval = (double)vel[axis].at(f[0], f[1], f[2]);
+                            double* Nr = &N[(size_t)r * RD * RD];
+                            for (int m = 0; m < RD; ++m) {
+                                for (int n = 0; n < RD; ++n) Nr[m * RD + n] += C[m] * C[n];
+                                rhs[(size_t)r * RD + m] += uval * C[m];
+                            }
+                        }
+                }
+    }
     cfit.assign((size_t)R * RD, 0.);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(setupThreads > 1 ? setupThreads : 1)
     for (int64_t r = 0; r < R; ++r) fullPivLuSolve(&N[(size_t)r * RD * RD], &rhs[(size_t)r * RD], &cfit[(size_t)r * RD]);
     fitN = N; fitRhs = rhs;   // kept for diagnostics (conditioning of the per-tile normal systems)
 }
@@ -253,31 +283,36 @@ void Oracle::computeLeastSquaresFits() {
 void Oracle::computeReducedMassMatrices() {
     const int64_t R = regionCount;
     Mr.assign((size_t)R * RD * RD, 0.);
-    for (int k = 0; k < nz; ++k)
-        for (int j = 0; j < ny; ++j)
-            for (int i = 0; i < nx; ++i) {
-                const int64_t r = reducedIdx[0].at(i, j, k);
-                if (r < 0) continue;
-                for (int axis = 0; axis < 3; ++axis)
-                    for (int dir = 0; dir < 2; ++dir) {
-                        bool doApplyFace = false;
-                        if (dir == 0) doApplyFace = true;
-                        else {
-                            int a[3] = {i, j, k};
-                            a[axis] += 1;
-                            if (isActive(labels[0].getConst(a[0], a[1], a[2], PS_UNASSIGNED))) doApplyFace = true;
+    std::vector<int32_t> box;
+    regionCellBoxes(box);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(setupThreads > 1 ? setupThreads : 1)
+    for (int64_t r = 0; r < R; ++r) {
+        const int32_t* b = &box[(size_t)r * 6];
+        for (int k = b[2]; k <= b[5]; ++k)
+            for (int j = b[1]; j <= b[4]; ++j)
+                for (int i = b[0]; i <= b[3]; ++i) {
+                    if (reducedIdx[0].at(i, j, k) != r) continue;
+                    for (int axis = 0; axis < 3; ++axis)
+                        for (int dir = 0; dir < 2; ++dir) {
+                            bool doApplyFace = false;
+                            if (dir == 0) doApplyFace = true;
+                            else {
+                                int a[3] = {i, j, k};
+                                a[axis] += 1;
+                                if (isActive(labels[0].getConst(a[0], a[1], a[2], PS_UNASSIGNED))) doApplyFace = true;
+                            }
+                            if (!doApplyFace) continue;
+                            double off[3] = {(double)i, (double)j, (double)k};
+                            off[axis] += dir == 0 ? -.5 : .5;
+                            for (int q = 0; q < 3; ++q) { off[q] *= dx; off[q] -= COM[(size_t)r * 3 + q]; }
+                            double C[RD];
+                            buildConversionCoefficients(off, axis, C);
+                            double* M = &Mr[(size_t)r * RD * RD];
+                            for (int m = 0; m < RD; ++m)
+                                for (int n = 0; n < RD; ++n) M[m * RD + n] += rho * C[m] * C[n];  // :1471 (rho*col)*row
                         }
-                        if (!doApplyFace) continue;
-                        double off[3] = {(double)i, (double)j, (double)k};
-                        off[axis] += dir == 0 ? -.5 : .5;
-                        for (int q = 0; q < 3; ++q) { off[q] *= dx; off[q] -= COM[(size_t)r * 3 + q]; }
-                        double C[RD];
-                        buildConversionCoefficients(off, axis, C);
-                        double* M = &Mr[(size_t)r * RD * RD];
-                        for (int m = 0; m < RD; ++m)
-                            for (int n = 0; n < RD; ++n) M[m * RD + n] += rho * C[m] * C[n];  // :1471 (rho*col)*row
-                    }
-            }
+                }
+    }
 }
 
 // Solver.cpp:468-490, 1484-1694
@@ -285,14 +320,22 @@ void Oracle::computeReducedViscosityMatricesInteriorOnly() {
     const int64_t R = regionCount;
     K.assign((size_t)R * RD * RD, 0.);
     const Dim cd = centerDim();
+    std::vector<int32_t> box;
+    regionCellBoxes(box);
+    // (a face carries the tile of the cell at the face or of the cell below it along its axis, Classifier.cpp:1473-1528: the tile's faces lie in
+    // the cells' box grown by one — walked per tile, axis by axis, in the serial nesting order: see computeLeastSquaresFits)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(setupThreads > 1 ? setupThreads : 1)
+    for (int64_t tile = 0; tile < R; ++tile)
     for (int faceAxis = 0; faceAxis < 3; ++faceAxis) {
         const Dim fd = faceDim(faceAxis);
         const Field<int32_t>& tileFaceIndex = reducedIdx[1 + faceAxis];
-        for (int k = 0; k < fd.n[2]; ++k)
-            for (int j = 0; j < fd.n[1]; ++j)
-                for (int i = 0; i < fd.n[0]; ++i) {
+        const int32_t* tb = &box[(size_t)tile * 6];
+        if (tb[3] < 0) continue;
+        for (int k = std::max(0, tb[2] - 1); k <= std::min(fd.n[2] - 1, tb[5] + 1); ++k)
+            for (int j = std::max(0, tb[1] - 1); j <= std::min(fd.n[1] - 1, tb[4] + 1); ++j)
+                for (int i = std::max(0, tb[0] - 1); i <= std::min(fd.n[0] - 1, tb[3] + 1); ++i) {
                     const int64_t self = tileFaceIndex.at(i, j, k);
-                    if (self < 0) continue;
+                    if (self != tile) continue;
                     double selfOff[3] = {(double)i, (double)j, (double)k};
                     selfOff[faceAxis] -= 0.5;
                     for (int q = 0; q < 3; ++q) { selfOff[q] *= dx; selfOff[q] -= COM[(size_t)self * 3 + q]; }
@@ -371,10 +414,32 @@ void Oracle::constructMatrixBlocks() {
     std::vector<Trip> tMc, tMcInv, tRhsA, tOld, tG, tJG, tDt, tJDt, tRhsP, tRhsT, tUInv, tU;
     const double MINWEIGHT = 0.1;
     const Dim cd = centerDim();
+    // Threads (setupThreads > 1): every sweep below is cut into `pieces` contiguous ranges of the serial traversal; a piece fills its own triplet
+    // lists and the lists are appended in piece order — the global lists hold the triplets in EXACTLY the serial order, so the sums over
+    // duplicates (toVec, fromTriplets: stable sort) add in the serial order too.
+    struct TripSet { std::vector<Trip> tMc, tMcInv, tRhsA, tOld, tG, tJG, tDt, tJDt, tRhsP, tRhsT, tUInv, tU; };
+    const int pieces = setupThreads > 1 ? setupThreads * 4 : 1;
+    auto gatherSets = [&](std::vector<TripSet>& sets) {
+        std::vector<Trip> TripSet::*member[12] = {&TripSet::tMc, &TripSet::tMcInv, &TripSet::tRhsA, &TripSet::tOld, &TripSet::tG, &TripSet::tJG, &TripSet::tDt,
+                                                  &TripSet::tJDt, &TripSet::tRhsP, &TripSet::tRhsT, &TripSet::tUInv, &TripSet::tU};
+        std::vector<Trip>* dst[12] = {&tMc, &tMcInv, &tRhsA, &tOld, &tG, &tJG, &tDt, &tJDt, &tRhsP, &tRhsT, &tUInv, &tU};
+        for (int q = 0; q < 12; ++q) {
+            size_t add = 0;
+            for (TripSet& S : sets) add += (S.*member[q]).size();
+            dst[q]->reserve(dst[q]->size() + add);
+            for (TripSet& S : sets) {
+                std::vector<Trip>& v = S.*member[q];
+                dst[q]->insert(dst[q]->end(), v.begin(), v.end());
+                std::vector<Trip>().swap(v);
+            }
+        }
+    };
 
     for (int faceAxis = 0; faceAxis < 3; ++faceAxis) {   // :320-648
         const Dim fd = faceDim(faceAxis);
-        forEachOrdered(fd, [&](int i, int j, int k) {
+        std::vector<TripSet> sets((size_t)pieces);
+        forEachOrderedPieces(fd, pieces, [&](int pc, int i, int j, int k) {
+            TripSet& T = sets[(size_t)pc];
             const int32_t selfLabel = labels[1 + faceAxis].at(i, j, k);
             const int64_t selfActiveIndex = faceVelocityDOF(activeIdx[1 + faceAxis].at(i, j, k), faceAxis);
             const int64_t selfReducedIndex = reducedIdx[1 + faceAxis].at(i, j, k);
@@ -384,10 +449,10 @@ void Oracle::constructMatrixBlocks() {
             volume = clampd(volume, MINWEIGHT * MINWEIGHT, 1.0);
             const double localVelocity = (double)vel[faceAxis].at(i, j, k);
             if (isActive(selfLabel)) {   // :369-391
-                tMc.push_back({selfActiveIndex, selfActiveIndex, volume * localDensity});
-                tMcInv.push_back({selfActiveIndex, selfActiveIndex, 1. / (volume * localDensity)});
-                tRhsA.push_back({selfActiveIndex, 0, localVelocity * volume * localDensity});
-                tOld.push_back({selfActiveIndex, 0, localVelocity});
+                T.tMc.push_back(mkT(selfActiveIndex, selfActiveIndex, volume * localDensity));
+                T.tMcInv.push_back(mkT(selfActiveIndex, selfActiveIndex, 1. / (volume * localDensity)));
+                T.tRhsA.push_back(mkT(selfActiveIndex, 0, localVelocity * volume * localDensity));
+                T.tOld.push_back(mkT(selfActiveIndex, 0, localVelocity));
             }
             if (!(isActive(selfLabel) || isReduced(selfLabel))) return;
             double colVec[RD];
@@ -410,17 +475,17 @@ void Oracle::constructMatrixBlocks() {
                 const double contribution = gradSign * coeff;
                 if (coeff <= 0.) continue;
                 if (isActive(selfLabel)) {
-                    tG.push_back({selfActiveIndex, cellPressureIndex, contribution});
+                    T.tG.push_back(mkT(selfActiveIndex, cellPressureIndex, contribution));
                     if (fluidW[0].at(c[0], c[1], c[2]) < 1.f) {   // :424-432 (solidCoeff unused)
                         const double solidContribution = gradSign * coeff;
-                        tRhsP.push_back({cellPressureIndex, 0, -1. * solidContribution * svel});
+                        T.tRhsP.push_back(mkT(cellPressureIndex, 0, -1. * solidContribution * svel));
                     }
                     if (fluidW[1 + faceAxis].at(i, j, k) < 1.f) {  // :433-441
                         const double solidContribution = gradSign * coeff;
-                        tRhsP.push_back({cellPressureIndex, 0, solidContribution * svel});
+                        T.tRhsP.push_back(mkT(cellPressureIndex, 0, solidContribution * svel));
                     }
                 } else {
-                    for (int n = 0; n < RD; ++n) tJG.push_back({RD * selfReducedIndex + n, cellPressureIndex, contribution * colVec[n]});
+                    for (int n = 0; n < RD; ++n) T.tJG.push_back(mkT(RD * selfReducedIndex + n, cellPressureIndex, contribution * colVec[n]));
                 }
             }
             // stress stencils, centres :466-550
@@ -436,17 +501,17 @@ void Oracle::constructMatrixBlocks() {
                 const double contribution = -1. * divSign * coeff;
                 if (coeff <= 0.) continue;
                 if (isActive(selfLabel)) {
-                    tDt.push_back({selfActiveIndex, cellStressIndex, contribution});
+                    T.tDt.push_back(mkT(selfActiveIndex, cellStressIndex, contribution));
                     if (fluidW[0].at(c[0], c[1], c[2]) < 1.f) {
                         const double solidContribution = divSign * coeff;
-                        tRhsT.push_back({cellStressIndex, 0, -1. * solidContribution * svel});
+                        T.tRhsT.push_back(mkT(cellStressIndex, 0, -1. * solidContribution * svel));
                     }
                     if (fluidW[1 + faceAxis].at(i, j, k) < 1.f) {
                         const double solidContribution = divSign * coeff;
-                        tRhsT.push_back({cellStressIndex, 0, solidContribution * svel});
+                        T.tRhsT.push_back(mkT(cellStressIndex, 0, solidContribution * svel));
                     }
                 } else {
-                    for (int n = 0; n < RD; ++n) tJDt.push_back({RD * selfReducedIndex + n, cellStressIndex, contribution * colVec[n]});
+                    for (int n = 0; n < RD; ++n) T.tJDt.push_back(mkT(RD * selfReducedIndex + n, cellStressIndex, contribution * colVec[n]));
                 }
             }
             // stress stencils, edges :553-639
@@ -463,48 +528,55 @@ void Oracle::constructMatrixBlocks() {
                     const double contribution = -1. * divSign * coeff;
                     if (coeff <= 0.) continue;
                     if (isActive(selfLabel)) {
-                        tDt.push_back({selfActiveIndex, edgeStressIndex, contribution});
+                        T.tDt.push_back(mkT(selfActiveIndex, edgeStressIndex, contribution));
                         if (fluidW[4 + edgeAxis].at(e[0], e[1], e[2]) < 1.f) {
                             const double solidContribution = divSign * coeff;
-                            tRhsT.push_back({edgeStressIndex, 0, -1. * solidContribution * svel});
+                            T.tRhsT.push_back(mkT(edgeStressIndex, 0, -1. * solidContribution * svel));
                         }
                         if (fluidW[1 + faceAxis].at(i, j, k) < 1.f) {
                             const double solidContribution = divSign * coeff;
-                            tRhsT.push_back({edgeStressIndex, 0, solidContribution * svel});
+                            T.tRhsT.push_back(mkT(edgeStressIndex, 0, solidContribution * svel));
                         }
                     } else {
-                        for (int n = 0; n < RD; ++n) tJDt.push_back({RD * selfReducedIndex + n, edgeStressIndex, contribution * colVec[n]});
+                        for (int n = 0; n < RD; ++n) T.tJDt.push_back(mkT(RD * selfReducedIndex + n, edgeStressIndex, contribution * colVec[n]));
                     }
                 }
             }
         });
+        gatherSets(sets);
     }
     // edge stress diagonal :651-735
     for (int edgeAxis = 0; edgeAxis < 3; ++edgeAxis) {
         const Dim ed = edgeDim(edgeAxis);
-        forEachOrdered(ed, [&](int i, int j, int k) {
+        std::vector<TripSet> sets((size_t)pieces);
+        forEachOrderedPieces(ed, pieces, [&](int pc, int i, int j, int k) {
+            TripSet& T = sets[(size_t)pc];
             const int32_t edgeLabel = labels[4 + edgeAxis].at(i, j, k);
             if (!isActive(edgeLabel)) return;
             const int64_t edgeStressIndex = stressDOF(activeIdx[4 + edgeAxis].at(i, j, k), 3 + edgeAxis);
             const double volumeWeight = clampd((double)fluidW[4 + edgeAxis].at(i, j, k), MINWEIGHT, 1.0) * (double)liquidW[4 + edgeAxis].at(i, j, k);
             const double localViscosity = (double)localViscosityAtEdge(edgeAxis, i, j, k);
             const double invLocalViscosity = clampd(1. / localViscosity, 0., 1e10);
-            tUInv.push_back({edgeStressIndex, edgeStressIndex, 2. * invLocalViscosity * volumeWeight});
-            tU.push_back({edgeStressIndex, edgeStressIndex, 0.5 * localViscosity * clampd(1. / volumeWeight, 0., 1.e2)});
+            T.tUInv.push_back(mkT(edgeStressIndex, edgeStressIndex, 2. * invLocalViscosity * volumeWeight));
+            T.tU.push_back(mkT(edgeStressIndex, edgeStressIndex, 0.5 * localViscosity * clampd(1. / volumeWeight, 0., 1.e2)));
         });
+        gatherSets(sets);
     }
     // centre stress diagonal :737-867
-    forEachOrdered(cd, [&](int i, int j, int k) {
+    std::vector<TripSet> csets((size_t)pieces);
+    forEachOrderedPieces(cd, pieces, [&](int pc, int i, int j, int k) {
+        TripSet& T = csets[(size_t)pc];
         if (!isActive(labels[0].at(i, j, k))) return;
         const int64_t ci = activeIdx[0].at(i, j, k);
         const double volumeWeight = clampd((double)fluidW[0].at(i, j, k), MINWEIGHT, 1.0) * (double)liquidW[0].at(i, j, k);
         const double localViscosity = (double)localViscosityAtCell(i, j, k);
         const double invLocalViscosity = clampd(1. / localViscosity, 0., 1.e10);
         for (int t = 0; t < 3; ++t) {
-            tUInv.push_back({stressDOF(ci, t), stressDOF(ci, t), invLocalViscosity * clampd(volumeWeight, 1.e-2, 1.)});
-            tU.push_back({stressDOF(ci, t), stressDOF(ci, t), localViscosity * clampd(1. / volumeWeight, 0., 1.e2)});
+            T.tUInv.push_back(mkT(stressDOF(ci, t), stressDOF(ci, t), invLocalViscosity * clampd(volumeWeight, 1.e-2, 1.)));
+            T.tU.push_back(mkT(stressDOF(ci, t), stressDOF(ci, t), localViscosity * clampd(1. / volumeWeight, 0., 1.e2)));
         }
     });
+    gatherSets(csets);
 
     auto toVec = [](std::vector<Trip>& t, int64_t n, std::vector<double>& out, bool diag) {
         out.assign((size_t)n, 0.);
@@ -519,10 +591,10 @@ void Oracle::constructMatrixBlocks() {
     toVec(tRhsT, nStresses, stressRHS, false);
     toVec(tUInv, nStresses, uInv, true);
     toVec(tU, nStresses, u, true);
-    G.fromTriplets(nActiveVs, nPressures, tG);
-    Dt.fromTriplets(nActiveVs, nStresses, tDt);
-    JG.fromTriplets(nReducedVs, nPressures, tJG);
-    JDt.fromTriplets(nReducedVs, nStresses, tJDt);
+    G.fromTriplets(nActiveVs, nPressures, tG, setupThreads);
+    Dt.fromTriplets(nActiveVs, nStresses, tDt, setupThreads);
+    JG.fromTriplets(nReducedVs, nPressures, tJG, setupThreads);
+    JDt.fromTriplets(nReducedVs, nStresses, tJDt, setupThreads);
 }
 
 // AssembleBlocks.cpp:147-244,356-367 + AssembleSystem.cpp:432-470

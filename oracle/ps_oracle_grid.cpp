@@ -68,6 +68,7 @@ void Oracle::computeSDFWeightsSampled(Field<float>& dst, const Dim& d, const flo
                                       const Field<float>& sdf, bool negate) const {
     dst.init(d, 0.f);
     const float sub[2] = {-0.25f, 0.25f};
+#pragma omp parallel for schedule(dynamic, 1) num_threads(setupThreads > 1 ? setupThreads : 1)   // (independent samples: identical bits)
     for (int k = 0; k < d.n[2]; ++k)
         for (int j = 0; j < d.n[1]; ++j)
             for (int i = 0; i < d.n[0]; ++i) {

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE — see ps_oracle.hpp.  Operator, Krylov solvers, recovery, write-back, C API.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -511,31 +513,42 @@ int Oracle::setup(const ps_params* p, const ps_fields_in* in) {
     if (rc != PS_SUCCESS) return rc;
     const std::clock_t c0 = std::clock();
     const auto w0 = std::chrono::high_resolution_clock::now();
-    buildIntegrationWeightsAlt(in);
+    // PS_ORACLE_TIMING=1: wall time of every setup stage on stderr (where the restatement's setup spends its time: bench.py's CPU leg)
+    const bool timing = std::getenv("PS_ORACLE_TIMING") != nullptr;
+    auto tl = std::chrono::high_resolution_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto t = std::chrono::high_resolution_clock::now();
+        std::fprintf(stderr, "[oracle] %-44s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tl).count());
+        tl = t;
+    };
+    buildIntegrationWeightsAlt(in); lap("buildIntegrationWeightsAlt");
     classifyCells();
     if (P.doReducedRegions) constructReducedRegions(); else constructOnlyActiveRegions();
     classifyFaces();
-    classifyEdges();
+    classifyEdges(); lap("classify cells / regions / faces / edges");
     if (P.doReducedRegions) {
         constructCenterReducedIndices();
         constructFacesReducedIndices();
         constructEdgesReducedIndices();
     }
-    constructActiveIndices();
+    lap("reduced indices (components, fixes)");
+    constructActiveIndices(); lap("constructActiveIndices");
     if (P.doReducedRegions) {
         computeCenterOfMasses();
-        computeLeastSquaresFits();
-        computeReducedMassMatrices();
-        computeReducedViscosityMatricesInteriorOnly();
+        computeLeastSquaresFits(); lap("COM + least-squares fits");
+        computeReducedMassMatrices(); lap("computeReducedMassMatrices");
+        computeReducedViscosityMatricesInteriorOnly(); lap("computeReducedViscosityMatricesInteriorOnly");
     } else {
         COM.clear(); cfit.clear(); Mr.clear(); K.clear();
     }
-    constructMatrixBlocks();
+    constructMatrixBlocks(); lap("constructMatrixBlocks");
     // HDK_PolyStokes.C:462-467: initializeGuessVectors(); if (getUseWarmStart()) constructGuessVectors();
-    constructGuessVectors();
-    assembleSystemPressureStressFactored();
+    constructGuessVectors(); lap("constructGuessVectors");
+    assembleSystemPressureStressFactored(); lap("assembleSystemPressureStressFactored");
     if (P.preconditioner == PS_PRE_DIAGONAL || P.preconditioner == PS_PRE_CHEBYSHEV || P.preconditioner == PS_PRE_CHEBYSHEV_F32) buildJacobiDiagonal();
     if (P.preconditioner == PS_PRE_CHEBYSHEV || P.preconditioner == PS_PRE_CHEBYSHEV_F32) estimateLambdaMax();
+    lap("preconditioner");
     const auto w1 = std::chrono::high_resolution_clock::now();
     stats.solveData[4] = 1000.0 * (double)(std::clock() - c0) / CLOCKS_PER_SEC;
     stats.solveData[5] = std::chrono::duration<double, std::milli>(w1 - w0).count();
@@ -698,6 +711,7 @@ void po_precondition(void* h, const double* r, double* z) {
 }
 double po_cheb_lmax(void* h) { return ((Oracle*)h)->chebLmax; }
 void po_set_exact_diagonal(void* h, int32_t on) { ((Oracle*)h)->exactDiagonal = on != 0; }
+void po_set_setup_threads(void* h, int32_t n) { ((Oracle*)h)->setupThreads = n > 1 ? n : 1; }
 int32_t po_reduced_dof(void) { return psoracle::RD; }
 void po_basis(const double* off, int32_t axis, double* out) { psoracle::buildConversionCoefficients(off, axis, out); }
 int32_t po_fullpivlu_solve(const double* N, const double* rhs, double* x) { return psoracle::fullPivLuSolve(N, rhs, x) ? 1 : 0; }

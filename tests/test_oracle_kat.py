@@ -263,3 +263,39 @@ def test_jacobi_on_the_stored_diagonal_equals_exact_jacobi_on_the_cpu(oracle_mod
     assert 0 < np.abs(d16 / dex - 1.0).max() <= 2.0 ** -8 * (1 + 1e-12)
     assert abs(it16 - itex) <= max(2, 0.02 * itex), (it16, itex)
     assert np.linalg.norm(x16 - xex) <= 10 * 1e-6 * np.linalg.norm(xex)
+
+
+@pytest.mark.parametrize("name", ["cavity24_t12_jacobi", "blob1_t7", "blob2_notile", "cavity22_linear"])
+def test_threaded_setup_is_bit_identical_to_the_serial_setup(oracle_mod, name):
+    """bench.py's CPU leg builds the benchmark-size system with the oracle's setup sweeps on many threads (Oracle::setupThreads; the reference's
+    own setup is threaded, exec/HDK_PolyStokesSolver.cpp:154).  The threaded sweeps must restate the SAME arithmetic: per-tile sums whole on one
+    thread in the serial order, triplets generated per contiguous piece of the serial traversal and concatenated in order, a stable parallel
+    sort — every block, vector and the solve itself equal bit for bit (tiles, a ragged tile size, no tiling = one region, the linear order)."""
+    def mk():
+        if name == "cavity24_t12_jacobi":
+            return scenes.cavity(24, tile=12, pad=2, precond=abi.PRE_DIAGONAL)
+        if name == "blob1_t7":
+            return scenes.blob(30, 26, 22, seed=1, tile=7, pad=2)
+        if name == "blob2_notile":
+            sc, p = scenes.blob(seed=2)
+            p.doTile = 0
+            return sc, p
+        sc, p = scenes.cavity(22, tile=11)
+        p.indexOrder = abi.ORDER_LINEAR
+        return sc, p
+    out = []
+    for threads in (1, 3):
+        sc, p = mk()
+        p.preconditioner = abi.PRE_DIAGONAL
+        o = oracle_mod.Oracle()
+        o.set_setup_threads(threads)
+        assert o.run(sc, p) == abi.SUCCESS
+        st = {n: o.array(n) for n in ("centerLiquidWeights", "edgeXYFluidWeights", "reducedMassMatrices", "reducedViscosityMatrices", "reducedRegionBestFitVectors",
+                                      "Inv_Mr_plus_2JDtuDJ", "McInv", "uInv", "activeRHSVector", "pressureRHSVector", "stressRHSVector", "b", "diagA", "solutionVector", "velX")}
+        for m in ("G", "Dt", "JG", "JDt"):
+            for k in (".ptr", ".col", ".val"):
+                st[m + k] = o.array(m + k)
+        out.append((st, int(o.stats.solveData[1])))
+    assert out[0][1] == out[1][1]
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
