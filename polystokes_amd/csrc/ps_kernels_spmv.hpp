@@ -1115,8 +1115,13 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 
 // ... and for MODE 2 (one term of the Chebyshev preconditioner in the epilogue; coded uInv): two units in flight per wave.
 // TV: element type of t, xin (z_j), cheb.zprev (z_{j-1}) and out (z_{j+1}); r and every sum stay fp64
+#ifdef PS_ST2C_WAVES      // A/B build knob (scripts/build_variant.sh): waves per SIMD the Chebyshev-term kernel is compiled for
+#define PS_ST2C_ATTR __attribute__((amdgpu_waves_per_eu(PS_ST2C_WAVES, PS_ST2C_WAVES)))
+#else
+#define PS_ST2C_ATTR
+#endif
 template <int POL, class TV = double>
-__global__ void __launch_bounds__(BS) k_spmv_St_ell2c(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
+__global__ void __launch_bounds__(BS) PS_ST2C_ATTR k_spmv_St_ell2c(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                       const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                       const TV* __restrict__ t, int cols, int rows, const TV* __restrict__ xin, TV* __restrict__ out,
                                                       double* __restrict__ partial, const int* __restrict__ done, int nChunks, ChebArgs cheb,

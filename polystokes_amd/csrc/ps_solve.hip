@@ -349,6 +349,8 @@ struct Launch {
     }
     int stGridFor(int mode) const {
         if (stGrid > 0) return stGrid;
+        static const int g2 = PS_ENV("PS_PIPE_GRID_ST2") ? atoi(PS_ENV("PS_PIPE_GRID_ST2")) : 0;   // A/B: the Chebyshev term's launch alone
+        if (mode == 2 && g2 > 0) return g2;
         if (mode != 3 || pipeGrid < 1536) return 0;
         if (stDual()) return 1536;   // k_spmv_St_ell2: 80 VGPRs, six workgroups per CU
         return (plain3Hint && c->St.ellok && c->St.packed && pipeGrid >= 1792) ? 1792 : 1536;

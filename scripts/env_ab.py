@@ -12,7 +12,7 @@ if os.environ.get("ENV_AB_CHILD"):
     import numpy as np
     import polystokes_amd
     from polystokes_amd import scenes, _abi as abi
-    sc, p = scenes.cavity(res, tile=16, pad=2, precond={"jacobi": abi.PRE_DIAGONAL, "identity": abi.PRE_IDENTITY, "chebyshev": abi.PRE_CHEBYSHEV}[pre])
+    sc, p = scenes.cavity(res, tile=16, pad=2, precond={"jacobi": abi.PRE_DIAGONAL, "identity": abi.PRE_IDENTITY, "chebyshev": abi.PRE_CHEBYSHEV, "chebyshev32": abi.PRE_CHEBYSHEV_F32}[pre])
     s = polystokes_amd.Solver(0)
     s.upload(sc, p)
     s.step_device()
