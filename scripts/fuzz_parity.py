@@ -35,7 +35,8 @@ for case in range(n_cases):
     p.doTile = int(rng.rand() < 0.85)
     p.doReducedRegions = int(rng.rand() < 0.9)
     p.indexOrder = int(rng.choice([abi.ORDER_VOXEL_TILES, abi.ORDER_VOXEL_TILES, abi.ORDER_LINEAR]))
-    p.preconditioner = int(rng.choice([abi.PRE_IDENTITY, abi.PRE_DIAGONAL]))
+    # FUZZ_PRECONDS="1,5,6,7": the preconditioners drawn from (default identity / Jacobi; 6 / 7 = the Chebyshev polynomial, fp64 / fp32 inner vectors)
+    p.preconditioner = int(rng.choice([int(v) for v in os.environ.get("FUZZ_PRECONDS", "1,5").split(",")]))
     o = ps_oracle.Oracle(); o.run(sc, p, solve=True)
     rc = g.step(sc, p)
     msgs = []
@@ -96,6 +97,6 @@ for case in range(n_cases):
     bad += bool(msgs)
     print(tag, case, fam, (nx, ny, nz), "tile", tile, p.tilePadding, "L/S", p.activeLiquidBoundaryLayerSize, p.activeSolidBoundaryLayerSize, "doTile", p.doTile,
           "red", p.doReducedRegions, "order", p.indexOrder, "pre", p.preconditioner, "| dofs", int(g.stats.dimData[21]), "regions", int(g.stats.dimData[24]),
-          "iters", int(it_g), int(it_o), msgs, notes, flush=True)
+          "iters", int(it_g), int(it_o), "cheb32" if (p.preconditioner == 7 and int(g.array("chebInner32")[0])) else "", msgs, notes, flush=True)
 print("cases", n_cases, "bad", bad, "time %.0fs" % (time.time() - t0))
 sys.exit(1 if bad else 0)
