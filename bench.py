@@ -610,11 +610,15 @@ def main():
         others = {}
         # chebyshev4: the polynomial with its inner vectors stored as fp32 (PS_PRE_CHEBYSHEV_F32, r06; every sum, r, the outer PCG and its stop
         # rule fp64); chebyshev4_fp64: the all-fp64 polynomial of r04 / r05 under the same key those rounds reported it
-        for nm, code in (("jacobi", abi.PRE_DIAGONAL), ("identity", abi.PRE_IDENTITY), ("chebyshev4", abi.PRE_CHEBYSHEV_F32), ("chebyshev4_fp64", abi.PRE_CHEBYSHEV)):
-            if code == pre:
+        # chebyshev10: the same with ten terms (profiles/r06_cheb32_degree.txt: the degree is flat on the cavity and the coil — 625 ... 657 ms at 3 ... 12 terms —
+        # and worth 30 % on the stiff spheres scene; ten terms also mean 2.3x fewer outer iterations, i.e. all-reduces, for a decomposition)
+        for nm, code, deg in (("jacobi", abi.PRE_DIAGONAL, 0), ("identity", abi.PRE_IDENTITY, 0), ("chebyshev4", abi.PRE_CHEBYSHEV_F32, 0), ("chebyshev4_fp64", abi.PRE_CHEBYSHEV, 0),
+                              ("chebyshev10", abi.PRE_CHEBYSHEV_F32, 10)):
+            if code == pre and deg == 0:
                 continue
             try:
                 p.preconditioner = code
+                p.preconditionerDegree = deg
                 solver.upload(sc, p)
                 solver.step_device()
                 torch.cuda.synchronize()
@@ -630,6 +634,7 @@ def main():
             except Exception as e:                               # noqa: BLE001  (the headline is already measured: never lose it)
                 others[nm] = {"error": str(e)[:300]}
         p.preconditioner = pre
+        p.preconditionerDegree = 0
         out["other_preconditioners"] = others
     redundant = strong and scene_name == "coil" and n == args.strong_res
     if not args.no_strong_512 and not redundant and args.maxit == 0:

@@ -290,7 +290,8 @@ def test_bench_single_gpu_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and c["unit"].startswith("ms/step")
     o = d["other_preconditioners"]
-    assert set(o) == {"identity", "chebyshev4", "chebyshev4_fp64"}
+    assert set(o) == {"identity", "chebyshev4", "chebyshev4_fp64", "chebyshev10"}
+    assert o["chebyshev10"]["cg_iterations"] < o["chebyshev4"]["cg_iterations"]
     assert o["chebyshev4_fp64"]["inner_vectors"] == "fp64" and o["chebyshev4"]["inner_vectors"] in ("fp32", "fp64")   # (fp32 where its kernels run: DESIGN.md)
     assert abs(o["chebyshev4"]["cg_iterations"] - o["chebyshev4_fp64"]["cg_iterations"]) <= max(2, 0.05 * o["chebyshev4_fp64"]["cg_iterations"])
     for v in o.values():
