@@ -70,7 +70,7 @@ enum ps_solver_type { PS_PCG_MATRIX_VECTOR_PRODUCTS = 0, PS_EIGEN = 1 };
  * applies — stored in single precision (half the bytes of those applies; every product, sum and recurrence, the residual r, the outer PCG
  * and its stop rule stay fp64).  The preconditioner only approximates an inverse, so its storage rounding (6e-8 relative per stored value)
  * perturbs the iteration count (<= +5 % accepted; equal on the scenes measured), not the solution: x converges to the same tolerance.  It runs
- * where the row-per-lane two-unit kernels run (coded stencil values and diagonals, single domain, >= 8 chunks); elsewhere — fallback
+ * where the row-per-lane two-unit kernels run (coded stencil values, a value-set coded McInv, single domain, >= 8 chunks); elsewhere — fallback
  * formats, decompositions — the fp64 form above runs (array "chebInner32" says which). */
 enum ps_preconditioner { PS_PRE_IDENTITY = 1, PS_PRE_DIAGONAL = 5, PS_PRE_CHEBYSHEV = 6, PS_PRE_CHEBYSHEV_F32 = 7 };
 #define PS_CHEB_INTERVAL_RATIO 250.0   /* lmax / lmin of the Chebyshev interval: flat optimum 120..1000 on the 256^3 scenes (30: 5 % slower) */

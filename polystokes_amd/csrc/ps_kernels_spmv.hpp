@@ -1012,7 +1012,9 @@ __global__ void __launch_bounds__(BS) k_spmv_S_ell2(const uint16_t* __restrict__
 // HALO (DIST only, r06): the launch may hold halo rows — rows outside [fr.ownLo, fr.ownHi) whose y is this rank's share of a neighbour's A p: it goes
 // to fr.yOut and r is left alone there (k_spmv_St_ell's generic MODE 3 did this on one unit per wave; the rank's launch over the chunks next
 // to a cut and the whole-rank launch of the sequential exchange now run two units per wave like the owned-rows launch)
-template <int POL, bool CZ, bool DIST, bool LIST, class TZ = double, bool HALO = false>
+// UC (r06): the stress diagonal uInv comes as one-byte codes into a 256-entry table (true) or, when it takes more than 256 values — a viscosity FIELD —, as the
+// fp64 array itself, passed in uCode's place (false: 7 more bytes per row; until r06 such scenes ran the one-unit kernels and the fp64 polynomial)
+template <int POL, bool CZ, bool DIST, bool LIST, class TZ = double, bool HALO = false, bool UC = true>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_spmv_St_ell2(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                      const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                      const double* __restrict__ t, int cols, int rows, const double* __restrict__ xin,
@@ -1020,8 +1022,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
                                                      const int32_t* __restrict__ list) {
     if (done && *done) return;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
-    __shared__ double dict[256];
-    dict[threadIdx.x] = uDict[threadIdx.x];
+    __shared__ double dict[UC ? 256 : 1];
+    if (UC) dict[threadIdx.x] = uDict[threadIdx.x];
     double alpha;
     {   // as k_spmv_St_ell MODE 3
         CGScalars* sc = fr.sc;
@@ -1042,7 +1044,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * 8),
-                                 rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, (size_t)rows),
+                                 rE0 = bufRsrc(xin, (size_t)rows * 8), rUc = bufRsrc(uCode, UC ? (size_t)rows : (size_t)rows * 8),
                                  rFr = bufRsrc(fr.r, (size_t)rows * 8), rFd = bufRsrc(fr.dinvF, (!CZ && fr.dinvF) ? (size_t)rows * sizeof(diag_t) : 0),
                                  rF64 = bufRsrc(fr.dinvC, CZ ? (size_t)rows * sizeof(diag_t) : 0), rFcz = bufRsrc(fr.cz, CZ ? (size_t)rows * sizeof(TZ) : 0),
                                  rFy = bufRsrc(fr.yOut, HALO ? (size_t)rows * 8 : 0);
@@ -1076,8 +1078,12 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const bool liveA = (int)lane < ua.rows, liveB = (int)lane < ub.rows;
             const unsigned rowA = liveA ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = liveB ? (unsigned)ub.row0 + lane : ROW_NONE;
             const double eA = bufLoadF64epi<NT>(rE0, rowA * 8u), eB = bufLoadF64epi<NT>(rE0, rowB * 8u);
-            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_UC_AUX : 0);
-            const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_UC_AUX : 0);
+            int ucA = 0, ucB = 0;
+            double uvA = 0., uvB = 0.;
+            if (UC) {
+                ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_UC_AUX : 0);
+                ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_UC_AUX : 0);
+            } else { uvA = bufLoadF64epi<NT>(rUc, rowA * 8u); uvB = bufLoadF64epi<NT>(rUc, rowB * 8u); }
             const double crA = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(rowA * 8u), 0, NT ? PS_EPI_AUX : 0));
             const double crB = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rFr, (int)(rowB * 8u), 0, NT ? PS_EPI_AUX : 0));
             float fdA = 1.f, fdB = 1.f;
@@ -1090,8 +1096,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const EllX XA = ellGatherW(ua.W, sa, myBase, rT);
             const EllX XB = ellGatherW(ub.W, sb, myBase, rT);
             const double a = ellSumW(ua.W, sa, XA, scale), b = ellSumW(ub.W, sb, XB, scale);
-            double yA = -a; yA -= 0.5 * dict[ucA] * eA;
-            double yB = -b; yB -= 0.5 * dict[ucB] * eB;
+            double yA = -a; yA -= 0.5 * (UC ? dict[ucA] : uvA) * eA;
+            double yB = -b; yB -= 0.5 * (UC ? dict[ucB] : uvB) * eB;
             const bool mineA = HALO ? ((int)rowA >= fr.ownLo && (int)rowA < fr.ownHi) : liveA, mineB = HALO ? ((int)rowB >= fr.ownLo && (int)rowB < fr.ownHi) : liveB;   // (idle lanes: ROW_NONE is beyond ownHi)
             if (HALO) {                                                      // a neighbour's row: its share of A p
                 bufStoreF64nt<NT>(rFy, (!mineA && liveA) ? rowA * 8u : 0xfffffff8u, yA);
@@ -1120,7 +1126,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 #else
 #define PS_ST2C_ATTR
 #endif
-template <int POL, class TV = double>
+template <int POL, class TV = double, bool UC = true>
 __global__ void __launch_bounds__(BS) PS_ST2C_ATTR k_spmv_St_ell2c(const uint16_t* __restrict__ ecol, const int8_t* __restrict__ ecode, unsigned colBytes, unsigned codeBytes,
                                                       const int32_t* __restrict__ winBase, const int4* __restrict__ echunk, double scale,
                                                       const TV* __restrict__ t, int cols, int rows, const TV* __restrict__ xin, TV* __restrict__ out,
@@ -1128,11 +1134,11 @@ __global__ void __launch_bounds__(BS) PS_ST2C_ATTR k_spmv_St_ell2c(const uint16_
                                                       const uint8_t* __restrict__ uCode, const double* __restrict__ uDict) {
     if (done && *done) return;
     constexpr bool NT = (POL & 1) != 0, SNT = (POL & 2) != 0;
-    __shared__ double dict[256];
-    dict[threadIdx.x] = uDict[threadIdx.x];
+    __shared__ double dict[UC ? 256 : 1];
+    if (UC) dict[threadIdx.x] = uDict[threadIdx.x];
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rCol = bufRsrc(ecol, colBytes), rCode = bufRsrc(ecode, codeBytes), rT = bufRsrc(t, (size_t)cols * sizeof(TV)),
-                                 rE0 = bufRsrc(xin, (size_t)rows * sizeof(TV)), rUc = bufRsrc(uCode, (size_t)rows), rOut = bufRsrc(out, (size_t)rows * sizeof(TV)),
+                                 rE0 = bufRsrc(xin, (size_t)rows * sizeof(TV)), rUc = bufRsrc(uCode, UC ? (size_t)rows : (size_t)rows * 8), rOut = bufRsrc(out, (size_t)rows * sizeof(TV)),
                                  rCr = bufRsrc(cheb.r, (size_t)rows * 8), rCi = bufRsrc(cheb.dinv, (size_t)rows * sizeof(diag_t)),
                                  rCd = bufRsrc(cheb.zprev, cheb.zprev ? (size_t)rows * sizeof(TV) : 0);   // (cheb.zprev points at TV elements)
     const unsigned lane = threadIdx.x & 63;
@@ -1163,16 +1169,20 @@ __global__ void __launch_bounds__(BS) PS_ST2C_ATTR k_spmv_St_ell2c(const uint16_
             if (nchunk >= 0) { nci = echunk[nchunk]; nBase = winBase[nchunk * 16 + (lane & 15)]; }
             const unsigned rowA = (int)lane < ua.rows ? (unsigned)ua.row0 + lane : ROW_NONE, rowB = (int)lane < ub.rows ? (unsigned)ub.row0 + lane : ROW_NONE;
             const double eA = VecIO<TV>::template loadEpi<NT>(rE0, rowA), eB = VecIO<TV>::template loadEpi<NT>(rE0, rowB);
-            const int ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_UC_AUX : 0);
-            const int ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_UC_AUX : 0);
+            int ucA = 0, ucB = 0;
+            double uvA = 0., uvB = 0.;
+            if (UC) {
+                ucA = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowA, 0, NT ? PS_UC_AUX : 0);
+                ucB = (int)__builtin_amdgcn_raw_buffer_load_b8(rUc, (int)rowB, 0, NT ? PS_UC_AUX : 0);
+            } else { uvA = bufLoadF64epi<NT>(rUc, rowA * 8u); uvB = bufLoadF64epi<NT>(rUc, rowB * 8u); }
             const double crA = bufLoadF64(rCr, rowA * 8u), crB = bufLoadF64(rCr, rowB * 8u);
             const double ciA = (double)bufLoadDiag<false>(rCi, rowA), ciB = (double)bufLoadDiag<false>(rCi, rowB);
             const double cdA = VecIO<TV>::load(rCd, rowA), cdB = VecIO<TV>::load(rCd, rowB);     // z_{j-1} (0: no buffer)
             const EllX XA = ellGatherW<TV>(ua.W, sa, myBase, rT);
             const EllX XB = ellGatherW<TV>(ub.W, sb, myBase, rT);
             const double a = ellSumW(ua.W, sa, XA, scale), b = ellSumW(ub.W, sb, XB, scale);
-            double azA = -a; azA -= 0.5 * dict[ucA] * eA;
-            double azB = -b; azB -= 0.5 * dict[ucB] * eB;
+            double azA = -a; azA -= 0.5 * (UC ? dict[ucA] : uvA) * eA;
+            double azB = -b; azB -= 0.5 * (UC ? dict[ucB] : uvB) * eB;
             const double yA = VecIO<TV>::stored(eA + (cheb.c1 * (eA - cdA) + cheb.c2 * (ciA * (crA - azA))));
             const double yB = VecIO<TV>::stored(eB + (cheb.c1 * (eB - cdB) + cheb.c2 * (ciB * (crB - azB))));
             dacc += crA * yA; dacc += crB * yB;                          // r.z of the updated z AS STORED (0 past the last row: every load returned 0)

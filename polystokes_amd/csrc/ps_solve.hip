@@ -158,7 +158,7 @@ struct Launch {
     bool cheb32Ok() const {
         static const bool dualS = !(PS_ENV("PS_S_DUAL") && atoi(PS_ENV("PS_S_DUAL")) == 0), dualT = !(PS_ENV("PS_ST_DUAL") && atoi(PS_ENV("PS_ST_DUAL")) == 0);
         static const bool noFuse = PS_ENV("PS_TILE_SPLIT") && atoi(PS_ENV("PS_TILE_SPLIT")) != 0;
-        return dualS && dualT && listsOk() && c->mcCoded && c->uCoded && !c->slabEnabled && !sList && !stList && xcdAware > 0 && c->S.nChunks >= 8 && c->St.nChunks >= 8 &&
+        return dualS && dualT && listsOk() && c->mcCoded && !c->slabEnabled && !sList && !stList && xcdAware > 0 && c->S.nChunks >= 8 && c->St.nChunks >= 8 &&
                rowsS > 0 && rowsSt > 0 && (c->regionCount == 0 || (c->maxRegionRows <= TILE_FUSED_MAX_ROWS && !noFuse));
     }
     void spmvS32(const float* x, float* out) const {
@@ -187,9 +187,11 @@ struct Launch {
         int xcd = xcdAware;
         const dim3 gr(pipeBlocks(M.nChunks, xcd, true, stGridFor(2))), bl(BS);
         const int pol = policy(M);
-#define PS_LAUNCH_T2CF(POL_) hipLaunchKernelGGL((k_spmv_St_ell2c<POL_, float>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                                M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, out, partial, done, M.nChunks, ca, (const uint8_t*)c->uCode.p, c->uDict.p)
-        if (pol == 3) PS_LAUNCH_T2CF(3); else if (pol == 1) PS_LAUNCH_T2CF(1); else PS_LAUNCH_T2CF(0);
+        const uint8_t* uArg = c->uCoded ? (const uint8_t*)c->uCode.p : (const uint8_t*)c->uInv.p;
+#define PS_LAUNCH_T2CF(POL_, UC_) hipLaunchKernelGGL((k_spmv_St_ell2c<POL_, float, UC_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                                M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, out, partial, done, M.nChunks, ca, uArg, c->uDict.p)
+        if (c->uCoded) { if (pol == 3) PS_LAUNCH_T2CF(3, true); else if (pol == 1) PS_LAUNCH_T2CF(1, true); else PS_LAUNCH_T2CF(0, true); }
+        else { if (pol == 3) PS_LAUNCH_T2CF(3, false); else if (pol == 1) PS_LAUNCH_T2CF(1, false); else PS_LAUNCH_T2CF(0, false); }
 #undef PS_LAUNCH_T2CF
         return (int)gr.x;
     }
@@ -225,38 +227,46 @@ struct Launch {
                                                      M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, c->uInv.p, xin, add, out, partial, done, nChunks, xcdAware, ca, c->uCoded ? c->uCode.p : (const uint8_t*)nullptr, c->uDict.p, fr, stList)
 #define PS_LAUNCH_TE2(MODE_) do { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TE(MODE_, 3); else if (pol == 1) PS_LAUNCH_TE(MODE_, 1); else PS_LAUNCH_TE(MODE_, 0); } while (0)
             // MODE 3 specialisations (k_spmv_St_ell: FX): coded uInv without the Chebyshev term, in a single domain (3) or on a slab rank (1)
-            const bool coded3 = mode == 3 && c->uCoded && !fr.cz, single3 = coded3 && plain3Hint && !fr.yOut && !fr.red && fr.rStride == 0;
+            // (r06: the two-unit kernels also take the stress diagonal as the fp64 array — UC = false, a viscosity field with more than 256 values —; the one-unit
+            // FX forms stay coded-only)
+            const bool codedU = c->uCoded;
+            const uint8_t* uArg = codedU ? (const uint8_t*)c->uCode.p : (const uint8_t*)c->uInv.p;
+            const bool coded3 = mode == 3 && codedU && !fr.cz, single3 = mode == 3 && !fr.cz && plain3Hint && !fr.yOut && !fr.red && fr.rStride == 0;
             // two units in flight per wave (k_spmv_St_ell2; r04): 256^3, one box, interleaved rounds: St with the residual update 0.4251 / 0.4242 ->
             // 0.3923 / 0.3918 ms in sequence at 5 waves per SIMD on 1280 workgroups, step 1124.5 / 1122.6 -> 1098.3 / 1096.6 ms; compiled for 6 waves per
             // SIMD on 1536 workgroups another 0.6 % (profiles/r04_st_dual.txt).  PS_ST_DUAL=0: the one-unit kernel on 1792 workgroups.
             static const bool dualC = !(PS_ENV("PS_ST_DUAL") && atoi(PS_ENV("PS_ST_DUAL")) == 0);
-            if (mode == 2 && dualC && c->uCoded && !stList && (gr.x & 7) == 0 && !c->slabEnabled) {   // a Chebyshev term, two units in flight per wave
+            if (mode == 2 && dualC && !stList && (gr.x & 7) == 0 && !c->slabEnabled) {   // a Chebyshev term, two units in flight per wave
                 const int pol = policy(M);
-#define PS_LAUNCH_T2C(POL_) hipLaunchKernelGGL((k_spmv_St_ell2c<POL_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, out, partial, done, nChunks, ca, (const uint8_t*)c->uCode.p, c->uDict.p)
-                if (pol == 3) PS_LAUNCH_T2C(3); else if (pol == 1) PS_LAUNCH_T2C(1); else PS_LAUNCH_T2C(0);
+#define PS_LAUNCH_T2C(POL_, UC_) hipLaunchKernelGGL((k_spmv_St_ell2c<POL_, double, UC_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, out, partial, done, nChunks, ca, uArg, c->uDict.p)
+                if (codedU) { if (pol == 3) PS_LAUNCH_T2C(3, true); else if (pol == 1) PS_LAUNCH_T2C(1, true); else PS_LAUNCH_T2C(0, true); }
+                else { if (pol == 3) PS_LAUNCH_T2C(3, false); else if (pol == 1) PS_LAUNCH_T2C(1, false); else PS_LAUNCH_T2C(0, false); }
 #undef PS_LAUNCH_T2C
                 return;
             }
-            if (mode == 3 && dualC && plain3Hint2 && c->uCoded && fr.cz && !fr.dinvF && !fr.yOut && !fr.red && fr.rStride == 0 && !stList && (gr.x & 7) == 0) {
+            if (mode == 3 && dualC && plain3Hint2 && fr.cz && !fr.dinvF && !fr.yOut && !fr.red && fr.rStride == 0 && !stList && (gr.x & 7) == 0) {
                 const int pol = policy(M);   // the Chebyshev step's St launch (first term of the polynomial in the epilogue), two units in flight per wave
-#define PS_LAUNCH_T2Z(POL_, TZ_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, true, false, false, TZ_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, (const int32_t*)nullptr)
-                if (cz32) { if (pol == 3) PS_LAUNCH_T2Z(3, float); else if (pol == 1) PS_LAUNCH_T2Z(1, float); else PS_LAUNCH_T2Z(0, float); }
-                else { if (pol == 3) PS_LAUNCH_T2Z(3, double); else if (pol == 1) PS_LAUNCH_T2Z(1, double); else PS_LAUNCH_T2Z(0, double); }
+#define PS_LAUNCH_T2Z(POL_, TZ_, UC_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, true, false, false, TZ_, false, UC_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, uArg, c->uDict.p, fr, (const int32_t*)nullptr)
+#define PS_LAUNCH_T2Z2(POL_, TZ_) do { if (codedU) PS_LAUNCH_T2Z(POL_, TZ_, true); else PS_LAUNCH_T2Z(POL_, TZ_, false); } while (0)
+                if (cz32) { if (pol == 3) PS_LAUNCH_T2Z2(3, float); else if (pol == 1) PS_LAUNCH_T2Z2(1, float); else PS_LAUNCH_T2Z2(0, float); }
+                else { if (pol == 3) PS_LAUNCH_T2Z2(3, double); else if (pol == 1) PS_LAUNCH_T2Z2(1, double); else PS_LAUNCH_T2Z2(0, double); }
+#undef PS_LAUNCH_T2Z2
 #undef PS_LAUNCH_T2Z
                 return;
             }
             if (cz32 && mode == 3 && fr.cz) throw Error("internal: single-precision Chebyshev vectors without the two-unit St kernel");
             if (single3 && stDual() && !stList && (gr.x & 7) == 0) {
                 const int pol = policy(M);
-#define PS_LAUNCH_T2(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, false, false>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                              M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, (const int32_t*)nullptr)
-                if (pol == 3) PS_LAUNCH_T2(3); else if (pol == 1) PS_LAUNCH_T2(1); else PS_LAUNCH_T2(0);
+#define PS_LAUNCH_T2(POL_, UC_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, false, false, double, false, UC_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                              M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, uArg, c->uDict.p, fr, (const int32_t*)nullptr)
+                if (codedU) { if (pol == 3) PS_LAUNCH_T2(3, true); else if (pol == 1) PS_LAUNCH_T2(1, true); else PS_LAUNCH_T2(0, true); }
+                else { if (pol == 3) PS_LAUNCH_T2(3, false); else if (pol == 1) PS_LAUNCH_T2(1, false); else PS_LAUNCH_T2(0, false); }
 #undef PS_LAUNCH_T2
                 return;
             }
-            if (single3) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 3); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 3); else PS_LAUNCH_TEX(3, 0, 3); }
+            if (single3 && codedU) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 3); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 3); else PS_LAUNCH_TEX(3, 0, 3); }
             else if (coded3 && stOwnedOnly && stList && dualC && fr.red && (gr.x & 7) == 0) {   // a rank's launch over owned rows only, two units in flight per wave
                 const int pol = policy(M);
 #define PS_LAUNCH_T2D(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, true, true>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
@@ -353,7 +363,7 @@ struct Launch {
         if (mode == 2 && g2 > 0) return g2;
         if (mode != 3 || pipeGrid < 1536) return 0;
         if (stDual()) return 1536;   // k_spmv_St_ell2: 80 VGPRs, six workgroups per CU
-        return (plain3Hint && c->St.ellok && c->St.packed && pipeGrid >= 1792) ? 1792 : 1536;
+        return (plain3Hint && c->uCoded && c->St.ellok && c->St.packed && pipeGrid >= 1792) ? 1792 : 1536;
     }
     int stBlocks(int mode = 0) const {   // number of partials the St kernel writes: one per block
         int xcd = xcdAware;
@@ -381,8 +391,8 @@ Launch mk(ps_context* c, const int* done) {
     const int run = wr >= 0 ? wr : ((c->S.ellok && c->St.ellok) ? 1 : 0);
     if (L.xcdAware > 0) L.xcdAware |= (run & 7) << 16;
     L.ntSpmv = c->ntLevel() >= 1;
-    L.plain3Hint = c->uCoded && c->P.preconditioner != PS_PRE_CHEBYSHEV && !c->slabEnabled;
-    L.plain3Hint2 = c->uCoded && c->P.preconditioner == PS_PRE_CHEBYSHEV && !c->slabEnabled;
+    L.plain3Hint = c->P.preconditioner != PS_PRE_CHEBYSHEV && !c->slabEnabled;     // (the stress diagonal coded or not: the two-unit kernels take both, r06)
+    L.plain3Hint2 = c->P.preconditioner == PS_PRE_CHEBYSHEV && !c->slabEnabled;
     return L;
 }
 constexpr int64_t FUSED_STEP_MIN_ROWS = 1200000;   // see solve() (r05: 2 M -> 1.2 M: the coil 128^3 of BASELINE config 2, 1.49 M rows, solves 3 % faster in four kernels — 10.55 against 10.86 ms,

@@ -341,8 +341,8 @@ def test_chebyshev_f32_inner_vectors_match_oracle(gpu, oracle_mod, scene):
     """PS_PRE_CHEBYSHEV_F32 (r06): the polynomial with its inner vectors STORED as fp32, restated in the oracle first
     (ps_oracle_solve.cpp: chebyshev32 — rounding at the iterates and the active face rows; the tile rows' storage is not restatable there, so
     the comparison is to the rounding LEVEL).  z = M^-1 r within 5e-6 of max |z| (fp64 form: 1e-10), the iteration count within 2 % (or 2) of the
-    oracle's AND of the product's own fp64 polynomial (growth <= 5 % accepted, none seen), x within 10 tol.  Scenes whose diagonals are not
-    value-set coded (blob6: variable viscosity) fall back to the fp64 form: array chebInner32 says which ran."""
+    oracle's AND of the product's own fp64 polynomial (growth <= 5 % accepted, none seen), x within 10 tol.  blob6 has a viscosity FIELD: its stress
+    diagonal is not value-set coded and the two-unit kernels read it as fp64 (UC = false, r06) — the fp32 inner vectors run there too (array chebInner32)."""
     deg = 0
     if scene == "cavity32":
         sc, p = scenes.cavity(32)
@@ -369,7 +369,8 @@ def test_chebyshev_f32_inner_vectors_match_oracle(gpu, oracle_mod, scene):
     o.run(sc, p)
     assert gpu.step(sc, p) == o.result == abi.SUCCESS
     ran32 = int(gpu.array("chebInner32")[0])
-    assert ran32 == (0 if scene == "blob6" else 1), scene
+    assert ran32 == 1, scene
+    assert int(gpu.array("diagonalsCoded")[0]) == (2 if scene == "blob6" else 3)          # bit 0: uInv coded, bit 1: McInv coded
     r = np.random.RandomState(11).standard_normal(gpu.nP + gpu.nT)
     zo, zg = o.precondition(r), gpu.precondition(r)
     assert int(gpu.array("chebInner32")[0]) == ran32
