@@ -274,6 +274,12 @@ __global__ void k_relabel(int32_t* __restrict__ lab, int64_t n, int from, int to
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n && lab[c] == from) lab[c] = to;
 }
+struct FillMany { int32_t* p[16]; int64_t n[16]; };   // blockIdx.y = the array, grid-stride over its entries
+__global__ void k_fill_i32_many(FillMany F, int v) {
+    int32_t* __restrict__ a = F.p[blockIdx.y];
+    const int64_t n = F.n[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = v;
+}
 __global__ void k_fill_i32(int32_t* __restrict__ a, int64_t n, int v) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n) a[c] = v;
@@ -1298,16 +1304,16 @@ void ps_context::buildInternalNumbering() {
     const int64_t nC = nCenter, nPq = nCenter;
     const int64_t nSys = 4 * nCenter + nEdge[0] + nEdge[1] + nEdge[2];
     const int64_t nAct = nFace[0] + nFace[1] + nFace[2];
-    for (int s : {0, 4, 5, 6}) {
-        sysIdx[s].alloc((size_t)g.count(s));
-        hipLaunchKernelGGL(k_fill_i32, dim3(gridFor(g.count(s), BS)), dim3(BS), 0, stream, sysIdx[s].p, g.count(s), -1);
+    {   // the ten index arrays of the numbering start at -1: ONE launch (r06: ten before)
+        FillMany F;
+        int q = 0;
+        int64_t most = 1;
+        auto add = [&](int32_t* ptr, int64_t n) { F.p[q] = ptr; F.n[q] = n; ++q; most = std::max(most, n); };
+        for (int s : {0, 4, 5, 6}) { sysIdx[s].alloc((size_t)g.count(s)); add(sysIdx[s].p, g.count(s)); }
+        for (int a = 0; a < 3; ++a) { sysIdxT[a].alloc((size_t)g.count(0)); add(sysIdxT[a].p, g.count(0)); }
+        for (int a = 0; a < 3; ++a) add(faceRow[a].p, g.count(1 + a));
+        hipLaunchKernelGGL(k_fill_i32_many, dim3((unsigned)std::min<int64_t>(512, gridFor(most, BS)), (unsigned)q), dim3(BS), 0, stream, F, -1);
     }
-    for (int a = 0; a < 3; ++a) {
-        sysIdxT[a].alloc((size_t)g.count(0));
-        hipLaunchKernelGGL(k_fill_i32, dim3(gridFor(g.count(0), BS)), dim3(BS), 0, stream, sysIdxT[a].p, g.count(0), -1);
-    }
-    for (int a = 0; a < 3; ++a)
-        hipLaunchKernelGGL(k_fill_i32, dim3(gridFor(g.count(1 + a), BS)), dim3(BS), 0, stream, faceRow[a].p, g.count(1 + a), -1);
     {
         // seven groups, one per kind of DOF: p, txx, tyy, tzz (all on the cell grid), then the YZ / XZ / XY edge stresses
         const int samples[7] = {0, 0, 0, 0, 4, 5, 6}, weights[7] = {1, 1, 1, 1, 1, 1, 1};
