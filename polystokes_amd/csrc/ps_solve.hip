@@ -267,19 +267,21 @@ struct Launch {
                 return;
             }
             if (single3 && codedU) { const int pol = policy(M); if (pol == 3) PS_LAUNCH_TEX(3, 3, 3); else if (pol == 1) PS_LAUNCH_TEX(3, 1, 3); else PS_LAUNCH_TEX(3, 0, 3); }
-            else if (coded3 && stOwnedOnly && stList && dualC && fr.red && (gr.x & 7) == 0) {   // a rank's launch over owned rows only, two units in flight per wave
+            else if (mode == 3 && !fr.cz && stOwnedOnly && stList && dualC && fr.red && (gr.x & 7) == 0) {   // a rank's launch over owned rows only, two units in flight per wave
                 const int pol = policy(M);
-#define PS_LAUNCH_T2D(POL_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, true, true>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, stList)
-                if (pol == 3) PS_LAUNCH_T2D(3); else if (pol == 1) PS_LAUNCH_T2D(1); else PS_LAUNCH_T2D(0);
+#define PS_LAUNCH_T2D(POL_, UC_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, true, true, double, false, UC_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, uArg, c->uDict.p, fr, stList)
+                if (codedU) { if (pol == 3) PS_LAUNCH_T2D(3, true); else if (pol == 1) PS_LAUNCH_T2D(1, true); else PS_LAUNCH_T2D(0, true); }
+                else { if (pol == 3) PS_LAUNCH_T2D(3, false); else if (pol == 1) PS_LAUNCH_T2D(1, false); else PS_LAUNCH_T2D(0, false); }
 #undef PS_LAUNCH_T2D
             }
-            else if (coded3 && dualC && fr.red && fr.yOut && !stOwnedOnly && (gr.x & 7) == 0) {   // a rank's launch that holds halo rows (the chunks next to a cut, or the whole rank), two units in flight per wave
+            else if (mode == 3 && !fr.cz && dualC && fr.red && fr.yOut && !stOwnedOnly && (gr.x & 7) == 0) {   // a rank's launch that holds halo rows (the chunks next to a cut, or the whole rank), two units in flight per wave
                 const int pol = policy(M);
-#define PS_LAUNCH_T2H(POL_, LIST_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, true, LIST_, double, true>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
-                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, (const uint8_t*)c->uCode.p, c->uDict.p, fr, stList)
-#define PS_LAUNCH_T2H2(POL_) do { if (stList) PS_LAUNCH_T2H(POL_, true); else PS_LAUNCH_T2H(POL_, false); } while (0)
-                if (pol == 3) PS_LAUNCH_T2H2(3); else if (pol == 1) PS_LAUNCH_T2H2(1); else PS_LAUNCH_T2H2(0);
+#define PS_LAUNCH_T2H(POL_, LIST_, UC_) hipLaunchKernelGGL((k_spmv_St_ell2<POL_, false, true, LIST_, double, true, UC_>), gr, bl, 0, c->stream, M.ecol.p, M.ecode.p, (unsigned)(M.ellCols * 2), (unsigned)M.ellCodes, M.winBase.p, \
+                                               M.echunk.p, c->valScale, t, (int)M.cols, rowsSt, xin, done, nChunks, uArg, c->uDict.p, fr, stList)
+#define PS_LAUNCH_T2H2(POL_, UC_) do { if (stList) PS_LAUNCH_T2H(POL_, true, UC_); else PS_LAUNCH_T2H(POL_, false, UC_); } while (0)
+                if (codedU) { if (pol == 3) PS_LAUNCH_T2H2(3, true); else if (pol == 1) PS_LAUNCH_T2H2(1, true); else PS_LAUNCH_T2H2(0, true); }
+                else { if (pol == 3) PS_LAUNCH_T2H2(3, false); else if (pol == 1) PS_LAUNCH_T2H2(1, false); else PS_LAUNCH_T2H2(0, false); }
 #undef PS_LAUNCH_T2H2
 #undef PS_LAUNCH_T2H
             }
